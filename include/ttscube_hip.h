@@ -1,0 +1,120 @@
+/*
+ * ttscube_hip.h — C ABI of libttscube_hip.so: the MI355X (gfx950) waveform-synthesis hot path of
+ * TTS-Cube, hand-written HIP behind plain pointers and sizes (no torch types).
+ *
+ * The reference (tiberiu44/TTS-Cube) is 100 % Python and has no FFI; the boundary it exposes for this
+ * path is `nn.Module.forward/inference` + the `state_dict` key layout.  Each entry point
+ * below names the reference interface it replaces; `ttscube_amd/` (Python, ctypes) mirrors the
+ * reference classes on top of these symbols and INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions
+ *   - every function returns TTSC_OK (0) or a negative TTSC_E* code; ttsc_last_error() returns a
+ *     thread-local, human-readable message for the last failure on the calling thread.
+ *   - `*_dev` pointers are device (HBM) pointers owned by the caller and valid for the call;
+ *     host pointers are copied before the function returns.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all work is
+ *     enqueued on it, nothing synchronises the device unless stated.
+ *   - handles are not thread-safe; distinct handles are independent.
+ *   - activations are fp32, channel-major `[B, C, L]` contiguous (torch NCL), exactly what the
+ *     reference modules exchange.
+ */
+#ifndef TTSCUBE_HIP_H
+#define TTSCUBE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TTSC_OK 0
+#define TTSC_EINVAL (-1)   /* bad argument / shape / name */
+#define TTSC_EHIP (-2)     /* HIP runtime error (message has hipGetErrorString) */
+#define TTSC_ESTATE (-3)   /* weights missing / handle not ready */
+#define TTSC_ENOMEM (-4)   /* workspace too small */
+
+const char* ttsc_version(void);
+const char* ttsc_last_error(void);
+/* number of visible HIP devices, or negative error (used by the loader to fail loudly) */
+int ttsc_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Conv1d / ConvTranspose1d layer (fp32 MFMA implicit GEMM).
+ * Replaces torch.nn.Conv1d / ConvTranspose1d as used by cube/networks/modules.py:37-55 (ConvNorm),
+ * modules.py:117-145 (PostNet), modules.py:416-420 (WaveRNN low-res convs), textcoder.py:44-53 /
+ * modules.py:850-871 (char CNN) and the [EXTERNAL] hifigan Generator convs (cubegan.py:43).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ttsc_conv1d ttsc_conv1d;
+
+typedef struct {
+    int32_t in_channels;
+    int32_t out_channels;
+    int32_t kernel_size;
+    int32_t stride;      /* Conv1d: must be 1.  ConvTranspose1d: upsample factor */
+    int32_t padding;
+    int32_t dilation;    /* ConvTranspose1d: must be 1 */
+    int32_t transposed;  /* 0 = Conv1d (weight [Cout,Cin,K]), 1 = ConvTranspose1d (weight [Cin,Cout,K]) */
+} ttsc_conv1d_cfg;
+
+enum { TTSC_ACT_NONE = 0, TTSC_ACT_TANH = 1, TTSC_ACT_RELU = 2, TTSC_ACT_SIGMOID = 3 };
+
+typedef struct {
+    float in_scale;      /* x is staged as leaky_relu(x * in_scale, in_slope); 1 / 1 = identity */
+    float in_slope;
+    float out_scale;     /* y = act((conv + bias + resid) * out_scale)  */
+    int32_t out_act;     /* TTSC_ACT_* */
+    int32_t accumulate;  /* 1: y += result (running sum of residual blocks) */
+} ttsc_conv1d_epilogue;
+
+int ttsc_conv1d_create(const ttsc_conv1d_cfg* cfg, ttsc_conv1d** out);
+/* weight: host fp32 in torch layout (already weight-norm folded); bias: host [Cout] or NULL */
+int ttsc_conv1d_set_weight(ttsc_conv1d* c, const float* weight_host, const float* bias_host);
+int64_t ttsc_conv1d_out_len(const ttsc_conv1d* c, int64_t Lin);
+/* x_dev [B,Cin,Lin] -> y_dev [B,Cout,Lout]; resid_dev NULL or [B,Cout,Lout]; ep NULL = plain conv */
+int ttsc_conv1d_forward(const ttsc_conv1d* c, const float* x_dev, int32_t B, int64_t Lin, float* y_dev,
+                        const float* resid_dev, const ttsc_conv1d_epilogue* ep, void* stream);
+void ttsc_conv1d_destroy(ttsc_conv1d* c);
+
+/* ------------------------------------------------------------------------------------------------
+ * HiFi-GAN generator.  Replaces `hifigan.models.Generator(h)` [EXTERNAL submodule]:
+ * constructed cube/networks/cubegan.py:41-43 and cube/io_utils/runtime.py:49-51,
+ * called cubegan.py:72,83,131,234 and runtime.py:78 as generator(mel[B,80,T]) -> [B,1,L].
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ttsc_hifigan ttsc_hifigan;
+
+#define TTSC_HIFIGAN_MAX_UPS 8
+#define TTSC_HIFIGAN_MAX_RB 8
+#define TTSC_HIFIGAN_MAX_DIL 8
+
+typedef struct {
+    int32_t num_mels;                 /* 80 */
+    int32_t upsample_initial_channel; /* 512 */
+    int32_t resblock;                 /* 1 or 2 (config key "resblock") */
+    int32_t num_upsamples;
+    int32_t upsample_rates[TTSC_HIFIGAN_MAX_UPS];
+    int32_t upsample_kernel_sizes[TTSC_HIFIGAN_MAX_UPS];
+    int32_t num_kernels;
+    int32_t resblock_kernel_sizes[TTSC_HIFIGAN_MAX_RB];
+    int32_t num_dilations[TTSC_HIFIGAN_MAX_RB];
+    int32_t resblock_dilation_sizes[TTSC_HIFIGAN_MAX_RB][TTSC_HIFIGAN_MAX_DIL];
+} ttsc_hifigan_cfg;
+
+int ttsc_hifigan_create(const ttsc_hifigan_cfg* cfg, ttsc_hifigan** out);
+/* name = folded state_dict key: "conv_pre.weight", "ups.0.bias", "resblocks.3.convs1.2.weight",
+ * "conv_post.weight" ...; host fp32, torch layout, shape checked. */
+int ttsc_hifigan_set_weight(ttsc_hifigan* g, const char* name, const float* host, const int64_t* shape, int32_t nd);
+int64_t ttsc_hifigan_out_len(const ttsc_hifigan* g, int64_t T);
+size_t ttsc_hifigan_workspace_bytes(const ttsc_hifigan* g, int32_t B, int64_t T);
+/* mel_dev [B,num_mels,T] -> wav_dev [B,1,out_len(T)] (tanh output in (-1,1)) */
+int ttsc_hifigan_forward(const ttsc_hifigan* g, const float* mel_dev, int32_t B, int64_t T, float* wav_dev,
+                         void* workspace_dev, size_t workspace_bytes, void* stream);
+/* debug/parity: copy of the activation after upsample stage `stage` (0 = conv_pre) left in the workspace
+ * by the last forward; returns its channel count/length via out params. */
+int ttsc_hifigan_algorithmic_flops(const ttsc_hifigan* g, int32_t B, int64_t T, double* flops_out);
+void ttsc_hifigan_destroy(ttsc_hifigan* g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTSCUBE_HIP_H */

@@ -1,0 +1,101 @@
+"""ctypes binding of libttscube_hip.so (the C ABI declared in include/ttscube_hip.h).
+
+The product path fails loudly when the HIP extension is missing — there is no CPU fallback."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libttscube_hip.so')
+
+
+class TTSCError(RuntimeError):
+    pass
+
+
+class Conv1dCfg(C.Structure):
+    _fields_ = [('in_channels', C.c_int32), ('out_channels', C.c_int32), ('kernel_size', C.c_int32),
+                ('stride', C.c_int32), ('padding', C.c_int32), ('dilation', C.c_int32), ('transposed', C.c_int32)]
+
+
+class Conv1dEpilogue(C.Structure):
+    _fields_ = [('in_scale', C.c_float), ('in_slope', C.c_float), ('out_scale', C.c_float),
+                ('out_act', C.c_int32), ('accumulate', C.c_int32)]
+
+
+MAX_UPS, MAX_RB, MAX_DIL = 8, 8, 8
+
+
+class HifiganCfg(C.Structure):
+    _fields_ = [('num_mels', C.c_int32), ('upsample_initial_channel', C.c_int32), ('resblock', C.c_int32),
+                ('num_upsamples', C.c_int32), ('upsample_rates', C.c_int32 * MAX_UPS),
+                ('upsample_kernel_sizes', C.c_int32 * MAX_UPS), ('num_kernels', C.c_int32),
+                ('resblock_kernel_sizes', C.c_int32 * MAX_RB), ('num_dilations', C.c_int32 * MAX_RB),
+                ('resblock_dilation_sizes', (C.c_int32 * MAX_DIL) * MAX_RB)]
+
+
+ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
+
+_lib = None
+
+# symbol -> (restype, argtypes); also the list the CPU test checks against include/ttscube_hip.h
+SIGNATURES = {
+    'ttsc_version': (C.c_char_p, []),
+    'ttsc_last_error': (C.c_char_p, []),
+    'ttsc_device_count': (C.c_int, []),
+    'ttsc_conv1d_create': (C.c_int, [C.POINTER(Conv1dCfg), C.POINTER(C.c_void_p)]),
+    'ttsc_conv1d_set_weight': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ttsc_conv1d_out_len': (C.c_int64, [C.c_void_p, C.c_int64]),
+    'ttsc_conv1d_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
+                                      C.POINTER(Conv1dEpilogue), C.c_void_p]),
+    'ttsc_conv1d_destroy': (None, [C.c_void_p]),
+    'ttsc_hifigan_create': (C.c_int, [C.POINTER(HifiganCfg), C.POINTER(C.c_void_p)]),
+    'ttsc_hifigan_set_weight': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
+    'ttsc_hifigan_out_len': (C.c_int64, [C.c_void_p, C.c_int64]),
+    'ttsc_hifigan_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int64]),
+    'ttsc_hifigan_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
+                                       C.c_size_t, C.c_void_p]),
+    'ttsc_hifigan_algorithmic_flops': (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_double)]),
+    'ttsc_hifigan_destroy': (None, [C.c_void_p]),
+}
+
+
+def lib():
+    """Load libttscube_hip.so once; raise (never fall back) if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TTSCError('HIP extension not built: %s is missing. Run `python -c "import __graft_entry__ as g; '
+                        'g.build()"` or `make -C ttscube_amd/csrc`. There is no CPU fallback.' % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().ttsc_last_error()
+        raise TTSCError('%s failed (code %d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+def require_gpu():
+    n = lib().ttsc_device_count()
+    if n <= 0:
+        raise TTSCError('no HIP device visible (ttsc_device_count=%d); the HIP path has no CPU fallback' % n)
+    return n
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev_ptr(t):
+    """Device pointer of a contiguous fp32 CUDA(HIP) tensor."""
+    import torch
+    assert t.is_cuda and t.is_contiguous(), 'expected a contiguous device tensor'
+    return C.c_void_p(t.data_ptr())

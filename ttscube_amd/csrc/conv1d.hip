@@ -1,0 +1,368 @@
+// Conv1d / ConvTranspose1d as an fp32-MFMA implicit GEMM for gfx950 (CDNA4).
+//
+//   out[b, co, q*os + oo] = act( ( bias[co] + resid + sum_{j<ntaps} sum_{ci} W_j[co, ci] *
+//                                  lrelu(in_scale * x[b, ci, q + tap_base + j*tap_step]) ) * out_scale )
+//
+// A plain (dilated) Conv1d is one launch with tap_step = dilation, tap_base = -padding, os = 1.
+// A ConvTranspose1d with stride s is s polyphase launches: phase r owns outputs o with
+// (o + p) % s == r, its taps are k = r + j*s and it reads x[q - j]  (tap_step = -1).
+//
+// GEMM view per workgroup: M = output channels (MT rows), N = NT consecutive q positions, K = Cin*ntaps.
+// v_mfma_f32_32x32x2_f32 is an exact k-ordered fp32 fmaf chain at the fp32 vector rate (157 TF/chip);
+// one wave per SIMD with >=4 independent accumulators saturates the pipe, so the design goal is simply
+// "never starve it": the B operand (activations, with the dilation halo) is staged once per 16-channel
+// chunk through LDS with the leaky-relu prologue fused into the staging pass, and the A operand
+// (weights) is pre-packed on the host into MFMA fragment order so every fragment is ONE coalesced
+// 256-byte wave load that hits L2.  Epilogue fuses bias, residual add, scaling, tanh and the running
+// sum over residual blocks.
+#include "common.hpp"
+
+namespace ttsc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int KC = 16;  // input channels staged per LDS chunk
+
+struct ConvArgs {
+    const float* x;
+    float* y;
+    const float* resid;
+    const float* wp;    // [ntaps][CinP/2][CoutP/32][64]
+    const float* bias;  // [Cout] or null
+    int Cin, CinP, Cout, CoutP;
+    int Lin, Lout;
+    int ntaps, tap_base, tap_step;
+    int out_stride, out_off;
+    int q_lo, q_cnt;
+    int span, span_pad, min_shift;
+    float in_scale, in_slope, out_scale;
+    int out_act, accumulate;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == TTSC_ACT_TANH) return tanhf(v);
+    if (act == TTSC_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == TTSC_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    return v;
+}
+
+template <int MI, int NJ, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [KC][span_pad]
+    constexpr int NT = WN * NJ * 32;
+    constexpr int NTHREADS = WM * WN * 64;
+    constexpr int NWAVES = WM * WN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int b = blockIdx.z;
+    const int q0 = a.q_lo + blockIdx.x * NT;
+    const int cot0 = (blockIdx.y * WM + wm) * MI;  // first 32-row tile of this wave
+    const int cotN = a.CoutP >> 5;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const float* xb = a.x + (size_t)b * a.Cin * a.Lin;
+    const int lo = q0 + a.min_shift;  // x position of LDS column 0
+    const int cipN = a.CinP >> 1;
+
+    for (int cc = 0; cc < a.CinP; cc += KC) {
+        __syncthreads();
+        // ---- stage x[b, cc:cc+KC, lo:lo+span] -> LDS, leaky-relu prologue fused -------------------
+        for (int c = wave; c < KC; c += NWAVES) {
+            const int ci = cc + c;
+            const float* xr = xb + (size_t)ci * a.Lin;
+            float* dst = xs + c * a.span_pad;
+            const bool cok = ci < a.Cin;
+            for (int p = lane; p < a.span; p += 64) {
+                const int pos = lo + p;
+                float v = 0.f;
+                if (cok && pos >= 0 && pos < a.Lin) {
+                    v = xr[pos] * a.in_scale;
+                    v = v > 0.f ? v : v * a.in_slope;
+                }
+                dst[p] = v;
+            }
+        }
+        __syncthreads();
+        // ---- MFMA over taps x channel pairs --------------------------------------------------
+        for (int j = 0; j < a.ntaps; ++j) {
+            const int shift = a.tap_base + j * a.tap_step - a.min_shift;  // >= 0
+            const float* wj = a.wp + ((size_t)(j * cipN + (cc >> 1)) * cotN + cot0) * 64 + lane;
+            const float* bj = xs + half * a.span_pad + wn * (NJ * 32) + l31 + shift;
+#pragma unroll
+            for (int cp = 0; cp < KC / 2; ++cp) {
+                float af[MI], bf[NJ];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[i] = wj[((size_t)cp * cotN + i) * 64];
+#pragma unroll
+                for (int n = 0; n < NJ; ++n) bf[n] = bj[(2 * cp) * a.span_pad + n * 32];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int n = 0; n < NJ; ++n)
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[n], acc[i][n], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: bias + residual + scale + activation (+ running sum) --------------------------
+    const int q_hi = a.q_lo + a.q_cnt;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int n = 0; n < NJ; ++n) {
+            const int q = q0 + wn * (NJ * 32) + n * 32 + l31;
+            const long o = (long)q * a.out_stride + a.out_off;
+            const bool qok = (q < q_hi) && (o >= 0) && (o < a.Lout);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int co = (cot0 + i) * 32 + row;
+                if (qok && co < a.Cout) {
+                    const size_t idx = ((size_t)b * a.Cout + co) * a.Lout + o;
+                    float v = acc[i][n][r];
+                    if (a.bias) v += a.bias[co];
+                    if (a.resid) v += a.resid[idx];
+                    v = apply_act(v * a.out_scale, a.out_act);
+                    if (a.accumulate) v += a.y[idx];
+                    a.y[idx] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int MI, int NJ, int WM, int WN>
+static int launch_cfg(const ConvArgs& a, int B, hipStream_t s) {
+    constexpr int NT = WN * NJ * 32;
+    constexpr int MT = WM * MI * 32;
+    dim3 grid((unsigned)ceil_div(a.q_cnt, NT), (unsigned)(a.CoutP / MT), (unsigned)B);
+    dim3 block(WM * WN * 64);
+    size_t lds = (size_t)KC * a.span_pad * sizeof(float);
+    hipLaunchKernelGGL((conv_mfma_kernel<MI, NJ, WM, WN>), grid, block, lds, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("conv_mfma_kernel launch failed: %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    return TTSC_OK;
+}
+
+static int pick_mt(int Cout) {
+    int best = 32, best_pad = (int)round_up(Cout, 32);
+    for (int mt : {64, 128}) {
+        int pad = (int)round_up(Cout, mt);
+        if (pad <= best_pad) {
+            best = mt;
+            best_pad = pad;
+        }
+    }
+    return best;
+}
+
+}  // namespace ttsc
+
+using namespace ttsc;
+
+struct ConvPhase {
+    float* wp_dev = nullptr;
+    int ntaps = 0, tap_base = 0, tap_step = 0;
+    int out_stride = 1, out_off = 0;
+    int r = 0;  // phase index (transposed)
+};
+
+struct ttsc_conv1d {
+    ttsc_conv1d_cfg cfg;
+    int MT = 32, NT = 512, CinP = 0, CoutP = 0;
+    std::vector<ConvPhase> phases;
+    float* bias_dev = nullptr;
+    bool has_weight = false;
+};
+
+extern "C" int ttsc_conv1d_create(const ttsc_conv1d_cfg* cfg, ttsc_conv1d** out) {
+    TTSC_REQUIRE(cfg && out, "ttsc_conv1d_create: null argument");
+    TTSC_REQUIRE(cfg->in_channels > 0 && cfg->out_channels > 0 && cfg->kernel_size > 0,
+                 "ttsc_conv1d_create: bad channels/kernel (%d,%d,%d)", cfg->in_channels, cfg->out_channels,
+                 cfg->kernel_size);
+    TTSC_REQUIRE(cfg->stride >= 1 && cfg->dilation >= 1 && cfg->padding >= 0, "ttsc_conv1d_create: bad stride/dilation/padding");
+    if (cfg->transposed) {
+        TTSC_REQUIRE(cfg->dilation == 1, "ttsc_conv1d_create: ConvTranspose1d supports dilation 1 only");
+    } else {
+        TTSC_REQUIRE(cfg->stride == 1, "ttsc_conv1d_create: Conv1d supports stride 1 only");
+    }
+    ttsc_conv1d* c = new ttsc_conv1d();
+    c->cfg = *cfg;
+    c->MT = pick_mt(cfg->out_channels);
+    c->NT = c->MT == 128 ? 128 : (c->MT == 64 ? 256 : 512);
+    c->CinP = (int)round_up(cfg->in_channels, KC);
+    c->CoutP = (int)round_up(cfg->out_channels, c->MT);
+    *out = c;
+    return TTSC_OK;
+}
+
+extern "C" void ttsc_conv1d_destroy(ttsc_conv1d* c) {
+    if (!c) return;
+    for (auto& p : c->phases)
+        if (p.wp_dev) (void)hipFree(p.wp_dev);
+    if (c->bias_dev) (void)hipFree(c->bias_dev);
+    delete c;
+}
+
+extern "C" int64_t ttsc_conv1d_out_len(const ttsc_conv1d* c, int64_t Lin) {
+    if (!c) return TTSC_EINVAL;
+    const auto& g = c->cfg;
+    if (g.transposed) return (Lin - 1) * g.stride - 2 * g.padding + g.kernel_size;
+    return Lin + 2 * g.padding - g.dilation * (g.kernel_size - 1);
+}
+
+// Pack W into MFMA A-fragment order: [tap][CinP/2][CoutP/32][lane], lane -> (co = cot*32 + (lane&31), ci = 2*cip + (lane>>5))
+static void pack_phase(const ttsc_conv1d* c, const float* w, const std::vector<int>& taps_k, std::vector<float>& out) {
+    const auto& g = c->cfg;
+    const int Cin = g.in_channels, Cout = g.out_channels, K = g.kernel_size;
+    const int cipN = c->CinP / 2, cotN = c->CoutP / 32;
+    out.assign((size_t)taps_k.size() * cipN * cotN * 64, 0.f);
+    for (size_t j = 0; j < taps_k.size(); ++j) {
+        const int k = taps_k[j];
+        for (int cip = 0; cip < cipN; ++cip)
+            for (int cot = 0; cot < cotN; ++cot)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int co = cot * 32 + (lane & 31);
+                    const int ci = 2 * cip + (lane >> 5);
+                    float v = 0.f;
+                    if (co < Cout && ci < Cin)
+                        v = g.transposed ? w[((size_t)ci * Cout + co) * K + k] : w[((size_t)co * Cin + ci) * K + k];
+                    out[(((size_t)j * cipN + cip) * cotN + cot) * 64 + lane] = v;
+                }
+    }
+}
+
+extern "C" int ttsc_conv1d_set_weight(ttsc_conv1d* c, const float* w, const float* bias) {
+    TTSC_REQUIRE(c && w, "ttsc_conv1d_set_weight: null argument");
+    const auto& g = c->cfg;
+    for (auto& p : c->phases)
+        if (p.wp_dev) (void)hipFree(p.wp_dev);
+    c->phases.clear();
+    std::vector<float> packed;
+    auto upload = [&](ConvPhase& ph) -> int {
+        TTSC_HIP_CHECK(hipMalloc((void**)&ph.wp_dev, packed.size() * sizeof(float)));
+        TTSC_HIP_CHECK(hipMemcpy(ph.wp_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+        return TTSC_OK;
+    };
+    if (!g.transposed) {
+        ConvPhase ph;
+        std::vector<int> taps;
+        for (int k = 0; k < g.kernel_size; ++k) taps.push_back(k);
+        ph.ntaps = g.kernel_size;
+        ph.tap_base = -g.padding;
+        ph.tap_step = g.dilation;
+        ph.out_stride = 1;
+        ph.out_off = 0;
+        pack_phase(c, w, taps, packed);
+        int rc = upload(ph);
+        if (rc) return rc;
+        c->phases.push_back(ph);
+    } else {
+        for (int r = 0; r < g.stride; ++r) {
+            ConvPhase ph;
+            std::vector<int> taps;
+            for (int k = r; k < g.kernel_size; k += g.stride) taps.push_back(k);
+            if (taps.empty()) continue;  // K < stride: this phase only gets the bias (handled below)
+            ph.r = r;
+            ph.ntaps = (int)taps.size();
+            ph.tap_base = 0;
+            ph.tap_step = -1;
+            ph.out_stride = g.stride;
+            ph.out_off = r - g.padding;
+            pack_phase(c, w, taps, packed);
+            int rc = upload(ph);
+            if (rc) return rc;
+            c->phases.push_back(ph);
+        }
+        TTSC_REQUIRE((int)c->phases.size() == g.stride, "ConvTranspose1d with kernel_size < stride is not supported");
+    }
+    if (c->bias_dev) {
+        (void)hipFree(c->bias_dev);
+        c->bias_dev = nullptr;
+    }
+    if (bias) {
+        TTSC_HIP_CHECK(hipMalloc((void**)&c->bias_dev, g.out_channels * sizeof(float)));
+        TTSC_HIP_CHECK(hipMemcpy(c->bias_dev, bias, g.out_channels * sizeof(float), hipMemcpyHostToDevice));
+    }
+    c->has_weight = true;
+    return TTSC_OK;
+}
+
+extern "C" int ttsc_conv1d_forward(const ttsc_conv1d* c, const float* x, int32_t B, int64_t Lin, float* y,
+                                   const float* resid, const ttsc_conv1d_epilogue* ep, void* stream) {
+    TTSC_REQUIRE(c && x && y, "ttsc_conv1d_forward: null argument");
+    if (!c->has_weight) {
+        set_error("ttsc_conv1d_forward: weights not set");
+        return TTSC_ESTATE;
+    }
+    TTSC_REQUIRE(B > 0 && Lin > 0, "ttsc_conv1d_forward: bad B/Lin (%d, %lld)", B, (long long)Lin);
+    const auto& g = c->cfg;
+    const int64_t Lout = ttsc_conv1d_out_len(c, Lin);
+    TTSC_REQUIRE(Lout > 0, "ttsc_conv1d_forward: output length %lld <= 0", (long long)Lout);
+    TTSC_REQUIRE(Lin < (1ll << 30) && Lout < (1ll << 30), "ttsc_conv1d_forward: length too large");
+    hipStream_t s = (hipStream_t)stream;
+    for (const auto& ph : c->phases) {
+        ConvArgs a;
+        a.x = x;
+        a.y = y;
+        a.resid = resid;
+        a.wp = ph.wp_dev;
+        a.bias = c->bias_dev;
+        a.Cin = g.in_channels;
+        a.CinP = c->CinP;
+        a.Cout = g.out_channels;
+        a.CoutP = c->CoutP;
+        a.Lin = (int)Lin;
+        a.Lout = (int)Lout;
+        a.ntaps = ph.ntaps;
+        a.tap_base = ph.tap_base;
+        a.tap_step = ph.tap_step;
+        a.out_stride = ph.out_stride;
+        a.out_off = ph.out_off;
+        if (!g.transposed) {
+            a.q_lo = 0;
+            a.q_cnt = (int)Lout;
+        } else {
+            // o = q*s + r - p in [0, Lout)
+            int64_t qlo = -floor_div(ph.r - g.padding, g.stride);  // ceil((p - r) / s)
+            int64_t qhi = floor_div(Lout - 1 - ph.r + g.padding, g.stride) + 1;      // exclusive
+            if (qhi <= qlo) continue;
+            a.q_lo = (int)qlo;
+            a.q_cnt = (int)(qhi - qlo);
+        }
+        const int last = (ph.ntaps - 1) * ph.tap_step;
+        a.min_shift = ph.tap_base + (last < 0 ? last : 0);
+        a.span = c->NT + (last < 0 ? -last : last);
+        a.span_pad = a.span + 1;
+        a.in_scale = ep ? ep->in_scale : 1.f;
+        a.in_slope = ep ? ep->in_slope : 1.f;
+        a.out_scale = ep ? ep->out_scale : 1.f;
+        a.out_act = ep ? ep->out_act : TTSC_ACT_NONE;
+        a.accumulate = ep ? ep->accumulate : 0;
+        int rc;
+        if (c->MT == 128)
+            rc = launch_cfg<2, 2, 2, 2>(a, B, s);
+        else if (c->MT == 64)
+            rc = launch_cfg<2, 2, 1, 4>(a, B, s);
+        else
+            rc = launch_cfg<1, 4, 1, 4>(a, B, s);
+        if (rc) return rc;
+    }
+    return TTSC_OK;
+}

@@ -1,0 +1,262 @@
+// HiFi-GAN generator forward (V1/V2/V3 style configs; ResBlock1 and ResBlock2) as a chain of fused
+// conv launches on one stream.  Mirrors `hifigan.models.Generator.forward` [EXTERNAL submodule of the
+// reference; call sites cube/networks/cubegan.py:72,83,131 and cube/io_utils/runtime.py:78]:
+//
+//   x = conv_pre(mel)
+//   for each upsample i:  x = ups[i](lrelu(x, 0.1));  x = mean_j resblock[i*nk+j](x)
+//   wav = tanh(conv_post(lrelu(x, 0.01)))
+//
+// Fusions (all inside the conv kernel's prologue/epilogue, see conv1d.hip):
+//   - every leaky-relu is applied while staging the conv's input tile into LDS,
+//   - the residual add `x = xt + x` is the epilogue of the second conv of each pair,
+//   - the sum over the nk residual blocks is accumulated by the epilogue of each block's last conv and the
+//     division by nk rides in the next layer's staging scale, i.e. (rb0 + rb1 + rb2) / nk exactly as
+//     the reference computes it,
+//   - tanh is the epilogue of conv_post.
+//
+// HBM layout: four activation buffers carved from the caller's workspace (X: stage input, XT: inner
+// activation of a residual pair, R: running residual stream, S: sum over residual blocks), each
+// [B, C_i, L_i] fp32 channel-major, sized for the largest stage.
+#include <map>
+#include <memory>
+
+#include "common.hpp"
+
+using namespace ttsc;
+
+namespace {
+struct Layer {
+    ttsc_conv1d* c = nullptr;
+    std::vector<float> w;  // staged host weight until bias+weight are both present
+    std::vector<float> b;
+    bool has_w = false, has_b = false, uploaded = false;
+    std::vector<int64_t> wshape;
+    ~Layer() { ttsc_conv1d_destroy(c); }
+};
+}  // namespace
+
+struct ttsc_hifigan {
+    ttsc_hifigan_cfg cfg;
+    std::map<std::string, std::unique_ptr<Layer>> layers;
+    std::vector<int> stage_ch;  // channels after upsample i
+    bool ready() const {
+        for (auto& kv : layers)
+            if (!kv.second->uploaded) return false;
+        return true;
+    }
+};
+
+static int add_layer(ttsc_hifigan* g, const std::string& name, int cin, int cout, int k, int stride, int pad, int dil,
+                     int transposed) {
+    ttsc_conv1d_cfg c{cin, cout, k, stride, pad, dil, transposed};
+    std::unique_ptr<Layer> L(new Layer());
+    int rc = ttsc_conv1d_create(&c, &L->c);
+    if (rc) return rc;
+    if (transposed)
+        L->wshape = {cin, cout, k};
+    else
+        L->wshape = {cout, cin, k};
+    g->layers[name] = std::move(L);
+    return TTSC_OK;
+}
+
+extern "C" int ttsc_hifigan_create(const ttsc_hifigan_cfg* cfg, ttsc_hifigan** out) {
+    TTSC_REQUIRE(cfg && out, "ttsc_hifigan_create: null argument");
+    TTSC_REQUIRE(cfg->num_upsamples > 0 && cfg->num_upsamples <= TTSC_HIFIGAN_MAX_UPS, "bad num_upsamples %d", cfg->num_upsamples);
+    TTSC_REQUIRE(cfg->num_kernels > 0 && cfg->num_kernels <= TTSC_HIFIGAN_MAX_RB, "bad num_kernels %d", cfg->num_kernels);
+    TTSC_REQUIRE(cfg->resblock == 1 || cfg->resblock == 2, "resblock must be 1 or 2, got %d", cfg->resblock);
+    TTSC_REQUIRE(cfg->num_mels > 0 && cfg->upsample_initial_channel > 0, "bad num_mels / upsample_initial_channel");
+    TTSC_REQUIRE((cfg->upsample_initial_channel >> cfg->num_upsamples) >= 1, "upsample_initial_channel too small");
+    std::unique_ptr<ttsc_hifigan> g(new ttsc_hifigan());
+    g->cfg = *cfg;
+    int rc = add_layer(g.get(), "conv_pre", cfg->num_mels, cfg->upsample_initial_channel, 7, 1, 3, 1, 0);
+    if (rc) return rc;
+    int ch = cfg->upsample_initial_channel;
+    for (int i = 0; i < cfg->num_upsamples; ++i) {
+        const int u = cfg->upsample_rates[i], k = cfg->upsample_kernel_sizes[i];
+        TTSC_REQUIRE(u >= 1 && k >= u, "upsample %d: need kernel_size >= rate >= 1 (k=%d,u=%d)", i, k, u);
+        const int cout = ch / 2;
+        rc = add_layer(g.get(), "ups." + std::to_string(i), ch, cout, k, u, (k - u) / 2, 1, 1);
+        if (rc) return rc;
+        for (int j = 0; j < cfg->num_kernels; ++j) {
+            const int rk = cfg->resblock_kernel_sizes[j];
+            TTSC_REQUIRE(rk % 2 == 1, "resblock kernel size must be odd, got %d", rk);
+            TTSC_REQUIRE(cfg->num_dilations[j] > 0 && cfg->num_dilations[j] <= TTSC_HIFIGAN_MAX_DIL, "bad num_dilations");
+            const std::string rb = "resblocks." + std::to_string(i * cfg->num_kernels + j);
+            for (int m = 0; m < cfg->num_dilations[j]; ++m) {
+                const int d = cfg->resblock_dilation_sizes[j][m];
+                if (cfg->resblock == 1) {
+                    rc = add_layer(g.get(), rb + ".convs1." + std::to_string(m), cout, cout, rk, 1, d * (rk - 1) / 2, d, 0);
+                    if (rc) return rc;
+                    rc = add_layer(g.get(), rb + ".convs2." + std::to_string(m), cout, cout, rk, 1, (rk - 1) / 2, 1, 0);
+                    if (rc) return rc;
+                } else {
+                    rc = add_layer(g.get(), rb + ".convs." + std::to_string(m), cout, cout, rk, 1, d * (rk - 1) / 2, d, 0);
+                    if (rc) return rc;
+                }
+            }
+        }
+        ch = cout;
+        g->stage_ch.push_back(ch);
+    }
+    rc = add_layer(g.get(), "conv_post", ch, 1, 7, 1, 3, 1, 0);
+    if (rc) return rc;
+    *out = g.release();
+    return TTSC_OK;
+}
+
+extern "C" void ttsc_hifigan_destroy(ttsc_hifigan* g) { delete g; }
+
+extern "C" int ttsc_hifigan_set_weight(ttsc_hifigan* g, const char* name, const float* host, const int64_t* shape,
+                                       int32_t nd) {
+    TTSC_REQUIRE(g && name && host && shape, "ttsc_hifigan_set_weight: null argument");
+    std::string n(name);
+    const bool is_w = n.size() > 7 && n.compare(n.size() - 7, 7, ".weight") == 0;
+    const bool is_b = n.size() > 5 && n.compare(n.size() - 5, 5, ".bias") == 0;
+    TTSC_REQUIRE(is_w || is_b, "ttsc_hifigan_set_weight: '%s' is neither .weight nor .bias (fold weight_norm first)", name);
+    std::string base = n.substr(0, n.size() - (is_w ? 7 : 5));
+    auto it = g->layers.find(base);
+    TTSC_REQUIRE(it != g->layers.end(), "ttsc_hifigan_set_weight: unknown layer '%s'", base.c_str());
+    Layer* L = it->second.get();
+    if (is_w) {
+        TTSC_REQUIRE(nd == 3 && shape[0] == L->wshape[0] && shape[1] == L->wshape[1] && shape[2] == L->wshape[2],
+                     "ttsc_hifigan_set_weight: '%s' expects shape [%lld,%lld,%lld]", name, (long long)L->wshape[0],
+                     (long long)L->wshape[1], (long long)L->wshape[2]);
+        L->w.assign(host, host + shape[0] * shape[1] * shape[2]);
+        L->has_w = true;
+    } else {
+        TTSC_REQUIRE(nd == 1, "ttsc_hifigan_set_weight: '%s' must be 1-D", name);
+        L->b.assign(host, host + shape[0]);
+        L->has_b = true;
+    }
+    if (L->has_w && L->has_b) {
+        // bias length check against the layer's Cout (weight dim 0 for Conv1d, dim 1 for ConvTranspose1d)
+        const bool transposed = base.compare(0, 4, "ups.") == 0;
+        const int64_t cout = transposed ? L->wshape[1] : L->wshape[0];
+        TTSC_REQUIRE((int64_t)L->b.size() == cout, "ttsc_hifigan_set_weight: '%s.bias' expects %lld elements", base.c_str(),
+                     (long long)cout);
+        int rc = ttsc_conv1d_set_weight(L->c, L->w.data(), L->b.data());
+        if (rc) return rc;
+        L->uploaded = true;
+        std::vector<float>().swap(L->w);
+    }
+    return TTSC_OK;
+}
+
+extern "C" int64_t ttsc_hifigan_out_len(const ttsc_hifigan* g, int64_t T) {
+    if (!g) return TTSC_EINVAL;
+    int64_t L = T;
+    for (int i = 0; i < g->cfg.num_upsamples; ++i) {
+        const int u = g->cfg.upsample_rates[i], k = g->cfg.upsample_kernel_sizes[i];
+        L = (L - 1) * u - 2 * ((k - u) / 2) + k;
+    }
+    return L;
+}
+
+static size_t buf_elems(const ttsc_hifigan* g, int32_t B, int64_t T) {
+    size_t mx = (size_t)B * g->cfg.upsample_initial_channel * T;
+    int64_t L = T;
+    for (int i = 0; i < g->cfg.num_upsamples; ++i) {
+        const int u = g->cfg.upsample_rates[i], k = g->cfg.upsample_kernel_sizes[i];
+        L = (L - 1) * u - 2 * ((k - u) / 2) + k;
+        size_t e = (size_t)B * g->stage_ch[i] * L;
+        if (e > mx) mx = e;
+    }
+    return (size_t)round_up((int64_t)mx, 64);
+}
+
+extern "C" size_t ttsc_hifigan_workspace_bytes(const ttsc_hifigan* g, int32_t B, int64_t T) {
+    if (!g || B <= 0 || T <= 0) return 0;
+    return 4 * buf_elems(g, B, T) * sizeof(float);
+}
+
+extern "C" int ttsc_hifigan_algorithmic_flops(const ttsc_hifigan* g, int32_t B, int64_t T, double* out) {
+    TTSC_REQUIRE(g && out && B > 0 && T > 0, "ttsc_hifigan_algorithmic_flops: bad argument");
+    const auto& c = g->cfg;
+    double mac = (double)T * c.num_mels * c.upsample_initial_channel * 7;
+    int64_t L = T;
+    int ch = c.upsample_initial_channel;
+    for (int i = 0; i < c.num_upsamples; ++i) {
+        const int u = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
+        mac += (double)L * ch * (ch / 2) * k;  // every input sample meets every tap once
+        L = (L - 1) * u - 2 * ((k - u) / 2) + k;
+        ch /= 2;
+        for (int j = 0; j < c.num_kernels; ++j)
+            mac += (double)L * ch * ch * c.resblock_kernel_sizes[j] * c.num_dilations[j] * (c.resblock == 1 ? 2 : 1);
+    }
+    mac += (double)L * ch * 7;
+    *out = 2.0 * mac * B;
+    return TTSC_OK;
+}
+
+extern "C" int ttsc_hifigan_forward(const ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, float* wav, void* ws,
+                                    size_t ws_bytes, void* stream) {
+    TTSC_REQUIRE(g && mel && wav && ws, "ttsc_hifigan_forward: null argument");
+    TTSC_REQUIRE(B > 0 && T > 0, "ttsc_hifigan_forward: bad B/T (%d, %lld)", B, (long long)T);
+    if (!g->ready()) {
+        std::string missing;
+        for (auto& kv : g->layers)
+            if (!kv.second->uploaded) {
+                missing = kv.first;
+                break;
+            }
+        set_error("ttsc_hifigan_forward: weights missing (first: '%s')", missing.c_str());
+        return TTSC_ESTATE;
+    }
+    const size_t need = ttsc_hifigan_workspace_bytes(g, B, T);
+    if (ws_bytes < need) {
+        set_error("ttsc_hifigan_forward: workspace %zu < required %zu bytes", ws_bytes, need);
+        return TTSC_ENOMEM;
+    }
+    const auto& c = g->cfg;
+    const size_t be = buf_elems(g, B, T);
+    float* X = (float*)ws;
+    float* XT = X + be;
+    float* R = XT + be;
+    float* S = R + be;
+    auto layer = [&](const std::string& n) -> const ttsc_conv1d* { return g->layers.at(n)->c; };
+    int rc;
+
+    ttsc_conv1d_epilogue ep{1.f, 1.f, 1.f, TTSC_ACT_NONE, 0};
+    rc = ttsc_conv1d_forward(layer("conv_pre"), mel, B, T, S, nullptr, &ep, stream);
+    if (rc) return rc;
+    int64_t L = T;
+    float sum_scale = 1.f;  // pending division by nk of the previous stage's block sum
+    for (int i = 0; i < c.num_upsamples; ++i) {
+        // x = ups[i](lrelu(x / nk_prev, 0.1))
+        ttsc_conv1d_epilogue eu{sum_scale, 0.1f, 1.f, TTSC_ACT_NONE, 0};
+        const ttsc_conv1d* up = layer("ups." + std::to_string(i));
+        rc = ttsc_conv1d_forward(up, S, B, L, X, nullptr, &eu, stream);
+        if (rc) return rc;
+        L = ttsc_conv1d_out_len(up, L);
+        for (int j = 0; j < c.num_kernels; ++j) {
+            const std::string rb = "resblocks." + std::to_string(i * c.num_kernels + j);
+            const int nd = c.num_dilations[j];
+            for (int m = 0; m < nd; ++m) {
+                const float* src = (m == 0) ? X : R;
+                const bool last = (m == nd - 1);
+                float* dst = last ? S : R;
+                ttsc_conv1d_epilogue e2{1.f, 0.1f, 1.f, TTSC_ACT_NONE, (last && j > 0) ? 1 : 0};
+                if (c.resblock == 1) {
+                    ttsc_conv1d_epilogue e1{1.f, 0.1f, 1.f, TTSC_ACT_NONE, 0};
+                    rc = ttsc_conv1d_forward(layer(rb + ".convs1." + std::to_string(m)), src, B, L, XT, nullptr, &e1, stream);
+                    if (rc) return rc;
+                    rc = ttsc_conv1d_forward(layer(rb + ".convs2." + std::to_string(m)), XT, B, L, dst, src, &e2, stream);
+                    if (rc) return rc;
+                } else {
+                    // ResBlock2 reads src both as conv input and residual; dst != src unless m>0 && !last (R->R),
+                    // where an in-place update would race with neighbouring tiles' halo reads -> ping-pong via XT.
+                    float* d2 = dst;
+                    if (dst == src) d2 = XT;
+                    rc = ttsc_conv1d_forward(layer(rb + ".convs." + std::to_string(m)), src, B, L, d2, src, &e2, stream);
+                    if (rc) return rc;
+                    if (d2 != dst) std::swap(R, XT);
+                }
+            }
+        }
+        sum_scale = 1.f / (float)c.num_kernels;
+    }
+    ttsc_conv1d_epilogue epost{sum_scale, 0.01f, 1.f, TTSC_ACT_TANH, 0};
+    rc = ttsc_conv1d_forward(layer("conv_post"), S, B, L, wav, nullptr, &epost, stream);
+    return rc;
+}

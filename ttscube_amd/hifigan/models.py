@@ -1,0 +1,222 @@
+"""``hifigan.models.Generator`` on MI355X.
+
+Drop-in for the generator class of the reference's un-vendored ``hifigan`` submodule
+(constructed at cube/networks/cubegan.py:41-43 and cube/io_utils/runtime.py:49-51; called as
+``generator(mel[B,80,T]) -> [B,1,L]`` at cubegan.py:72,83,131 and runtime.py:78).  Same constructor
+(``Generator(h)`` with ``h = AttrDict(json)``), same ``state_dict`` key layout (``conv_pre``, ``ups.N``,
+``resblocks.N.convs{1,2}.M``, ``conv_post``; each ``weight_g``/``weight_v``/``bias``), same
+``remove_weight_norm()``.  forward() runs entirely in the HIP kernels of libttscube_hip.so through
+``ttsc_hifigan_forward``; there is no PyTorch/CPU compute path.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+LRELU_SLOPE = 0.1
+
+
+def get_padding(kernel_size, dilation=1):
+    return int((kernel_size * dilation - dilation) / 2)
+
+
+class WNConv(nn.Module):
+    """Parameter holder with torch.nn.utils.weight_norm's key layout (weight_g, weight_v, bias).
+
+    ``shape`` is the torch weight shape: Conv1d [Cout,Cin,K], ConvTranspose1d [Cin,Cout,K]; the norm is taken
+    over every dim but 0, exactly as weight_norm(dim=0) does for both."""
+
+    def __init__(self, shape, bias_len, init_std=None):
+        super().__init__()
+        v = torch.empty(shape)
+        if init_std is None:
+            fan_in = shape[1] * shape[2]
+            bound = 1.0 / (fan_in ** 0.5)
+            v.uniform_(-bound, bound)
+        else:
+            v.normal_(0.0, init_std)  # hifigan utils.init_weights: N(0, 0.01)
+        self.weight_g = nn.Parameter(v.reshape(shape[0], -1).norm(dim=1).reshape(shape[0], 1, 1).clone())
+        self.weight_v = nn.Parameter(v)
+        self.bias = nn.Parameter(torch.zeros(bias_len))
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        # accept: folded 'weight' (after remove_weight_norm) and torch>=2.1 parametrization keys
+        wk, gk, vk = prefix + 'weight', prefix + 'weight_g', prefix + 'weight_v'
+        p0, p1 = prefix + 'parametrizations.weight.original0', prefix + 'parametrizations.weight.original1'
+        if p0 in state_dict and p1 in state_dict:
+            state_dict[gk] = state_dict.pop(p0)
+            state_dict[vk] = state_dict.pop(p1)
+        if wk in state_dict and not hasattr(self, 'weight'):
+            self.remove_weight_norm()
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
+    def folded_weight(self):
+        if hasattr(self, 'weight'):
+            return self.weight.detach()
+        v = self.weight_v.detach().float()
+        g = self.weight_g.detach().float()
+        norm = v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, 1, 1)
+        return g * v / norm
+
+    def remove_weight_norm(self):
+        if hasattr(self, 'weight'):
+            return
+        w = self.folded_weight()
+        del self.weight_g
+        del self.weight_v
+        self.weight = nn.Parameter(w)
+
+
+class ResBlock1(nn.Module):
+    def __init__(self, h, channels, kernel_size=3, dilation=(1, 3, 5)):
+        super().__init__()
+        self.h = h
+        self.convs1 = nn.ModuleList([WNConv((channels, channels, kernel_size), channels, 0.01) for _ in dilation])
+        self.convs2 = nn.ModuleList([WNConv((channels, channels, kernel_size), channels, 0.01) for _ in dilation])
+
+    def remove_weight_norm(self):
+        for l in list(self.convs1) + list(self.convs2):
+            l.remove_weight_norm()
+
+
+class ResBlock2(nn.Module):
+    def __init__(self, h, channels, kernel_size=3, dilation=(1, 3)):
+        super().__init__()
+        self.h = h
+        self.convs = nn.ModuleList([WNConv((channels, channels, kernel_size), channels, 0.01) for _ in dilation])
+
+    def remove_weight_norm(self):
+        for l in self.convs:
+            l.remove_weight_norm()
+
+
+class Generator(nn.Module):
+    def __init__(self, h):
+        super().__init__()
+        self.h = h
+        self.num_kernels = len(h['resblock_kernel_sizes'])
+        self.num_upsamples = len(h['upsample_rates'])
+        num_mels = int(h.get('num_mels', 80))
+        ch = int(h['upsample_initial_channel'])
+        self.conv_pre = WNConv((ch, num_mels, 7), ch)
+        rb_cls = ResBlock1 if str(h.get('resblock', '1')) == '1' else ResBlock2
+        self.ups = nn.ModuleList()
+        self.resblocks = nn.ModuleList()
+        for i, (u, k) in enumerate(zip(h['upsample_rates'], h['upsample_kernel_sizes'])):
+            cin, cout = ch // (2 ** i), ch // (2 ** (i + 1))
+            self.ups.append(WNConv((cin, cout, k), cout, 0.01))
+            for k_r, d_r in zip(h['resblock_kernel_sizes'], h['resblock_dilation_sizes']):
+                self.resblocks.append(rb_cls(h, cout, k_r, tuple(d_r)))
+        self.conv_post = WNConv((1, ch // (2 ** self.num_upsamples), 7), 1, 0.01)
+        self._handle = None
+        self._sig = None
+        self._ws = None
+
+    # ---- C-ABI plumbing ---------------------------------------------------------------------------------
+    def _cfg(self):
+        h = self.h
+        c = _lib.HifiganCfg()
+        c.num_mels = int(h.get('num_mels', 80))
+        c.upsample_initial_channel = int(h['upsample_initial_channel'])
+        c.resblock = 1 if str(h.get('resblock', '1')) == '1' else 2
+        c.num_upsamples = self.num_upsamples
+        for i, (u, k) in enumerate(zip(h['upsample_rates'], h['upsample_kernel_sizes'])):
+            c.upsample_rates[i] = int(u)
+            c.upsample_kernel_sizes[i] = int(k)
+        c.num_kernels = self.num_kernels
+        for j, (k_r, d_r) in enumerate(zip(h['resblock_kernel_sizes'], h['resblock_dilation_sizes'])):
+            c.resblock_kernel_sizes[j] = int(k_r)
+            c.num_dilations[j] = len(d_r)
+            for m, d in enumerate(d_r):
+                c.resblock_dilation_sizes[j][m] = int(d)
+        return c
+
+    def _named_convs(self):
+        yield 'conv_pre', self.conv_pre
+        for i, l in enumerate(self.ups):
+            yield 'ups.%d' % i, l
+        for n, rb in enumerate(self.resblocks):
+            if isinstance(rb, ResBlock1):
+                for m, l in enumerate(rb.convs1):
+                    yield 'resblocks.%d.convs1.%d' % (n, m), l
+                for m, l in enumerate(rb.convs2):
+                    yield 'resblocks.%d.convs2.%d' % (n, m), l
+            else:
+                for m, l in enumerate(rb.convs):
+                    yield 'resblocks.%d.convs.%d' % (n, m), l
+        yield 'conv_post', self.conv_post
+
+    def _sync(self):
+        """(Re)upload folded weights to the HIP handle when any parameter changed."""
+        L = _lib.lib()
+        sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._handle is not None and sig == self._sig:
+            return
+        if self._handle is None:
+            _lib.require_gpu()
+            hnd = C.c_void_p()
+            cfg = self._cfg()
+            _lib.check(L.ttsc_hifigan_create(C.byref(cfg), C.byref(hnd)), 'ttsc_hifigan_create')
+            self._handle = hnd
+        for name, l in self._named_convs():
+            for suffix, t in (('.weight', l.folded_weight()), ('.bias', l.bias.detach())):
+                t = t.float().cpu().contiguous()
+                shape = (C.c_int64 * t.dim())(*t.shape)
+                _lib.check(L.ttsc_hifigan_set_weight(self._handle, (name + suffix).encode(), C.c_void_p(t.data_ptr()),
+                                                     shape, t.dim()), 'ttsc_hifigan_set_weight(%s)' % (name + suffix))
+        self._sig = sig
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                _lib.lib().ttsc_hifigan_destroy(self._handle)
+        except Exception:
+            pass
+
+    def out_len(self, T):
+        L = T
+        for u, k in zip(self.h['upsample_rates'], self.h['upsample_kernel_sizes']):
+            L = (L - 1) * u - 2 * ((k - u) // 2) + k
+        return L
+
+    def algorithmic_flops(self, B, T):
+        self._sync()
+        out = C.c_double()
+        _lib.check(_lib.lib().ttsc_hifigan_algorithmic_flops(self._handle, B, T, C.byref(out)), 'algorithmic_flops')
+        return out.value
+
+    def forward(self, x):
+        """x: [B, num_mels, T] fp32 on a HIP device -> [B, 1, L]."""
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from .autograd import generator_forward_with_grad
+            return generator_forward_with_grad(self, x)
+        return self._forward_hip(x)
+
+    def _forward_hip(self, x):
+        if not x.is_cuda:
+            raise _lib.TTSCError('Generator.forward: input must live on a HIP device (got %s); no CPU path' % x.device)
+        L = _lib.lib()
+        self._sync()
+        x = x.detach().float().contiguous()
+        B, _, T = x.shape
+        Lout = self.out_len(T)
+        need = L.ttsc_hifigan_workspace_bytes(self._handle, B, T)
+        if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != x.device:
+            self._ws = None
+            self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+        y = torch.empty((B, 1, Lout), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.ttsc_hifigan_forward(self._handle, _lib.dev_ptr(x), B, T, _lib.dev_ptr(y), _lib.dev_ptr(self._ws),
+                                              self._ws.numel() * 4, _lib.current_stream()), 'ttsc_hifigan_forward')
+        return y
+
+    def remove_weight_norm(self):
+        self.conv_pre.remove_weight_norm()
+        for l in self.ups:
+            l.remove_weight_norm()
+        for rb in self.resblocks:
+            rb.remove_weight_norm()
+        self.conv_post.remove_weight_norm()
+        self._sig = None
