@@ -102,15 +102,15 @@ typedef struct {
 
 int ttsc_hifigan_create(const ttsc_hifigan_cfg* cfg, ttsc_hifigan** out);
 /* name = folded state_dict key: "conv_pre.weight", "ups.0.bias", "resblocks.3.convs1.2.weight",
- * "conv_post.weight" ...; host fp32, torch layout, shape checked. */
+ * "conv_post.weight" ...; host fp32, torch layout, shape checked.  The host copy is kept and
+ * packed/uploaded lazily by the next forward, so weights may be updated any number of times. */
 int ttsc_hifigan_set_weight(ttsc_hifigan* g, const char* name, const float* host, const int64_t* shape, int32_t nd);
 int64_t ttsc_hifigan_out_len(const ttsc_hifigan* g, int64_t T);
 size_t ttsc_hifigan_workspace_bytes(const ttsc_hifigan* g, int32_t B, int64_t T);
 /* mel_dev [B,num_mels,T] -> wav_dev [B,1,out_len(T)] (tanh output in (-1,1)) */
-int ttsc_hifigan_forward(const ttsc_hifigan* g, const float* mel_dev, int32_t B, int64_t T, float* wav_dev,
+int ttsc_hifigan_forward(ttsc_hifigan* g, const float* mel_dev, int32_t B, int64_t T, float* wav_dev,
                          void* workspace_dev, size_t workspace_bytes, void* stream);
-/* debug/parity: copy of the activation after upsample stage `stage` (0 = conv_pre) left in the workspace
- * by the last forward; returns its channel count/length via out params. */
+/* algorithmic FLOPs (2 x MAC) of one forward at (B, T): the roofline numerator used by bench.py */
 int ttsc_hifigan_algorithmic_flops(const ttsc_hifigan* g, int32_t B, int64_t T, double* flops_out);
 void ttsc_hifigan_destroy(ttsc_hifigan* g);
 

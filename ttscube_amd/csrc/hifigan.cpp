@@ -29,7 +29,7 @@ struct Layer {
     ttsc_conv1d* c = nullptr;
     std::vector<float> w;  // staged host weight until bias+weight are both present
     std::vector<float> b;
-    bool has_w = false, has_b = false, uploaded = false;
+    bool has_w = false, has_b = false, dirty = false, uploaded = false;
     std::vector<int64_t> wshape;
     ~Layer() { ttsc_conv1d_destroy(c); }
 };
@@ -39,10 +39,22 @@ struct ttsc_hifigan {
     ttsc_hifigan_cfg cfg;
     std::map<std::string, std::unique_ptr<Layer>> layers;
     std::vector<int> stage_ch;  // channels after upsample i
-    bool ready() const {
-        for (auto& kv : layers)
-            if (!kv.second->uploaded) return false;
-        return true;
+    // pack + upload every layer whose host copy changed; returns the name of the first incomplete layer (or "")
+    int flush_weights(std::string* missing) {
+        for (auto& kv : layers) {
+            Layer* L = kv.second.get();
+            if (!(L->has_w && L->has_b)) {
+                *missing = kv.first;
+                return TTSC_ESTATE;
+            }
+            if (L->dirty) {
+                int rc = ttsc_conv1d_set_weight(L->c, L->w.data(), L->b.data());
+                if (rc) return rc;
+                L->dirty = false;
+                L->uploaded = true;
+            }
+        }
+        return TTSC_OK;
     }
 };
 
@@ -135,11 +147,8 @@ extern "C" int ttsc_hifigan_set_weight(ttsc_hifigan* g, const char* name, const 
         const int64_t cout = transposed ? L->wshape[1] : L->wshape[0];
         TTSC_REQUIRE((int64_t)L->b.size() == cout, "ttsc_hifigan_set_weight: '%s.bias' expects %lld elements", base.c_str(),
                      (long long)cout);
-        int rc = ttsc_conv1d_set_weight(L->c, L->w.data(), L->b.data());
-        if (rc) return rc;
-        L->uploaded = true;
-        std::vector<float>().swap(L->w);
     }
+    L->dirty = true;  // packed + uploaded lazily by the next forward (flush_weights)
     return TTSC_OK;
 }
 
@@ -189,19 +198,18 @@ extern "C" int ttsc_hifigan_algorithmic_flops(const ttsc_hifigan* g, int32_t B, 
     return TTSC_OK;
 }
 
-extern "C" int ttsc_hifigan_forward(const ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, float* wav, void* ws,
+extern "C" int ttsc_hifigan_forward(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, float* wav, void* ws,
                                     size_t ws_bytes, void* stream) {
     TTSC_REQUIRE(g && mel && wav && ws, "ttsc_hifigan_forward: null argument");
     TTSC_REQUIRE(B > 0 && T > 0, "ttsc_hifigan_forward: bad B/T (%d, %lld)", B, (long long)T);
-    if (!g->ready()) {
+    {
         std::string missing;
-        for (auto& kv : g->layers)
-            if (!kv.second->uploaded) {
-                missing = kv.first;
-                break;
-            }
-        set_error("ttsc_hifigan_forward: weights missing (first: '%s')", missing.c_str());
-        return TTSC_ESTATE;
+        int frc = g->flush_weights(&missing);
+        if (frc == TTSC_ESTATE) {
+            set_error("ttsc_hifigan_forward: weights missing (first: '%s')", missing.c_str());
+            return TTSC_ESTATE;
+        }
+        if (frc) return frc;
     }
     const size_t need = ttsc_hifigan_workspace_bytes(g, B, T);
     if (ws_bytes < need) {
