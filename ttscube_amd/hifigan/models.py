@@ -189,14 +189,14 @@ class Generator(nn.Module):
 
     def forward(self, x):
         """x: [B, num_mels, T] fp32 on a HIP device -> [B, 1, L]."""
+        if not x.is_cuda:
+            raise _lib.TTSCError('Generator.forward: input must live on a HIP device (got %s); no CPU path' % x.device)
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             from .autograd import generator_forward_with_grad
             return generator_forward_with_grad(self, x)
         return self._forward_hip(x)
 
     def _forward_hip(self, x):
-        if not x.is_cuda:
-            raise _lib.TTSCError('Generator.forward: input must live on a HIP device (got %s); no CPU path' % x.device)
         L = _lib.lib()
         self._sync()
         x = x.detach().float().contiguous()
