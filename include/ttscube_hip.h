@@ -114,6 +114,47 @@ int ttsc_hifigan_forward(ttsc_hifigan* g, const float* mel_dev, int32_t B, int64
 int ttsc_hifigan_algorithmic_flops(const ttsc_hifigan* g, int32_t B, int64_t T, double* flops_out);
 void ttsc_hifigan_destroy(ttsc_hifigan* g);
 
+/* ------------------------------------------------------------------------------------------------
+ * WaveRNN autoregressive vocoder network.  Replaces `cube.networks.modules.WaveRNN._inference`
+ * (cube/networks/modules.py:453-503; constructed vocoder.py:45-57) — the per-sample python loop of
+ * nn.GRU(seq=1) -> tanh(Linear) -> Linear -> Categorical.sample -> µ-law decode — with one persistent kernel.
+ * Weight names are the reference state_dict keys: "_rnns.<l>.weight_ih_l0", "_rnns.<l>.weight_hh_l0",
+ * "_rnns.<l>.bias_ih_l0", "_rnns.<l>.bias_hh_l0", "_lowres_conv.<i>.conv.weight|bias",
+ * "_preoutput.linear_layer.weight|bias", "_output.linear_layer.weight|bias"; "_skip.*" is accepted and ignored
+ * (dead layer, modules.py:424).  Arithmetic contract: include/ttscube_math.h + oracle/wavernn_ref.c.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ttsc_wavernn ttsc_wavernn;
+
+enum { TTSC_WR_OUT_MULAW = 0, TTSC_WR_OUT_RAW = 1 };
+/* sampler: argmax(logits) | argmax(logits + injected Gumbel noise[B,L,S]) | argmax(logits + Philox Gumbel noise) */
+enum { TTSC_WR_MODE_ARGMAX = 0, TTSC_WR_MODE_NOISE = 1, TTSC_WR_MODE_PHILOX = 2 };
+
+typedef struct {
+    int32_t H;            /* layer_size (GRU hidden), multiple of 8, <= 512 */
+    int32_t num_layers;   /* stacked GRUs (1..4) */
+    int32_t use_lowres;   /* 1: high-res net conditioned on x_low (in_dim 102); 0: low-res net (in_dim 81) */
+    int32_t upsample;     /* mel repeat factor: 240 (hr) / 24 (lr) */
+    int32_t upsample_low; /* 10 */
+    int32_t S;            /* output_functions.sample_size: 256 for mulaw/raw */
+    int32_t n_mel;        /* 80 */
+    int32_t out_kind;     /* TTSC_WR_OUT_* */
+} ttsc_wavernn_cfg;
+
+int ttsc_wavernn_create(const ttsc_wavernn_cfg* cfg, ttsc_wavernn** out);
+int ttsc_wavernn_set_weight(ttsc_wavernn* w, const char* name, const float* host, const int64_t* shape, int32_t nd);
+/* samples emitted for T mel frames / Tl low-res samples: min(T*upsample, Tl*upsample_low) (modules.py:467) */
+int64_t ttsc_wavernn_out_len(const ttsc_wavernn* w, int64_t T, int64_t Tl);
+size_t ttsc_wavernn_workspace_bytes(const ttsc_wavernn* w, int32_t B, int64_t T, int64_t Tl);
+/* mel_dev [B,T,n_mel]; xlow_dev [B,Tl] (hr net) or NULL; noise_dev [B,L,S] (mode NOISE) or NULL;
+ * forced_x_dev [B,L] or NULL (teacher forcing: feedback = forced_x[t], logits then equal _train_forward);
+ * outputs idx_dev uint8 [B,L], wav_dev fp32 [B,L] (decoded samples, what _inference returns), logits_dev
+ * fp32 [B,L,S] or NULL. */
+int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel_dev, const float* xlow_dev, int32_t B, int64_t T, int64_t Tl,
+                        int32_t mode, const float* noise_dev, uint64_t seed, const float* forced_x_dev,
+                        uint8_t* idx_dev, float* wav_dev, float* logits_dev, void* workspace_dev, size_t workspace_bytes,
+                        void* stream);
+void ttsc_wavernn_destroy(ttsc_wavernn* w);
+
 #ifdef __cplusplus
 }
 #endif

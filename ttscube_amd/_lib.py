@@ -35,6 +35,15 @@ class HifiganCfg(C.Structure):
 
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 
+
+class WavernnCfg(C.Structure):
+    _fields_ = [('H', C.c_int32), ('num_layers', C.c_int32), ('use_lowres', C.c_int32), ('upsample', C.c_int32),
+                ('upsample_low', C.c_int32), ('S', C.c_int32), ('n_mel', C.c_int32), ('out_kind', C.c_int32)]
+
+
+WR_OUT_MULAW, WR_OUT_RAW = 0, 1
+WR_MODE_ARGMAX, WR_MODE_NOISE, WR_MODE_PHILOX = 0, 1, 2
+
 _lib = None
 
 # symbol -> (restype, argtypes); also the list the CPU test checks against include/ttscube_hip.h
@@ -56,6 +65,14 @@ SIGNATURES = {
                                        C.c_size_t, C.c_void_p]),
     'ttsc_hifigan_algorithmic_flops': (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_double)]),
     'ttsc_hifigan_destroy': (None, [C.c_void_p]),
+    'ttsc_wavernn_create': (C.c_int, [C.POINTER(WavernnCfg), C.POINTER(C.c_void_p)]),
+    'ttsc_wavernn_set_weight': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
+    'ttsc_wavernn_out_len': (C.c_int64, [C.c_void_p, C.c_int64, C.c_int64]),
+    'ttsc_wavernn_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64]),
+    'ttsc_wavernn_decode': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
+                                      C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_size_t, C.c_void_p]),
+    'ttsc_wavernn_destroy': (None, [C.c_void_p]),
 }
 
 

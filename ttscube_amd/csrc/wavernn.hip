@@ -1,0 +1,581 @@
+// WaveRNN autoregressive decode as ONE persistent kernel per call (gfx950).
+//
+// Reference loop: cube/networks/modules.py:453-503 (WaveRNN._inference): per output sample ~10 ATen launches
+// (cat, N x nn.GRU(seq=1), Linear+tanh, Linear, Categorical.sample, decode).  Here the whole L-step loop of an
+// utterance tile runs inside one workgroup, with no inter-workgroup communication at all (utterances are
+// independent), so the sequential dependency costs only workgroup barriers:
+//
+//   * thread j owns hidden unit j: it streams the three gate rows (r,z,n) of W_hh (pre-transposed to [k][3H],
+//     so every load is one coalesced 256-B wave read from L2) and keeps the six gate accumulators of each of the
+//     BT utterances of the tile in registers; the GRU state h lives in LDS (double-buffered) and is read as LDS
+//     broadcasts; the point-wise GRU update is done by the same thread, so no exchange is needed between the
+//     mat-vec and the state update.
+//   * the input projection W_ih.x is an fmaf chain over [mel(80) | low-res feats(20) | interp(1) | last_x(1)] in
+//     that (reference concat) order, so its prefix over the mel frame is constant for `upsample` (240) steps and
+//     its prefix over the low-res features for 10 steps: both prefixes are cached in registers and only the last
+//     two terms are evaluated per step — bit-identical to evaluating the whole chain every step.
+//   * pre-output (tanh Linear H->256), output (Linear 256->S), Gumbel-max sampling, µ-law decode and the
+//     feedback of the sample all stay inside the workgroup (LDS + 3 barriers).
+//
+// Arithmetic contract = oracle/wavernn_ref.c: every dot product is one k-ordered fp32 fmaf chain seeded with the
+// bias, transcendental functions from include/ttscube_math.h, compiled with -ffp-contract=off.  That makes the
+// uint8 sample indices bit-exact against the oracle (tests/test_wavernn_gpu.py).
+#include "common.hpp"
+#include "../../include/ttscube_math.h"
+#include "../../include/ttscube_mulaw_lut.h"
+
+namespace ttsc {
+
+constexpr int WR_THREADS = 512;
+constexpr int WR_MAXL = 4;
+
+struct WrArgs {
+    const float* mel;     // [B, T, n_mel]
+    const float* interp;  // [B, Tl*up_low]   (hr only)
+    const float* feats;   // [B, 20, Tl]      (hr only)
+    const float* wt_ih[WR_MAXL];  // [in_l][3H]
+    const float* wt_hh[WR_MAXL];  // [H][3H]
+    const float* b_ih[WR_MAXL];
+    const float* b_hh[WR_MAXL];
+    const float* wt_pre;  // [H][256]
+    const float* b_pre;
+    const float* wt_out;  // [256][S]
+    const float* b_out;
+    const float* lut;
+    const float* noise;     // [B, L, S] or null
+    const float* forced_x;  // [B, L] or null
+    uint8_t* out_idx;       // [B, L]
+    float* out_wav;         // [B, L]
+    float* out_logits;      // [B, L, S] or null
+    int B, T, Tl, H, NL, use_lowres, up, up_low, S, n_mel, out_kind, mode;
+    long L;
+    unsigned long long seed;
+};
+
+// ---- conditioning: linear interpolation x10 and the three tanh(Conv1d k7) low-res layers --------------------
+// (modules.py:353,416-420,458-461).  One workgroup per utterance; chain order = (ci outer, k inner), bias seed.
+__global__ __launch_bounds__(256) void wr_cond_kernel(const float* __restrict__ x_low, const float* w0, const float* b0,
+                                                      const float* w1, const float* b1, const float* w2, const float* b2,
+                                                      float* interp, float* fa, float* fb, int Tl, int up_low) {
+    const int b = blockIdx.x;
+    const float* x = x_low + (size_t)b * Tl;
+    const int n = Tl * up_low;
+    const float scale = (float)Tl / (float)n;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        float src = scale * ((float)t + 0.5f) - 0.5f;
+        if (src < 0.f) src = 0.f;
+        int i0 = (int)src;
+        if (i0 > Tl - 1) i0 = Tl - 1;
+        const int i1 = i0 + (i0 < Tl - 1 ? 1 : 0);
+        const float l1 = src - (float)i0;
+        const float l0 = 1.0f - l1;
+        const float p0 = l0 * x[i0];
+        const float p1 = l1 * x[i1];
+        interp[(size_t)b * n + t] = p0 + p1;
+    }
+    float* A = fa + (size_t)b * 20 * Tl;
+    float* Bf = fb + (size_t)b * 20 * Tl;
+    for (int layer = 0; layer < 3; ++layer) {
+        const float* in = layer == 0 ? x : (layer == 1 ? A : Bf);
+        float* out = layer == 1 ? Bf : A;
+        const float* w = layer == 0 ? w0 : (layer == 1 ? w1 : w2);
+        const float* bb = layer == 0 ? b0 : (layer == 1 ? b1 : b2);
+        const int cin = layer == 0 ? 1 : 20;
+        for (int idx = threadIdx.x; idx < 20 * Tl; idx += blockDim.x) {
+            const int co = idx / Tl, t = idx - co * Tl;
+            float acc = bb[co];
+            for (int ci = 0; ci < cin; ++ci)
+                for (int k = 0; k < 7; ++k) {
+                    const int p = t + k - 3;
+                    const float v = (p >= 0 && p < Tl) ? in[ci * Tl + p] : 0.f;
+                    acc = fmaf(w[(co * cin + ci) * 7 + k], v, acc);
+                }
+            out[idx] = ttsc_tanhf(acc);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+template <int BT>
+__global__ __launch_bounds__(WR_THREADS) void wr_decode_kernel(WrArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int H = a.H, S = a.S, NL = a.NL, NM = a.n_mel;
+    float* hbuf = sm;                          // [2][NL][BT][H]
+    float* pre = hbuf + 2 * NL * BT * H;       // [BT][256]
+    float* score = pre + BT * 256;             // [BT][S]
+    float* xin = score + BT * S;               // [BT][128]: mel frame | low-res feats
+    float* lastx = xin + BT * 128;             // [BT]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = tid;                          // hidden unit owned by this thread
+    const bool unit = j < H;
+    const int H3 = 3 * H;
+    const int I0 = NM + (a.use_lowres ? 21 : 0) + 1;
+
+    int bidx[BT];
+    bool bok[BT];
+#pragma unroll
+    for (int u = 0; u < BT; ++u) {
+        const int b = blockIdx.x * BT + u;
+        bok[u] = b < a.B;
+        bidx[u] = bok[u] ? b : a.B - 1;
+    }
+    for (int i = tid; i < 2 * NL * BT * H; i += WR_THREADS) hbuf[i] = 0.f;
+    if (tid < BT) lastx[tid] = 0.f;
+
+    // per-thread constants of layer 0: biases and the weights of the two per-step input features
+    float bih0[3] = {0, 0, 0}, w_int[3] = {0, 0, 0}, w_lx[3] = {0, 0, 0};
+    if (unit) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            bih0[g] = a.b_ih[0][g * H + j];
+            w_lx[g] = a.wt_ih[0][(size_t)(I0 - 1) * H3 + g * H + j];
+            if (a.use_lowres) w_int[g] = a.wt_ih[0][(size_t)(I0 - 2) * H3 + g * H + j];
+        }
+    }
+    float pmel[BT][3], plow[BT][3];
+#pragma unroll
+    for (int u = 0; u < BT; ++u)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) pmel[u][g] = plow[u][g] = 0.f;
+    __syncthreads();
+
+    int cur = 0;
+    for (long t = 0; t < a.L; ++t) {
+        // ---- refresh the cached prefixes of the layer-0 input chain --------------------------------------
+        const bool new_frame = (t % a.up) == 0;
+        const bool new_low = a.use_lowres && (t % a.up_low) == 0;
+        if (new_frame || new_low) {
+            if (new_frame) {
+                for (int i = tid; i < BT * NM; i += WR_THREADS) {
+                    const int u = i / NM, k = i - u * NM;
+                    xin[u * 128 + k] = a.mel[((size_t)bidx[u] * a.T + (t / a.up)) * NM + k];
+                }
+            }
+            if (new_low) {
+                for (int i = tid; i < BT * 20; i += WR_THREADS) {
+                    const int u = i / 20, q = i - u * 20;
+                    xin[u * 128 + NM + q] = a.feats[((size_t)bidx[u] * 20 + q) * a.Tl + (t / a.up_low)];
+                }
+            }
+            __syncthreads();
+            if (unit) {
+                if (new_frame) {
+#pragma unroll
+                    for (int u = 0; u < BT; ++u)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) pmel[u][g] = bih0[g];
+                    const float* w = a.wt_ih[0] + j;
+                    for (int k = 0; k < NM; ++k) {
+                        const float w0 = w[(size_t)k * H3], w1 = w[(size_t)k * H3 + H], w2 = w[(size_t)k * H3 + 2 * H];
+#pragma unroll
+                        for (int u = 0; u < BT; ++u) {
+                            const float v = xin[u * 128 + k];
+                            pmel[u][0] = fmaf(w0, v, pmel[u][0]);
+                            pmel[u][1] = fmaf(w1, v, pmel[u][1]);
+                            pmel[u][2] = fmaf(w2, v, pmel[u][2]);
+                        }
+                    }
+                }
+                if (new_low) {
+#pragma unroll
+                    for (int u = 0; u < BT; ++u)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) plow[u][g] = pmel[u][g];
+                    const float* w = a.wt_ih[0] + (size_t)NM * H3 + j;
+                    for (int k = 0; k < 20; ++k) {
+                        const float w0 = w[(size_t)k * H3], w1 = w[(size_t)k * H3 + H], w2 = w[(size_t)k * H3 + 2 * H];
+#pragma unroll
+                        for (int u = 0; u < BT; ++u) {
+                            const float v = xin[u * 128 + NM + k];
+                            plow[u][0] = fmaf(w0, v, plow[u][0]);
+                            plow[u][1] = fmaf(w1, v, plow[u][1]);
+                            plow[u][2] = fmaf(w2, v, plow[u][2]);
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- GRU layers ----------------------------------------------------------------------------------
+        const int nxt = cur ^ 1;
+        for (int l = 0; l < NL; ++l) {
+            const float* hc = hbuf + ((size_t)(cur * NL + l) * BT) * H;   // h_{t-1} of layer l
+            float* hn = hbuf + ((size_t)(nxt * NL + l) * BT) * H;         // h_t of layer l
+            if (unit) {
+                float gi[BT][3], gh[BT][3];
+                if (l == 0) {
+#pragma unroll
+                    for (int u = 0; u < BT; ++u) {
+                        const float lx = lastx[u];
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) {
+                            float acc = a.use_lowres ? plow[u][g] : pmel[u][g];
+                            if (a.use_lowres) acc = fmaf(w_int[g], a.interp[(size_t)bidx[u] * ((size_t)a.Tl * a.up_low) + t], acc);
+                            gi[u][g] = fmaf(w_lx[g], lx, acc);
+                        }
+                    }
+                } else {
+                    const float* hp = hbuf + ((size_t)(nxt * NL + (l - 1)) * BT) * H;  // fresh output of layer l-1
+#pragma unroll
+                    for (int u = 0; u < BT; ++u)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) gi[u][g] = a.b_ih[l][g * H + j];
+                    const float* w = a.wt_ih[l] + j;
+#pragma unroll 8
+                    for (int k = 0; k < H; ++k) {
+                        const float w0 = w[(size_t)k * H3], w1 = w[(size_t)k * H3 + H], w2 = w[(size_t)k * H3 + 2 * H];
+#pragma unroll
+                        for (int u = 0; u < BT; ++u) {
+                            const float v = hp[u * H + k];
+                            gi[u][0] = fmaf(w0, v, gi[u][0]);
+                            gi[u][1] = fmaf(w1, v, gi[u][1]);
+                            gi[u][2] = fmaf(w2, v, gi[u][2]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < BT; ++u)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) gh[u][g] = a.b_hh[l][g * H + j];
+                const float* w = a.wt_hh[l] + j;
+#pragma unroll 8
+                for (int k = 0; k < H; ++k) {
+                    const float w0 = w[(size_t)k * H3], w1 = w[(size_t)k * H3 + H], w2 = w[(size_t)k * H3 + 2 * H];
+#pragma unroll
+                    for (int u = 0; u < BT; ++u) {
+                        const float v = hc[u * H + k];
+                        gh[u][0] = fmaf(w0, v, gh[u][0]);
+                        gh[u][1] = fmaf(w1, v, gh[u][1]);
+                        gh[u][2] = fmaf(w2, v, gh[u][2]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < BT; ++u) {
+                    const float r = ttsc_sigmoidf(gi[u][0] + gh[u][0]);
+                    const float z = ttsc_sigmoidf(gi[u][1] + gh[u][1]);
+                    const float rg = r * gh[u][2];
+                    const float nn = ttsc_tanhf(gi[u][2] + rg);
+                    const float d = hc[u * H + j] - nn;
+                    hn[u * H + j] = fmaf(z, d, nn);
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- pre-output: tanh(Linear H -> 256) -------------------------------------------------------------
+        {
+            const float* ht = hbuf + ((size_t)(nxt * NL + (NL - 1)) * BT) * H;
+            const int row = tid & 255;
+            for (int u = tid >> 8; u < BT; u += WR_THREADS / 256) {
+                float acc = a.b_pre[row];
+                const float* w = a.wt_pre + row;
+#pragma unroll 8
+                for (int k = 0; k < H; ++k) acc = fmaf(w[(size_t)k * 256], ht[u * H + k], acc);
+                pre[u * 256 + row] = ttsc_tanhf(acc);
+            }
+        }
+        __syncthreads();
+        // ---- output logits + noise ------------------------------------------------------------------------
+        {
+            const int row = tid & 255;
+            for (int u = tid >> 8; u < BT; u += WR_THREADS / 256) {
+                if (row < S) {
+                    float acc = a.b_out[row];
+                    const float* w = a.wt_out + row;
+#pragma unroll 8
+                    for (int k = 0; k < 256; ++k) acc = fmaf(w[(size_t)k * S], pre[u * 256 + k], acc);
+                    const size_t o = ((size_t)bidx[u] * a.L + t) * S + row;
+                    if (a.out_logits && bok[u]) a.out_logits[o] = acc;
+                    float g = 0.f;
+                    if (a.mode == 1) {
+                        g = a.noise[o];
+                    } else if (a.mode == 2) {
+                        uint32_t r4[4];
+                        ttsc_philox4x32((uint32_t)(row >> 2), (uint32_t)t, (uint32_t)bidx[u], (uint32_t)((unsigned long long)t >> 32),
+                                        (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r4);
+                        g = ttsc_gumbel(r4[row & 3]);
+                    }
+                    score[u * S + row] = acc + g;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- Gumbel-max: first maximum wins; wave u reduces utterance u ------------------------------------
+        for (int u = wave; u < BT; u += WR_THREADS / 64) {
+            float bs = score[u * S + lane];
+            int bi = lane;
+            for (int s = lane + 64; s < S; s += 64) {
+                const float v = score[u * S + s];
+                if (v > bs) {
+                    bs = v;
+                    bi = s;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float os = __shfl_xor(bs, off);
+                const int oi = __shfl_xor(bi, off);
+                if (os > bs || (os == bs && oi < bi)) {
+                    bs = os;
+                    bi = oi;
+                }
+            }
+            if (lane == 0) {
+                float wv;
+                if (a.out_kind == 0)
+                    wv = a.lut[bi];
+                else
+                    wv = (((float)bi / 255.0f) - 0.5f) * 2.0f;
+                const size_t o = (size_t)bidx[u] * a.L + t;
+                if (bok[u]) {
+                    a.out_idx[o] = (uint8_t)bi;
+                    a.out_wav[o] = wv;
+                }
+                lastx[u] = a.forced_x ? a.forced_x[o] : wv;
+            }
+        }
+        __syncthreads();
+        cur = nxt;
+    }
+}
+
+}  // namespace ttsc
+
+using namespace ttsc;
+
+struct ttsc_wavernn {
+    ttsc_wavernn_cfg cfg;
+    int in0 = 0;
+    float* wt_ih[WR_MAXL] = {nullptr, nullptr, nullptr, nullptr};
+    float* wt_hh[WR_MAXL] = {nullptr, nullptr, nullptr, nullptr};
+    float* b_ih[WR_MAXL] = {nullptr, nullptr, nullptr, nullptr};
+    float* b_hh[WR_MAXL] = {nullptr, nullptr, nullptr, nullptr};
+    float *wt_pre = nullptr, *b_pre = nullptr, *wt_out = nullptr, *b_out = nullptr, *lut = nullptr;
+    float* lc_w[3] = {nullptr, nullptr, nullptr};
+    float* lc_b[3] = {nullptr, nullptr, nullptr};
+    std::vector<std::string> have;
+    bool has(const std::string& n) const {
+        for (auto& s : have)
+            if (s == n) return true;
+        return false;
+    }
+};
+
+static int upload(float** dst, const float* host, size_t n) {
+    if (*dst) (void)hipFree(*dst);
+    *dst = nullptr;
+    TTSC_HIP_CHECK(hipMalloc((void**)dst, n * sizeof(float)));
+    TTSC_HIP_CHECK(hipMemcpy(*dst, host, n * sizeof(float), hipMemcpyHostToDevice));
+    return TTSC_OK;
+}
+
+// torch [rows, cols] -> device [cols][rows] so that consecutive threads (rows) read consecutive addresses
+static int upload_transposed(float** dst, const float* host, int64_t rows, int64_t cols) {
+    std::vector<float> t((size_t)rows * cols);
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t c = 0; c < cols; ++c) t[(size_t)c * rows + r] = host[(size_t)r * cols + c];
+    return upload(dst, t.data(), t.size());
+}
+
+extern "C" int ttsc_wavernn_create(const ttsc_wavernn_cfg* cfg, ttsc_wavernn** out) {
+    TTSC_REQUIRE(cfg && out, "ttsc_wavernn_create: null argument");
+    TTSC_REQUIRE(cfg->H >= 8 && cfg->H <= WR_THREADS && cfg->H % 8 == 0, "ttsc_wavernn_create: layer_size must be a multiple of 8 in [8, %d], got %d",
+                 WR_THREADS, cfg->H);
+    TTSC_REQUIRE(cfg->num_layers >= 1 && cfg->num_layers <= WR_MAXL, "ttsc_wavernn_create: num_layers must be in [1,%d]", WR_MAXL);
+    TTSC_REQUIRE(cfg->S >= 1 && cfg->S <= 256, "ttsc_wavernn_create: sample_size must be in [1,256] (mulaw/raw = 256)");
+    TTSC_REQUIRE(cfg->n_mel >= 1 && cfg->n_mel <= 100, "ttsc_wavernn_create: n_mel must be in [1,100]");
+    TTSC_REQUIRE(cfg->upsample >= 1 && cfg->upsample_low >= 1, "ttsc_wavernn_create: bad upsample factors");
+    TTSC_REQUIRE(cfg->out_kind == TTSC_WR_OUT_MULAW || cfg->out_kind == TTSC_WR_OUT_RAW, "ttsc_wavernn_create: output must be mulaw or raw");
+    ttsc_wavernn* w = new ttsc_wavernn();
+    w->cfg = *cfg;
+    w->in0 = cfg->n_mel + 1 + (cfg->use_lowres ? 21 : 0);
+    int rc = upload(&w->lut, TTSC_MULAW_LUT, 256);
+    if (rc) {
+        delete w;
+        return rc;
+    }
+    *out = w;
+    return TTSC_OK;
+}
+
+extern "C" void ttsc_wavernn_destroy(ttsc_wavernn* w) {
+    if (!w) return;
+    for (int l = 0; l < WR_MAXL; ++l) {
+        if (w->wt_ih[l]) (void)hipFree(w->wt_ih[l]);
+        if (w->wt_hh[l]) (void)hipFree(w->wt_hh[l]);
+        if (w->b_ih[l]) (void)hipFree(w->b_ih[l]);
+        if (w->b_hh[l]) (void)hipFree(w->b_hh[l]);
+    }
+    for (float* p : {w->wt_pre, w->b_pre, w->wt_out, w->b_out, w->lut, w->lc_w[0], w->lc_w[1], w->lc_w[2], w->lc_b[0], w->lc_b[1], w->lc_b[2]})
+        if (p) (void)hipFree(p);
+    delete w;
+}
+
+static bool shape_is(const int64_t* shape, int nd, std::initializer_list<int64_t> want) {
+    if (nd != (int)want.size()) return false;
+    int i = 0;
+    for (int64_t v : want)
+        if (shape[i++] != v) return false;
+    return true;
+}
+
+extern "C" int ttsc_wavernn_set_weight(ttsc_wavernn* w, const char* name, const float* host, const int64_t* shape, int32_t nd) {
+    TTSC_REQUIRE(w && name && host && shape, "ttsc_wavernn_set_weight: null argument");
+    const std::string n(name);
+    const int H = w->cfg.H, S = w->cfg.S;
+    int rc = TTSC_OK;
+    int l = -1, idx = -1;
+    char kind[32] = {0};
+    if (n.compare(0, 6, "_skip.") == 0) return TTSC_OK;  // dead layer in every reference checkpoint (modules.py:424)
+    if (sscanf(name, "_rnns.%d.%31s", &l, kind) == 2) {
+        TTSC_REQUIRE(l >= 0 && l < w->cfg.num_layers, "ttsc_wavernn_set_weight: '%s': layer out of range", name);
+        const int in_l = l == 0 ? w->in0 : H;
+        const std::string k(kind);
+        if (k == "weight_ih_l0") {
+            TTSC_REQUIRE(shape_is(shape, nd, {3 * H, in_l}), "ttsc_wavernn_set_weight: '%s' expects [%d,%d]", name, 3 * H, in_l);
+            rc = upload_transposed(&w->wt_ih[l], host, 3 * H, in_l);
+        } else if (k == "weight_hh_l0") {
+            TTSC_REQUIRE(shape_is(shape, nd, {3 * H, H}), "ttsc_wavernn_set_weight: '%s' expects [%d,%d]", name, 3 * H, H);
+            rc = upload_transposed(&w->wt_hh[l], host, 3 * H, H);
+        } else if (k == "bias_ih_l0") {
+            TTSC_REQUIRE(shape_is(shape, nd, {3 * H}), "ttsc_wavernn_set_weight: '%s' expects [%d]", name, 3 * H);
+            rc = upload(&w->b_ih[l], host, 3 * H);
+        } else if (k == "bias_hh_l0") {
+            TTSC_REQUIRE(shape_is(shape, nd, {3 * H}), "ttsc_wavernn_set_weight: '%s' expects [%d]", name, 3 * H);
+            rc = upload(&w->b_hh[l], host, 3 * H);
+        } else {
+            TTSC_REQUIRE(false, "ttsc_wavernn_set_weight: unknown key '%s'", name);
+        }
+    } else if (sscanf(name, "_lowres_conv.%d.conv.%31s", &idx, kind) == 2) {
+        TTSC_REQUIRE(w->cfg.use_lowres && idx >= 0 && idx < 3, "ttsc_wavernn_set_weight: '%s' not part of this network", name);
+        const int cin = idx == 0 ? 1 : 20;
+        if (std::string(kind) == "weight") {
+            TTSC_REQUIRE(shape_is(shape, nd, {20, cin, 7}), "ttsc_wavernn_set_weight: '%s' expects [20,%d,7]", name, cin);
+            rc = upload(&w->lc_w[idx], host, 20 * cin * 7);
+        } else {
+            TTSC_REQUIRE(shape_is(shape, nd, {20}), "ttsc_wavernn_set_weight: '%s' expects [20]", name);
+            rc = upload(&w->lc_b[idx], host, 20);
+        }
+    } else if (n == "_preoutput.linear_layer.weight") {
+        TTSC_REQUIRE(shape_is(shape, nd, {256, H}), "ttsc_wavernn_set_weight: '%s' expects [256,%d]", name, H);
+        rc = upload_transposed(&w->wt_pre, host, 256, H);
+    } else if (n == "_preoutput.linear_layer.bias") {
+        TTSC_REQUIRE(shape_is(shape, nd, {256}), "ttsc_wavernn_set_weight: '%s' expects [256]", name);
+        rc = upload(&w->b_pre, host, 256);
+    } else if (n == "_output.linear_layer.weight") {
+        TTSC_REQUIRE(shape_is(shape, nd, {S, 256}), "ttsc_wavernn_set_weight: '%s' expects [%d,256]", name, S);
+        rc = upload_transposed(&w->wt_out, host, S, 256);
+    } else if (n == "_output.linear_layer.bias") {
+        TTSC_REQUIRE(shape_is(shape, nd, {S}), "ttsc_wavernn_set_weight: '%s' expects [%d]", name, S);
+        rc = upload(&w->b_out, host, S);
+    } else {
+        TTSC_REQUIRE(false, "ttsc_wavernn_set_weight: unknown key '%s'", name);
+    }
+    if (rc == TTSC_OK && !w->has(n)) w->have.push_back(n);
+    return rc;
+}
+
+extern "C" int64_t ttsc_wavernn_out_len(const ttsc_wavernn* w, int64_t T, int64_t Tl) {
+    if (!w) return TTSC_EINVAL;
+    int64_t L = T * w->cfg.upsample;
+    if (w->cfg.use_lowres) {
+        const int64_t l2 = Tl * w->cfg.upsample_low;
+        if (l2 < L) L = l2;
+    }
+    return L;
+}
+
+extern "C" size_t ttsc_wavernn_workspace_bytes(const ttsc_wavernn* w, int32_t B, int64_t T, int64_t Tl) {
+    if (!w || !w->cfg.use_lowres) return 256;
+    return ((size_t)B * Tl * w->cfg.upsample_low + 2 * (size_t)B * 20 * Tl) * sizeof(float) + 256;
+}
+
+extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const float* x_low, int32_t B, int64_t T, int64_t Tl,
+                                   int32_t mode, const float* noise, uint64_t seed, const float* forced_x, uint8_t* idx,
+                                   float* wav, float* logits, void* ws, size_t ws_bytes, void* stream) {
+    TTSC_REQUIRE(w && mel && idx && wav, "ttsc_wavernn_decode: null argument");
+    TTSC_REQUIRE(B > 0 && T > 0, "ttsc_wavernn_decode: bad B/T");
+    TTSC_REQUIRE(mode >= 0 && mode <= 2, "ttsc_wavernn_decode: mode must be 0 (argmax), 1 (injected noise) or 2 (philox)");
+    TTSC_REQUIRE(mode != TTSC_WR_MODE_NOISE || noise, "ttsc_wavernn_decode: mode=noise needs a noise buffer");
+    const auto& c = w->cfg;
+    for (int l = 0; l < c.num_layers; ++l)
+        if (!(w->wt_ih[l] && w->wt_hh[l] && w->b_ih[l] && w->b_hh[l])) {
+            set_error("ttsc_wavernn_decode: weights of _rnns.%d missing", l);
+            return TTSC_ESTATE;
+        }
+    if (!(w->wt_pre && w->b_pre && w->wt_out && w->b_out)) {
+        set_error("ttsc_wavernn_decode: _preoutput/_output weights missing");
+        return TTSC_ESTATE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    WrArgs a;
+    memset(&a, 0, sizeof(a));
+    if (c.use_lowres) {
+        TTSC_REQUIRE(x_low && Tl > 0, "ttsc_wavernn_decode: the high-res network needs x_low");
+        for (int i = 0; i < 3; ++i)
+            if (!(w->lc_w[i] && w->lc_b[i])) {
+                set_error("ttsc_wavernn_decode: _lowres_conv.%d weights missing", i);
+                return TTSC_ESTATE;
+            }
+        const size_t need = ttsc_wavernn_workspace_bytes(w, B, T, Tl);
+        if (!ws || ws_bytes < need) {
+            set_error("ttsc_wavernn_decode: workspace %zu < required %zu bytes", ws_bytes, need);
+            return TTSC_ENOMEM;
+        }
+        float* interp = (float*)ws;
+        float* fa = interp + (size_t)B * Tl * c.upsample_low;
+        float* fb = fa + (size_t)B * 20 * Tl;
+        hipLaunchKernelGGL(wr_cond_kernel, dim3(B), dim3(256), 0, s, x_low, w->lc_w[0], w->lc_b[0], w->lc_w[1], w->lc_b[1],
+                           w->lc_w[2], w->lc_b[2], interp, fa, fb, (int)Tl, c.upsample_low);
+        a.interp = interp;
+        a.feats = fa;
+    }
+    a.mel = mel;
+    for (int l = 0; l < c.num_layers; ++l) {
+        a.wt_ih[l] = w->wt_ih[l];
+        a.wt_hh[l] = w->wt_hh[l];
+        a.b_ih[l] = w->b_ih[l];
+        a.b_hh[l] = w->b_hh[l];
+    }
+    a.wt_pre = w->wt_pre;
+    a.b_pre = w->b_pre;
+    a.wt_out = w->wt_out;
+    a.b_out = w->b_out;
+    a.lut = w->lut;
+    a.noise = noise;
+    a.forced_x = forced_x;
+    a.out_idx = idx;
+    a.out_wav = wav;
+    a.out_logits = logits;
+    a.B = B;
+    a.T = (int)T;
+    a.Tl = (int)Tl;
+    a.H = c.H;
+    a.NL = c.num_layers;
+    a.use_lowres = c.use_lowres;
+    a.up = c.upsample;
+    a.up_low = c.upsample_low;
+    a.S = c.S;
+    a.n_mel = c.n_mel;
+    a.out_kind = c.out_kind;
+    a.mode = mode;
+    a.L = ttsc_wavernn_out_len(w, T, Tl);
+    a.seed = seed;
+    TTSC_REQUIRE(a.L > 0, "ttsc_wavernn_decode: nothing to decode (L=%ld)", a.L);
+    // utterances per workgroup: 1 while the batch does not fill the chip, 2 beyond (halves the weight stream per sample)
+    const int bt = (B > 256) ? 2 : 1;
+    const size_t lds = ((size_t)2 * c.num_layers * bt * c.H + (size_t)bt * 256 + (size_t)bt * c.S + (size_t)bt * 128 + 16) * sizeof(float);
+    dim3 grid((unsigned)ceil_div(B, bt));
+    if (bt == 1)
+        hipLaunchKernelGGL(wr_decode_kernel<1>, grid, dim3(WR_THREADS), lds, s, a);
+    else
+        hipLaunchKernelGGL(wr_decode_kernel<2>, grid, dim3(WR_THREADS), lds, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("wr_decode_kernel launch failed: %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    return TTSC_OK;
+}
