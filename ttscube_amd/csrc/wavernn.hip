@@ -20,6 +20,8 @@
 // Arithmetic contract = oracle/wavernn_ref.c: every dot product is one k-ordered fp32 fmaf chain seeded with the
 // bias, transcendental functions from include/ttscube_math.h, compiled with -ffp-contract=off.  That makes the
 // uint8 sample indices bit-exact against the oracle (tests/test_wavernn_gpu.py).
+#include <cstdlib>
+
 #include "common.hpp"
 #include "../../include/ttscube_math.h"
 #include "../../include/ttscube_mulaw_lut.h"
@@ -113,14 +115,10 @@ __global__ __launch_bounds__(WR_THREADS) void wr_decode_kernel(WrArgs a) {
     const int H3 = 3 * H;
     const int I0 = NM + (a.use_lowres ? 21 : 0) + 1;
 
-    int bidx[BT];
-    bool bok[BT];
-#pragma unroll
-    for (int u = 0; u < BT; ++u) {
-        const int b = blockIdx.x * BT + u;
-        bok[u] = b < a.B;
-        bidx[u] = bok[u] ? b : a.B - 1;
-    }
+    // utterance index of tile slot u (clamped for reads; writes are guarded by BOK).  Computed, not stored in an
+    // array: a runtime-indexed register array would be demoted to scratch.
+#define BIDX(u) (min((int)blockIdx.x * BT + (u), a.B - 1))
+#define BOK(u) ((int)blockIdx.x * BT + (u) < a.B)
     for (int i = tid; i < 2 * NL * BT * H; i += WR_THREADS) hbuf[i] = 0.f;
     if (tid < BT) lastx[tid] = 0.f;
 
@@ -150,13 +148,13 @@ __global__ __launch_bounds__(WR_THREADS) void wr_decode_kernel(WrArgs a) {
             if (new_frame) {
                 for (int i = tid; i < BT * NM; i += WR_THREADS) {
                     const int u = i / NM, k = i - u * NM;
-                    xin[u * 128 + k] = a.mel[((size_t)bidx[u] * a.T + (t / a.up)) * NM + k];
+                    xin[u * 128 + k] = a.mel[((size_t)BIDX(u) * a.T + (t / a.up)) * NM + k];
                 }
             }
             if (new_low) {
                 for (int i = tid; i < BT * 20; i += WR_THREADS) {
                     const int u = i / 20, q = i - u * 20;
-                    xin[u * 128 + NM + q] = a.feats[((size_t)bidx[u] * 20 + q) * a.Tl + (t / a.up_low)];
+                    xin[u * 128 + NM + q] = a.feats[((size_t)BIDX(u) * 20 + q) * a.Tl + (t / a.up_low)];
                 }
             }
             __syncthreads();
@@ -212,7 +210,7 @@ __global__ __launch_bounds__(WR_THREADS) void wr_decode_kernel(WrArgs a) {
 #pragma unroll
                         for (int g = 0; g < 3; ++g) {
                             float acc = a.use_lowres ? plow[u][g] : pmel[u][g];
-                            if (a.use_lowres) acc = fmaf(w_int[g], a.interp[(size_t)bidx[u] * ((size_t)a.Tl * a.up_low) + t], acc);
+                            if (a.use_lowres) acc = fmaf(w_int[g], a.interp[(size_t)BIDX(u) * ((size_t)a.Tl * a.up_low) + t], acc);
                             gi[u][g] = fmaf(w_lx[g], lx, acc);
                         }
                     }
@@ -286,14 +284,14 @@ __global__ __launch_bounds__(WR_THREADS) void wr_decode_kernel(WrArgs a) {
                     const float* w = a.wt_out + row;
 #pragma unroll 8
                     for (int k = 0; k < 256; ++k) acc = fmaf(w[(size_t)k * S], pre[u * 256 + k], acc);
-                    const size_t o = ((size_t)bidx[u] * a.L + t) * S + row;
-                    if (a.out_logits && bok[u]) a.out_logits[o] = acc;
+                    const size_t o = ((size_t)BIDX(u) * a.L + t) * S + row;
+                    if (a.out_logits && BOK(u)) a.out_logits[o] = acc;
                     float g = 0.f;
                     if (a.mode == 1) {
                         g = a.noise[o];
                     } else if (a.mode == 2) {
                         uint32_t r4[4];
-                        ttsc_philox4x32((uint32_t)(row >> 2), (uint32_t)t, (uint32_t)bidx[u], (uint32_t)((unsigned long long)t >> 32),
+                        ttsc_philox4x32((uint32_t)(row >> 2), (uint32_t)t, (uint32_t)BIDX(u), (uint32_t)((unsigned long long)t >> 32),
                                         (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r4);
                         g = ttsc_gumbel(r4[row & 3]);
                     }
@@ -328,8 +326,8 @@ __global__ __launch_bounds__(WR_THREADS) void wr_decode_kernel(WrArgs a) {
                     wv = a.lut[bi];
                 else
                     wv = (((float)bi / 255.0f) - 0.5f) * 2.0f;
-                const size_t o = (size_t)bidx[u] * a.L + t;
-                if (bok[u]) {
+                const size_t o = (size_t)BIDX(u) * a.L + t;
+                if (BOK(u)) {
                     a.out_idx[o] = (uint8_t)bi;
                     a.out_wav[o] = wv;
                 }
@@ -340,6 +338,9 @@ __global__ __launch_bounds__(WR_THREADS) void wr_decode_kernel(WrArgs a) {
         cur = nxt;
     }
 }
+
+#undef BIDX
+#undef BOK
 
 }  // namespace ttsc
 
@@ -564,14 +565,23 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
     a.L = ttsc_wavernn_out_len(w, T, Tl);
     a.seed = seed;
     TTSC_REQUIRE(a.L > 0, "ttsc_wavernn_decode: nothing to decode (L=%ld)", a.L);
-    // utterances per workgroup: 1 while the batch does not fill the chip, 2 beyond (halves the weight stream per sample)
-    const int bt = (B > 256) ? 2 : 1;
+    // Utterances per workgroup (BT).  Every workgroup streams the full weight set from L2/MALL once per step, so
+    // the stream is shared by BT utterances; more workgroups than ~8 per XCD only add L2 traffic (the fp32 weight set
+    // of a 512-unit layer is ~3.8 MB per step against 4 MB of L2 per XCD), fewer leave FMA lanes idle.
+    int bt = 1;
+    if (B >= 512) bt = 8; else if (B >= 128) bt = 4; else if (B >= 32) bt = 2;
+    if (const char* ev = getenv("TTSC_WR_BT")) {
+        const int v = atoi(ev);
+        if (v == 1 || v == 2 || v == 4 || v == 8) bt = v;
+    }
     const size_t lds = ((size_t)2 * c.num_layers * bt * c.H + (size_t)bt * 256 + (size_t)bt * c.S + (size_t)bt * 128 + 16) * sizeof(float);
     dim3 grid((unsigned)ceil_div(B, bt));
-    if (bt == 1)
-        hipLaunchKernelGGL(wr_decode_kernel<1>, grid, dim3(WR_THREADS), lds, s, a);
-    else
-        hipLaunchKernelGGL(wr_decode_kernel<2>, grid, dim3(WR_THREADS), lds, s, a);
+    switch (bt) {
+        case 1: hipLaunchKernelGGL(wr_decode_kernel<1>, grid, dim3(WR_THREADS), lds, s, a); break;
+        case 2: hipLaunchKernelGGL(wr_decode_kernel<2>, grid, dim3(WR_THREADS), lds, s, a); break;
+        case 4: hipLaunchKernelGGL(wr_decode_kernel<4>, grid, dim3(WR_THREADS), lds, s, a); break;
+        default: hipLaunchKernelGGL(wr_decode_kernel<8>, grid, dim3(WR_THREADS), lds, s, a); break;
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("wr_decode_kernel launch failed: %s", hipGetErrorString(e));
