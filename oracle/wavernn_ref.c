@@ -179,7 +179,7 @@ int wr_decode(const wr_cfg* c, const wr_weights* w, const float* mel, const floa
                     g = noise[((size_t)b * L + t) * S + s];
                 } else if (mode == MODE_PHILOX) {
                     uint32_t r4[4];
-                    ttsc_philox4x32((uint32_t)(s >> 2), (uint32_t)t, (uint32_t)b, (uint32_t)((uint64_t)t >> 32),
+                    ttsc_philox4x32((uint32_t)(s >> 2), (uint32_t)t, (uint32_t)b, 0u,
                                     (uint32_t)seed, (uint32_t)(seed >> 32), r4);
                     g = ttsc_gumbel(r4[s & 3]);
                 }

@@ -98,3 +98,29 @@ def test_wavernn_errors():
     net = net.cuda()
     with pytest.raises(TTSCError):
         net.decode({'mel': torch.zeros(1, 2, 80), 'x_low': torch.zeros(1, 48)}, mode='noise', noise=None)
+
+
+def test_cubenet_vocoder_fold_and_decode(golden_dir):
+    """CubenetVocoder (vocoder.py:96-131): fold/unfold equal the reference's own outputs (fixture made by import), and
+    the two-network decode equals lr-oracle -> fold -> hr-oracle bit-exactly in argmax mode."""
+    from ttscube_amd.networks.vocoder import CubenetVocoder
+    z = np.load(os.path.join(golden_dir, 'vocoder_fold.npz'))
+    voc = CubenetVocoder(num_layers_lr=1, layer_size_lr=64, num_layers_hr=1, layer_size_hr=64, upsample=240, upsample_low=10,
+                         output='mulaw')
+    sd_hr = O.synthetic_state_dict(H=64, num_layers=1, use_lowres=True, seed=21)
+    sd_lr = O.synthetic_state_dict(H=64, num_layers=1, use_lowres=False, seed=22)
+    sd = {'_wavernn_hr.' + k: torch.from_numpy(v) for k, v in sd_hr.items()}
+    sd.update({'_wavernn_lr.' + k: torch.from_numpy(v) for k, v in sd_lr.items()})
+    voc.load_state_dict(sd, strict=True)
+    voc = voc.cuda().eval()
+    f = voc._inference_batch(torch.from_numpy(z['mel']).cuda(), torch.from_numpy(z['x_low']).cuda(), num_batches=20)
+    assert np.array_equal(f['mel'].cpu().numpy(), z['fold_mel']) and np.array_equal(f['x_low'].cpu().numpy(), z['fold_x_low'])
+    assert np.array_equal(voc._compose_batched_inference(torch.from_numpy(z['hr']).cuda()).cpu().numpy(), z['composed'])
+    mel = z['mel'][:, :40]
+    x_lr, x_hr = voc({'mel': torch.from_numpy(mel)}, mode='argmax') if False else voc._inference({'mel': torch.from_numpy(mel)}, mode='argmax')
+    _, r_lr, _ = O.decode(sd_lr, mel, None, num_layers=1, H=64, use_lowres=False, upsample=24, mode=O.MODE_ARGMAX)
+    fo = O.inference_batch(mel, r_lr, num_batches=20)
+    _, r_hr, _ = O.decode(sd_hr, fo['mel'], fo['x_low'], num_layers=1, H=64, mode=O.MODE_ARGMAX)
+    assert x_lr.shape == (1, 960, 1) and x_hr.shape == (1, 6800)  # SURVEY.md §8 a4: T=40 -> lr 960, hr 6800
+    assert np.array_equal(x_lr[:, :, 0], r_lr)
+    assert np.array_equal(x_hr, O.compose_batched_inference(r_hr))

@@ -35,13 +35,13 @@ struct WrArgs {
     const float* mel;     // [B, T, n_mel]
     const float* interp;  // [B, Tl*up_low]   (hr only)
     const float* feats;   // [B, 20, Tl]      (hr only)
-    const float* wt_ih[WR_MAXL];  // [in_l][3H]
-    const float* wt_hh[WR_MAXL];  // [H][3H]
+    const float* wt_ih[WR_MAXL];  // layer 0: [in_0][3H]; layers > 0: [H/4][3H][4]
+    const float* wt_hh[WR_MAXL];  // [H/4][3H][4]
     const float* b_ih[WR_MAXL];
     const float* b_hh[WR_MAXL];
-    const float* wt_pre;  // [H][256]
+    const float* wt_pre;  // [H/4][256][4]
     const float* b_pre;
-    const float* wt_out;  // [256][S]
+    const float* wt_out;  // [256/4][S][4]
     const float* b_out;
     const float* lut;
     const float* noise;     // [B, L, S] or null
@@ -50,7 +50,7 @@ struct WrArgs {
     float* out_wav;         // [B, L]
     float* out_logits;      // [B, L, S] or null
     int B, T, Tl, H, NL, use_lowres, up, up_low, S, n_mel, out_kind, mode;
-    long L;
+    int L;
     unsigned long long seed;
 };
 
@@ -99,6 +99,35 @@ __global__ __launch_bounds__(256) void wr_cond_kernel(const float* __restrict__ 
     }
 }
 
+// acc[u][g] <- k-ordered fmaf chain over K inputs for NG rows (row g at rows-offset g*gstride + row) of a weight matrix
+// packed as [K/4][rows][4] (four consecutive k of one row are one 16-byte load; consecutive threads = consecutive rows, so
+// a wave reads 1 KiB contiguous per load).  v: LDS vector(s) [BT][vstride], read as 16-byte broadcasts.
+template <int BT, int NG, int UN>
+__device__ __forceinline__ void chain_matvec(float (&acc)[BT][NG], const float* __restrict__ wp, int rows, int gstride, int row,
+                                             const float* v, int vstride, int K) {
+    const float4* w4 = reinterpret_cast<const float4*>(wp) + row;
+    const int KB = K >> 2;
+#pragma unroll UN
+    for (int kb = 0; kb < KB; ++kb) {
+        float4 w[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) w[g] = w4[(size_t)kb * rows + g * gstride];
+#pragma unroll
+        for (int u = 0; u < BT; ++u) {
+            const float4 hv = *reinterpret_cast<const float4*>(v + u * vstride + 4 * kb);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                float x = acc[u][g];
+                x = fmaf(w[g].x, hv.x, x);
+                x = fmaf(w[g].y, hv.y, x);
+                x = fmaf(w[g].z, hv.z, x);
+                x = fmaf(w[g].w, hv.w, x);
+                acc[u][g] = x;
+            }
+        }
+    }
+}
+
 template <int BT>
 __global__ __launch_bounds__(WR_THREADS) void wr_decode_kernel(WrArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -140,21 +169,23 @@ __global__ __launch_bounds__(WR_THREADS) void wr_decode_kernel(WrArgs a) {
     __syncthreads();
 
     int cur = 0;
-    for (long t = 0; t < a.L; ++t) {
+    int fr = 0, fr_phase = 0;  // t / up, t % up   (incremental: no integer division in the step loop)
+    int lo = 0, lo_phase = 0;  // t / up_low, t % up_low
+    for (int t = 0; t < a.L; ++t) {
         // ---- refresh the cached prefixes of the layer-0 input chain --------------------------------------
-        const bool new_frame = (t % a.up) == 0;
-        const bool new_low = a.use_lowres && (t % a.up_low) == 0;
+        const bool new_frame = fr_phase == 0;
+        const bool new_low = a.use_lowres && lo_phase == 0;
         if (new_frame || new_low) {
             if (new_frame) {
                 for (int i = tid; i < BT * NM; i += WR_THREADS) {
                     const int u = i / NM, k = i - u * NM;
-                    xin[u * 128 + k] = a.mel[((size_t)BIDX(u) * a.T + (t / a.up)) * NM + k];
+                    xin[u * 128 + k] = a.mel[((size_t)BIDX(u) * a.T + fr) * NM + k];
                 }
             }
             if (new_low) {
                 for (int i = tid; i < BT * 20; i += WR_THREADS) {
                     const int u = i / 20, q = i - u * 20;
-                    xin[u * 128 + NM + q] = a.feats[((size_t)BIDX(u) * 20 + q) * a.Tl + (t / a.up_low)];
+                    xin[u * 128 + NM + q] = a.feats[((size_t)BIDX(u) * 20 + q) * a.Tl + lo];
                 }
             }
             __syncthreads();
@@ -220,35 +251,13 @@ __global__ __launch_bounds__(WR_THREADS) void wr_decode_kernel(WrArgs a) {
                     for (int u = 0; u < BT; ++u)
 #pragma unroll
                         for (int g = 0; g < 3; ++g) gi[u][g] = a.b_ih[l][g * H + j];
-                    const float* w = a.wt_ih[l] + j;
-#pragma unroll 8
-                    for (int k = 0; k < H; ++k) {
-                        const float w0 = w[(size_t)k * H3], w1 = w[(size_t)k * H3 + H], w2 = w[(size_t)k * H3 + 2 * H];
-#pragma unroll
-                        for (int u = 0; u < BT; ++u) {
-                            const float v = hp[u * H + k];
-                            gi[u][0] = fmaf(w0, v, gi[u][0]);
-                            gi[u][1] = fmaf(w1, v, gi[u][1]);
-                            gi[u][2] = fmaf(w2, v, gi[u][2]);
-                        }
-                    }
+                    chain_matvec<BT, 3, (BT == 1 ? 4 : 2)>(gi, a.wt_ih[l], H3, H, j, hp, H, H);
                 }
 #pragma unroll
                 for (int u = 0; u < BT; ++u)
 #pragma unroll
                     for (int g = 0; g < 3; ++g) gh[u][g] = a.b_hh[l][g * H + j];
-                const float* w = a.wt_hh[l] + j;
-#pragma unroll 8
-                for (int k = 0; k < H; ++k) {
-                    const float w0 = w[(size_t)k * H3], w1 = w[(size_t)k * H3 + H], w2 = w[(size_t)k * H3 + 2 * H];
-#pragma unroll
-                    for (int u = 0; u < BT; ++u) {
-                        const float v = hc[u * H + k];
-                        gh[u][0] = fmaf(w0, v, gh[u][0]);
-                        gh[u][1] = fmaf(w1, v, gh[u][1]);
-                        gh[u][2] = fmaf(w2, v, gh[u][2]);
-                    }
-                }
+                chain_matvec<BT, 3, (BT == 1 ? 4 : 2)>(gh, a.wt_hh[l], H3, H, j, hc, H, H);
 #pragma unroll
                 for (int u = 0; u < BT; ++u) {
                     const float r = ttsc_sigmoidf(gi[u][0] + gh[u][0]);
@@ -267,11 +276,9 @@ __global__ __launch_bounds__(WR_THREADS) void wr_decode_kernel(WrArgs a) {
             const float* ht = hbuf + ((size_t)(nxt * NL + (NL - 1)) * BT) * H;
             const int row = tid & 255;
             for (int u = tid >> 8; u < BT; u += WR_THREADS / 256) {
-                float acc = a.b_pre[row];
-                const float* w = a.wt_pre + row;
-#pragma unroll 8
-                for (int k = 0; k < H; ++k) acc = fmaf(w[(size_t)k * 256], ht[u * H + k], acc);
-                pre[u * 256 + row] = ttsc_tanhf(acc);
+                float acc[1][1] = {{a.b_pre[row]}};
+                chain_matvec<1, 1, 16>(acc, a.wt_pre, 256, 0, row, ht + u * H, H, H);
+                pre[u * 256 + row] = ttsc_tanhf(acc[0][0]);
             }
         }
         __syncthreads();
@@ -280,10 +287,9 @@ __global__ __launch_bounds__(WR_THREADS) void wr_decode_kernel(WrArgs a) {
             const int row = tid & 255;
             for (int u = tid >> 8; u < BT; u += WR_THREADS / 256) {
                 if (row < S) {
-                    float acc = a.b_out[row];
-                    const float* w = a.wt_out + row;
-#pragma unroll 8
-                    for (int k = 0; k < 256; ++k) acc = fmaf(w[(size_t)k * S], pre[u * 256 + k], acc);
+                    float accv[1][1] = {{a.b_out[row]}};
+                    chain_matvec<1, 1, 16>(accv, a.wt_out, S, 0, row, pre + u * 256, 256, 256);
+                    const float acc = accv[0][0];
                     const size_t o = ((size_t)BIDX(u) * a.L + t) * S + row;
                     if (a.out_logits && BOK(u)) a.out_logits[o] = acc;
                     float g = 0.f;
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(WR_THREADS) void wr_decode_kernel(WrArgs a) {
                         g = a.noise[o];
                     } else if (a.mode == 2) {
                         uint32_t r4[4];
-                        ttsc_philox4x32((uint32_t)(row >> 2), (uint32_t)t, (uint32_t)BIDX(u), (uint32_t)((unsigned long long)t >> 32),
+                        ttsc_philox4x32((uint32_t)(row >> 2), (uint32_t)t, (uint32_t)BIDX(u), 0u,
                                         (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r4);
                         g = ttsc_gumbel(r4[row & 3]);
                     }
@@ -336,6 +342,8 @@ __global__ __launch_bounds__(WR_THREADS) void wr_decode_kernel(WrArgs a) {
         }
         __syncthreads();
         cur = nxt;
+        if (++fr_phase == a.up) { fr_phase = 0; ++fr; }
+        if (++lo_phase == a.up_low) { lo_phase = 0; ++lo; }
     }
 }
 
@@ -370,6 +378,14 @@ static int upload(float** dst, const float* host, size_t n) {
     TTSC_HIP_CHECK(hipMalloc((void**)dst, n * sizeof(float)));
     TTSC_HIP_CHECK(hipMemcpy(*dst, host, n * sizeof(float), hipMemcpyHostToDevice));
     return TTSC_OK;
+}
+
+// torch [rows, K] -> device [K/4][rows][4]: thread `row` reads four consecutive k as one 16-byte load (K % 4 == 0)
+static int upload_packed4(float** dst, const float* host, int64_t rows, int64_t K) {
+    std::vector<float> t((size_t)rows * K);
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t k = 0; k < K; ++k) t[((size_t)(k >> 2) * rows + r) * 4 + (k & 3)] = host[(size_t)r * K + k];
+    return upload(dst, t.data(), t.size());
 }
 
 // torch [rows, cols] -> device [cols][rows] so that consecutive threads (rows) read consecutive addresses
@@ -436,10 +452,10 @@ extern "C" int ttsc_wavernn_set_weight(ttsc_wavernn* w, const char* name, const 
         const std::string k(kind);
         if (k == "weight_ih_l0") {
             TTSC_REQUIRE(shape_is(shape, nd, {3 * H, in_l}), "ttsc_wavernn_set_weight: '%s' expects [%d,%d]", name, 3 * H, in_l);
-            rc = upload_transposed(&w->wt_ih[l], host, 3 * H, in_l);
+            rc = (l == 0) ? upload_transposed(&w->wt_ih[l], host, 3 * H, in_l) : upload_packed4(&w->wt_ih[l], host, 3 * H, in_l);
         } else if (k == "weight_hh_l0") {
             TTSC_REQUIRE(shape_is(shape, nd, {3 * H, H}), "ttsc_wavernn_set_weight: '%s' expects [%d,%d]", name, 3 * H, H);
-            rc = upload_transposed(&w->wt_hh[l], host, 3 * H, H);
+            rc = upload_packed4(&w->wt_hh[l], host, 3 * H, H);
         } else if (k == "bias_ih_l0") {
             TTSC_REQUIRE(shape_is(shape, nd, {3 * H}), "ttsc_wavernn_set_weight: '%s' expects [%d]", name, 3 * H);
             rc = upload(&w->b_ih[l], host, 3 * H);
@@ -461,13 +477,13 @@ extern "C" int ttsc_wavernn_set_weight(ttsc_wavernn* w, const char* name, const 
         }
     } else if (n == "_preoutput.linear_layer.weight") {
         TTSC_REQUIRE(shape_is(shape, nd, {256, H}), "ttsc_wavernn_set_weight: '%s' expects [256,%d]", name, H);
-        rc = upload_transposed(&w->wt_pre, host, 256, H);
+        rc = upload_packed4(&w->wt_pre, host, 256, H);
     } else if (n == "_preoutput.linear_layer.bias") {
         TTSC_REQUIRE(shape_is(shape, nd, {256}), "ttsc_wavernn_set_weight: '%s' expects [256]", name);
         rc = upload(&w->b_pre, host, 256);
     } else if (n == "_output.linear_layer.weight") {
         TTSC_REQUIRE(shape_is(shape, nd, {S, 256}), "ttsc_wavernn_set_weight: '%s' expects [%d,256]", name, S);
-        rc = upload_transposed(&w->wt_out, host, S, 256);
+        rc = upload_packed4(&w->wt_out, host, S, 256);
     } else if (n == "_output.linear_layer.bias") {
         TTSC_REQUIRE(shape_is(shape, nd, {S}), "ttsc_wavernn_set_weight: '%s' expects [%d]", name, S);
         rc = upload(&w->b_out, host, S);
@@ -562,14 +578,18 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
     a.n_mel = c.n_mel;
     a.out_kind = c.out_kind;
     a.mode = mode;
-    a.L = ttsc_wavernn_out_len(w, T, Tl);
+    {
+        const int64_t L64 = ttsc_wavernn_out_len(w, T, Tl);
+        TTSC_REQUIRE(L64 < (1ll << 31), "ttsc_wavernn_decode: more than 2^31 samples per utterance");
+        a.L = (int)L64;
+    }
     a.seed = seed;
-    TTSC_REQUIRE(a.L > 0, "ttsc_wavernn_decode: nothing to decode (L=%ld)", a.L);
-    // Utterances per workgroup (BT).  Every workgroup streams the full weight set from L2/MALL once per step, so
-    // the stream is shared by BT utterances; more workgroups than ~8 per XCD only add L2 traffic (the fp32 weight set
-    // of a 512-unit layer is ~3.8 MB per step against 4 MB of L2 per XCD), fewer leave FMA lanes idle.
+    TTSC_REQUIRE(a.L > 0, "ttsc_wavernn_decode: nothing to decode (L=%d)", a.L);
+    // Utterances per workgroup (BT).  Measured on MI355X (H=512, 1 layer): one utterance per workgroup is fastest
+    // per step (60 us) while the batch fits the 256 CUs; beyond that a tile of 2/4 utterances shares one weight
+    // stream (74 / 98 us per step) and raises throughput (B=1024, BT=4: 9.6 M samples/s).
     int bt = 1;
-    if (B >= 512) bt = 8; else if (B >= 128) bt = 4; else if (B >= 32) bt = 2;
+    if (B > 512) bt = 4; else if (B > 256) bt = 2;
     if (const char* ev = getenv("TTSC_WR_BT")) {
         const int v = atoi(ev);
         if (v == 1 || v == 2 || v == 4 || v == 8) bt = v;
