@@ -155,6 +155,31 @@ int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel_dev, const float* xlow
                         void* stream);
 void ttsc_wavernn_destroy(ttsc_wavernn* w);
 
+/* ------------------------------------------------------------------------------------------------
+ * Linear (fp32 MFMA NT GEMM): y[M, :N] = act(x[M, :K] . w[N,K]^T + bias) [+ y if accumulate].
+ * Replaces torch.nn.Linear inside LinearNorm (cube/networks/modules.py:24-34) for _dur_output, _pitch_output,
+ * _cond_output, _mel_output, PreNet, and carries the hoisted LSTM input projections.  All pointers are device
+ * pointers (the weight is whatever torch holds: [out, in] row-major).
+ * ------------------------------------------------------------------------------------------------ */
+int ttsc_linear_forward(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int64_t M, int32_t N,
+                        int32_t K, int64_t ldx, int64_t ldy, int32_t act, int32_t accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LSTM / BiLSTM recurrence.  Replaces the sequential part of torch.nn.LSTM (gate order i,f,g,o, `_reverse`
+ * direction) for Languasito2 (modules.py:873-905) and CubenetTextcoder (textcoder.py:55-92).
+ *   xg_dev        [B, T, ndir*4H]  pre-activations  x.W_ih^T + b_ih + b_hh  (from ttsc_linear_forward)
+ *   whh_packed    from ttsc_lstm_pack_whh(weight_hh_l{k}[, weight_hh_l{k}_reverse] stacked [ndir,4H,H] on the host)
+ *   y_dev         [B, T, ldy]; direction d writes columns [yoff + d*H, yoff + (d+1)*H)
+ *   lengths_dev   int32 [B] or NULL: pack_padded_sequence semantics (outputs beyond the length are zero)
+ *   h0/c0/hn/cn   optional [ndir, B, H] initial / final states (NULL = zeros / not returned)
+ * ------------------------------------------------------------------------------------------------ */
+int ttsc_lstm_pack_whh(const float* whh_host, int32_t ndir, int32_t H, float** whh_dev_out);
+int ttsc_lstm_seq_forward(const float* xg_dev, const float* whh_packed_dev, float* y_dev, const int32_t* lengths_dev,
+                          int32_t B, int32_t T, int32_t H, int32_t ndir, int64_t ldy, int32_t yoff, const float* h0_dev,
+                          const float* c0_dev, float* hn_dev, float* cn_dev, void* stream);
+/* frees a device buffer returned by a ttsc_*_pack_* function */
+void ttsc_device_free(void* p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,171 @@
+// LSTM / BiLSTM sequence recurrence as one persistent workgroup per (utterance tile, direction) — gfx950.
+//
+// torch.nn.LSTM semantics (gate order i,f,g,o; `_reverse` direction; stacked layers) as used by the mel decoders:
+//   Languasito2  _char_rnn_{t,g}, _dur_rnn, _pitch_rnn, _cond_rnn, _lm_{t,g}   cube/networks/modules.py:873-905
+//   CubenetTextcoder _rnn_char, _rnn_overlay, _dur_rnn, _pitch_rnn, _mel_rnn    cube/networks/textcoder.py:55-92
+//
+// Split of one layer:  (1) input projection for ALL time steps as one MFMA GEMM (gemm.hip): xg[b,t,dir,4H] =
+// x[b,t,:] . W_ih^T + (b_ih + b_hh);  (2) this kernel: the sequential part  gates_t = xg_t + W_hh h_{t-1}, with thread j
+// owning hidden unit j (its four gate rows are streamed from L2 as 16-byte packed loads, c_j stays in a register,
+// h lives in LDS double-buffered) — no inter-workgroup communication, one workgroup barrier per step.
+// Ragged batches: `lengths[b]` gives pack_padded_sequence semantics (reverse direction starts at len-1, outputs
+// beyond len are zero), so a padded batch reproduces the per-utterance results exactly.
+#include "common.hpp"
+#include "../../include/ttscube_math.h"
+
+namespace ttsc {
+
+struct LstmArgs {
+    const float* xg;     // [B, T, ndir*4H]
+    const float* whh;    // [ndir][H/4][4H][4]
+    float* y;            // [B, T, ldy], direction d writes columns [yoff + d*H, yoff + (d+1)*H)
+    const int* lengths;  // [B] or null
+    float* h_n;          // optional [ndir, B, H] final hidden state
+    float* c_n;
+    const float* h_0;    // optional initial state [ndir, B, H]
+    const float* c_0;
+    int B, T, H, ndir, ldy, yoff;
+};
+
+template <int BT, int NG, int UN>
+__device__ __forceinline__ void lstm_chain(float (&acc)[BT][NG], const float* __restrict__ wp, int rows, int gstride, int row,
+                                           const float* v, int vstride, int K) {
+    const float4* w4 = reinterpret_cast<const float4*>(wp) + row;
+    const int KB = K >> 2;
+#pragma unroll UN
+    for (int kb = 0; kb < KB; ++kb) {
+        float4 w[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) w[g] = w4[(size_t)kb * rows + g * gstride];
+#pragma unroll
+        for (int u = 0; u < BT; ++u) {
+            const float4 hv = *reinterpret_cast<const float4*>(v + u * vstride + 4 * kb);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                float x = acc[u][g];
+                x = fmaf(w[g].x, hv.x, x);
+                x = fmaf(w[g].y, hv.y, x);
+                x = fmaf(w[g].z, hv.z, x);
+                x = fmaf(w[g].w, hv.w, x);
+                acc[u][g] = x;
+            }
+        }
+    }
+}
+
+template <int BT>
+__global__ __launch_bounds__(512) void lstm_seq_kernel(LstmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // h[2][BT][H]
+    const int H = a.H, H4 = 4 * H;
+    const int j = threadIdx.x;
+    const bool unit = j < H;
+    const int dir = blockIdx.y;
+    const float* whh = a.whh + (size_t)dir * H * H4;
+    int len[BT], bi[BT];
+    float c[BT];
+#pragma unroll
+    for (int u = 0; u < BT; ++u) {
+        const int b = blockIdx.x * BT + u;
+        bi[u] = b < a.B ? b : a.B - 1;
+        len[u] = b < a.B ? (a.lengths ? a.lengths[bi[u]] : a.T) : 0;
+        c[u] = (unit && a.c_0) ? a.c_0[((size_t)dir * a.B + bi[u]) * H + j] : 0.f;
+        if (unit) sm[u * H + j] = a.h_0 ? a.h_0[((size_t)dir * a.B + bi[u]) * H + j] : 0.f;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int s = 0; s < a.T; ++s) {
+        const float* hc = sm + cur * BT * H;
+        float* hn = sm + (cur ^ 1) * BT * H;
+        if (unit) {
+            float acc[BT][4];
+            int tpos[BT];
+#pragma unroll
+            for (int u = 0; u < BT; ++u) {
+                tpos[u] = dir == 0 ? s : (len[u] - 1 - s);
+                const bool ok = s < len[u];
+                const float* xr = a.xg + ((size_t)bi[u] * a.T + (ok ? tpos[u] : 0)) * ((size_t)a.ndir * H4) + (size_t)dir * H4 + j;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[u][g] = xr[g * H];
+            }
+            lstm_chain<BT, 4, (BT == 1 ? 4 : 2)>(acc, whh, H4, H, j, hc, H, H);
+#pragma unroll
+            for (int u = 0; u < BT; ++u) {
+                const bool ok = s < len[u];
+                const float ig = ttsc_sigmoidf(acc[u][0]);
+                const float fg = ttsc_sigmoidf(acc[u][1]);
+                const float gg = ttsc_tanhf(acc[u][2]);
+                const float og = ttsc_sigmoidf(acc[u][3]);
+                const float cn = fmaf(fg, c[u], ig * gg);
+                const float hv = og * ttsc_tanhf(cn);
+                if (ok) {
+                    c[u] = cn;
+                    hn[u * H + j] = hv;
+                    a.y[((size_t)bi[u] * a.T + tpos[u]) * a.ldy + a.yoff + dir * H + j] = hv;
+                } else {
+                    hn[u * H + j] = hc[u * H + j];
+                    // padded positions read as zeros (pad_packed_sequence); each padded t is written exactly once:
+                    // position s itself is >= len for both directions
+                    if (blockIdx.x * BT + u < a.B) a.y[((size_t)bi[u] * a.T + s) * a.ldy + a.yoff + dir * H + j] = 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (unit) {
+#pragma unroll
+        for (int u = 0; u < BT; ++u) {
+            if (blockIdx.x * BT + u < a.B) {
+                if (a.h_n) a.h_n[((size_t)dir * a.B + bi[u]) * H + j] = sm[cur * BT * H + u * H + j];
+                if (a.c_n) a.c_n[((size_t)dir * a.B + bi[u]) * H + j] = c[u];
+            }
+        }
+    }
+}
+
+}  // namespace ttsc
+
+using namespace ttsc;
+
+// Recurrent weights: host torch layout weight_hh [4H, H] per direction -> device [ndir][H/4][4H][4]
+extern "C" int ttsc_lstm_pack_whh(const float* whh_host, int32_t ndir, int32_t H, float** whh_dev_out) {
+    TTSC_REQUIRE(whh_host && whh_dev_out, "ttsc_lstm_pack_whh: null argument");
+    TTSC_REQUIRE(ndir >= 1 && ndir <= 2 && H >= 4 && H <= 512 && H % 4 == 0, "ttsc_lstm_pack_whh: need ndir in {1,2}, H %% 4 == 0, H <= 512 (got %d, %d)", ndir, H);
+    const size_t per = (size_t)4 * H * H;
+    std::vector<float> t(per * ndir);
+    for (int d = 0; d < ndir; ++d)
+        for (int r = 0; r < 4 * H; ++r)
+            for (int k = 0; k < H; ++k) t[d * per + ((size_t)(k >> 2) * 4 * H + r) * 4 + (k & 3)] = whh_host[d * per + (size_t)r * H + k];
+    float* dptr = nullptr;
+    TTSC_HIP_CHECK(hipMalloc((void**)&dptr, t.size() * sizeof(float)));
+    TTSC_HIP_CHECK(hipMemcpy(dptr, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+    *whh_dev_out = dptr;
+    return TTSC_OK;
+}
+
+extern "C" void ttsc_device_free(void* p) {
+    if (p) (void)hipFree(p);
+}
+
+extern "C" int ttsc_lstm_seq_forward(const float* xg_dev, const float* whh_packed_dev, float* y_dev, const int32_t* lengths_dev,
+                                     int32_t B, int32_t T, int32_t H, int32_t ndir, int64_t ldy, int32_t yoff, const float* h0_dev,
+                                     const float* c0_dev, float* hn_dev, float* cn_dev, void* stream) {
+    TTSC_REQUIRE(xg_dev && whh_packed_dev && y_dev, "ttsc_lstm_seq_forward: null argument");
+    TTSC_REQUIRE(B > 0 && T > 0 && ndir >= 1 && ndir <= 2 && H >= 4 && H <= 512 && H % 4 == 0, "ttsc_lstm_seq_forward: bad shape B=%d T=%d H=%d ndir=%d", B, T, H, ndir);
+    TTSC_REQUIRE(ldy >= (int64_t)yoff + (int64_t)ndir * H, "ttsc_lstm_seq_forward: ldy too small");
+    LstmArgs a{xg_dev, whh_packed_dev, y_dev, lengths_dev, hn_dev, cn_dev, h0_dev, c0_dev, B, T, H, ndir, (int)ldy, yoff};
+    const int threads = (int)round_up(H, 64);
+    const int bt = B * ndir > 512 ? 2 : 1;
+    dim3 grid((unsigned)ceil_div(B, bt), (unsigned)ndir);
+    const size_t lds = (size_t)2 * bt * H * sizeof(float);
+    if (bt == 1)
+        hipLaunchKernelGGL(lstm_seq_kernel<1>, grid, dim3(threads), lds, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(lstm_seq_kernel<2>, grid, dim3(threads), lds, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("lstm_seq_kernel launch failed: %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    return TTSC_OK;
+}

@@ -67,3 +67,116 @@ class Conv1dHip:
             _lib.lib().ttsc_conv1d_destroy(self._h)
         except Exception:
             pass
+
+
+def linear_hip(x, weight, bias=None, act=None, out=None, accumulate=False):
+    """y[..., :N] = act(x[..., :K] @ weight[N,K]^T + bias) on the MFMA GEMM (ttsc_linear_forward).
+    x: device tensor [..., K] (last dim contiguous, rows at a constant stride); weight/bias: device tensors."""
+    if not x.is_cuda:
+        raise _lib.TTSCError('linear_hip: input must live on a HIP device; no CPU path')
+    K = x.shape[-1]
+    N = weight.shape[0]
+    assert weight.shape[1] == K, (tuple(weight.shape), K)
+    x2 = x.float().contiguous().reshape(-1, K)
+    M = x2.shape[0]
+    w = weight.detach().float().contiguous()
+    b = bias.detach().float().contiguous() if bias is not None else None
+    if out is None:
+        out2 = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        ldy = N
+    else:
+        assert out.is_cuda and out.dtype == torch.float32 and out.stride(-1) == 1
+        out2 = out
+        ldy = out.stride(-2) if out.dim() > 1 else N
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().ttsc_linear_forward(_lib.dev_ptr(x2), _lib.dev_ptr(w), _lib.dev_ptr(b) if b is not None else None,
+                                                  C.c_void_p(out2.data_ptr()), M, N, K, K, ldy, ACT[act], int(accumulate),
+                                                  _lib.current_stream()), 'ttsc_linear_forward')
+    if out is None:
+        return out2.reshape(tuple(x.shape[:-1]) + (N,))
+    return out
+
+
+class LSTMHip:
+    """Device-side handle for a (stacked, optionally bidirectional) torch.nn.LSTM parameter set (batch_first).
+    Input projections of all time steps run as one MFMA GEMM per layer; the recurrence runs in the persistent
+    `lstm_seq_kernel` (one workgroup per utterance and direction)."""
+
+    def __init__(self, lstm_module):
+        self.m = lstm_module
+        self.H = lstm_module.hidden_size
+        self.num_layers = lstm_module.num_layers
+        self.ndir = 2 if lstm_module.bidirectional else 1
+        assert lstm_module.batch_first
+        self._sig = None
+        self._whh = []
+        self._wih = []
+        self._bias = []
+
+    def _free(self):
+        for p in self._whh:
+            _lib.lib().ttsc_device_free(p)
+        self._whh = []
+
+    def __del__(self):
+        try:
+            self._free()
+        except Exception:
+            pass
+
+    def _sync(self):
+        sig = tuple((p.data_ptr(), p._version) for p in self.m.parameters())
+        if sig == self._sig:
+            return
+        _lib.require_gpu()
+        self._free()
+        self._wih, self._bias = [], []
+        dev = next(self.m.parameters()).device
+        if dev.type == 'cpu':
+            raise _lib.TTSCError('LSTMHip: parameters live on the CPU; move the module to a HIP device (no CPU path)')
+        sfx = ['', '_reverse'][:self.ndir]
+        for l in range(self.num_layers):
+            g = lambda n: getattr(self.m, n).detach().float()
+            wih = torch.cat([g('weight_ih_l%d%s' % (l, s)) for s in sfx], dim=0).contiguous()             # [ndir*4H, in]
+            bias = torch.cat([g('bias_ih_l%d%s' % (l, s)) + g('bias_hh_l%d%s' % (l, s)) for s in sfx], dim=0).contiguous()
+            whh = torch.stack([g('weight_hh_l%d%s' % (l, s)) for s in sfx], dim=0).cpu().contiguous()      # [ndir,4H,H]
+            ptr = C.c_void_p()
+            _lib.check(_lib.lib().ttsc_lstm_pack_whh(C.c_void_p(whh.data_ptr()), self.ndir, self.H, C.byref(ptr)),
+                       'ttsc_lstm_pack_whh')
+            self._whh.append(ptr)
+            self._wih.append(wih.to(dev))
+            self._bias.append(bias.to(dev))
+        self._sig = sig
+
+    def __call__(self, x, lengths=None, hx=None, return_state=False):
+        """x [B, T, in] -> y [B, T, ndir*H] (and (h_n, c_n) [num_layers*ndir, B, H] if return_state)."""
+        self._sync()
+        if not x.is_cuda:
+            raise _lib.TTSCError('LSTMHip: input must live on a HIP device; no CPU path')
+        B, T, _ = x.shape
+        H, nd = self.H, self.ndir
+        len_dev = None
+        if lengths is not None:
+            len_dev = torch.as_tensor(lengths, dtype=torch.int32, device=x.device).contiguous()
+        hn = torch.empty((self.num_layers * nd, B, H), dtype=torch.float32, device=x.device) if return_state else None
+        cn = torch.empty_like(hn) if return_state else None
+        cur = x.float().contiguous()
+        for l in range(self.num_layers):
+            xg = linear_hip(cur, self._wih[l], self._bias[l])                       # [B, T, nd*4H]
+            y = torch.empty((B, T, nd * H), dtype=torch.float32, device=x.device)
+            h0 = c0 = None
+            if hx is not None:
+                h0 = hx[0][l * nd:(l + 1) * nd].float().contiguous()
+                c0 = hx[1][l * nd:(l + 1) * nd].float().contiguous()
+            P = _lib.dev_ptr
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.lib().ttsc_lstm_seq_forward(
+                    P(xg), self._whh[l], P(y), P(len_dev) if len_dev is not None else None, B, T, H, nd, nd * H, 0,
+                    P(h0) if h0 is not None else None, P(c0) if c0 is not None else None,
+                    C.c_void_p(hn[l * nd:(l + 1) * nd].data_ptr()) if hn is not None else None,
+                    C.c_void_p(cn[l * nd:(l + 1) * nd].data_ptr()) if cn is not None else None,
+                    _lib.current_stream()), 'ttsc_lstm_seq_forward')
+            cur = y
+        if return_state:
+            return cur, (hn, cn)
+        return cur
