@@ -190,3 +190,259 @@ class WaveRNN(nn.Module):
     @torch.jit.ignore
     def load(self, path):
         self.load_state_dict(torch.load(path, map_location='cpu'))
+
+
+# =====================================================================================================================
+# Mel decoders
+# =====================================================================================================================
+from ..hip_layers import Conv1dHip, LSTMHip, linear_hip  # noqa: E402
+
+
+class _ConvStack:
+    """Lazily synced Conv1dHip handles for a list of (conv_module, bn_module|None); BatchNorm1d (eval) is folded into
+    the conv weights at sync time: w' = w * g / sqrt(var + eps), b' = (b - mean) * g / sqrt(var + eps) + beta."""
+
+    def __init__(self, items):
+        self.items = items
+        self._sig = None
+        self.h = None
+
+    def sync(self):
+        mods = [m for it in self.items for m in it if m is not None]
+        sig = tuple((t.data_ptr(), t._version) for m in mods for t in list(m.parameters()) + list(m.buffers()))
+        if sig == self._sig:
+            return self.h
+        self.h = []
+        for conv, bn in self.items:
+            w, b = conv.weight.detach().float().cpu(), conv.bias.detach().float().cpu()
+            if bn is not None:
+                s = bn.weight.detach().float().cpu() / torch.sqrt(bn.running_var.detach().float().cpu() + bn.eps)
+                w = w * s[:, None, None]
+                b = (b - bn.running_mean.detach().float().cpu()) * s + bn.bias.detach().float().cpu()
+            c = Conv1dHip(conv.in_channels, conv.out_channels, conv.kernel_size[0], padding=conv.padding[0],
+                          dilation=conv.dilation[0])
+            c.set_weight(w, b)
+            self.h.append(c)
+        self._sig = sig
+        return self.h
+
+
+class PostNet(nn.Module):
+    """cube/networks/modules.py:117-145 (same nn.Sequential indices => same state_dict keys).  Inference-mode
+    forward on the HIP conv kernel: BatchNorm folded, tanh fused, dropout inactive (eval)."""
+
+    def __init__(self, num_mels=80, kernel_size=5, filter_size=512, output_size=None):
+        super().__init__()
+        if output_size is None:
+            output_size = num_mels
+        layers = []
+        ic = num_mels
+        for i in range(4):
+            layers += [ConvNorm(ic, filter_size, kernel_size, padding=kernel_size // 2, w_init_gain='tanh'),
+                       nn.BatchNorm1d(512), nn.Tanh(), nn.Dropout(0.1)]
+            ic = filter_size
+        layers.append(ConvNorm(filter_size, output_size, kernel_size, padding=kernel_size // 2, w_init_gain='linear'))
+        self.network = nn.Sequential(*layers)
+        self._stack = _ConvStack([(self.network[0].conv, self.network[1]), (self.network[4].conv, self.network[5]),
+                                  (self.network[8].conv, self.network[9]), (self.network[12].conv, self.network[13]),
+                                  (self.network[16].conv, None)])
+
+    def forward(self, x, add_residual=False):
+        """x [B, F, 80] -> [B, F, 80]; add_residual=True returns x + postnet(x) (textcoder.py:186-187) in one epilogue."""
+        if self.training:
+            raise _lib.TTSCError('PostNet: the HIP path implements eval-mode BatchNorm/Dropout (call .eval())')
+        hs = self._stack.sync()
+        xc = x.float().permute(0, 2, 1).contiguous()
+        h = xc
+        for c in hs[:-1]:
+            h = c(h, act='tanh')
+        y = hs[-1](h, resid=xc if add_residual else None)
+        return y.permute(0, 2, 1).contiguous()
+
+
+class PreNet(nn.Module):
+    """cube/networks/modules.py:148-164: 2 x [Linear -> ReLU -> dropout(p=0.5, ALWAYS on)]."""
+
+    def __init__(self, num_mels=80, hidden=256, layers=2):
+        super().__init__()
+        mods = []
+        inp = num_mels
+        for _ in range(layers):
+            mods.append(LinearNorm(inp, hidden, w_init_gain='linear'))
+            inp = hidden
+        self.layers_h = nn.ModuleList(mods)
+
+    def forward(self, x, masks=None):
+        """masks: optional list of {0,1} tensors (one per layer, broadcastable to the layer output) for parity tests;
+        by default Bernoulli(0.5) masks are drawn from torch's device generator."""
+        h = x
+        for i, layer in enumerate(self.layers_h):
+            h = linear_hip(h, layer.linear_layer.weight, layer.linear_layer.bias, act='relu')
+            m = masks[i] if masks is not None else (torch.rand(h.shape, device=h.device) >= 0.5).float()
+            h = h * (m.to(h.device) * 2.0)
+        return h
+
+
+def _cnn_forward(stack, emb, lengths):
+    """3 x tanh(Conv1d k3) over [B, N, C]; positions >= length are zeroed between layers so that a padded batch
+    reproduces the per-utterance (zero-padded conv) results."""
+    hs = stack.sync()
+    B, N, _ = emb.shape
+    mask = None
+    if lengths is not None and B > 1:
+        mask = (torch.arange(N, device=emb.device)[None, :] < torch.as_tensor(lengths, device=emb.device)[:, None]).float()[:, None, :]
+    h = emb.float().permute(0, 2, 1).contiguous()
+    if mask is not None:
+        h = h * mask
+    for c in hs:
+        h = c(h, act='tanh')
+        if mask is not None:
+            h = h * mask
+    return h.permute(0, 2, 1).contiguous()
+
+
+def _expand_rows(x, alignments, stride=1):
+    """Gather rows of x [B, N, C] by per-utterance frame->phone alignments (every `stride`-th frame), padding short
+    utterances with their last aligned row (Languasito2._expand_i modules.py:1043-1053 / Textcoder._expand 291-302)."""
+    sel = [[a[j * stride] for j in range(len(a) // stride)] for a in alignments]
+    m = max(len(s) for s in sel) if sel else 0
+    if m == 0:
+        return x[:, :0], [0] * len(sel)
+    idx = np.zeros((len(sel), m), dtype=np.int64)
+    for b, s in enumerate(sel):
+        if len(s):
+            idx[b, :len(s)] = s
+            idx[b, len(s):] = s[-1] if stride == 1 else x.shape[1] - 1
+    idx_t = torch.from_numpy(idx).to(x.device)
+    return torch.gather(x, 1, idx_t[:, :, None].expand(-1, -1, x.shape[2])).contiguous(), [len(s) for s in sel]
+
+
+class Languasito2(nn.Module):
+    """cube/networks/modules.py:805-1094 — text -> 80-d per-frame conditioning for the HiFi-GAN generator.
+    Same constructor and state_dict keys; `inference` runs on the HIP conv / GEMM / LSTM kernels and additionally
+    accepts padded batches (x_char padded with 0), which the reference (B=1 only, modules.py:946-953) does not."""
+
+    def __init__(self, num_phones, num_speakers, max_pitch, max_duration, cond_type=None, lr: float = 2e-4):
+        super().__init__()
+        if cond_type in ('fasttext', 'hf'):
+            in_sz = 300 if cond_type == 'fasttext' else 768
+            ext = 512
+            self._lm_t = nn.LSTM(input_size=in_sz, num_layers=2, hidden_size=256, batch_first=True, bidirectional=True)
+            self._lm_g = nn.LSTM(input_size=in_sz, num_layers=2, hidden_size=256, batch_first=True, bidirectional=True)
+            self._use_cond = True
+        else:
+            ext = 0
+            self._lm_t = nn.Linear(1, 1)
+            self._lm_g = nn.Linear(1, 1)
+            self._use_cond = False
+        self._pframes = 1
+        self._lr = lr
+        self._max_pitch = max_pitch
+        self._max_dur = max_duration
+        self._phon_emb_t = nn.Embedding(num_phones + 1, 64, padding_idx=0)
+        self._phon_emb_g = nn.Embedding(num_phones + 1, 64, padding_idx=0)
+        self._speaker_emb_t = nn.Embedding(num_speakers + 1, 128, padding_idx=0)
+        self._speaker_emb_g = nn.Embedding(num_speakers + 1, 128, padding_idx=0)
+        cnn_t, cnn_g = [], []
+        inp = 64
+        for _ in range(3):
+            cnn_t += [ConvNorm(inp, 256, kernel_size=3, padding=1, w_init_gain='tanh'), nn.Tanh()]
+            cnn_g += [ConvNorm(inp, 256, kernel_size=3, padding=1, w_init_gain='tanh'), nn.Tanh()]
+            inp = 256
+        self._char_cnn_t = nn.ModuleList(cnn_t)
+        self._char_cnn_g = nn.ModuleList(cnn_g)
+        self._char_rnn_t = nn.LSTM(input_size=256, hidden_size=256, num_layers=2, bidirectional=True, batch_first=True)
+        self._char_rnn_g = nn.LSTM(input_size=256, hidden_size=256, num_layers=2, bidirectional=True, batch_first=True)
+        self._dur_rnn = nn.LSTM(input_size=512 + 128 + ext, hidden_size=256, num_layers=2, bidirectional=True, batch_first=True)
+        self._dur_output = LinearNorm(512, max_duration + 1)
+        self._pitch_rnn = nn.LSTM(input_size=512 + 128 + ext, hidden_size=256, num_layers=2, bidirectional=True, batch_first=True)
+        self._pitch_output = LinearNorm(512, 2)
+        self._cond_rnn = nn.LSTM(input_size=512 + 128 + ext + 1, hidden_size=64, num_layers=2, bidirectional=True, batch_first=True)
+        self._cond_output = LinearNorm(128, 80)
+        self._hip = {}
+
+    def _lstm(self, name):
+        if name not in self._hip:
+            self._hip[name] = LSTMHip(getattr(self, name))
+        return self._hip[name]
+
+    def _cnn(self, name):
+        if name not in self._hip:
+            ml = getattr(self, name)
+            self._hip[name] = _ConvStack([(ml[0].conv, None), (ml[2].conv, None), (ml[4].conv, None)])
+        return self._hip[name]
+
+    @torch.jit.ignore
+    def _get_device(self):
+        p = self._dur_output.linear_layer.weight
+        if p.device.type == 'cpu':
+            raise _lib.TTSCError('Languasito2: parameters live on the CPU; move the module to a HIP device (no CPU path)')
+        return p.device
+
+    def _text_stack(self, which, x_char, x_speaker, lengths, X, hf_cond):
+        emb = getattr(self, '_phon_emb_' + which).weight[x_char]
+        spk = getattr(self, '_speaker_emb_' + which).weight[x_speaker]       # [B,1,128]
+        h = _cnn_forward(self._cnn('_char_cnn_' + which), emb, lengths)
+        h = self._lstm('_char_rnn_' + which)(h, lengths=lengths)
+        h = torch.cat([h, spk.expand(-1, h.shape[1], -1)], dim=-1)
+        if self._use_cond:
+            x_words = X.get('x_words')
+            if X.get('x_tok_ids') is not None:
+                raise NotImplementedError('conditioning=hf:<model>: supply X["x_words"] ([B,Nw,768] encoder states per word); '
+                                          'pretrained encoders cannot be downloaded here (SURVEY.md §2.1)')
+            cond = self._lstm('_lm_' + which)(x_words.to(h.device).float())
+            p2w = X['x_phon2word'].to(h.device)
+            sel = torch.gather(cond, 1, p2w[:, :, None].expand(-1, -1, cond.shape[2]))
+            h = torch.cat([h, sel], dim=-1)
+        return h.contiguous()
+
+    def inference(self, X, hf_cond=None, return_aux=False):
+        """modules.py:1001-1009.  X: 'x_char' long [B,N] (0 = pad), 'x_speaker' long [B,1].  Returns conditioning [B,F,80]
+        (zero rows beyond each utterance's own frame count); X['y_frame2phone'] / X['y_pitch'] are (re)written like
+        the reference does."""
+        X.pop('y_frame2phone', None)
+        dev = self._get_device()
+        x_char = X['x_char'].to(dev)
+        x_speaker = X['x_speaker'].to(dev)
+        B, N = x_char.shape
+        lengths = (x_char != 0).sum(dim=1).tolist() if B > 1 else [N]
+        with torch.no_grad():
+            hcs = self._text_stack('t', x_char, x_speaker, lengths, X, hf_cond)
+            hd = self._lstm('_dur_rnn')(hcs, lengths=lengths)
+            out_dur = linear_hip(hd, self._dur_output.linear_layer.weight, self._dur_output.linear_layer.bias)
+            durs = torch.argmax(out_dur, dim=-1).cpu().numpy()           # device->host sync, as modules.py:946
+            f2p = []
+            for b in range(B):
+                a = []
+                for p in range(lengths[b]):
+                    a.extend([p] * int(durs[b, p]))
+                f2p.append(a)
+            X['y_frame2phone'] = f2p
+            hexp, flens = _expand_rows(hcs, f2p)
+            F_ = hexp.shape[1]
+            if F_ == 0:
+                X['y_pitch'] = torch.zeros((B, 0), device=dev)
+                cond = torch.zeros((B, 0, 80), device=dev)
+                return (cond, durs, flens) if return_aux else cond
+            hp = self._lstm('_pitch_rnn')(hexp, lengths=flens)
+            op = linear_hip(hp, self._pitch_output.linear_layer.weight, self._pitch_output.linear_layer.bias, act='sigmoid')
+            vuv = torch.round(op[:, :, 1])
+            pitch = (op[:, :, 0] * self._max_pitch) * vuv
+            X['y_pitch'] = pitch
+            g = self._text_stack('g', x_char, X['x_speaker'].to(dev), lengths, X, hf_cond)
+            g, _ = _expand_rows(g, f2p)
+            g = torch.cat([g, (pitch / self._max_pitch).unsqueeze(2)], dim=-1).contiguous()
+            g = self._lstm('_cond_rnn')(g, lengths=flens)
+            cond = linear_hip(g, self._cond_output.linear_layer.weight, self._cond_output.linear_layer.bias)
+            if B > 1:
+                fmask = (torch.arange(F_, device=dev)[None, :] < torch.as_tensor(flens, device=dev)[:, None]).float()
+                cond = cond * fmask[:, :, None]
+        return (cond, durs, flens) if return_aux else cond
+
+    @torch.jit.ignore
+    def save(self, path):
+        torch.save(self.state_dict(), path)
+
+    @torch.jit.ignore
+    def load(self, path):
+        self.load_state_dict(torch.load(path, map_location='cpu'))
