@@ -74,6 +74,12 @@ int64_t ttsc_conv1d_out_len(const ttsc_conv1d* c, int64_t Lin);
 /* x_dev [B,Cin,Lin] -> y_dev [B,Cout,Lout]; resid_dev NULL or [B,Cout,Lout]; ep NULL = plain conv */
 int ttsc_conv1d_forward(const ttsc_conv1d* c, const float* x_dev, int32_t B, int64_t Lin, float* y_dev,
                         const float* resid_dev, const ttsc_conv1d_epilogue* ep, void* stream);
+/* ragged batch: in_len_dev / out_len_dev int32 [B] (device) give each utterance's valid input / output length inside
+ * the padded [B,C,L] tensors; input beyond in_len[b] reads as zero (== the utterance run alone), tiles wholly beyond
+ * out_len[b] are skipped (their output is unspecified).  NULL = dense. */
+int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x_dev, int32_t B, int64_t Lin, float* y_dev,
+                               const float* resid_dev, const ttsc_conv1d_epilogue* ep, const int32_t* in_len_dev,
+                               const int32_t* out_len_dev, void* stream);
 void ttsc_conv1d_destroy(ttsc_conv1d* c);
 
 /* ------------------------------------------------------------------------------------------------
@@ -110,6 +116,11 @@ size_t ttsc_hifigan_workspace_bytes(const ttsc_hifigan* g, int32_t B, int64_t T)
 /* mel_dev [B,num_mels,T] -> wav_dev [B,1,out_len(T)] (tanh output in (-1,1)) */
 int ttsc_hifigan_forward(ttsc_hifigan* g, const float* mel_dev, int32_t B, int64_t T, float* wav_dev,
                          void* workspace_dev, size_t workspace_bytes, void* stream);
+/* ragged batch: frames_host int32 [B] (HOST pointer, copied) = valid mel frames per utterance (<= T).  Every layer masks
+ * its input beyond the utterance's own length, so wav_dev[b, 0, :out_len(frames[b])] equals that utterance run alone
+ * and padding-only tiles are skipped.  The workspace must hold ttsc_hifigan_workspace_bytes(g,B,T) bytes. */
+int ttsc_hifigan_forward_ragged(ttsc_hifigan* g, const float* mel_dev, int32_t B, int64_t T, const int32_t* frames_host,
+                                float* wav_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 /* algorithmic FLOPs (2 x MAC) of one forward at (B, T): the roofline numerator used by bench.py */
 int ttsc_hifigan_algorithmic_flops(const ttsc_hifigan* g, int32_t B, int64_t T, double* flops_out);
 void ttsc_hifigan_destroy(ttsc_hifigan* g);

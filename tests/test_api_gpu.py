@@ -1,0 +1,92 @@
+"""GPU: Cubegan + TTSCube API — checkpoint layout, end-to-end parity against the oracle chain
+(Languasito2 oracle -> HiFi-GAN oracle -> int16), batched == per-sentence, rank sharding."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from oracle import hifigan_ref as R
+from oracle import meldecoder_ref as M
+
+pytestmark = pytest.mark.gpu
+
+
+class _Enc:
+    def __init__(self):
+        self.phon2int = {p: i for i, p in enumerate('a b c d e f g h i j k l m n o p'.split())}
+        self.speaker2int = {'s0': 0, 's1': 1}
+        self.max_pitch = 280
+        self.max_duration = 7
+
+
+def _make_model_dir(tmp_path):
+    """Writes <dir>/cubegan.{yaml,encodings,model} exactly as scripts/train_cubegan.py:80-91 + export_model.py:12-27 do."""
+    from ttscube_amd.io_utils.io_cubegan import CubeganEncodings
+    from ttscube_amd.networks.cubegan import Cubegan
+    enc = CubeganEncodings()
+    e = _Enc()
+    enc.phon2int, enc.speaker2int, enc.max_pitch, enc.max_duration = e.phon2int, e.speaker2int, e.max_pitch, e.max_duration
+    base = os.path.join(str(tmp_path), 'cubegan')
+    enc.save(base + '.encodings')
+    yaml.dump({'sample_rate': 24000, 'hop_size': 240, 'conditioning': None}, open(base + '.yaml', 'w'))
+    model = Cubegan(enc, conditioning=None, train=True)   # training layout: _generator, _languasito, _mpd, _msd, _dummy
+    keys = list(model.state_dict().keys())
+    assert any(k.startswith('_mpd.') for k in keys) and any(k.startswith('_msd.') for k in keys) and '_dummy.weight' in keys
+    lsd = M.fill_state_dict(M.named_shapes(model._languasito), 5)
+    gsd = R.synthetic_state_dict(dict(R.CONFIG_V1), seed=6)
+    sd = model.state_dict()
+    sd.update({'_languasito.' + k: v for k, v in lsd.items()})
+    sd.update({'_generator.' + k: v for k, v in gsd.items()})
+    model.load_state_dict(sd, strict=True)
+    # export_model.py:21-25 drops the discriminators and the dummy optimiser target
+    del model._mpd, model._msd, model._dummy
+    model.save(base + '.model')
+    return base, lsd, gsd
+
+
+def test_ttscube_end_to_end_matches_oracle_chain(tmp_path):
+    from ttscube_amd.api import TTSCube
+    base, lsd, gsd = _make_model_dir(tmp_path)
+    tts = TTSCube(base, None)
+    text = 'a b c | d e f g | h a'
+    audio = tts(text, speaker='s1')
+    assert audio.dtype == np.int16 and audio.ndim == 1
+    e = _Enc()
+    x_char = torch.tensor([[e.phon2int[p] + 1 for p in text.replace('|', ' ').split()]])
+    with torch.no_grad():
+        cond, durs, _ = M.languasito2_inference(lsd, x_char, torch.tensor([[2]]), e.max_pitch)
+        ref = R.generator_forward(R.fold_state_dict(gsd), dict(R.CONFIG_V1), cond.permute(0, 2, 1))
+    ref16 = np.asarray(ref.numpy().squeeze() * 32767, dtype=np.int16)
+    assert audio.shape == ref16.shape == (240 * sum(durs) + 64,)
+    assert np.abs(audio.astype(np.int32) - ref16.astype(np.int32)).max() <= 4   # 1e-4 of full scale = 3.3 LSB
+
+
+def test_batched_synthesis_equals_per_sentence_and_sharding(tmp_path):
+    from ttscube_amd.api import TTSCube
+    base, _, _ = _make_model_dir(tmp_path)
+    tts = TTSCube(base, None)
+    rng = np.random.RandomState(0)
+    syms = 'a b c d e f g h i j k l m n o p'.split()
+    texts = [' '.join(rng.choice(syms, size=n)) for n in (9, 3, 14, 6, 11)]
+    batch = tts.synthesize_batch(texts, speaker='s0', max_batch=3)
+    for t, got in zip(texts, batch):
+        solo = tts(t, speaker='s0')
+        assert got.shape == solo.shape and np.array_equal(got, solo)
+    # utterance sharding over ranks: the union of the shards is the whole list, in order, no collectives involved
+    shards = [TTSCube.shard(texts, r, 2) for r in range(2)]
+    assert shards[0] + shards[1] == texts
+
+
+def test_cubegan_load_is_non_strict_and_device_checked(tmp_path):
+    from ttscube_amd._lib import TTSCError
+    from ttscube_amd.io_utils.io_cubegan import CubeganEncodings
+    from ttscube_amd.networks.cubegan import Cubegan
+    base, _, _ = _make_model_dir(tmp_path)
+    enc = CubeganEncodings(base + '.encodings')
+    m = Cubegan(enc, conditioning=None, train=True)   # exported .model lacks _mpd/_msd/_dummy: strict=False load (cubegan.py:319)
+    m.load(base + '.model')
+    with pytest.raises(TTSCError):
+        m.inference({'x_char': torch.tensor([[1, 2]]), 'x_speaker': torch.tensor([[1]])})   # parameters on CPU

@@ -56,6 +56,8 @@ SIGNATURES = {
     'ttsc_conv1d_out_len': (C.c_int64, [C.c_void_p, C.c_int64]),
     'ttsc_conv1d_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
                                       C.POINTER(Conv1dEpilogue), C.c_void_p]),
+    'ttsc_conv1d_forward_ragged': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
+                                             C.POINTER(Conv1dEpilogue), C.c_void_p, C.c_void_p, C.c_void_p]),
     'ttsc_conv1d_destroy': (None, [C.c_void_p]),
     'ttsc_hifigan_create': (C.c_int, [C.POINTER(HifiganCfg), C.POINTER(C.c_void_p)]),
     'ttsc_hifigan_set_weight': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
@@ -63,6 +65,8 @@ SIGNATURES = {
     'ttsc_hifigan_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int64]),
     'ttsc_hifigan_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_size_t, C.c_void_p]),
+    'ttsc_hifigan_forward_ragged': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_size_t, C.c_void_p]),
     'ttsc_hifigan_algorithmic_flops': (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_double)]),
     'ttsc_hifigan_destroy': (None, [C.c_void_p]),
     'ttsc_wavernn_create': (C.c_int, [C.POINTER(WavernnCfg), C.POINTER(C.c_void_p)]),

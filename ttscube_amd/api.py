@@ -1,0 +1,101 @@
+"""Mirror of cube/api.py: ``TTSCube.load(model_name)`` / ``TTSCube(model_path, phonemizer_path)`` /
+``tts(text, speaker) -> np.int16 @ 24 kHz``.
+
+The text front-end (phonemizer network + tokenizers, cube/io_utils/io_text.py) is outside the hot path (SURVEY.md
+§2.1): pass ``text2feat`` = any callable ``text -> {'phones': [...], 'words': [...], 'phon2word': [...]}`` (the
+reference's Text2Feat* objects satisfy it); without one, the text is read as whitespace-separated phoneme symbols.
+New on top of the reference (B=1 only): ``synthesize_batch`` runs many sentences per call, length-bucketed, and
+``shard`` splits a sentence list across ranks (one process per GPU, no collectives)."""
+import os
+from pathlib import Path
+
+import numpy as np
+import torch
+import yaml
+
+from .io_utils.io_cubegan import CubeganCollate, CubeganEncodings
+from .networks.cubegan import Cubegan
+
+
+class PhoneText2Feat:
+    """Fallback front-end: 'text' is a whitespace-separated phoneme string; '|' separates words."""
+
+    def __call__(self, text):
+        words, phones, p2w = [], [], []
+        for wi, w in enumerate(text.split('|')):
+            words.append(w.strip())
+            for p in w.split():
+                phones.append(p)
+                p2w.append(wi)
+        return {'orig_text': text, 'words': words, 'phones': phones, 'phon2word': p2w}
+
+
+class TTSCube:
+    def __init__(self, model_path: str, phonemizer_path: str = None, text2feat=None, device='cuda:0'):
+        encodings = CubeganEncodings('{0}.encodings'.format(model_path))
+        conf = yaml.load(open('{0}.yaml'.format(model_path)), yaml.Loader)
+        cond_type = conf.get('conditioning')
+        self._model = Cubegan(encodings, conditioning=cond_type, train=False)
+        self._model.load('{0}.model'.format(model_path))
+        self._collate = CubeganCollate(encodings, conditioning_type=cond_type)
+        self._text2feat = text2feat if text2feat is not None else PhoneText2Feat()
+        self._model.eval()
+        self._model.to(device)
+
+    @staticmethod
+    def load(model_name: str, **kw):
+        base_name = '{0}/.ttscube/models/{1}'.format(str(Path.home()), model_name)
+        if not os.path.exists('{0}/cubegan.model'.format(base_name)):
+            raise FileNotFoundError('%s/cubegan.{model,yaml,encodings} not found and this build has no network access to '
+                                    'download it (cube/io_utils/repository.py:27-61); unpack the exported model there' % base_name)
+        return TTSCube('{0}/cubegan'.format(base_name), '{0}/phonemizer'.format(base_name), **kw)
+
+    def _example(self, text, speaker):
+        """The dummy-target example cube/api.py:47-57 builds around the front-end output."""
+        rez = {'meta': dict(self._text2feat(text))}
+        rez['meta']['speaker'] = speaker
+        rez['pitch'] = np.zeros((100))
+        rez['mgc'] = np.zeros((100, 80))
+        rez['meta']['words_left'] = []
+        rez['meta']['words_right'] = []
+        rez['meta']['frame2phon'] = [0] * 100
+        return rez
+
+    def __call__(self, text, speaker='none'):
+        """cube/api.py:45-66: one sentence -> int16 audio at 24 kHz."""
+        with torch.no_grad():
+            X = self._collate.collate_fn([self._example(text, speaker)])
+            for key in X:
+                if isinstance(X[key], torch.Tensor):
+                    X[key] = X[key].to(self._model.get_device())
+            audio = self._model.inference(X)
+            audio = audio.detach().cpu().numpy().squeeze()
+            return np.asarray(audio * 32767, dtype=np.int16)
+
+    def synthesize_batch(self, texts, speaker='none', max_batch=64):
+        """Many sentences -> list of int16 arrays (same order).  Sentences are sorted by phoneme count and run in
+        padded batches of up to `max_batch`; ragged lengths are handled inside the kernels (masked BiLSTMs), so each
+        result equals the single-sentence call."""
+        speakers = speaker if isinstance(speaker, (list, tuple)) else [speaker] * len(texts)
+        ex = [self._example(t, s) for t, s in zip(texts, speakers)]
+        order = sorted(range(len(ex)), key=lambda i: len(ex[i]['meta']['phones']))
+        out = [None] * len(ex)
+        with torch.no_grad():
+            for s in range(0, len(order), max_batch):
+                ids = order[s:s + max_batch]
+                X = self._collate.collate_fn([ex[i] for i in ids])
+                for key in X:
+                    if isinstance(X[key], torch.Tensor):
+                        X[key] = X[key].to(self._model.get_device())
+                wav, lens = self._model.inference(X, return_lengths=True)
+                wav = wav.detach().cpu().numpy()
+                for j, i in enumerate(ids):
+                    out[i] = np.asarray(wav[j, 0, :lens[j]] * 32767, dtype=np.int16)
+        return out
+
+    @staticmethod
+    def shard(items, rank, world_size):
+        """Contiguous utterance shard for one rank (inference is embarrassingly parallel: no collectives)."""
+        n = len(items)
+        lo, hi = rank * n // world_size, (rank + 1) * n // world_size
+        return items[lo:hi]

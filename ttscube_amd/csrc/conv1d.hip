@@ -29,6 +29,8 @@ struct ConvArgs {
     const float* resid;
     const float* wp;    // [ntaps][CinP/2][CoutP/32][64]
     const float* bias;  // [Cout] or null
+    const int* in_len;  // [B] per-utterance valid input length (ragged batches) or null
+    const int* out_len; // [B] per-utterance valid output length or null (tiles wholly beyond it are skipped)
     int Cin, CinP, Cout, CoutP;
     int Lin, Lout;
     int ntaps, tap_base, tap_step;
@@ -60,6 +62,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
     const int wn = wave % WN;
     const int b = blockIdx.z;
     const int q0 = a.q_lo + blockIdx.x * NT;
+    const int lin = a.in_len ? a.in_len[b] : a.Lin;   // positions >= lin read as zero (== that utterance run alone)
+    if (a.out_len && (long)q0 * a.out_stride + a.out_off >= a.out_len[b]) return;  // padding-only tile
     const int cot0 = (blockIdx.y * WM + wm) * MI;  // first 32-row tile of this wave
     const int cotN = a.CoutP >> 5;
     const int half = lane >> 5;
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
             for (int p = lane; p < a.span; p += 64) {
                 const int pos = lo + p;
                 float v = 0.f;
-                if (cok && pos >= 0 && pos < a.Lin) {
+                if (cok && pos >= 0 && pos < lin) {
                     v = xr[pos] * a.in_scale;
                     v = v > 0.f ? v : v * a.in_slope;
                 }
@@ -306,6 +310,12 @@ extern "C" int ttsc_conv1d_set_weight(ttsc_conv1d* c, const float* w, const floa
 
 extern "C" int ttsc_conv1d_forward(const ttsc_conv1d* c, const float* x, int32_t B, int64_t Lin, float* y,
                                    const float* resid, const ttsc_conv1d_epilogue* ep, void* stream) {
+    return ttsc_conv1d_forward_ragged(c, x, B, Lin, y, resid, ep, nullptr, nullptr, stream);
+}
+
+extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, int32_t B, int64_t Lin, float* y,
+                                          const float* resid, const ttsc_conv1d_epilogue* ep, const int32_t* in_len_dev,
+                                          const int32_t* out_len_dev, void* stream) {
     TTSC_REQUIRE(c && x && y, "ttsc_conv1d_forward: null argument");
     if (!c->has_weight) {
         set_error("ttsc_conv1d_forward: weights not set");
@@ -324,6 +334,8 @@ extern "C" int ttsc_conv1d_forward(const ttsc_conv1d* c, const float* x, int32_t
         a.resid = resid;
         a.wp = ph.wp_dev;
         a.bias = c->bias_dev;
+        a.in_len = in_len_dev;
+        a.out_len = out_len_dev;
         a.Cin = g.in_channels;
         a.CinP = c->CinP;
         a.Cout = g.out_channels;

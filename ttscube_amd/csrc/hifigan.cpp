@@ -174,9 +174,13 @@ static size_t buf_elems(const ttsc_hifigan* g, int32_t B, int64_t T) {
     return (size_t)round_up((int64_t)mx, 64);
 }
 
+static size_t len_table_bytes(const ttsc_hifigan* g, int32_t B) {
+    return (size_t)round_up((int64_t)(g->cfg.num_upsamples + 1) * B * sizeof(int32_t), 256);
+}
+
 extern "C" size_t ttsc_hifigan_workspace_bytes(const ttsc_hifigan* g, int32_t B, int64_t T) {
     if (!g || B <= 0 || T <= 0) return 0;
-    return 4 * buf_elems(g, B, T) * sizeof(float);
+    return 4 * buf_elems(g, B, T) * sizeof(float) + len_table_bytes(g, B);
 }
 
 extern "C" int ttsc_hifigan_algorithmic_flops(const ttsc_hifigan* g, int32_t B, int64_t T, double* out) {
@@ -200,6 +204,11 @@ extern "C" int ttsc_hifigan_algorithmic_flops(const ttsc_hifigan* g, int32_t B, 
 
 extern "C" int ttsc_hifigan_forward(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, float* wav, void* ws,
                                     size_t ws_bytes, void* stream) {
+    return ttsc_hifigan_forward_ragged(g, mel, B, T, nullptr, wav, ws, ws_bytes, stream);
+}
+
+extern "C" int ttsc_hifigan_forward_ragged(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, const int32_t* frames,
+                                           float* wav, void* ws, size_t ws_bytes, void* stream) {
     TTSC_REQUIRE(g && mel && wav && ws, "ttsc_hifigan_forward: null argument");
     TTSC_REQUIRE(B > 0 && T > 0, "ttsc_hifigan_forward: bad B/T (%d, %lld)", B, (long long)T);
     {
@@ -222,11 +231,30 @@ extern "C" int ttsc_hifigan_forward(ttsc_hifigan* g, const float* mel, int32_t B
     float* XT = X + be;
     float* R = XT + be;
     float* S = R + be;
+    // per-stage valid lengths of every utterance: row 0 = mel frames, row i+1 = samples after upsample i
+    const int32_t* lens[TTSC_HIFIGAN_MAX_UPS + 1] = {nullptr};
+    if (frames) {
+        std::vector<int32_t> tab((size_t)(c.num_upsamples + 1) * B);
+        for (int b = 0; b < B; ++b) {
+            TTSC_REQUIRE(frames[b] >= 0 && frames[b] <= T, "ttsc_hifigan_forward_ragged: frames[%d]=%d outside [0,%lld]", b, frames[b], (long long)T);
+            int64_t Lb = frames[b];
+            tab[b] = (int32_t)Lb;
+            for (int i = 0; i < c.num_upsamples; ++i) {
+                const int u = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
+                Lb = Lb > 0 ? (Lb - 1) * u - 2 * ((k - u) / 2) + k : 0;
+                tab[(size_t)(i + 1) * B + b] = (int32_t)Lb;
+            }
+        }
+        int32_t* dtab = (int32_t*)(S + be);
+        TTSC_HIP_CHECK(hipMemcpyAsync(dtab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, (hipStream_t)stream));
+        TTSC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));  // `tab` is pageable host memory going out of scope
+        for (int i = 0; i <= c.num_upsamples; ++i) lens[i] = dtab + (size_t)i * B;
+    }
     auto layer = [&](const std::string& n) -> const ttsc_conv1d* { return g->layers.at(n)->c; };
     int rc;
 
     ttsc_conv1d_epilogue ep{1.f, 1.f, 1.f, TTSC_ACT_NONE, 0};
-    rc = ttsc_conv1d_forward(layer("conv_pre"), mel, B, T, S, nullptr, &ep, stream);
+    rc = ttsc_conv1d_forward_ragged(layer("conv_pre"), mel, B, T, S, nullptr, &ep, lens[0], lens[0], stream);
     if (rc) return rc;
     int64_t L = T;
     float sum_scale = 1.f;  // pending division by nk of the previous stage's block sum
@@ -234,7 +262,7 @@ extern "C" int ttsc_hifigan_forward(ttsc_hifigan* g, const float* mel, int32_t B
         // x = ups[i](lrelu(x / nk_prev, 0.1))
         ttsc_conv1d_epilogue eu{sum_scale, 0.1f, 1.f, TTSC_ACT_NONE, 0};
         const ttsc_conv1d* up = layer("ups." + std::to_string(i));
-        rc = ttsc_conv1d_forward(up, S, B, L, X, nullptr, &eu, stream);
+        rc = ttsc_conv1d_forward_ragged(up, S, B, L, X, nullptr, &eu, lens[i], lens[i + 1], stream);
         if (rc) return rc;
         L = ttsc_conv1d_out_len(up, L);
         for (int j = 0; j < c.num_kernels; ++j) {
@@ -247,16 +275,16 @@ extern "C" int ttsc_hifigan_forward(ttsc_hifigan* g, const float* mel, int32_t B
                 ttsc_conv1d_epilogue e2{1.f, 0.1f, 1.f, TTSC_ACT_NONE, (last && j > 0) ? 1 : 0};
                 if (c.resblock == 1) {
                     ttsc_conv1d_epilogue e1{1.f, 0.1f, 1.f, TTSC_ACT_NONE, 0};
-                    rc = ttsc_conv1d_forward(layer(rb + ".convs1." + std::to_string(m)), src, B, L, XT, nullptr, &e1, stream);
+                    rc = ttsc_conv1d_forward_ragged(layer(rb + ".convs1." + std::to_string(m)), src, B, L, XT, nullptr, &e1, lens[i + 1], lens[i + 1], stream);
                     if (rc) return rc;
-                    rc = ttsc_conv1d_forward(layer(rb + ".convs2." + std::to_string(m)), XT, B, L, dst, src, &e2, stream);
+                    rc = ttsc_conv1d_forward_ragged(layer(rb + ".convs2." + std::to_string(m)), XT, B, L, dst, src, &e2, lens[i + 1], lens[i + 1], stream);
                     if (rc) return rc;
                 } else {
                     // ResBlock2 reads src both as conv input and residual; dst != src unless m>0 && !last (R->R),
                     // where an in-place update would race with neighbouring tiles' halo reads -> ping-pong via XT.
                     float* d2 = dst;
                     if (dst == src) d2 = XT;
-                    rc = ttsc_conv1d_forward(layer(rb + ".convs." + std::to_string(m)), src, B, L, d2, src, &e2, stream);
+                    rc = ttsc_conv1d_forward_ragged(layer(rb + ".convs." + std::to_string(m)), src, B, L, d2, src, &e2, lens[i + 1], lens[i + 1], stream);
                     if (rc) return rc;
                     if (d2 != dst) std::swap(R, XT);
                 }
@@ -265,6 +293,6 @@ extern "C" int ttsc_hifigan_forward(ttsc_hifigan* g, const float* mel, int32_t B
         sum_scale = 1.f / (float)c.num_kernels;
     }
     ttsc_conv1d_epilogue epost{sum_scale, 0.01f, 1.f, TTSC_ACT_TANH, 0};
-    rc = ttsc_conv1d_forward(layer("conv_post"), S, B, L, wav, nullptr, &epost, stream);
+    rc = ttsc_conv1d_forward_ragged(layer("conv_post"), S, B, L, wav, nullptr, &epost, lens[c.num_upsamples], lens[c.num_upsamples], stream);
     return rc;
 }

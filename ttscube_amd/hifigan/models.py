@@ -187,16 +187,18 @@ class Generator(nn.Module):
         _lib.check(_lib.lib().ttsc_hifigan_algorithmic_flops(self._handle, B, T, C.byref(out)), 'algorithmic_flops')
         return out.value
 
-    def forward(self, x):
-        """x: [B, num_mels, T] fp32 on a HIP device -> [B, 1, L]."""
+    def forward(self, x, frames=None):
+        """x: [B, num_mels, T] fp32 on a HIP device -> [B, 1, L].  frames (optional, list[int] per utterance): valid mel
+        frames of a padded batch — every layer then masks beyond the utterance's own length, so
+        y[b, 0, :out_len(frames[b])] equals that utterance run alone (ragged batching; not in the reference, B=1)."""
         if not x.is_cuda:
             raise _lib.TTSCError('Generator.forward: input must live on a HIP device (got %s); no CPU path' % x.device)
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             from .autograd import generator_forward_with_grad
             return generator_forward_with_grad(self, x)
-        return self._forward_hip(x)
+        return self._forward_hip(x, frames)
 
-    def _forward_hip(self, x):
+    def _forward_hip(self, x, frames=None):
         L = _lib.lib()
         self._sync()
         x = x.detach().float().contiguous()
@@ -208,8 +210,13 @@ class Generator(nn.Module):
             self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
         y = torch.empty((B, 1, Lout), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            _lib.check(L.ttsc_hifigan_forward(self._handle, _lib.dev_ptr(x), B, T, _lib.dev_ptr(y), _lib.dev_ptr(self._ws),
-                                              self._ws.numel() * 4, _lib.current_stream()), 'ttsc_hifigan_forward')
+            fr = None
+            if frames is not None:
+                assert len(frames) == B
+                fr = (C.c_int32 * B)(*[int(f) for f in frames])
+            _lib.check(L.ttsc_hifigan_forward_ragged(self._handle, _lib.dev_ptr(x), B, T, fr, _lib.dev_ptr(y),
+                                                     _lib.dev_ptr(self._ws), self._ws.numel() * 4, _lib.current_stream()),
+                       'ttsc_hifigan_forward')
         return y
 
     def remove_weight_norm(self):

@@ -1,0 +1,93 @@
+"""Mirror of cube/io_utils/io_cubegan.py:112-231: ``CubeganEncodings`` (same JSON file format) and
+``CubeganCollate.collate_fn`` (same batch-dict keys, dtypes and padding values — SURVEY.md §8b).  Dataset reading
+(librosa) is outside the hot path; external text conditioning (fastText / HF encoders) needs downloads and is not
+available here — pass pre-computed ``x_words`` instead."""
+import json
+
+import numpy as np
+import torch
+
+
+class CubeganEncodings:
+    def __init__(self, filename: str = None):
+        self.speaker2int = {}
+        self.phon2int = {}
+        self.max_duration = 0
+        self.max_pitch = 0
+        if filename is not None:
+            self.load(filename)
+
+    def compute(self, dataset):
+        """io_cubegan.py:120-137 (np.long -> np.int64 for numpy >= 1.24)."""
+        for example in dataset:
+            speaker = example['meta']['speaker']
+            if speaker not in self.speaker2int:
+                self.speaker2int[speaker] = len(self.speaker2int)
+            for phone in example['meta']['phones']:
+                if phone not in self.phon2int:
+                    self.phon2int[phone] = len(self.phon2int)
+            self.max_pitch = max(self.max_pitch, np.max(example['pitch']))
+            durs = np.zeros((len(example['meta']['phones'])), dtype=np.int64)
+            for item in example['meta']['frame2phon']:
+                durs[item] += 1
+            self.max_duration = max(self.max_duration, np.max(durs))
+
+    def load(self, filename: str):
+        input_obj = json.load(open(filename))
+        self.speaker2int = input_obj['speaker2int']
+        self.phon2int = input_obj['phon2int']
+        self.max_pitch = input_obj['max_pitch']
+        self.max_duration = input_obj['max_duration']
+
+    def save(self, filename: str):
+        json.dump({'speaker2int': self.speaker2int, 'phon2int': self.phon2int, 'max_duration': int(self.max_duration),
+                   'max_pitch': int(self.max_pitch)}, open(filename, 'w'))
+
+
+class CubeganCollate:
+    def __init__(self, encodings: CubeganEncodings, conditioning_type=None, training=True):
+        self._encodings = encodings
+        self._ignore_index = int(max(encodings.max_pitch, encodings.max_duration) + 1)
+        self._training = training
+        if conditioning_type not in (None, 'none'):
+            raise NotImplementedError("conditioning_type=%r needs a downloaded fastText / HuggingFace model; this build "
+                                      "supports conditioning=None (SURVEY.md §2.1)" % (conditioning_type,))
+        self._conditioning_type = None
+
+    def collate_fn(self, batch):
+        """io_cubegan.py:169-231."""
+        max_char = max(len(e['meta']['phones']) for e in batch)
+        max_mel = max(e['mgc'].shape[0] for e in batch)
+        B = len(batch)
+        x_char = np.zeros((B, max_char))
+        x_p2w = np.zeros((B, max_char), dtype=np.int64)
+        y_mgc = np.ones((B, max_mel, 80)) * -5
+        x_speaker = np.zeros((B, 1))
+        y_dur = np.zeros((B, max_char))
+        y_pitch = np.zeros((B, max_mel))
+        y_frame2phone = []
+        y_audio = np.zeros((B, max_mel * 240), dtype=np.float64)
+        for ii, example in enumerate(batch):
+            y_mgc[ii, :example['mgc'].shape[0], :] = example['mgc']
+            x_speaker[ii] = self._encodings.speaker2int[example['meta']['speaker']] + 1
+            for jj, phoneme in enumerate(example['meta']['phones']):
+                if phoneme in self._encodings.phon2int:
+                    x_char[ii, jj] = self._encodings.phon2int[phoneme] + 1
+            y_frame2phone.append(example['meta']['frame2phon'])
+            p2w = example['meta'].get('phon2word', [])
+            x_p2w[ii, :len(p2w)] = np.array(p2w, dtype=np.int64)
+            for phone_idx in y_frame2phone[-1]:
+                y_dur[ii, phone_idx] += 1
+            y_dur[ii, len(example['meta']['phones']):] = self._ignore_index
+            y_pitch[ii, :example['pitch'].shape[0]] = example['pitch']
+            if 'audio' in example:
+                m = min(y_audio.shape[1], example['audio'].shape[0])
+                y_audio[ii, :m] = example['audio'][:m]
+        for ii, example in enumerate(batch):
+            m = len(example['meta']['phones'])
+            y_dur[ii, :m] = np.clip(y_dur[ii, :m], 0, 100)
+        return {'x_char': torch.tensor(x_char, dtype=torch.long), 'x_words': None, 'x_tok_ids': None, 'x_word2tok': None,
+                'x_phon2word': torch.tensor(x_p2w), 'x_speaker': torch.tensor(x_speaker, dtype=torch.long),
+                'y_mgc': torch.tensor(y_mgc, dtype=torch.float), 'y_frame2phone': y_frame2phone,
+                'y_pitch': torch.tensor(y_pitch, dtype=torch.long), 'y_dur': torch.tensor(y_dur, dtype=torch.long),
+                'y_audio': torch.tensor(y_audio, dtype=torch.float)}

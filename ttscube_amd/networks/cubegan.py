@@ -1,0 +1,85 @@
+"""Mirror of cube/networks/cubegan.py: ``Cubegan`` = Languasito2 (text -> 80-d conditioning) + HiFi-GAN Generator.
+Same constructor, ``inference`` / ``forward`` / ``load`` (strict=False) / ``save`` / ``get_device`` and state_dict
+prefixes (`_generator.`, `_languasito.`, `_mpd.`, `_msd.`, `_dummy.`).  The generator config is resolved from the JSON
+shipped in this package (same keys as the reference's CWD-relative `hifigan/config_v1.json`, cubegan.py:41), or from a
+`hifigan/config_v1.json` in the CWD when one exists."""
+import json
+import os
+
+import torch
+import torch.nn as nn
+
+from ..hifigan.env import AttrDict
+from ..hifigan.models import Generator
+from .modules import Languasito2
+
+
+def _load_hifigan_config():
+    for p in ('hifigan/config_v1.json', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'hifigan', 'config_v1.json')):
+        if os.path.exists(p):
+            return AttrDict(json.load(open(p)))
+    raise FileNotFoundError('hifigan/config_v1.json')
+
+
+class Cubegan(nn.Module):
+    def __init__(self, encodings, lr: float = 2e-4, conditioning=None, train=True):
+        super().__init__()
+        self._current_lr = lr
+        self._learning_rate = lr
+        self._global_step = 0
+        self._encodings = encodings
+        self._val_loss = 9999
+        self._conditioning = conditioning
+        self._loaded_optimizer_states = None
+        cond_type = conditioning.split(':')[0] if conditioning not in (None, 'none') else None
+        self._cond_type = cond_type
+        self._generator = Generator(_load_hifigan_config())
+        if train:
+            from ..hifigan.discriminators import MultiPeriodDiscriminator, MultiScaleDiscriminator
+            self._mpd = MultiPeriodDiscriminator()
+            self._msd = MultiScaleDiscriminator()
+        self._languasito = Languasito2(len(encodings.phon2int), len(encodings.speaker2int), encodings.max_pitch,
+                                       encodings.max_duration, cond_type=cond_type)
+        self._hf = None
+        if cond_type == 'hf':
+            raise NotImplementedError("conditioning='hf:<model>' needs a downloaded HuggingFace encoder (no network here); "
+                                      "use conditioning=None, or 'fasttext'-style pre-computed X['x_words']")
+        if train:
+            self._dummy = nn.Linear(1, 1)
+        self._loss_l1 = nn.L1Loss()
+        self.automatic_optimization = False
+
+    def inference(self, X, return_lengths=False):
+        """cubegan.py:74-83: text -> conditioning (predicted durations/pitch) -> waveform [B,1,L] in (-1,1).
+        With a padded batch (B>1, new capability) `return_lengths=True` also returns each utterance's sample count."""
+        with torch.no_grad():
+            cond, _, flens = self._languasito.inference(X, return_aux=True)
+            if cond.shape[1] == 0:
+                cond = torch.zeros((cond.shape[0], 1, cond.shape[2]), device=self.get_device())
+                flens = [1] * cond.shape[0]
+            wav = self._generator(cond.permute(0, 2, 1).contiguous(), frames=flens if cond.shape[0] > 1 else None)
+        if return_lengths:
+            return wav, [self._generator.out_len(f) if f > 0 else 0 for f in flens]
+        return wav
+
+    def forward(self, X):
+        """cubegan.py:65-72: forced alignment path (X carries y_frame2phone / y_pitch)."""
+        from .training import languasito_forward
+        with torch.no_grad():
+            _, _, _, cond = languasito_forward(self._languasito, X)
+            return self._generator(cond.permute(0, 2, 1).contiguous())
+
+    @torch.jit.ignore
+    def save(self, path):
+        torch.save(self.state_dict(), path)
+
+    @torch.jit.ignore
+    def load(self, path):
+        self.load_state_dict(torch.load(path, map_location='cpu'), strict=False)
+
+    @staticmethod
+    def _compute_lr(initial_lr, delta, step):
+        return initial_lr / (1 + delta * step)
+
+    def get_device(self):
+        return self._languasito._get_device()
