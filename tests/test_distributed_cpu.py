@@ -1,0 +1,79 @@
+"""CPU, world_size=2, gloo: the flat-bucket gradient exchange used by the data-parallel training step."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ttscube_amd.distributed import FlatBucketReducer, broadcast_parameters
+    torch.manual_seed(100 + rank)                       # ranks start different on purpose
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    frozen = torch.nn.Linear(2, 2)                      # a parameter that never receives a grad
+    broadcast_parameters(net)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(8, 7, generator=g)
+    y = torch.randn(8, 3, generator=g)
+    xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]   # rank-distinct shard of the global batch
+    loss = ((net(xs) - ys) ** 2).mean()
+    loss.backward()
+    red = FlatBucketReducer(list(net.parameters()) + list(frozen.parameters()), bucket_mb=0.0001)  # forces several buckets
+    red.reduce()
+    q.put((rank, [p.grad.clone() for p in net.parameters()], [p.detach().clone() for p in net.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_allreduce_matches_single_process_gradient():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, grads, params = q.get(timeout=120)
+        res[r] = (grads, params)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # both ranks hold the same parameters (broadcast) and the same averaged gradients
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.allclose(a, b, atol=1e-7)
+    # ... equal to the gradient of the mean loss over the whole global batch computed in one process
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    with torch.no_grad():
+        for p, v in zip(net.parameters(), res[0][1]):
+            p.copy_(v)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(8, 7, generator=g)
+    y = torch.randn(8, 3, generator=g)
+    ((net(x) - y) ** 2).mean().backward()
+    for p, gr in zip(net.parameters(), res[0][0]):
+        assert torch.allclose(p.grad, gr, atol=1e-6)
+
+
+def test_utterance_sharding_is_a_partition():
+    from ttscube_amd.api import TTSCube
+    items = list(range(13))
+    for world in (1, 2, 4, 8):
+        parts = [TTSCube.shard(items, r, world) for r in range(world)]
+        assert sum(parts, []) == items
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1

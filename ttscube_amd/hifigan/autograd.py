@@ -1,5 +1,6 @@
-"""Training path of the Generator (placeholder until the conv dgrad/wgrad kernels land)."""
+"""Training path of the Generator: differentiable forward on torch-ROCm ops (see networks/training.py)."""
 
 
 def generator_forward_with_grad(gen, x):
-    raise NotImplementedError('Generator training (autograd) path is not built yet; wrap inference in torch.no_grad()')
+    from ..networks.training import generator_forward_train
+    return generator_forward_train(gen, x)

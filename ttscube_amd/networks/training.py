@@ -43,3 +43,246 @@ def wavernn_loss(net, X):
     logits = net._train_forward(Xt)
     L = logits.shape[1]
     return net._output_functions.loss(logits, gs[:, :L].to(logits.device))
+
+
+# =====================================================================================================================
+# Training steps (torch-ROCm autograd + explicit RCCL gradient exchange).
+#
+# Status (round 1): the backward pass runs through torch-ROCm (MIOpen) ops on the SAME parameter tensors the HIP
+# inference kernels read, exactly like the reference trains on a GPU (pl.Trainer -> torch autograd); what is new is
+# the explicit flat-bucket RCCL exchange (ttscube_amd/distributed.py) replacing Lightning's implicit DDP.  The
+# training forward is checked against the HIP inference path in tests/test_training_gpu.py (<= 1e-4 RMS).
+# =====================================================================================================================
+import itertools
+import random
+
+import torch.nn.functional as F
+
+from ..hifigan.models import ResBlock1
+
+
+def _wn(l):
+    """live weight-norm: w = g * v / ||v|| (so that gradients reach weight_g and weight_v)."""
+    if hasattr(l, 'weight'):
+        return l.weight
+    v, g = l.weight_v, l.weight_g
+    return g * v / v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, 1, 1)
+
+
+def generator_forward_train(gen, x):
+    """Differentiable HiFi-GAN generator forward (same math as `ttsc_hifigan_forward`), torch-ROCm ops."""
+    h = gen.h
+    x = F.conv1d(x, _wn(gen.conv_pre), gen.conv_pre.bias, padding=3)
+    nk = gen.num_kernels
+    for i, (u, k) in enumerate(zip(h['upsample_rates'], h['upsample_kernel_sizes'])):
+        x = F.leaky_relu(x, 0.1)
+        x = F.conv_transpose1d(x, _wn(gen.ups[i]), gen.ups[i].bias, stride=u, padding=(k - u) // 2)
+        xs = None
+        for j in range(nk):
+            rb = gen.resblocks[i * nk + j]
+            kr, ds = h['resblock_kernel_sizes'][j], h['resblock_dilation_sizes'][j]
+            r = x
+            if isinstance(rb, ResBlock1):
+                for c1, c2, d in zip(rb.convs1, rb.convs2, ds):
+                    xt = F.conv1d(F.leaky_relu(r, 0.1), _wn(c1), c1.bias, dilation=d, padding=d * (kr - 1) // 2)
+                    xt = F.conv1d(F.leaky_relu(xt, 0.1), _wn(c2), c2.bias, padding=(kr - 1) // 2)
+                    r = xt + r
+            else:
+                for c, d in zip(rb.convs, ds):
+                    r = F.conv1d(F.leaky_relu(r, 0.1), _wn(c), c.bias, dilation=d, padding=d * (kr - 1) // 2) + r
+            xs = r if xs is None else xs + r
+        x = xs / nk
+    x = F.leaky_relu(x)
+    x = F.conv1d(x, _wn(gen.conv_post), gen.conv_post.bias, padding=3)
+    return torch.tanh(x)
+
+
+def languasito_forward_train(lang, X):
+    """Differentiable Languasito2.forward (modules.py:996-999): (output_dur, output_pitch, output_vuv, conditioning)."""
+    dev = lang._get_device()
+    x_char, x_speaker = X['x_char'].to(dev), X['x_speaker'].to(dev)
+
+    def stack(which):
+        h = getattr(lang, '_phon_emb_' + which)(x_char).permute(0, 2, 1)
+        for layer in getattr(lang, '_char_cnn_' + which):
+            h = torch.tanh(F.conv1d(h, layer.conv.weight, layer.conv.bias, padding=1)) if hasattr(layer, 'conv') else h
+        h, _ = getattr(lang, '_char_rnn_' + which)(h.permute(0, 2, 1))
+        spk = getattr(lang, '_speaker_emb_' + which)(x_speaker)
+        return torch.cat([h, spk.repeat(1, h.shape[1], 1)], dim=-1)
+
+    def expand(x, alignments):
+        m = max(len(a) for a in alignments)
+        idx = torch.zeros((len(alignments), m), dtype=torch.long)
+        for b, a in enumerate(alignments):
+            idx[b, :len(a)] = torch.as_tensor(a)
+            idx[b, len(a):] = a[-1]
+        return torch.gather(x, 1, idx.to(x.device)[:, :, None].expand(-1, -1, x.shape[2]))
+
+    hcs = stack('t')
+    hd, _ = lang._dur_rnn(hcs)
+    out_dur = F.linear(hd, lang._dur_output.linear_layer.weight, lang._dur_output.linear_layer.bias)
+    hp, _ = lang._pitch_rnn(expand(hcs, X['y_frame2phone']))
+    op = F.linear(hp, lang._pitch_output.linear_layer.weight, lang._pitch_output.linear_layer.bias)
+    g = expand(stack('g'), X['y_frame2phone'])
+    pitch = X['y_pitch'].to(dev).float().unsqueeze(2) / lang._max_pitch
+    m = min(g.shape[1], pitch.shape[1])
+    g, _ = lang._cond_rnn(torch.cat([g[:, :m], pitch[:, :m]], dim=-1))
+    cond = F.linear(g, lang._cond_output.linear_layer.weight, lang._cond_output.linear_layer.bias)
+    return out_dur, torch.sigmoid(op[:, :, 0]), torch.sigmoid(op[:, :, 1]), cond
+
+
+def cubegan_param_groups(model):
+    """The three parameter groups of cubegan.py:275-298 (generator side, discriminators, text side)."""
+    l = model._languasito
+    g = list(itertools.chain(model._generator.parameters(), l._phon_emb_g.parameters(), l._speaker_emb_g.parameters(),
+                             l._char_cnn_g.parameters(), l._char_rnn_g.parameters(), l._lm_g.parameters(),
+                             l._cond_rnn.parameters(), l._cond_output.parameters()))
+    d = list(itertools.chain(model._msd.parameters(), model._mpd.parameters()))
+    t = list(itertools.chain(l._phon_emb_t.parameters(), l._speaker_emb_t.parameters(), l._char_cnn_t.parameters(),
+                             l._char_rnn_t.parameters(), l._lm_t.parameters(), l._dur_rnn.parameters(),
+                             l._dur_output.parameters(), l._pitch_rnn.parameters(), l._pitch_output.parameters()))
+    return g, d, t
+
+
+def cubegan_configure_optimizers(model):
+    """cubegan.py:275-311: AdamW(0.8,0.99) x3 + Adam(1e-6) on the dummy; restores `.opt.last` states when present
+    (the reference sets `_loaded_optimizer_state` but reads `_loaded_optimizer_states`, so its resume silently skips this)."""
+    g, d, t = cubegan_param_groups(model)
+    opt_g = torch.optim.AdamW(g, model._current_lr, betas=[0.8, 0.99])
+    opt_d = torch.optim.AdamW(d, model._current_lr, betas=[0.8, 0.99])
+    opt_t = torch.optim.AdamW(t, model._current_lr, betas=[0.8, 0.99])
+    opt_b = torch.optim.Adam(model._dummy.parameters(), lr=1e-6)
+    if model._loaded_optimizer_states is not None:
+        for k, opt in zip(['0', '1', '2', '3'], [opt_g, opt_d, opt_t, opt_b]):
+            if k in model._loaded_optimizer_states:
+                opt.load_state_dict(model._loaded_optimizer_states[k])
+        model._loaded_optimizer_states = None
+    return opt_g, opt_d, opt_t, opt_b
+
+
+def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
+    """Cubegan.training_step (cubegan.py:85-189): discriminator step, generator step (adv + feature + 45 x mel-L1),
+    text step (duration CE + pitch/vuv L1); one gradient exchange per backward pass (reducers = (g, d, t))."""
+    from ..hifigan.discriminators import discriminator_loss, feature_loss, generator_loss, mel_spectrogram
+    opt_g, opt_d, opt_t, opt_b = optimizers
+    rng = rng or random
+    dev = model.get_device()
+    lang = model._languasito
+    p_dur, p_pitch, p_vuv, conditioning = languasito_forward_train(lang, batch)
+    t_dur = batch['y_dur'].to(dev)
+    t_pitch = batch['y_pitch'].to(dev)
+    t_vuv = (t_pitch > 1).float()
+    m = min(t_dur.shape[1], p_dur.shape[1])
+    t_dur, p_dur = t_dur[:, :m], p_dur[:, :m, :]
+    m = min(t_pitch.shape[1], p_pitch.shape[1])
+    t_pitch, p_pitch, t_vuv, p_vuv = t_pitch[:, :m], p_pitch[:, :m], t_vuv[:, :m], p_vuv[:, :m]
+    ignore = int(max(model._encodings.max_pitch, model._encodings.max_duration) + 1)
+    loss_duration = F.cross_entropy(p_dur.reshape(-1, p_dur.shape[2]), t_dur.reshape(-1), ignore_index=ignore)
+    loss_pitch = (torch.abs(t_pitch / lang._max_pitch - p_pitch) * t_vuv).mean() + torch.abs(t_vuv - p_vuv).mean()
+    y = batch['y_audio'].to(dev)
+    if y.shape[1] > 12000 - 240:   # random 50-frame / 12000-sample crop per item (cubegan.py:116-128)
+        ys, cs = [], []
+        for ii in range(y.shape[0]):
+            max_frame = len(batch['y_frame2phone'][ii])
+            r = rng.randint(0, max_frame - 50 - 1) if max_frame > 51 else 0
+            cs.append(conditioning[ii, r:r + 50, :].unsqueeze(0))
+            ys.append(y[ii, r * 240:r * 240 + 12000].unsqueeze(0))
+        y = torch.cat(ys, dim=0)
+        conditioning = torch.cat(cs, dim=0)
+    y = y.unsqueeze(1)
+    y_g_hat = generator_forward_train(model._generator, conditioning.permute(0, 2, 1))
+    m = min(y.shape[2], y_g_hat.shape[2])
+    y, y_g_hat = y[:, :, :m], y_g_hat[:, :, :m]
+    y_mel = mel_spectrogram(y.squeeze(1), 1024, 80, 24000, 240, 1024, 0, 12000)
+    y_g_hat_mel = mel_spectrogram(y_g_hat.squeeze(1), 1024, 80, 24000, 240, 1024, 0, 12000)
+    opt_b.zero_grad()
+    opt_d.zero_grad()
+    y_df_hat_r, y_df_hat_g, _, _ = model._mpd(y, y_g_hat.detach())
+    loss_disc_f, _, _ = discriminator_loss(y_df_hat_r, y_df_hat_g)
+    y_ds_hat_r, y_ds_hat_g, _, _ = model._msd(y, y_g_hat.detach())
+    loss_disc_s, _, _ = discriminator_loss(y_ds_hat_r, y_ds_hat_g)
+    loss_disc_all = loss_disc_s + loss_disc_f
+    loss_disc_all.backward()
+    if reducers:
+        reducers[1].reduce()
+    opt_d.step()
+    opt_g.zero_grad()
+    loss_mel = F.l1_loss(y_mel, y_g_hat_mel) * 45
+    y_df_hat_r, y_df_hat_g, fmap_f_r, fmap_f_g = model._mpd(y, y_g_hat)
+    y_ds_hat_r, y_ds_hat_g, fmap_s_r, fmap_s_g = model._msd(y, y_g_hat)
+    loss_gen_all = (generator_loss(y_ds_hat_g)[0] + generator_loss(y_df_hat_g)[0] + feature_loss(fmap_s_r, fmap_s_g)
+                    + feature_loss(fmap_f_r, fmap_f_g) + loss_mel)
+    loss_gen_all.backward(retain_graph=True)
+    if reducers:
+        reducers[0].reduce()
+    opt_g.step()
+    opt_t.zero_grad()
+    loss_text = loss_pitch + loss_duration
+    loss_text.backward()
+    if reducers:
+        reducers[2].reduce()
+    opt_t.step()
+    opt_b.step()
+    model._global_step += 1
+    model._current_lr = model._compute_lr(model._learning_rate, 1e-5, model._global_step)
+    for o in (opt_d, opt_g, opt_t):
+        o.param_groups[0]['lr'] = model._current_lr
+    return {'loss_g': float(loss_gen_all), 'loss_t': float(loss_text), 'loss_d': float(loss_disc_all),
+            'loss_mel': float(loss_mel) / 45, 'lr': model._current_lr}
+
+
+def wavernn_logits_train(net, X):
+    """Differentiable WaveRNN._train_forward (modules.py:505-539) on torch-ROCm ops (full-sequence nn.GRU)."""
+    mel, gs_x = X['mel'], X['x']
+    up = mel.repeat_interleave(net._upsample, dim=1)
+    if net._use_lowres:
+        low_x = X['x_low']
+        interp = F.interpolate(low_x.unsqueeze(1), net._upsample_low * low_x.shape[1], mode='linear').squeeze(1)
+        hidden = low_x.unsqueeze(1)
+        for conv in net._lowres_conv:
+            hidden = torch.tanh(F.conv1d(hidden, conv.conv.weight, conv.conv.bias, padding=3))
+        ux = hidden.repeat_interleave(net._upsample_low, dim=2).permute(0, 2, 1)
+        m = min(up.shape[1], gs_x.shape[1], ux.shape[1], interp.shape[1])
+        hidden = torch.cat([up[:, :m], ux[:, :m], interp[:, :m].unsqueeze(2), gs_x[:, :m].unsqueeze(2)], dim=-1)
+    else:
+        m = min(up.shape[1], gs_x.shape[1])
+        hidden = torch.cat([up[:, :m], gs_x[:, :m].unsqueeze(2)], dim=-1)
+    for rnn in net._rnns:
+        hidden, _ = rnn(hidden)
+    pre = torch.tanh(F.linear(hidden, net._preoutput.linear_layer.weight, net._preoutput.linear_layer.bias))
+    return F.linear(pre, net._output.linear_layer.weight, net._output.linear_layer.bias)
+
+
+def wavernn_train_loss(net, batch):
+    """WaveRNN.training_step (modules.py:553-563): target shifted right by one with a 0, CE on the encoded target."""
+    gs = batch['x']
+    b = dict(batch)
+    b['x'] = F.pad(gs[:, :-1], (1, 0), mode='constant', value=0)
+    out = wavernn_logits_train(net, b)
+    return net._output_functions.loss(out, gs[:, :out.shape[1]])
+
+
+def vocoder_training_step(voc, batch, optimizers, reducers=None):
+    """CubenetVocoder.training_step (vocoder.py:136-156): two independent networks, clip_grad_norm 5, Adam x2,
+    lr = lr0 / (1 + 5e-5 * step)."""
+    opt_lr, opt_hr = optimizers
+    dev = voc._wavernn_hr._get_device()
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    opt_lr.zero_grad()
+    opt_hr.zero_grad()
+    loss_hr = wavernn_train_loss(voc._wavernn_hr, {'x': batch['x'], 'x_low': batch['x_low'], 'mel': batch['mel']})
+    loss_lr = wavernn_train_loss(voc._wavernn_lr, {'x': batch['x_low'], 'mel': batch['mel']})
+    loss_lr.backward()
+    loss_hr.backward()
+    if reducers:
+        reducers[0].reduce()
+        reducers[1].reduce()
+    torch.nn.utils.clip_grad_norm_(voc._wavernn_lr.parameters(), 5)
+    torch.nn.utils.clip_grad_norm_(voc._wavernn_hr.parameters(), 5)
+    opt_lr.step()
+    opt_hr.step()
+    voc._global_step += 1
+    alpha = voc._compute_lr(voc._learning_rate, 5e-5, voc._global_step)
+    opt_lr.param_groups[0]['lr'] = alpha
+    opt_hr.param_groups[0]['lr'] = alpha
+    return {'lr': float(loss_lr), 'hr': float(loss_hr), 'loss': float(loss_hr + loss_lr) / 2, 'alpha': alpha}
