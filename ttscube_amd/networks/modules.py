@@ -140,8 +140,10 @@ class WaveRNN(nn.Module):
             seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if mode == 'philox' else 0
         fx = None
         if forced_x is not None:
-            fx = torch.as_tensor(forced_x).to(dev).float()[:, :Lout].contiguous()
-            assert fx.shape[1] == Lout
+            fx = torch.as_tensor(forced_x).to(dev).float()[:, :Lout]
+            if fx.shape[1] < Lout:   # shorter target than conditioning: the net is causal, pad the tail (caller slices)
+                fx = torch.nn.functional.pad(fx, (0, Lout - fx.shape[1]))
+            fx = fx.contiguous()
         need = L.ttsc_wavernn_workspace_bytes(self._handle, B, T, Tl)
         if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != mel.device:
             self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
@@ -174,7 +176,7 @@ class WaveRNN(nn.Module):
             raise _lib.TTSCError('WaveRNN._train_forward: X["x"] must be the target shifted right by one with a leading 0 '
                                  '(modules.py:555-558)')
         _, _, logits = self.decode({k: v for k, v in X.items() if k != 'x'}, mode='argmax', forced_x=fx, want_logits=True)
-        return logits
+        return logits[:, :x.shape[1]]   # msize = min(conditioning, target) as modules.py:519-522
 
     @torch.jit.ignore
     def _get_device(self):

@@ -227,8 +227,8 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
     model._current_lr = model._compute_lr(model._learning_rate, 1e-5, model._global_step)
     for o in (opt_d, opt_g, opt_t):
         o.param_groups[0]['lr'] = model._current_lr
-    return {'loss_g': float(loss_gen_all), 'loss_t': float(loss_text), 'loss_d': float(loss_disc_all),
-            'loss_mel': float(loss_mel) / 45, 'lr': model._current_lr}
+    return {'loss_g': float(loss_gen_all.detach()), 'loss_t': float(loss_text.detach()), 'loss_d': float(loss_disc_all.detach()),
+            'loss_mel': float(loss_mel.detach()) / 45, 'lr': model._current_lr}
 
 
 def wavernn_logits_train(net, X):
@@ -285,4 +285,4 @@ def vocoder_training_step(voc, batch, optimizers, reducers=None):
     alpha = voc._compute_lr(voc._learning_rate, 5e-5, voc._global_step)
     opt_lr.param_groups[0]['lr'] = alpha
     opt_hr.param_groups[0]['lr'] = alpha
-    return {'lr': float(loss_lr), 'hr': float(loss_hr), 'loss': float(loss_hr + loss_lr) / 2, 'alpha': alpha}
+    return {'lr': float(loss_lr.detach()), 'hr': float(loss_hr.detach()), 'loss': float((loss_hr + loss_lr).detach()) / 2, 'alpha': alpha}
