@@ -58,6 +58,10 @@ typedef struct {
 } ttsc_conv1d_cfg;
 
 enum { TTSC_ACT_NONE = 0, TTSC_ACT_TANH = 1, TTSC_ACT_RELU = 2, TTSC_ACT_SIGMOID = 3 };
+/* arithmetic of the implicit GEMM: exact fp32 MFMA (k-ordered fmaf chain), or split precision — every fp32 value as
+ * fp16 hi + lo halves, three fp16 MFMAs per product with fp32 accumulation (~2^-21 relative, 5.3x the MFMA rate;
+ * activations must stay inside fp16 range |x| < 65504). */
+enum { TTSC_PREC_FP32 = 0, TTSC_PREC_F16X3 = 1 };
 
 typedef struct {
     float in_scale;      /* x is staged as leaky_relu(x * in_scale, in_slope); 1 / 1 = identity */
@@ -70,6 +74,8 @@ typedef struct {
 int ttsc_conv1d_create(const ttsc_conv1d_cfg* cfg, ttsc_conv1d** out);
 /* weight: host fp32 in torch layout (already weight-norm folded); bias: host [Cout] or NULL */
 int ttsc_conv1d_set_weight(ttsc_conv1d* c, const float* weight_host, const float* bias_host);
+/* switch the arithmetic (TTSC_PREC_*); weights are re-packed from the host copy kept by set_weight */
+int ttsc_conv1d_set_precision(ttsc_conv1d* c, int32_t precision);
 int64_t ttsc_conv1d_out_len(const ttsc_conv1d* c, int64_t Lin);
 /* x_dev [B,Cin,Lin] -> y_dev [B,Cout,Lout]; resid_dev NULL or [B,Cout,Lout]; ep NULL = plain conv */
 int ttsc_conv1d_forward(const ttsc_conv1d* c, const float* x_dev, int32_t B, int64_t Lin, float* y_dev,
@@ -111,6 +117,8 @@ int ttsc_hifigan_create(const ttsc_hifigan_cfg* cfg, ttsc_hifigan** out);
  * "conv_post.weight" ...; host fp32, torch layout, shape checked.  The host copy is kept and
  * packed/uploaded lazily by the next forward, so weights may be updated any number of times. */
 int ttsc_hifigan_set_weight(ttsc_hifigan* g, const char* name, const float* host, const int64_t* shape, int32_t nd);
+/* TTSC_PREC_* for every conv of the generator (default: TTSC_PREC_F16X3, overridable with env TTSC_HIFIGAN_PRECISION=fp32) */
+int ttsc_hifigan_set_precision(ttsc_hifigan* g, int32_t precision);
 int64_t ttsc_hifigan_out_len(const ttsc_hifigan* g, int64_t T);
 size_t ttsc_hifigan_workspace_bytes(const ttsc_hifigan* g, int32_t B, int64_t T);
 /* mel_dev [B,num_mels,T] -> wav_dev [B,1,out_len(T)] (tanh output in (-1,1)) */

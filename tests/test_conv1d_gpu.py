@@ -86,3 +86,58 @@ def test_conv1d_errors():
         conv(torch.zeros(1, 8, 10))  # CPU tensor: no CPU path
     with pytest.raises(TTSCError):
         Conv1dHip(8, 8, 3, stride=2)
+
+
+# ---- split-precision path (fp16 hi/lo halves, three fp16 MFMAs per product, fp32 accumulation) ----------------------
+F16X3_TOL = 1e-5  # ~2^-21 relative per product on O(1) outputs
+
+
+@pytest.mark.parametrize('cin,cout,k,d,L,B', [
+    (32, 32, 3, 1, 700, 2), (32, 32, 11, 5, 1030, 2), (64, 64, 7, 3, 513, 1), (128, 128, 11, 1, 300, 2),
+    (256, 256, 3, 5, 97, 1), (80, 512, 7, 1, 50, 2), (32, 1, 7, 1, 999, 2), (20, 20, 7, 1, 65, 1), (8, 4, 11, 5, 9, 2),
+])
+def test_conv1d_f16x3_matches_torch(cin, cout, k, d, L, B):
+    from ttscube_amd.hip_layers import Conv1dHip
+    pad = d * (k - 1) // 2
+    w = _mk((cout, cin, k), 1, 1.0 / (cin * k) ** 0.5)
+    b = _mk((cout,), 2, 0.1)
+    x = _mk((B, cin, L), 3)
+    conv = Conv1dHip(cin, cout, k, padding=pad, dilation=d).set_precision('f16x3')
+    conv.set_weight(w, b)
+    y = conv(x.cuda(), in_slope=0.1).cpu()
+    ref = F.conv1d(F.leaky_relu(x, 0.1), w, b, padding=pad, dilation=d)
+    assert y.shape == ref.shape
+    assert float((y - ref).abs().max()) < F16X3_TOL
+    # switching back re-packs from the host copy and restores the exact path
+    conv.set_precision('fp32')
+    y2 = conv(x.cuda(), in_slope=0.1).cpu()
+    assert float((y2 - ref).abs().max()) < TOL
+
+
+@pytest.mark.parametrize('cin,cout,k,s,L,B', [(512, 256, 16, 5, 50, 2), (128, 64, 4, 4, 304, 2), (64, 32, 4, 4, 1216, 1), (16, 8, 3, 2, 5, 1)])
+def test_conv_transpose1d_f16x3_matches_torch(cin, cout, k, s, L, B):
+    from ttscube_amd.hip_layers import Conv1dHip
+    pad = (k - s) // 2
+    w = _mk((cin, cout, k), 1, 1.0 / (cin * k / s) ** 0.5)
+    b = _mk((cout,), 2, 0.1)
+    x = _mk((B, cin, L), 3)
+    conv = Conv1dHip(cin, cout, k, stride=s, padding=pad, transposed=True).set_precision('f16x3')
+    conv.set_weight(w, b)
+    y = conv(x.cuda(), in_slope=0.1).cpu()
+    ref = F.conv_transpose1d(F.leaky_relu(x, 0.1), w, b, stride=s, padding=pad)
+    assert float((y - ref).abs().max()) < F16X3_TOL
+
+
+def test_conv1d_f16x3_small_and_large_magnitudes():
+    """weights of very different scale (power-of-two pre-scaling) and activations from 1e-4 to 1e3 keep ~fp32 accuracy"""
+    from ttscube_amd.hip_layers import Conv1dHip
+    cin = cout = 64
+    for wscale, xscale in [(1e-3, 1.0), (30.0, 1e-2), (0.02, 500.0)]:
+        w = _mk((cout, cin, 3), 1, wscale)
+        x = _mk((1, cin, 300), 3, xscale)
+        conv = Conv1dHip(cin, cout, 3, padding=1).set_precision('f16x3')
+        conv.set_weight(w, None)
+        y = conv(x.cuda()).cpu()
+        ref = F.conv1d(x, w, None, padding=1)
+        rel = float((y - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+        assert rel < 2e-6, (wscale, xscale, rel)

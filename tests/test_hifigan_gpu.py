@@ -13,12 +13,32 @@ pytestmark = pytest.mark.gpu
 RMS_TOL = 1e-4  # BASELINE.json north_star: "vocoder output within 1e-4 RMS of reference on fixed mel input"
 
 
-def _gen(h, sd):
+def _gen(h, sd, precision=None):
     from ttscube_amd.hifigan.env import AttrDict
     from ttscube_amd.hifigan.models import Generator
     g = Generator(AttrDict(h))
     missing, unexpected = g.load_state_dict(sd, strict=True)
+    if precision:
+        g.set_precision(precision)
     return g.cuda().eval()
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'f16x3'])
+def test_generator_both_precisions_meet_the_parity_gate(precision):
+    """exact fp32 MFMA and the split-precision (default) path, full V1 config, against the oracle"""
+    h = dict(R.CONFIG_V1)
+    sd = R.synthetic_state_dict(h, seed=21)
+    g = _gen(h, sd, precision)
+    w = R.fold_state_dict(sd)
+    mel = R.synthetic_mel(2, 40, seed=22)
+    ref = R.generator_forward(w, h, mel)
+    with torch.no_grad():
+        out = g(mel.cuda()).cpu()
+    rms = float((out - ref).pow(2).mean().sqrt())
+    rel = rms / float(ref.pow(2).mean().sqrt())
+    print(precision, 'rms', rms, 'rel', rel)
+    assert rms < RMS_TOL and rel < 1e-3, (precision, rms, rel)
+    assert rms < (2e-6 if precision == 'fp32' else 2e-5)   # what the two paths actually deliver
 
 
 @pytest.mark.parametrize('name', ['hifigan_c64_r5344.npz', 'hifigan_c32_r3544.npz'])

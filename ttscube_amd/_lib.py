@@ -34,6 +34,7 @@ class HifiganCfg(C.Structure):
 
 
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
+PREC_FP32, PREC_F16X3 = 0, 1
 
 
 class WavernnCfg(C.Structure):
@@ -53,6 +54,7 @@ SIGNATURES = {
     'ttsc_device_count': (C.c_int, []),
     'ttsc_conv1d_create': (C.c_int, [C.POINTER(Conv1dCfg), C.POINTER(C.c_void_p)]),
     'ttsc_conv1d_set_weight': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ttsc_conv1d_set_precision': (C.c_int, [C.c_void_p, C.c_int32]),
     'ttsc_conv1d_out_len': (C.c_int64, [C.c_void_p, C.c_int64]),
     'ttsc_conv1d_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
                                       C.POINTER(Conv1dEpilogue), C.c_void_p]),
@@ -61,6 +63,7 @@ SIGNATURES = {
     'ttsc_conv1d_destroy': (None, [C.c_void_p]),
     'ttsc_hifigan_create': (C.c_int, [C.POINTER(HifiganCfg), C.POINTER(C.c_void_p)]),
     'ttsc_hifigan_set_weight': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
+    'ttsc_hifigan_set_precision': (C.c_int, [C.c_void_p, C.c_int32]),
     'ttsc_hifigan_out_len': (C.c_int64, [C.c_void_p, C.c_int64]),
     'ttsc_hifigan_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int64]),
     'ttsc_hifigan_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,

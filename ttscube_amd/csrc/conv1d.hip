@@ -15,6 +15,8 @@
 // (weights) is pre-packed on the host into MFMA fragment order so every fragment is ONE coalesced
 // 256-byte wave load that hits L2.  Epilogue fuses bias, residual add, scaling, tanh and the running
 // sum over residual blocks.
+#include <cmath>
+
 #include "common.hpp"
 
 namespace ttsc {
@@ -27,7 +29,9 @@ struct ConvArgs {
     const float* x;
     float* y;
     const float* resid;
-    const float* wp;    // [ntaps][CinP/2][CoutP/32][64]
+    const float* wp;    // fp32 path: [ntaps][CinP/2][CoutP/32][64]
+    const void* wph;    // f16x3 path: [ntaps][CinP/16][CoutP/32][2 (hi,lo)][64 lanes][8 half]
+    float w_unscale;    // f16x3 path: weights are stored multiplied by 2^s; the epilogue multiplies by 2^-s
     const float* bias;  // [Cout] or null
     const int* in_len;  // [B] per-utterance valid input length (ragged batches) or null
     const int* out_len; // [B] per-utterance valid output length or null (tiles wholly beyond it are skipped)
@@ -148,6 +152,175 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Split-precision path: every fp32 value v is carried as two halves  v = hi + lo  (hi = fp16(v), lo = fp16(v - hi),
+// 22 significant bits) and the product is evaluated as  hi_w*hi_x + hi_w*lo_x + lo_w*hi_x  on
+// v_mfma_f32_32x32x16_f16 with fp32 accumulation: fp16 x fp16 products are exact in fp32, the dropped lo*lo term is
+// 2^-22 relative, so the result carries ~fp32 accuracy at 16/3 = 5.3x the fp32-MFMA rate.  Weights are pre-scaled by a
+// power of two so that their low halves stay in fp16's normal range (unscaled exactly in the epilogue).
+// Activations are expected within fp16 range (|x| < 65504).
+//
+// Workgroup = 4 waves side by side along N (time); all four share the M tile, so the weight fragments are staged
+// ONCE per workgroup through LDS (double-buffered, prefetched one tap ahead) instead of once per wave from L2.
+// Activation tile: LDS [position][16 channels] fp16 (hi and lo planes), so a B fragment (8 consecutive channels of
+// one position) is a single 16-byte ds_read; the fp32 -> (hi,lo) split and the leaky-relu prologue happen while staging.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+template <int MI, int NJ>
+__global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int NT = 4 * NJ * 32;
+    constexpr int AFR = MI * 2 * 64;  // half8 elements of one (tap, chunk) weight block of this workgroup
+    _Float16* Xhi = reinterpret_cast<_Float16*>(smem_raw);
+    _Float16* Xlo = Xhi + (size_t)a.span_pad * 16;
+    half8* Abuf = reinterpret_cast<half8*>(Xlo + (size_t)a.span_pad * 16);  // [2][AFR]
+
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z;
+    const int q0 = a.q_lo + blockIdx.x * NT;
+    const int lin = a.in_len ? a.in_len[b] : a.Lin;
+    if (a.out_len && (long)q0 * a.out_stride + a.out_off >= a.out_len[b]) return;
+    const int cot0 = blockIdx.y * MI;
+    const int cotN = a.CoutP >> 5;
+    const int nchunks = a.CinP >> 4;
+    const int n_it = nchunks * a.ntaps;
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const float* xb = a.x + (size_t)b * a.Cin * a.Lin;
+    const int lo = q0 + a.min_shift;
+    const half8* wsrc = reinterpret_cast<const half8*>(a.wph);
+    // block of (tap j, chunk c) for this workgroup's M tile: ((j*nchunks + c)*cotN + cot0)*128 half8, AFR contiguous
+    auto a_src = [&](int it) {
+        const int c = it / a.ntaps, j = it - c * a.ntaps;
+        return wsrc + ((size_t)(j * nchunks + c) * cotN + cot0) * 128;
+    };
+    constexpr int APT = (AFR + 255) / 256;  // half8 per thread
+    half8 areg[APT];
+#pragma unroll
+    for (int e = 0; e < APT; ++e) {
+        const int idx = tid + e * 256;
+        if (idx < AFR) Abuf[idx] = a_src(0)[idx];
+    }
+
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();
+        // ---- stage x[b, 16c:16c+16, lo:lo+span] -> LDS as (hi, lo) fp16, [pos][16 ch]; leaky-relu prologue fused ----
+        for (int h = 0; h < 2; ++h) {
+            const int cb = c * 16 + h * 8;
+            for (int p = tid; p < a.span; p += 256) {
+                const int pos = lo + p;
+                const bool pok = pos >= 0 && pos < lin;
+                half8 vh, vl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = 0.f;
+                    if (pok && cb + e < a.Cin) {
+                        v = xb[(size_t)(cb + e) * a.Lin + pos] * a.in_scale;
+                        v = v > 0.f ? v : v * a.in_slope;
+                    }
+                    const _Float16 hh = (_Float16)v;
+                    vh[e] = hh;
+                    vl[e] = (_Float16)(v - (float)hh);
+                }
+                *reinterpret_cast<half8*>(Xhi + (size_t)p * 16 + h * 8) = vh;
+                *reinterpret_cast<half8*>(Xlo + (size_t)p * 16 + h * 8) = vl;
+            }
+        }
+        __syncthreads();
+        for (int j = 0; j < a.ntaps; ++j) {
+            const int it = c * a.ntaps + j;
+            const bool more = it + 1 < n_it;
+            if (more) {
+                const half8* src = a_src(it + 1);
+#pragma unroll
+                for (int e = 0; e < APT; ++e) {
+                    const int idx = tid + e * 256;
+                    if (idx < AFR) areg[e] = src[idx];
+                }
+            }
+            const half8* Ab = Abuf + (it & 1) * AFR;
+            const int shift = a.tap_base + j * a.tap_step - a.min_shift;
+            half8 ah[MI], al[MI], bh[NJ], bl[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                ah[i] = Ab[(i * 2 + 0) * 64 + lane];
+                al[i] = Ab[(i * 2 + 1) * 64 + lane];
+            }
+#pragma unroll
+            for (int n = 0; n < NJ; ++n) {
+                const size_t off = (size_t)(wn * (NJ * 32) + n * 32 + l31 + shift) * 16 + half * 8;
+                bh[n] = *reinterpret_cast<const half8*>(Xhi + off);
+                bl[n] = *reinterpret_cast<const half8*>(Xlo + off);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int n = 0; n < NJ; ++n) {
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[n], acc[i][n], 0, 0, 0);
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[n], acc[i][n], 0, 0, 0);
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[n], acc[i][n], 0, 0, 0);
+                }
+            if (more) {
+                half8* Aw = Abuf + ((it + 1) & 1) * AFR;
+#pragma unroll
+                for (int e = 0; e < APT; ++e) {
+                    const int idx = tid + e * 256;
+                    if (idx < AFR) Aw[idx] = areg[e];
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    const int q_hi = a.q_lo + a.q_cnt;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int n = 0; n < NJ; ++n) {
+            const int q = q0 + wn * (NJ * 32) + n * 32 + l31;
+            const long o = (long)q * a.out_stride + a.out_off;
+            const bool qok = (q < q_hi) && (o >= 0) && (o < a.Lout);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int co = (cot0 + i) * 32 + row;
+                if (qok && co < a.Cout) {
+                    const size_t idx = ((size_t)b * a.Cout + co) * a.Lout + o;
+                    float v = acc[i][n][r] * a.w_unscale;
+                    if (a.bias) v += a.bias[co];
+                    if (a.resid) v += a.resid[idx];
+                    v = apply_act(v * a.out_scale, a.out_act);
+                    if (a.accumulate) v += a.y[idx];
+                    a.y[idx] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int MI, int NJ>
+static int launch_f16(const ConvArgs& a, int B, hipStream_t s) {
+    constexpr int NT = 4 * NJ * 32;
+    constexpr int MT = MI * 32;
+    dim3 grid((unsigned)ceil_div(a.q_cnt, NT), (unsigned)(a.CoutP / MT), (unsigned)B);
+    const size_t lds = (size_t)a.span_pad * 16 * 2 * 2 + (size_t)2 * MI * 2 * 64 * 16;
+    hipLaunchKernelGGL((conv_f16x3_kernel<MI, NJ>), grid, dim3(256), lds, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("conv_f16x3_kernel launch failed: %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    return TTSC_OK;
+}
+
 template <int MI, int NJ, int WM, int WN>
 static int launch_cfg(const ConvArgs& a, int B, hipStream_t s) {
     constexpr int NT = WN * NJ * 32;
@@ -182,6 +355,7 @@ using namespace ttsc;
 
 struct ConvPhase {
     float* wp_dev = nullptr;
+    void* wph_dev = nullptr;  // f16x3 fragments
     int ntaps = 0, tap_base = 0, tap_step = 0;
     int out_stride = 1, out_off = 0;
     int r = 0;  // phase index (transposed)
@@ -193,6 +367,10 @@ struct ttsc_conv1d {
     std::vector<ConvPhase> phases;
     float* bias_dev = nullptr;
     bool has_weight = false;
+    int precision = TTSC_PREC_FP32;
+    float w_unscale = 1.f;
+    std::vector<float> w_host, b_host;  // kept so that the precision can be switched (repack) at any time
+    bool has_bias = false;
 };
 
 extern "C" int ttsc_conv1d_create(const ttsc_conv1d_cfg* cfg, ttsc_conv1d** out) {
@@ -216,10 +394,17 @@ extern "C" int ttsc_conv1d_create(const ttsc_conv1d_cfg* cfg, ttsc_conv1d** out)
     return TTSC_OK;
 }
 
+static void free_phases(ttsc_conv1d* c) {
+    for (auto& p : c->phases) {
+        if (p.wp_dev) (void)hipFree(p.wp_dev);
+        if (p.wph_dev) (void)hipFree(p.wph_dev);
+    }
+    c->phases.clear();
+}
+
 extern "C" void ttsc_conv1d_destroy(ttsc_conv1d* c) {
     if (!c) return;
-    for (auto& p : c->phases)
-        if (p.wp_dev) (void)hipFree(p.wp_dev);
+    free_phases(c);
     if (c->bias_dev) (void)hipFree(c->bias_dev);
     delete c;
 }
@@ -252,14 +437,86 @@ static void pack_phase(const ttsc_conv1d* c, const float* w, const std::vector<i
     }
 }
 
+// f16x3 packing: [tap][CinP/16][CoutP/32][2 (hi,lo)][64 lanes][8 half]; lane -> co = cot*32 + (lane&31),
+// ci = 16*chunk + 8*(lane>>5) + e.  Weights are multiplied by `scale` (a power of two) before the split.
+static void pack_phase_f16(const ttsc_conv1d* c, const float* w, const std::vector<int>& taps_k, float scale,
+                           std::vector<_Float16>& out) {
+    const auto& g = c->cfg;
+    const int Cin = g.in_channels, Cout = g.out_channels, K = g.kernel_size;
+    const int nch = c->CinP / 16, cotN = c->CoutP / 32;
+    out.assign((size_t)taps_k.size() * nch * cotN * 2 * 64 * 8, (_Float16)0.f);
+    for (size_t j = 0; j < taps_k.size(); ++j) {
+        const int k = taps_k[j];
+        for (int ch = 0; ch < nch; ++ch)
+            for (int cot = 0; cot < cotN; ++cot)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int co = cot * 32 + (lane & 31);
+                        const int ci = ch * 16 + 8 * (lane >> 5) + e;
+                        float v = 0.f;
+                        if (co < Cout && ci < Cin)
+                            v = g.transposed ? w[((size_t)ci * Cout + co) * K + k] : w[((size_t)co * Cin + ci) * K + k];
+                        v *= scale;
+                        const _Float16 hi = (_Float16)v;
+                        const _Float16 lo = (_Float16)(v - (float)hi);
+                        const size_t base = ((((size_t)j * nch + ch) * cotN + cot) * 2) * 64 * 8;
+                        out[base + (size_t)lane * 8 + e] = hi;
+                        out[base + (size_t)64 * 8 + (size_t)lane * 8 + e] = lo;
+                    }
+    }
+}
+
+static int conv_repack(ttsc_conv1d* c);
+
+extern "C" int ttsc_conv1d_set_precision(ttsc_conv1d* c, int32_t precision) {
+    TTSC_REQUIRE(c, "ttsc_conv1d_set_precision: null argument");
+    TTSC_REQUIRE(precision == TTSC_PREC_FP32 || precision == TTSC_PREC_F16X3, "ttsc_conv1d_set_precision: unknown precision %d", precision);
+    if (precision == c->precision) return TTSC_OK;
+    c->precision = precision;
+    return c->has_weight ? conv_repack(c) : TTSC_OK;
+}
+
 extern "C" int ttsc_conv1d_set_weight(ttsc_conv1d* c, const float* w, const float* bias) {
     TTSC_REQUIRE(c && w, "ttsc_conv1d_set_weight: null argument");
+    const auto& g0 = c->cfg;
+    c->w_host.assign(w, w + (size_t)g0.in_channels * g0.out_channels * g0.kernel_size);
+    c->has_bias = bias != nullptr;
+    if (bias) c->b_host.assign(bias, bias + g0.out_channels);
+    return conv_repack(c);
+}
+
+static int conv_repack(ttsc_conv1d* c) {
+    const float* w = c->w_host.data();
+    const float* bias = c->has_bias ? c->b_host.data() : nullptr;
+    TTSC_REQUIRE(c && w, "ttsc_conv1d_set_weight: null argument");
     const auto& g = c->cfg;
-    for (auto& p : c->phases)
-        if (p.wp_dev) (void)hipFree(p.wp_dev);
-    c->phases.clear();
+    free_phases(c);
     std::vector<float> packed;
+    std::vector<_Float16> packed_h;
+    // power-of-two weight scale for the split path: max|w| * 2^s in [512, 1024) keeps the low halves normal in fp16
+    float wscale = 1.f;
+    if (c->precision == TTSC_PREC_F16X3) {
+        float mx = 0.f;
+        for (float v : c->w_host) mx = fmaxf(mx, fabsf(v));
+        int e = 0;
+        if (mx > 0.f && std::isfinite(mx)) {
+            (void)frexpf(mx, &e);   // mx = m * 2^e, m in [0.5, 1)
+            e = 10 - e;             // mx * 2^e in [512, 1024)
+            if (e > 24) e = 24;
+            if (e < -8) e = -8;
+        }
+        wscale = ldexpf(1.f, e);
+        c->w_unscale = ldexpf(1.f, -e);
+    }
+    std::vector<int> cur_taps;
     auto upload = [&](ConvPhase& ph) -> int {
+        if (c->precision == TTSC_PREC_F16X3) {
+            pack_phase_f16(c, w, cur_taps, wscale, packed_h);
+            TTSC_HIP_CHECK(hipMalloc((void**)&ph.wph_dev, packed_h.size() * sizeof(_Float16)));
+            TTSC_HIP_CHECK(hipMemcpy(ph.wph_dev, packed_h.data(), packed_h.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+            return TTSC_OK;
+        }
+        pack_phase(c, w, cur_taps, packed);
         TTSC_HIP_CHECK(hipMalloc((void**)&ph.wp_dev, packed.size() * sizeof(float)));
         TTSC_HIP_CHECK(hipMemcpy(ph.wp_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
         return TTSC_OK;
@@ -273,7 +530,7 @@ extern "C" int ttsc_conv1d_set_weight(ttsc_conv1d* c, const float* w, const floa
         ph.tap_step = g.dilation;
         ph.out_stride = 1;
         ph.out_off = 0;
-        pack_phase(c, w, taps, packed);
+        cur_taps = taps;
         int rc = upload(ph);
         if (rc) return rc;
         c->phases.push_back(ph);
@@ -289,7 +546,7 @@ extern "C" int ttsc_conv1d_set_weight(ttsc_conv1d* c, const float* w, const floa
             ph.tap_step = -1;
             ph.out_stride = g.stride;
             ph.out_off = r - g.padding;
-            pack_phase(c, w, taps, packed);
+            cur_taps = taps;
             int rc = upload(ph);
             if (rc) return rc;
             c->phases.push_back(ph);
@@ -333,6 +590,8 @@ extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, 
         a.y = y;
         a.resid = resid;
         a.wp = ph.wp_dev;
+        a.wph = ph.wph_dev;
+        a.w_unscale = c->w_unscale;
         a.bias = c->bias_dev;
         a.in_len = in_len_dev;
         a.out_len = out_len_dev;
@@ -368,7 +627,18 @@ extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, 
         a.out_act = ep ? ep->out_act : TTSC_ACT_NONE;
         a.accumulate = ep ? ep->accumulate : 0;
         int rc;
-        if (c->MT == 128)
+        if (c->precision == TTSC_PREC_F16X3) {
+            // the split kernel's N tile is fixed by its 4-waves-along-N shape
+            const int nt = c->MT == 128 ? 256 : 512;
+            a.span = nt + (last < 0 ? -last : last);
+            a.span_pad = a.span;
+            if (c->MT == 128)
+                rc = launch_f16<4, 2>(a, B, s);
+            else if (c->MT == 64)
+                rc = launch_f16<2, 4>(a, B, s);
+            else
+                rc = launch_f16<1, 4>(a, B, s);
+        } else if (c->MT == 128)
             rc = launch_cfg<2, 2, 2, 2>(a, B, s);
         else if (c->MT == 64)
             rc = launch_cfg<2, 2, 1, 4>(a, B, s);

@@ -119,6 +119,15 @@ extern "C" int ttsc_hifigan_create(const ttsc_hifigan_cfg* cfg, ttsc_hifigan** o
 
 extern "C" void ttsc_hifigan_destroy(ttsc_hifigan* g) { delete g; }
 
+extern "C" int ttsc_hifigan_set_precision(ttsc_hifigan* g, int32_t precision) {
+    TTSC_REQUIRE(g, "ttsc_hifigan_set_precision: null argument");
+    for (auto& kv : g->layers) {
+        int rc = ttsc_conv1d_set_precision(kv.second->c, precision);
+        if (rc) return rc;
+    }
+    return TTSC_OK;
+}
+
 extern "C" int ttsc_hifigan_set_weight(ttsc_hifigan* g, const char* name, const float* host, const int64_t* shape,
                                        int32_t nd) {
     TTSC_REQUIRE(g && name && host && shape, "ttsc_hifigan_set_weight: null argument");

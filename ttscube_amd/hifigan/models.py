@@ -9,6 +9,7 @@ Drop-in for the generator class of the reference's un-vendored ``hifigan`` submo
 ``ttsc_hifigan_forward``; there is no PyTorch/CPU compute path.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -113,6 +114,17 @@ class Generator(nn.Module):
         self._handle = None
         self._sig = None
         self._ws = None
+        self._precision = os.environ.get('TTSC_HIFIGAN_PRECISION', 'f16x3')
+
+    def set_precision(self, precision):
+        """'f16x3' (default; split-precision fp16 MFMA, fp32 accumulate, ~2^-21 relative per product) or 'fp32'
+        (exact fp32 MFMA fmaf chains, 5x slower).  Both meet the 1e-4 RMS parity gate."""
+        assert precision in ('fp32', 'f16x3')
+        self._precision = precision
+        if self._handle is not None:
+            _lib.check(_lib.lib().ttsc_hifigan_set_precision(
+                self._handle, _lib.PREC_F16X3 if precision == 'f16x3' else _lib.PREC_FP32), 'ttsc_hifigan_set_precision')
+        return self
 
     # ---- C-ABI plumbing ---------------------------------------------------------------------------------
     def _cfg(self):
@@ -160,6 +172,7 @@ class Generator(nn.Module):
             cfg = self._cfg()
             _lib.check(L.ttsc_hifigan_create(C.byref(cfg), C.byref(hnd)), 'ttsc_hifigan_create')
             self._handle = hnd
+            self.set_precision(self._precision)
         for name, l in self._named_convs():
             for suffix, t in (('.weight', l.folded_weight()), ('.bias', l.bias.detach())):
                 t = t.float().cpu().contiguous()

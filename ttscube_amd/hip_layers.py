@@ -21,6 +21,12 @@ class Conv1dHip:
         self._h = C.c_void_p()
         _lib.check(L.ttsc_conv1d_create(C.byref(self.cfg), C.byref(self._h)), 'ttsc_conv1d_create')
 
+    def set_precision(self, precision):
+        """'fp32' (exact fp32 MFMA) or 'f16x3' (split-precision fp16 MFMA, ~2^-21 relative)."""
+        mode = {'fp32': _lib.PREC_FP32, 'f16x3': _lib.PREC_F16X3}[precision]
+        _lib.check(_lib.lib().ttsc_conv1d_set_precision(self._h, mode), 'ttsc_conv1d_set_precision')
+        return self
+
     def set_weight(self, weight, bias=None):
         w = weight.detach().float().cpu().contiguous()
         exp = ((self.cfg.in_channels, self.cfg.out_channels) if self.cfg.transposed else
