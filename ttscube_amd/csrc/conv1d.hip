@@ -210,31 +210,62 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
         if (idx < AFR) Abuf[idx] = a_src(0)[idx];
     }
 
-    for (int c = 0; c < nchunks; ++c) {
-        __syncthreads();
-        // ---- stage x[b, 16c:16c+16, lo:lo+span] -> LDS as (hi, lo) fp16, [pos][16 ch]; leaky-relu prologue fused ----
-        for (int h = 0; h < 2; ++h) {
+    // Activation staging is software-pipelined through registers: the global loads of chunk c+1 are issued before
+    // the MFMA loop of chunk c and consumed (leaky-relu, hi/lo split, LDS write) after it, so their latency hides
+    // behind ntaps*MI*NJ*3 MFMAs.  Work item = (position p, channel group h of 8); items are laid out so that
+    // consecutive lanes read consecutive positions (coalesced 256-B rows).  Addresses are clamped and the loads are
+    // unconditional (a select zeroes the padding) so that the compiler never branches around a load.
+    constexpr int XIT = ((NT + 64) * 2 + 255) / 256;
+    const int spanp = (a.span + 63) & ~63;
+    float xr[XIT][8];
+    auto x_issue = [&](int c) {
+#pragma unroll
+        for (int e = 0; e < XIT; ++e) {
+            const int i = tid + e * 256;
+            const int h = i >= spanp ? 1 : 0;
+            const int p = i - h * spanp;
+            int pos = lo + p;
+            pos = pos < 0 ? 0 : (pos > lin - 1 ? lin - 1 : pos);
+            pos = pos < 0 ? 0 : pos;
             const int cb = c * 16 + h * 8;
-            for (int p = tid; p < a.span; p += 256) {
-                const int pos = lo + p;
-                const bool pok = pos >= 0 && pos < lin;
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+                const int ci = cb + ch < a.Cin ? cb + ch : a.Cin - 1;
+                xr[e][ch] = xb[(size_t)ci * a.Lin + pos];
+            }
+        }
+    };
+    auto x_commit = [&](int c) {
+#pragma unroll
+        for (int e = 0; e < XIT; ++e) {
+            const int i = tid + e * 256;
+            const int h = i >= spanp ? 1 : 0;
+            const int p = i - h * spanp;
+            const int pos = lo + p;
+            const bool pok = pos >= 0 && pos < lin;
+            const int cb = c * 16 + h * 8;
+            if (p < a.span && i < 2 * spanp) {
                 half8 vh, vl;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float v = 0.f;
-                    if (pok && cb + e < a.Cin) {
-                        v = xb[(size_t)(cb + e) * a.Lin + pos] * a.in_scale;
-                        v = v > 0.f ? v : v * a.in_slope;
-                    }
+                for (int ch = 0; ch < 8; ++ch) {
+                    float v = (pok && cb + ch < a.Cin) ? xr[e][ch] * a.in_scale : 0.f;
+                    v = v > 0.f ? v : v * a.in_slope;
                     const _Float16 hh = (_Float16)v;
-                    vh[e] = hh;
-                    vl[e] = (_Float16)(v - (float)hh);
+                    vh[ch] = hh;
+                    vl[ch] = (_Float16)(v - (float)hh);
                 }
                 *reinterpret_cast<half8*>(Xhi + (size_t)p * 16 + h * 8) = vh;
                 *reinterpret_cast<half8*>(Xlo + (size_t)p * 16 + h * 8) = vl;
             }
         }
+    };
+
+    x_issue(0);
+    for (int c = 0; c < nchunks; ++c) {
+        // (the barrier closing the previous chunk's last tap guarantees nobody still reads the activation tile)
+        x_commit(c);
         __syncthreads();
+        if (c + 1 < nchunks) x_issue(c + 1);
         for (int j = 0; j < a.ntaps; ++j) {
             const int it = c * a.ntaps + j;
             const bool more = it + 1 < n_it;
@@ -471,6 +502,11 @@ static int conv_repack(ttsc_conv1d* c);
 extern "C" int ttsc_conv1d_set_precision(ttsc_conv1d* c, int32_t precision) {
     TTSC_REQUIRE(c, "ttsc_conv1d_set_precision: null argument");
     TTSC_REQUIRE(precision == TTSC_PREC_FP32 || precision == TTSC_PREC_F16X3, "ttsc_conv1d_set_precision: unknown precision %d", precision);
+    // the split kernel prefetches a fixed-size register window: tile + 64 positions of halo.  Layers with a larger
+    // receptive field (none on the hot path) silently stay on the exact fp32 kernel.
+    const int halo = c->cfg.transposed ? (c->cfg.kernel_size + c->cfg.stride - 1) / c->cfg.stride - 1
+                                       : (c->cfg.kernel_size - 1) * c->cfg.dilation;
+    if (precision == TTSC_PREC_F16X3 && halo > 64) precision = TTSC_PREC_FP32;
     if (precision == c->precision) return TTSC_OK;
     c->precision = precision;
     return c->has_weight ? conv_repack(c) : TTSC_OK;
