@@ -52,6 +52,37 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+// Epilogue of one 32x32 MFMA tile held by a wave: bias + residual + scale + activation (+ running sum) and store.
+// All residual / running-sum loads of the tile are issued BEFORE the first store: `resid` and `y` may alias
+// (in-place residual stream), which otherwise forces the compiler to order every load behind the previous store and
+// serialises 16 dependent round trips per tile.  Each lane only reads the addresses it writes, so this is safe.
+// C/D layout of v_mfma_*_32x32: column (time) = lane & 31, row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+__device__ __forceinline__ void epilogue_tile(const f32x16& acc, const ConvArgs& a, int b, int co_base, long o, bool qok,
+                                              int half, float acc_scale) {
+    float rv[16], yv[16];
+    const long o_c = qok ? o : 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int co_c = co < a.Cout ? co : a.Cout - 1;
+        const size_t idx = ((size_t)b * a.Cout + co_c) * a.Lout + o_c;
+        rv[r] = a.resid ? a.resid[idx] : 0.f;
+        yv[r] = a.accumulate ? a.y[idx] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (qok && co < a.Cout) {
+            const size_t idx = ((size_t)b * a.Cout + co) * a.Lout + o;
+            float v = acc[r] * acc_scale;
+            if (a.bias) v += a.bias[co];
+            v += rv[r];
+            v = apply_act(v * a.out_scale, a.out_act);
+            a.y[idx] = v + yv[r];
+        }
+    }
+}
+
 template <int MI, int NJ, int WM, int WN>
 __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float xs[];  // [KC][span_pad]
@@ -134,20 +165,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
             const int q = q0 + wn * (NJ * 32) + n * 32 + l31;
             const long o = (long)q * a.out_stride + a.out_off;
             const bool qok = (q < q_hi) && (o >= 0) && (o < a.Lout);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int co = (cot0 + i) * 32 + row;
-                if (qok && co < a.Cout) {
-                    const size_t idx = ((size_t)b * a.Cout + co) * a.Lout + o;
-                    float v = acc[i][n][r];
-                    if (a.bias) v += a.bias[co];
-                    if (a.resid) v += a.resid[idx];
-                    v = apply_act(v * a.out_scale, a.out_act);
-                    if (a.accumulate) v += a.y[idx];
-                    a.y[idx] = v;
-                }
-            }
+            epilogue_tile(acc[i][n], a, b, (cot0 + i) * 32, o, qok, half, 1.f);
         }
     }
 }
@@ -319,20 +337,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
             const int q = q0 + wn * (NJ * 32) + n * 32 + l31;
             const long o = (long)q * a.out_stride + a.out_off;
             const bool qok = (q < q_hi) && (o >= 0) && (o < a.Lout);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int co = (cot0 + i) * 32 + row;
-                if (qok && co < a.Cout) {
-                    const size_t idx = ((size_t)b * a.Cout + co) * a.Lout + o;
-                    float v = acc[i][n][r] * a.w_unscale;
-                    if (a.bias) v += a.bias[co];
-                    if (a.resid) v += a.resid[idx];
-                    v = apply_act(v * a.out_scale, a.out_act);
-                    if (a.accumulate) v += a.y[idx];
-                    a.y[idx] = v;
-                }
-            }
+            epilogue_tile(acc[i][n], a, b, (cot0 + i) * 32, o, qok, half, a.w_unscale);
         }
     }
 }
