@@ -86,6 +86,13 @@ int ttsc_conv1d_forward(const ttsc_conv1d* c, const float* x_dev, int32_t B, int
 int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x_dev, int32_t B, int64_t Lin, float* y_dev,
                                const float* resid_dev, const ttsc_conv1d_epilogue* ep, const int32_t* in_len_dev,
                                const int32_t* out_len_dev, void* stream);
+/* Fused residual pair  y = x + conv2(lrelu(conv1(lrelu(x), 0.1), 0.1)) [+ y if accumulate]  of a HiFi-GAN ResBlock1
+ * (both layers 32 -> 32 channels, odd kernel 3/7/11, conv2 undilated, both in TTSC_PREC_F16X3): the inner activation
+ * stays in LDS, which removes two of the five HBM passes of the unfused pair.  `supported` returns 1 when the fused
+ * kernel applies to the two layers; y must not alias x. */
+int ttsc_respair_supported(const ttsc_conv1d* conv1, const ttsc_conv1d* conv2);
+int ttsc_respair_forward(const ttsc_conv1d* conv1, const ttsc_conv1d* conv2, const float* x_dev, int32_t B, int64_t L,
+                         float* y_dev, int32_t accumulate, const int32_t* len_dev, void* stream);
 void ttsc_conv1d_destroy(ttsc_conv1d* c);
 
 /* ------------------------------------------------------------------------------------------------

@@ -141,3 +141,44 @@ def test_conv1d_f16x3_small_and_large_magnitudes():
         ref = F.conv1d(x, w, None, padding=1)
         rel = float((y - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
         assert rel < 2e-6, (wscale, xscale, rel)
+
+
+@pytest.mark.parametrize('k,d,L,B', [(3, 1, 1500, 2), (3, 5, 479, 1), (7, 3, 481, 2), (11, 5, 2000, 1), (11, 1, 7, 2), (7, 1, 960, 1)])
+def test_fused_residual_pair_matches_torch(k, d, L, B):
+    """respair32 kernel (through ttsc_respair_forward): y = x + conv2(lrelu(conv1_d(lrelu(x)))) [+ running sum]"""
+    import ctypes as C
+    from ttscube_amd import _lib
+    from ttscube_amd.hip_layers import Conv1dHip
+    c1 = Conv1dHip(32, 32, k, padding=d * (k - 1) // 2, dilation=d).set_precision('f16x3')
+    c2 = Conv1dHip(32, 32, k, padding=(k - 1) // 2).set_precision('f16x3')
+    w1, b1 = _mk((32, 32, k), 1, 1.0 / (32 * k) ** 0.5), _mk((32,), 2, 0.1)
+    w2, b2 = _mk((32, 32, k), 3, 1.0 / (32 * k) ** 0.5), _mk((32,), 4, 0.1)
+    c1.set_weight(w1, b1)
+    c2.set_weight(w2, b2)
+    L_ = _lib.lib()
+    assert L_.ttsc_respair_supported(c1._h, c2._h) == 1
+    x = _mk((B, 32, L), 5)
+    s0 = _mk((B, 32, L), 6)
+    ref = x + F.conv1d(F.leaky_relu(F.conv1d(F.leaky_relu(x, 0.1), w1, b1, padding=d * (k - 1) // 2, dilation=d), 0.1), w2, b2,
+                       padding=(k - 1) // 2)
+    xd = x.cuda()
+    for accumulate in (0, 1):
+        y = s0.clone().cuda()
+        _lib.check(L_.ttsc_respair_forward(c1._h, c2._h, _lib.dev_ptr(xd), B, L, _lib.dev_ptr(y), accumulate, None,
+                                           _lib.current_stream()), 'ttsc_respair_forward')
+        want = ref + s0 if accumulate else ref
+        assert float((y.cpu() - want).abs().max()) < 2e-5, (accumulate,)
+    # ragged: utterance 0 is shorter; its valid part equals the utterance run alone
+    if B > 1 and L > 300:
+        lens = torch.tensor([L - 257, L], dtype=torch.int32).cuda()
+        y = torch.zeros_like(xd)
+        _lib.check(L_.ttsc_respair_forward(c1._h, c2._h, _lib.dev_ptr(xd), B, L, _lib.dev_ptr(y), 0, _lib.dev_ptr(lens),
+                                           _lib.current_stream()), 'ttsc_respair_forward')
+        n = L - 257
+        xs = x[:1, :, :n]
+        solo = xs + F.conv1d(F.leaky_relu(F.conv1d(F.leaky_relu(xs, 0.1), w1, b1, padding=d * (k - 1) // 2, dilation=d), 0.1), w2,
+                             b2, padding=(k - 1) // 2)
+        assert float((y[:1, :, :n].cpu() - solo).abs().max()) < 2e-5
+    # not eligible: fp32 precision / other channel counts
+    c1.set_precision('fp32')
+    assert L_.ttsc_respair_supported(c1._h, c2._h) == 0

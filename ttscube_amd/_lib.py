@@ -60,6 +60,9 @@ SIGNATURES = {
                                       C.POINTER(Conv1dEpilogue), C.c_void_p]),
     'ttsc_conv1d_forward_ragged': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
                                              C.POINTER(Conv1dEpilogue), C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ttsc_respair_supported': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'ttsc_respair_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int32,
+                                       C.c_void_p, C.c_void_p]),
     'ttsc_conv1d_destroy': (None, [C.c_void_p]),
     'ttsc_hifigan_create': (C.c_int, [C.POINTER(HifiganCfg), C.POINTER(C.c_void_p)]),
     'ttsc_hifigan_set_weight': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),

@@ -17,6 +17,7 @@
 // HBM layout: four activation buffers carved from the caller's workspace (X: stage input, XT: inner
 // activation of a residual pair, R: running residual stream, S: sum over residual blocks), each
 // [B, C_i, L_i] fp32 channel-major, sized for the largest stage.
+#include <cstdlib>
 #include <map>
 #include <memory>
 
@@ -39,6 +40,7 @@ struct ttsc_hifigan {
     ttsc_hifigan_cfg cfg;
     std::map<std::string, std::unique_ptr<Layer>> layers;
     std::vector<int> stage_ch;  // channels after upsample i
+    bool use_fused = true;      // env TTSC_HIFIGAN_FUSED=0 disables the fused residual-pair kernel (A/B measurements)
     // pack + upload every layer whose host copy changed; returns the name of the first incomplete layer (or "")
     int flush_weights(std::string* missing) {
         for (auto& kv : layers) {
@@ -81,6 +83,7 @@ extern "C" int ttsc_hifigan_create(const ttsc_hifigan_cfg* cfg, ttsc_hifigan** o
     TTSC_REQUIRE((cfg->upsample_initial_channel >> cfg->num_upsamples) >= 1, "upsample_initial_channel too small");
     std::unique_ptr<ttsc_hifigan> g(new ttsc_hifigan());
     g->cfg = *cfg;
+    if (const char* ev = getenv("TTSC_HIFIGAN_FUSED")) g->use_fused = atoi(ev) != 0;
     int rc = add_layer(g.get(), "conv_pre", cfg->num_mels, cfg->upsample_initial_channel, 7, 1, 3, 1, 0);
     if (rc) return rc;
     int ch = cfg->upsample_initial_channel;
@@ -277,6 +280,23 @@ extern "C" int ttsc_hifigan_forward_ragged(ttsc_hifigan* g, const float* mel, in
         for (int j = 0; j < c.num_kernels; ++j) {
             const std::string rb = "resblocks." + std::to_string(i * c.num_kernels + j);
             const int nd = c.num_dilations[j];
+            // 32-channel ResBlock1 pairs run as ONE fused launch each (inner activation stays in LDS); the residual
+            // stream then ping-pongs between R and XT because a fused tile reads its neighbours' halo of the input.
+            bool fused = (c.resblock == 1) && g->use_fused;
+            for (int m = 0; fused && m < nd; ++m)
+                fused = ttsc_respair_supported(layer(rb + ".convs1." + std::to_string(m)), layer(rb + ".convs2." + std::to_string(m))) != 0;
+            if (fused) {
+                const float* src = X;
+                for (int m = 0; m < nd; ++m) {
+                    const bool last = (m == nd - 1);
+                    float* dst = last ? S : (src == R ? XT : R);
+                    rc = ttsc_respair_forward(layer(rb + ".convs1." + std::to_string(m)), layer(rb + ".convs2." + std::to_string(m)), src, B,
+                                              L, dst, (last && j > 0) ? 1 : 0, lens[i + 1], stream);
+                    if (rc) return rc;
+                    src = dst;
+                }
+                continue;
+            }
             for (int m = 0; m < nd; ++m) {
                 const float* src = (m == 0) ? X : R;
                 const bool last = (m == nd - 1);
