@@ -365,10 +365,10 @@ struct PairArgs {
     int L, d1, accumulate;
 };
 
-template <int K>
-__global__ __launch_bounds__(512, 2) void respair32_f16x3_kernel(PairArgs a) {
+template <int K, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 2)) void respair32_f16x3_kernel(PairArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int C = 32, NCOL = 512, NTO = 480, MARG = 16, XTP = NCOL + 16, H2 = (K - 1) / 2;
+    constexpr int C = 32, NCOL = 64 * NW, MARG = 16, NTO = NCOL - 2 * MARG, XTP = NCOL + 16, H2 = (K - 1) / 2, NTHR = 64 * NW;
     const int span1 = NCOL + (K - 1) * a.d1;
     _Float16* Xhi = reinterpret_cast<_Float16*>(smem_raw);
     _Float16* Xlo = Xhi + (size_t)span1 * 16;
@@ -388,13 +388,13 @@ __global__ __launch_bounds__(512, 2) void respair32_f16x3_kernel(PairArgs a) {
     f32x16 acc[2];
     half8 ah[K], al[K];
 
-    constexpr int XIT = 3;
+    constexpr int XIT = ((NCOL + 64) * 2 + NTHR - 1) / NTHR;
     const int spanp = (span1 + 63) & ~63;
     float xr[XIT][8];
     auto x_issue = [&](int c) {
 #pragma unroll
         for (int e = 0; e < XIT; ++e) {
-            const int i = tid + e * 512;
+            const int i = tid + e * NTHR;
             const int h = i >= spanp ? 1 : 0;
             const int p = i - h * spanp;
             int pos = lo + p;
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void respair32_f16x3_kernel(PairArgs a) {
     auto x_commit = [&]() {
 #pragma unroll
         for (int e = 0; e < XIT; ++e) {
-            const int i = tid + e * 512;
+            const int i = tid + e * NTHR;
             const int h = i >= spanp ? 1 : 0;
             const int p = i - h * spanp;
             const int pos = lo + p;
@@ -913,24 +913,26 @@ extern "C" int ttsc_respair_forward(const ttsc_conv1d* c1, const ttsc_conv1d* c2
     a.d1 = c1->cfg.dilation;
     a.accumulate = accumulate;
     const int k = c1->cfg.kernel_size;
-    const int span1 = 512 + (k - 1) * a.d1;
-    const size_t lds = (size_t)span1 * 16 * 2 * 2 + (size_t)(512 + 16) * 32 * 2 * 2;
-    dim3 grid((unsigned)ceil_div(L, 480), (unsigned)B);
+    // 4 waves / 256 columns (224 outputs) per workgroup: two workgroups share a CU and hide each other's load latency
+    constexpr int NW = 4, NCOL = 64 * NW, NTO = NCOL - 32;
+    const int span1 = NCOL + (k - 1) * a.d1;
+    const size_t lds = (size_t)span1 * 16 * 2 * 2 + (size_t)(NCOL + 16) * 32 * 2 * 2;
+    dim3 grid((unsigned)ceil_div(L, NTO), (unsigned)B);
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipSuccess;
-    if (k == 3) {
-        static bool attr3 = false;
-        if (!attr3) { e = hipFuncSetAttribute((const void*)respair32_f16x3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr3 = true; }
-        hipLaunchKernelGGL(respair32_f16x3_kernel<3>, grid, dim3(512), lds, s, a);
-    } else if (k == 7) {
-        static bool attr7 = false;
-        if (!attr7) { e = hipFuncSetAttribute((const void*)respair32_f16x3_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr7 = true; }
-        hipLaunchKernelGGL(respair32_f16x3_kernel<7>, grid, dim3(512), lds, s, a);
-    } else {
-        static bool attr11 = false;
-        if (!attr11) { e = hipFuncSetAttribute((const void*)respair32_f16x3_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr11 = true; }
-        hipLaunchKernelGGL(respair32_f16x3_kernel<11>, grid, dim3(512), lds, s, a);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)respair32_f16x3_kernel<3, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)respair32_f16x3_kernel<7, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)respair32_f16x3_kernel<11, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
     }
+    if (k == 3)
+        hipLaunchKernelGGL((respair32_f16x3_kernel<3, NW>), grid, dim3(64 * NW), lds, s, a);
+    else if (k == 7)
+        hipLaunchKernelGGL((respair32_f16x3_kernel<7, NW>), grid, dim3(64 * NW), lds, s, a);
+    else
+        hipLaunchKernelGGL((respair32_f16x3_kernel<11, NW>), grid, dim3(64 * NW), lds, s, a);
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("respair32_f16x3_kernel launch failed: %s", hipGetErrorString(e));
