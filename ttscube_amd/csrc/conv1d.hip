@@ -189,9 +189,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NT = 4 * NJ * 32;
     constexpr int AFR = MI * 2 * 64;  // half8 elements of one (tap, chunk) weight block of this workgroup
-    _Float16* Xhi = reinterpret_cast<_Float16*>(smem_raw);
-    _Float16* Xlo = Xhi + (size_t)a.span_pad * 16;
-    half8* Abuf = reinterpret_cast<half8*>(Xlo + (size_t)a.span_pad * 16);  // [2][AFR]
+    // activation tile: four planes [channel-half h][hi|lo][position] of 16-byte items (8 fp16 channels), so that the 32
+    // lanes of a half-wave read 32 CONSECUTIVE 16-byte slots (conflict-free ds_read_b128) and staging writes likewise
+    half8* Xp = reinterpret_cast<half8*>(smem_raw);            // plane (h, pl) at Xp + (h*2 + pl) * span_pad
+    half8* Abuf = Xp + (size_t)4 * a.span_pad;                  // [2][AFR]
 
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -272,8 +273,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
                     vh[ch] = hh;
                     vl[ch] = (_Float16)(v - (float)hh);
                 }
-                *reinterpret_cast<half8*>(Xhi + (size_t)p * 16 + h * 8) = vh;
-                *reinterpret_cast<half8*>(Xlo + (size_t)p * 16 + h * 8) = vl;
+                Xp[(size_t)(h * 2 + 0) * a.span_pad + p] = vh;
+                Xp[(size_t)(h * 2 + 1) * a.span_pad + p] = vl;
             }
         }
     };
@@ -305,9 +306,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
             }
 #pragma unroll
             for (int n = 0; n < NJ; ++n) {
-                const size_t off = (size_t)(wn * (NJ * 32) + n * 32 + l31 + shift) * 16 + half * 8;
-                bh[n] = *reinterpret_cast<const half8*>(Xhi + off);
-                bl[n] = *reinterpret_cast<const half8*>(Xlo + off);
+                const size_t pidx = (size_t)(wn * (NJ * 32) + n * 32 + l31 + shift);
+                bh[n] = Xp[(size_t)(half * 2 + 0) * a.span_pad + pidx];
+                bl[n] = Xp[(size_t)(half * 2 + 1) * a.span_pad + pidx];
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -370,10 +371,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 2)) void respair32_f16x3_ke
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int C = 32, NCOL = 64 * NW, MARG = 16, NTO = NCOL - 2 * MARG, XTP = NCOL + 16, H2 = (K - 1) / 2, NTHR = 64 * NW;
     const int span1 = NCOL + (K - 1) * a.d1;
-    _Float16* Xhi = reinterpret_cast<_Float16*>(smem_raw);
-    _Float16* Xlo = Xhi + (size_t)span1 * 16;
-    _Float16* Thi = Xlo + (size_t)span1 * 16;          // [XTP][32]
-    _Float16* Tlo = Thi + (size_t)XTP * C;
+    // plane layouts as in conv_f16x3_kernel: X planes (h, pl) of span1 items; T planes (chunk c, h, pl) of XTP items
+    half8* Xp = reinterpret_cast<half8*>(smem_raw);
+    half8* Tp = Xp + (size_t)4 * span1;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -423,8 +423,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 2)) void respair32_f16x3_ke
                     vh[ch] = hh;
                     vl[ch] = (_Float16)(v - (float)hh);
                 }
-                *reinterpret_cast<half8*>(Xhi + (size_t)p * 16 + h * 8) = vh;
-                *reinterpret_cast<half8*>(Xlo + (size_t)p * 16 + h * 8) = vl;
+                Xp[(size_t)(h * 2 + 0) * span1 + p] = vh;
+                Xp[(size_t)(h * 2 + 1) * span1 + p] = vl;
             }
         }
     };
@@ -453,9 +453,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 2)) void respair32_f16x3_ke
         for (int j = 0; j < K; ++j) {
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                const size_t off = (size_t)(wv * 64 + n * 32 + l31 + j * a.d1) * 16 + half * 8;
-                const half8 bh = *reinterpret_cast<const half8*>(Xhi + off);
-                const half8 bl = *reinterpret_cast<const half8*>(Xlo + off);
+                const size_t pidx = (size_t)(wv * 64 + n * 32 + l31 + j * a.d1);
+                const half8 bh = Xp[(size_t)(half * 2 + 0) * span1 + pidx];
+                const half8 bl = Xp[(size_t)(half * 2 + 1) * span1 + pidx];
                 acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], bh, acc[n], 0, 0, 0);
                 acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bl, acc[n], 0, 0, 0);
                 acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bh, acc[n], 0, 0, 0);
@@ -484,9 +484,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 2)) void respair32_f16x3_ke
                 vh[e] = hh;
                 vl[e] = (_Float16)(v - (float)hh);
             }
-            const size_t off = (size_t)(col + 8) * C + 8 * g + 4 * half;
-            *reinterpret_cast<half4*>(Thi + off) = vh;
-            *reinterpret_cast<half4*>(Tlo + off) = vl;
+            // channel group g (8 channels) = chunk g/2, channel-half g%2; this lane owns 4 of its 8 channels
+            _Float16* th = reinterpret_cast<_Float16*>(Tp + (size_t)(g * 2 + 0) * XTP + (col + 8)) + 4 * half;
+            _Float16* tl = reinterpret_cast<_Float16*>(Tp + (size_t)(g * 2 + 1) * XTP + (col + 8)) + 4 * half;
+            *reinterpret_cast<half4*>(th) = vh;
+            *reinterpret_cast<half4*>(tl) = vl;
         }
     }
     __syncthreads();
@@ -501,9 +503,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 2)) void respair32_f16x3_ke
         for (int j = 0; j < K; ++j) {
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                const size_t off = (size_t)(wv * 64 + n * 32 + l31 + 8 + j - H2) * C + c * 16 + half * 8;
-                const half8 bh = *reinterpret_cast<const half8*>(Thi + off);
-                const half8 bl = *reinterpret_cast<const half8*>(Tlo + off);
+                const size_t pidx = (size_t)(wv * 64 + n * 32 + l31 + 8 + j - H2);
+                const half8 bh = Tp[(size_t)((c * 2 + half) * 2 + 0) * XTP + pidx];
+                const half8 bl = Tp[(size_t)((c * 2 + half) * 2 + 1) * XTP + pidx];
                 acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], bh, acc[n], 0, 0, 0);
                 acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bl, acc[n], 0, 0, 0);
                 acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bh, acc[n], 0, 0, 0);
