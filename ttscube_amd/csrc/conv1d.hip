@@ -184,15 +184,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
 // one position) is a single 16-byte ds_read; the fp32 -> (hi,lo) split and the leaky-relu prologue happen while staging.
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-template <int MI, int NJ>
+template <int MI, int NJ, int TMAX>
 __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NT = 4 * NJ * 32;
-    constexpr int AFR = MI * 2 * 64;  // half8 elements of one (tap, chunk) weight block of this workgroup
+    constexpr int AFR = MI * 2 * 64;  // half8 items of one (tap, chunk) weight block of this workgroup's M tile
     // activation tile: four planes [channel-half h][hi|lo][position] of 16-byte items (8 fp16 channels), so that the 32
     // lanes of a half-wave read 32 CONSECUTIVE 16-byte slots (conflict-free ds_read_b128) and staging writes likewise
     half8* Xp = reinterpret_cast<half8*>(smem_raw);            // plane (h, pl) at Xp + (h*2 + pl) * span_pad
-    half8* Abuf = Xp + (size_t)4 * a.span_pad;                  // [2][AFR]
+    half8* Ap = Xp + (size_t)4 * a.span_pad;                    // [ntaps][AFR]: ALL taps of the current channel chunk
 
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -203,7 +203,6 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
     const int cot0 = blockIdx.y * MI;
     const int cotN = a.CoutP >> 5;
     const int nchunks = a.CinP >> 4;
-    const int n_it = nchunks * a.ntaps;
 
     f32x16 acc[MI][NJ];
 #pragma unroll
@@ -216,24 +215,31 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
     const float* xb = a.x + (size_t)b * a.Cin * a.Lin;
     const int lo = q0 + a.min_shift;
     const half8* wsrc = reinterpret_cast<const half8*>(a.wph);
-    // block of (tap j, chunk c) for this workgroup's M tile: ((j*nchunks + c)*cotN + cot0)*128 half8, AFR contiguous
-    auto a_src = [&](int it) {
-        const int c = it / a.ntaps, j = it - c * a.ntaps;
-        return wsrc + ((size_t)(j * nchunks + c) * cotN + cot0) * 128;
-    };
-    constexpr int APT = (AFR + 255) / 256;  // half8 per thread
-    half8 areg[APT];
-#pragma unroll
-    for (int e = 0; e < APT; ++e) {
-        const int idx = tid + e * 256;
-        if (idx < AFR) Abuf[idx] = a_src(0)[idx];
-    }
 
-    // Activation staging is software-pipelined through registers: the global loads of chunk c+1 are issued before
-    // the MFMA loop of chunk c and consumed (leaky-relu, hi/lo split, LDS write) after it, so their latency hides
-    // behind ntaps*MI*NJ*3 MFMAs.  Work item = (position p, channel group h of 8); items are laid out so that
-    // consecutive lanes read consecutive positions (coalesced 256-B rows).  Addresses are clamped and the loads are
-    // unconditional (a select zeroes the padding) so that the compiler never branches around a load.
+    // Both operands are software-pipelined through registers ONE CHANNEL CHUNK ahead: the global loads of chunk c+1
+    // (activation window and the weight fragments of all taps) are issued before the MFMA loop of chunk c and
+    // committed to LDS after it, so their latency hides behind ntaps*MI*NJ*3 MFMAs and the tap loop itself has no
+    // barrier and no global access.  Addresses are clamped and loads unconditional (selects zero the padding) so the
+    // compiler never branches around a load.
+    constexpr int APT = (TMAX * AFR + 255) / 256;  // weight items per thread per chunk
+    const int a_items = a.ntaps * AFR;
+    half8 areg[APT];
+    auto a_issue = [&](int c) {
+#pragma unroll
+        for (int e = 0; e < APT; ++e) {
+            int idx = tid + e * 256;
+            idx = idx < a_items ? idx : a_items - 1;
+            const int j = idx / AFR, r = idx - j * AFR;
+            areg[e] = wsrc[((size_t)(j * nchunks + c) * cotN + cot0) * 128 + r];
+        }
+    };
+    auto a_commit = [&]() {
+#pragma unroll
+        for (int e = 0; e < APT; ++e) {
+            const int idx = tid + e * 256;
+            if (idx < a_items) Ap[idx] = areg[e];
+        }
+    };
     constexpr int XIT = ((NT + 64) * 2 + 255) / 256;
     const int spanp = (a.span + 63) & ~63;
     float xr[XIT][8];
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
             const int h = i >= spanp ? 1 : 0;
             const int p = i - h * spanp;
             int pos = lo + p;
-            pos = pos < 0 ? 0 : (pos > lin - 1 ? lin - 1 : pos);
+            pos = pos > lin - 1 ? lin - 1 : pos;
             pos = pos < 0 ? 0 : pos;
             const int cb = c * 16 + h * 8;
 #pragma unroll
@@ -280,23 +286,18 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
     };
 
     x_issue(0);
+    a_issue(0);
     for (int c = 0; c < nchunks; ++c) {
-        // (the barrier closing the previous chunk's last tap guarantees nobody still reads the activation tile)
+        if (c) __syncthreads();  // everyone finished reading chunk c-1 from LDS
         x_commit(c);
+        a_commit();
         __syncthreads();
-        if (c + 1 < nchunks) x_issue(c + 1);
+        if (c + 1 < nchunks) {
+            x_issue(c + 1);
+            a_issue(c + 1);
+        }
         for (int j = 0; j < a.ntaps; ++j) {
-            const int it = c * a.ntaps + j;
-            const bool more = it + 1 < n_it;
-            if (more) {
-                const half8* src = a_src(it + 1);
-#pragma unroll
-                for (int e = 0; e < APT; ++e) {
-                    const int idx = tid + e * 256;
-                    if (idx < AFR) areg[e] = src[idx];
-                }
-            }
-            const half8* Ab = Abuf + (it & 1) * AFR;
+            const half8* Ab = Ap + (size_t)j * AFR;
             const int shift = a.tap_base + j * a.tap_step - a.min_shift;
             half8 ah[MI], al[MI], bh[NJ], bl[NJ];
 #pragma unroll
@@ -318,15 +319,6 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
                     acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[n], acc[i][n], 0, 0, 0);
                     acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[n], acc[i][n], 0, 0, 0);
                 }
-            if (more) {
-                half8* Aw = Abuf + ((it + 1) & 1) * AFR;
-#pragma unroll
-                for (int e = 0; e < APT; ++e) {
-                    const int idx = tid + e * 256;
-                    if (idx < AFR) Aw[idx] = areg[e];
-                }
-            }
-            __syncthreads();
         }
     }
 
@@ -531,19 +523,32 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 2)) void respair32_f16x3_ke
     }
 }
 
-template <int MI, int NJ>
-static int launch_f16(const ConvArgs& a, int B, hipStream_t s) {
+template <int MI, int NJ, int TMAX>
+static int launch_f16_t(const ConvArgs& a, int B, hipStream_t s) {
     constexpr int NT = 4 * NJ * 32;
     constexpr int MT = MI * 32;
     dim3 grid((unsigned)ceil_div(a.q_cnt, NT), (unsigned)(a.CoutP / MT), (unsigned)B);
-    const size_t lds = (size_t)a.span_pad * 16 * 2 * 2 + (size_t)2 * MI * 2 * 64 * 16;
-    hipLaunchKernelGGL((conv_f16x3_kernel<MI, NJ>), grid, dim3(256), lds, s, a);
+    const size_t lds = (size_t)a.span_pad * 4 * 16 + (size_t)a.ntaps * MI * 2 * 64 * 16;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv_f16x3_kernel<MI, NJ, TMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((conv_f16x3_kernel<MI, NJ, TMAX>), grid, dim3(256), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("conv_f16x3_kernel launch failed: %s", hipGetErrorString(e));
         return TTSC_EHIP;
     }
     return TTSC_OK;
+}
+
+template <int MI, int NJ>
+static int launch_f16(const ConvArgs& a, int B, hipStream_t s) {
+    if (a.ntaps <= 3) return launch_f16_t<MI, NJ, 3>(a, B, s);
+    if (a.ntaps <= 7) return launch_f16_t<MI, NJ, 7>(a, B, s);
+    if (a.ntaps <= 11) return launch_f16_t<MI, NJ, 11>(a, B, s);
+    return launch_f16_t<MI, NJ, 16>(a, B, s);
 }
 
 template <int MI, int NJ, int WM, int WN>
@@ -700,7 +705,8 @@ extern "C" int ttsc_conv1d_set_precision(ttsc_conv1d* c, int32_t precision) {
     // receptive field (none on the hot path) silently stay on the exact fp32 kernel.
     const int halo = c->cfg.transposed ? (c->cfg.kernel_size + c->cfg.stride - 1) / c->cfg.stride - 1
                                        : (c->cfg.kernel_size - 1) * c->cfg.dilation;
-    if (precision == TTSC_PREC_F16X3 && halo > 64) precision = TTSC_PREC_FP32;
+    const int taps = c->cfg.transposed ? (c->cfg.kernel_size + c->cfg.stride - 1) / c->cfg.stride : c->cfg.kernel_size;
+    if (precision == TTSC_PREC_F16X3 && (halo > 64 || taps > 16)) precision = TTSC_PREC_FP32;
     if (precision == c->precision) return TTSC_OK;
     c->precision = precision;
     return c->has_weight ? conv_repack(c) : TTSC_OK;
@@ -859,15 +865,14 @@ extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, 
         int rc;
         if (c->precision == TTSC_PREC_F16X3) {
             // the split kernel's N tile is fixed by its 4-waves-along-N shape
-            const int nt = c->MT == 128 ? 256 : 512;
+            const int nt = c->MT >= 64 ? 256 : 512;
             a.span = nt + (last < 0 ? -last : last);
             a.span_pad = a.span;
-            if (c->MT == 128)
-                rc = launch_f16<4, 2>(a, B, s);
-            else if (c->MT == 64)
-                rc = launch_f16<2, 4>(a, B, s);
+            TTSC_REQUIRE(ph.ntaps <= 16, "f16x3 path supports at most 16 taps per phase (got %d)", ph.ntaps);
+            if (c->MT >= 64)
+                rc = launch_f16<2, 2>(a, B, s);   // 64 x 256 tile (MT=128 layers run as two M tiles)
             else
-                rc = launch_f16<1, 4>(a, B, s);
+                rc = launch_f16<1, 4>(a, B, s);   // 32 x 512 tile
         } else if (c->MT == 128)
             rc = launch_cfg<2, 2, 2, 2>(a, B, s);
         else if (c->MT == 64)
