@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
 #pragma unroll
                 for (int ch = 0; ch < 8; ++ch) {
                     float v = (pok && cb + ch < a.Cin) ? xr[e][ch] * a.in_scale : 0.f;
-                    v = v > 0.f ? v : v * a.in_slope;
+                    v = fmaxf(v, v * a.in_slope);   // leaky-relu for slopes in [0,1] (1 = identity)
                     const _Float16 hh = (_Float16)v;
                     vh[ch] = hh;
                     vl[ch] = (_Float16)(v - (float)hh);
@@ -296,29 +296,39 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
             x_issue(c + 1);
             a_issue(c + 1);
         }
-        for (int j = 0; j < a.ntaps; ++j) {
-            const half8* Ab = Ap + (size_t)j * AFR;
-            const int shift = a.tap_base + j * a.tap_step - a.min_shift;
+        // per-lane LDS bases are loop invariants; inside the tap loop only `shift` / the tap's block offset are added
+        // (32-bit LDS addressing, immediate offsets for the fragment index) — VALU work per MFMA matters here because
+        // VALU and MFMA issue from the same in-order wave
+        const half8* xh = Xp + (unsigned)((half * 2 + 0) * a.span_pad + wn * (NJ * 32) + l31);
+        const half8* xl = Xp + (unsigned)((half * 2 + 1) * a.span_pad + wn * (NJ * 32) + l31);
+        const half8* al_base = Ap + lane;
+        int shift = a.tap_base - a.min_shift;
+        for (int j = 0; j < a.ntaps; ++j, shift += a.tap_step) {
+            const half8* Ab = al_base + j * AFR;
             half8 ah[MI], al[MI], bh[NJ], bl[NJ];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                ah[i] = Ab[(i * 2 + 0) * 64 + lane];
-                al[i] = Ab[(i * 2 + 1) * 64 + lane];
+                ah[i] = Ab[(i * 2 + 0) * 64];
+                al[i] = Ab[(i * 2 + 1) * 64];
             }
 #pragma unroll
             for (int n = 0; n < NJ; ++n) {
-                const size_t pidx = (size_t)(wn * (NJ * 32) + n * 32 + l31 + shift);
-                bh[n] = Xp[(size_t)(half * 2 + 0) * a.span_pad + pidx];
-                bl[n] = Xp[(size_t)(half * 2 + 1) * a.span_pad + pidx];
+                bh[n] = xh[shift + n * 32];
+                bl[n] = xl[shift + n * 32];
             }
+            // three product terms; consecutive MFMAs go to DIFFERENT accumulators (no back-to-back dependency)
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int n = 0; n < NJ; ++n) {
-                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[n], acc[i][n], 0, 0, 0);
-                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[n], acc[i][n], 0, 0, 0);
-                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[n], acc[i][n], 0, 0, 0);
-                }
+                for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[n], acc[i][n], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[n], acc[i][n], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[n], acc[i][n], 0, 0, 0);
         }
     }
 
@@ -410,7 +420,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 2)) void respair32_f16x3_ke
 #pragma unroll
                 for (int ch = 0; ch < 8; ++ch) {
                     float v = pok ? xr[e][ch] : 0.f;
-                    v = v > 0.f ? v : v * 0.1f;
+                    v = fmaxf(v, v * 0.1f);
                     const _Float16 hh = (_Float16)v;
                     vh[ch] = hh;
                     vl[ch] = (_Float16)(v - (float)hh);
@@ -441,17 +451,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 2)) void respair32_f16x3_ke
         x_commit();
         __syncthreads();
         if (c == 0) x_issue(1);
+        const half8* xh = Xp + (unsigned)((half * 2 + 0) * span1 + wv * 64 + l31);
+        const half8* xl = Xp + (unsigned)((half * 2 + 1) * span1 + wv * 64 + l31);
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const size_t pidx = (size_t)(wv * 64 + n * 32 + l31 + j * a.d1);
-                const half8 bh = Xp[(size_t)(half * 2 + 0) * span1 + pidx];
-                const half8 bl = Xp[(size_t)(half * 2 + 1) * span1 + pidx];
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], bh, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bl, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bh, acc[n], 0, 0, 0);
-            }
+            const half8 bh0 = xh[j * a.d1], bh1 = xh[j * a.d1 + 32];
+            const half8 bl0 = xl[j * a.d1], bl1 = xl[j * a.d1 + 32];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], bh0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], bh1, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bl0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bl1, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bh0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bh1, acc[1], 0, 0, 0);
         }
     }
     // conv1 epilogue -> LDS: xt = lrelu(conv1 + b1), zero outside the sequence (conv2 pads with zeros), hi/lo split.
@@ -470,7 +481,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 2)) void respair32_f16x3_ke
             for (int e = 0; e < 4; ++e) {
                 const int ch = 8 * g + 4 * half + e;
                 float v = acc[n][4 * g + e] * a.unscale1 + a.b1[ch];
-                v = v > 0.f ? v : v * 0.1f;
+                v = fmaxf(v, v * 0.1f);
                 v = pok ? v : 0.f;
                 const _Float16 hh = (_Float16)v;
                 vh[e] = hh;
@@ -491,17 +502,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 2)) void respair32_f16x3_ke
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
     for (int c = 0; c < 2; ++c) {
         if (c) load_a(a.w2, 1);
+        const half8* th = Tp + (unsigned)(((c * 2 + half) * 2 + 0) * XTP + wv * 64 + l31 + 8 - H2);
+        const half8* tl = Tp + (unsigned)(((c * 2 + half) * 2 + 1) * XTP + wv * 64 + l31 + 8 - H2);
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const size_t pidx = (size_t)(wv * 64 + n * 32 + l31 + 8 + j - H2);
-                const half8 bh = Tp[(size_t)((c * 2 + half) * 2 + 0) * XTP + pidx];
-                const half8 bl = Tp[(size_t)((c * 2 + half) * 2 + 1) * XTP + pidx];
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], bh, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bl, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bh, acc[n], 0, 0, 0);
-            }
+            const half8 bh0 = th[j], bh1 = th[j + 32];
+            const half8 bl0 = tl[j], bl1 = tl[j + 32];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], bh0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], bh1, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bl0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bl1, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bh0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bh1, acc[1], 0, 0, 0);
         }
     }
     // conv2 epilogue: + b2 + x (residual) [+ running sum]; only the 480 central columns are outputs
@@ -815,6 +827,7 @@ extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, 
         return TTSC_ESTATE;
     }
     TTSC_REQUIRE(B > 0 && Lin > 0, "ttsc_conv1d_forward: bad B/Lin (%d, %lld)", B, (long long)Lin);
+    TTSC_REQUIRE(!ep || (ep->in_slope >= 0.f && ep->in_slope <= 1.f), "ttsc_conv1d_forward: in_slope must be in [0,1]");
     const auto& g = c->cfg;
     const int64_t Lout = ttsc_conv1d_out_len(c, Lin);
     TTSC_REQUIRE(Lout > 0, "ttsc_conv1d_forward: output length %lld <= 0", (long long)Lout);
