@@ -59,26 +59,56 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // C/D layout of v_mfma_*_32x32: column (time) = lane & 31, row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 __device__ __forceinline__ void epilogue_tile(const f32x16& acc, const ConvArgs& a, int b, int co_base, long o, bool qok,
                                               int half, float acc_scale) {
-    float rv[16], yv[16];
+    // NOTE: the optional operands are tested ONCE per tile (wave-uniform branches around straight-line load groups).
+    // A per-element `ptr ? ptr[i] : 0` makes hipcc branch around every single load and wait for each one in turn.
+    float rv[16], yv[16], bv[16];
     const long o_c = qok ? o : 0;
+    size_t idx[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * half;
         const int co_c = co < a.Cout ? co : a.Cout - 1;
-        const size_t idx = ((size_t)b * a.Cout + co_c) * a.Lout + o_c;
-        rv[r] = a.resid ? a.resid[idx] : 0.f;
-        yv[r] = a.accumulate ? a.y[idx] : 0.f;
+        idx[r] = ((size_t)b * a.Cout + co_c) * a.Lout + o_c;
     }
+    if (a.bias) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (qok && co < a.Cout) {
-            const size_t idx = ((size_t)b * a.Cout + co) * a.Lout + o;
-            float v = acc[r] * acc_scale;
-            if (a.bias) v += a.bias[co];
-            v += rv[r];
-            v = apply_act(v * a.out_scale, a.out_act);
-            a.y[idx] = v + yv[r];
+        for (int r = 0; r < 16; ++r) {
+            const int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * half;
+            bv[r] = a.bias[co < a.Cout ? co : a.Cout - 1];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[r] = 0.f;
+    }
+    if (a.resid) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = a.resid[idx[r]];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+    }
+    if (a.accumulate) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yv[r] = a.y[idx[r]];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yv[r] = 0.f;
+    }
+    if (a.out_act == TTSC_ACT_NONE) {   // the common case gets its own straight-line copy (no inlined tanh/exp bodies)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (qok && co < a.Cout) a.y[idx[r]] = (acc[r] * acc_scale + bv[r] + rv[r]) * a.out_scale + yv[r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (qok && co < a.Cout) {
+                float v = acc[r] * acc_scale + bv[r] + rv[r];
+                v = apply_act(v * a.out_scale, a.out_act);
+                a.y[idx[r]] = v + yv[r];
+            }
         }
     }
 }
@@ -243,44 +273,51 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
     constexpr int XIT = ((NT + 64) * 2 + 255) / 256;
     const int spanp = (a.span + 63) & ~63;
     float xr[XIT][8];
+    // per-item invariants (position window is the same for every chunk): clamped load offset, LDS slot, validity
+    unsigned xoff[XIT];
+    int xslot[XIT];   // LDS item index of plane (h, hi) for this item, or -1
+    bool xok[XIT];
+    int xh[XIT];
+#pragma unroll
+    for (int e = 0; e < XIT; ++e) {
+        const int i = tid + e * 256;
+        const int h = i >= spanp ? 1 : 0;
+        const int p = i - h * spanp;
+        const int pos = lo + p;
+        xok[e] = pos >= 0 && pos < lin;
+        int pc = pos > lin - 1 ? lin - 1 : pos;
+        pc = pc < 0 ? 0 : pc;
+        xoff[e] = (unsigned)pc;
+        xh[e] = h;
+        xslot[e] = (p < a.span && i < 2 * spanp) ? (h * 2) * a.span_pad + p : -1;
+    }
     auto x_issue = [&](int c) {
 #pragma unroll
-        for (int e = 0; e < XIT; ++e) {
-            const int i = tid + e * 256;
-            const int h = i >= spanp ? 1 : 0;
-            const int p = i - h * spanp;
-            int pos = lo + p;
-            pos = pos > lin - 1 ? lin - 1 : pos;
-            pos = pos < 0 ? 0 : pos;
-            const int cb = c * 16 + h * 8;
+        for (int ch = 0; ch < 8; ++ch) {
+            // the two channel rows (h = 0 / 1) of this step are wave-uniform scalars: loads use sgpr base + vgpr offset
+            const int c0 = c * 16 + ch, c1 = c * 16 + 8 + ch;
+            const float* r0 = xb + (size_t)(c0 < a.Cin ? c0 : a.Cin - 1) * a.Lin;
+            const float* r1 = xb + (size_t)(c1 < a.Cin ? c1 : a.Cin - 1) * a.Lin;
 #pragma unroll
-            for (int ch = 0; ch < 8; ++ch) {
-                const int ci = cb + ch < a.Cin ? cb + ch : a.Cin - 1;
-                xr[e][ch] = xb[(size_t)ci * a.Lin + pos];
-            }
+            for (int e = 0; e < XIT; ++e) xr[e][ch] = (xh[e] ? r1 : r0)[xoff[e]];
         }
     };
     auto x_commit = [&](int c) {
 #pragma unroll
         for (int e = 0; e < XIT; ++e) {
-            const int i = tid + e * 256;
-            const int h = i >= spanp ? 1 : 0;
-            const int p = i - h * spanp;
-            const int pos = lo + p;
-            const bool pok = pos >= 0 && pos < lin;
-            const int cb = c * 16 + h * 8;
-            if (p < a.span && i < 2 * spanp) {
+            if (xslot[e] >= 0) {
+                const int cb = c * 16 + xh[e] * 8;
                 half8 vh, vl;
 #pragma unroll
                 for (int ch = 0; ch < 8; ++ch) {
-                    float v = (pok && cb + ch < a.Cin) ? xr[e][ch] * a.in_scale : 0.f;
+                    float v = (xok[e] && cb + ch < a.Cin) ? xr[e][ch] * a.in_scale : 0.f;
                     v = fmaxf(v, v * a.in_slope);   // leaky-relu for slopes in [0,1] (1 = identity)
                     const _Float16 hh = (_Float16)v;
                     vh[ch] = hh;
                     vl[ch] = (_Float16)(v - (float)hh);
                 }
-                Xp[(size_t)(h * 2 + 0) * a.span_pad + p] = vh;
-                Xp[(size_t)(h * 2 + 1) * a.span_pad + p] = vl;
+                Xp[xslot[e]] = vh;
+                Xp[xslot[e] + a.span_pad] = vl;
             }
         }
     };
