@@ -20,7 +20,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (no sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -53,7 +54,7 @@ def cpu_baseline(h, sd, budget_s=12.0):
             out = R.generator_forward(w, h, mel)
             n += 1
             el = time.perf_counter() - t0
-            if el > budget_s or n >= 8:
+            if el > budget_s or n >= 200:
                 break
     samples = n * out.shape[0] * out.shape[2]
     return {'value': samples / el, 'unit': 'audio samples/s', 'cores': cores, 'kind': 'port',
@@ -127,22 +128,34 @@ def main():
         samples_per_step = world * B * Lout
         value = samples_per_step * args.steps / elapsed
         flops_step = g.algorithmic_flops(B, T)  # per GPU, per step (1 168 559 FLOP/sample)
-        achieved = flops_step * args.steps / (dev_ms * 1e-3) / 1e12
+        achieved = flops_step * args.steps / (dev_ms * 1e-3) / 1e12   # ALGORITHMIC TFLOP/s (2 x MAC of the fp32 model)
         alg_bytes = B * (80 * T * 4 + Lout * 4)  # compulsory: mel in + wav out (5.33 B/sample)
+        precision = g._precision
+        if precision == 'f16x3':
+            # split precision: every algorithmic product is three fp16 MFMA products (hi*hi + hi*lo + lo*hi, fp32 accumulate),
+            # so the MFMA ceiling for fp32-accurate results is the dense f16 peak / 3
+            peak, kname = PEAK_F16_MFMA_TFLOPS / 3.0, 'conv_f16x3_kernel + respair32_f16x3_kernel (v_mfma_f32_32x32x16_f16 x3 split-precision implicit-GEMM conv; all launches of one forward)'
+            executed = 3.0 * achieved
+        else:
+            peak, kname = PEAK_FP32_MFMA_TFLOPS, 'conv_mfma_kernel (v_mfma_f32_32x32x2_f32 implicit-GEMM conv; all launches of one forward)'
+            executed = achieved
         res = {
             'metric': 'audio samples/sec (HiFi-GAN vocoder inference)', 'value': value, 'unit': 'samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 (split fp16 hi/lo x3 MFMA, fp32 accumulate)' if precision == 'f16x3' else 'f32',
+            'data': 'synthetic',
             'config': {'workload': 'HiFi-GAN V1 generator inference, batch=%d utterances x %.1f s per GPU, 24 kHz, '
                                    '80-bin mel, config_v1 [5,3,4,4]' % (B, T * 240 / 24000.0),
                        'global_batch': world * B, 'frames': T, 'samples_per_utt': Lout,
-                       'parallelism': 'utterance shards, no collective'},
+                       'parallelism': 'utterance shards, no collective', 'precision': precision},
             'rtf_24k': value / world / 24000.0, 'rtf_22k05': value / world / 22050.0,
             'per_gpu_samples_s': value / world,
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
-                         'kernel': 'conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv; all launches of one forward)',
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': achieved / peak, 'traffic': None, 'kernel': kname,
                          'flops_per_step': flops_step, 'device_ms_per_step': dev_ms / args.steps,
+                         'mfma_executed_tflops': executed, 'mfma_dense_peak_tflops': PEAK_F16_MFMA_TFLOPS if precision == 'f16x3' else PEAK_FP32_MFMA_TFLOPS,
+                         'x_fp32_mfma_peak': achieved / PEAK_FP32_MFMA_TFLOPS,
                          'hbm_compulsory_GBs': alg_bytes * args.steps / (dev_ms * 1e-3) / 1e9,
                          'hbm_frac_compulsory': alg_bytes * args.steps / (dev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
         }
