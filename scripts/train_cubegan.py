@@ -1,0 +1,110 @@
+#!/usr/bin/env python
+"""Counterpart of the reference's scripts/train_cubegan.py (flags, files written), without pytorch_lightning: one
+process per GPU under torch.distributed.run, explicit RCCL flat-bucket gradient exchange after each of the three
+backward passes of the GAN step (cube/networks/cubegan.py:153,170,174).
+
+Files (train_cubegan.py:38-91 of the reference): <base>.yaml {sample_rate, hop_size, conditioning}, <base>.encodings,
+<base>.best / <base>.last (Cubegan state_dict), <base>.opt.last {'0'..'3': optimizer state, 'global_step'}; --resume
+restores model AND optimizers (the reference's resume silently drops the optimizer state: attribute-name mismatch at
+train_cubegan.py:135 vs cubegan.py:304).  Data: `--synthetic N` (seeded synthetic examples, per-rank distinct)."""
+import os
+import random
+import sys
+from argparse import ArgumentParser
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import yaml
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ttscube_amd.distributed import FlatBucketReducer, broadcast_parameters  # noqa: E402
+from ttscube_amd.io_utils.io_cubegan import CubeganCollate, CubeganEncodings  # noqa: E402
+from ttscube_amd.networks import training as T  # noqa: E402
+from ttscube_amd.networks.cubegan import Cubegan  # noqa: E402
+
+
+def synthetic_examples(n, seed, nphones=40):
+    rng = np.random.RandomState(seed)
+    for _ in range(n):
+        nph = rng.randint(20, 60)
+        durs = rng.randint(2, 12, size=nph)
+        f2p = [p for p, d in enumerate(durs) for _ in range(d)]
+        F_ = len(f2p)
+        yield {'meta': {'phones': ['p%d' % v for v in rng.randint(0, nphones, size=nph)], 'speaker': 's%d' % rng.randint(0, 2),
+                        'frame2phon': f2p, 'phon2word': [0] * nph},
+               'mgc': np.clip(rng.randn(F_, 80) - 2, -5, 1), 'pitch': rng.randint(60, 300, size=F_).astype(np.float64),
+               'audio': (0.3 * np.sin(np.cumsum(rng.uniform(0.01, 0.3, size=F_ * 240)))).astype(np.float32)}
+
+
+def _train(params):
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+    conditioning = params.lm if params.lm not in (None, 'none') else None
+    examples = list(synthetic_examples(params.synthetic or 32, 1234 + rank))   # rank-distinct data and crops
+    enc = CubeganEncodings()
+    if params.resume:
+        enc.load('{0}.encodings'.format(params.output_base))
+    else:
+        enc.compute(list(synthetic_examples(params.synthetic or 32, 1234)) if world > 1 else examples)
+    if rank == 0:
+        yaml.dump({'sample_rate': params.sample_rate, 'hop_size': params.hop_size, 'conditioning': conditioning},
+                  open('{0}.yaml'.format(params.output_base), 'w'))
+        enc.save('{0}.encodings'.format(params.output_base))
+    model = Cubegan(enc, conditioning=conditioning, train=True)
+    if params.resume:
+        model.load('{0}.last'.format(params.output_base))
+        st = torch.load('{0}.opt.last'.format(params.output_base), map_location='cpu')
+        model._global_step = st['global_step']
+        model._loaded_optimizer_states = st
+    model = model.to(dev)
+    broadcast_parameters(model)
+    opts = T.cubegan_configure_optimizers(model)
+    g, d, t = T.cubegan_param_groups(model)
+    reducers = (FlatBucketReducer(g), FlatBucketReducer(d), FlatBucketReducer(t)) if world > 1 else None
+    collate = CubeganCollate(enc)
+    crop_rng = random.Random(99 + rank)
+    best = 9999.0
+    for epoch in range(params.epochs):
+        mel_loss, nb = 0.0, 0
+        for s in range(0, len(examples), params.batch_size):
+            out = T.cubegan_training_step(model, collate.collate_fn(examples[s:s + params.batch_size]), opts, reducers, rng=crop_rng)
+            mel_loss += out['loss_mel']
+            nb += 1
+        if rank == 0:
+            v = mel_loss / max(nb, 1)
+            if v < best:
+                best = v
+                model.save('{0}.best'.format(params.output_base))
+            model.save('{0}.last'.format(params.output_base))
+            od = {str(i): o.state_dict() for i, o in enumerate(opts)}
+            od['global_step'] = model._global_step
+            torch.save(od, '{0}.opt.last'.format(params.output_base))
+            sys.stdout.write('epoch %d  mel-L1 %.4f  step %d  lr %.3e\n' % (epoch, v, model._global_step, model._current_lr))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    p = ArgumentParser(description='Cubegan trainer (reference flags)')
+    p.add_argument('--output-base', dest='output_base', default='data/cubegan')
+    p.add_argument('--batch-size', dest='batch_size', default=16, type=int)
+    p.add_argument('--num-workers', dest='num_workers', default=4, type=int)
+    p.add_argument('--accelerator', dest='accelerator', default='gpu')
+    p.add_argument('--devices', dest='devices', default=1, type=int)
+    p.add_argument('--train-folder', dest='train_folder', default='data/processed/train')
+    p.add_argument('--dev-folder', dest='dev_folder', default='data/processed/dev')
+    p.add_argument('--sample-rate', dest='sample_rate', type=int, default=24000)
+    p.add_argument('--hop-size', dest='hop_size', type=int, default=240)
+    p.add_argument('--lr', dest='lr', default=2e-4, type=float)
+    p.add_argument('--lm', dest='lm', default=None, help='external conditioning (none | fasttext:<lang> | hf:<model>); only none is built')
+    p.add_argument('--resume', dest='resume', action='store_true')
+    p.add_argument('--epochs', type=int, default=1)
+    p.add_argument('--synthetic', type=int, default=0, help='train on N synthetic examples per rank')
+    _train(p.parse_args())
