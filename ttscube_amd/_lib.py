@@ -56,10 +56,15 @@ SIGNATURES = {
     'ttsc_conv1d_set_weight': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'ttsc_conv1d_set_precision': (C.c_int, [C.c_void_p, C.c_int32]),
     'ttsc_conv1d_out_len': (C.c_int64, [C.c_void_p, C.c_int64]),
+    'ttsc_conv1d_in_channels': (C.c_int32, [C.c_void_p]),
     'ttsc_conv1d_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
                                       C.POINTER(Conv1dEpilogue), C.c_void_p]),
     'ttsc_conv1d_forward_ragged': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
                                              C.POINTER(Conv1dEpilogue), C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ttsc_split_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int64]),
+    'ttsc_conv1d_forward_split': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
+                                            C.c_float, C.c_float, C.c_void_p, C.POINTER(Conv1dEpilogue), C.c_void_p, C.c_void_p,
+                                            C.c_void_p]),
     'ttsc_respair_supported': (C.c_int, [C.c_void_p, C.c_void_p]),
     'ttsc_respair_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int32,
                                        C.c_void_p, C.c_void_p]),

@@ -43,6 +43,13 @@ struct ConvArgs {
     int span, span_pad, min_shift;
     float in_scale, in_slope, out_scale;
     int out_act, accumulate;
+    // "split activation" tensors: [B][C/8][hi|lo][L] items of 8 fp16 channels (16 B) = the LDS plane layout of the
+    // f16x3 kernels.  A producer's epilogue writes  split(lrelu(ys_scale * y, ys_slope))  ONCE per element, so that the
+    // consumer stages pure 16-byte copies instead of converting fp32 -> (hi,lo) in every output-channel tile.
+    const void* xs;   // split input (then x / in_scale / in_slope are ignored) or null
+    void* ys;         // split output or null
+    float ys_scale, ys_slope;
+    int write_f32;    // 0: only the split output is written
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -94,20 +101,41 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& acc, const ConvArgs&
 #pragma unroll
         for (int r = 0; r < 16; ++r) yv[r] = 0.f;
     }
+    float res[16];
     if (a.out_act == TTSC_ACT_NONE) {   // the common case gets its own straight-line copy (no inlined tanh/exp bodies)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (qok && co < a.Cout) a.y[idx[r]] = (acc[r] * acc_scale + bv[r] + rv[r]) * a.out_scale + yv[r];
-        }
+        for (int r = 0; r < 16; ++r) res[r] = (acc[r] * acc_scale + bv[r] + rv[r]) * a.out_scale + yv[r];
     } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) res[r] = apply_act((acc[r] * acc_scale + bv[r] + rv[r]) * a.out_scale, a.out_act) + yv[r];
+    }
+    if (a.write_f32) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (qok && co < a.Cout) {
-                float v = acc[r] * acc_scale + bv[r] + rv[r];
-                v = apply_act(v * a.out_scale, a.out_act);
-                a.y[idx[r]] = v + yv[r];
+            if (qok && co < a.Cout) a.y[idx[r]] = res[r];
+        }
+    }
+    if (a.ys && qok) {
+        // this lane owns channels {8g + 4*half + e} of its column: four 8-byte pieces, one per 8-channel item
+        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+        const size_t c8n = (size_t)(a.Cout >> 3);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (co_base + 8 * g + 4 * half < a.Cout) {
+                half4 vh, vl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = res[4 * g + e] * a.ys_scale;
+                    v = fmaxf(v, v * a.ys_slope);
+                    const _Float16 hh = (_Float16)v;
+                    vh[e] = hh;
+                    vl[e] = (_Float16)(v - (float)hh);
+                }
+                const size_t item = (((size_t)b * c8n + (size_t)((co_base >> 3) + g)) * 2) * a.Lout + (size_t)o;
+                _Float16* ph = reinterpret_cast<_Float16*>(a.ys) + item * 8 + 4 * half;
+                *reinterpret_cast<half4*>(ph) = vh;
+                *reinterpret_cast<half4*>(ph + (size_t)a.Lout * 8) = vl;
             }
         }
     }
@@ -214,7 +242,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
 // one position) is a single 16-byte ds_read; the fp32 -> (hi,lo) split and the leaky-relu prologue happen while staging.
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-template <int MI, int NJ, int TMAX>
+template <int MI, int NJ, int TMAX, bool SPLIT_IN>
 __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NT = 4 * NJ * 32;
@@ -270,18 +298,22 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
             if (idx < a_items) Ap[idx] = areg[e];
         }
     };
-    constexpr int XIT = ((NT + 64) * 2 + 255) / 256;
+    // ---- activation staging, two input formats --------------------------------------------------------------
+    //  fp32 [B,C,L]: work item = (position p, channel group h of 8): 8 dword loads, leaky-relu + hi/lo split in x_commit
+    //  split [B,C/8,2,L] items: work item = (plane, position): ONE 16-byte load, committed unchanged (the producer's
+    //  epilogue already applied the activation and the split)
+    constexpr int XIT = SPLIT_IN ? ((NT + 64) * 4 + 255) / 256 : ((NT + 64) * 2 + 255) / 256;
     const int spanp = (a.span + 63) & ~63;
-    float xr[XIT][8];
-    // per-item invariants (position window is the same for every chunk): clamped load offset, LDS slot, validity
+    float xr[SPLIT_IN ? 1 : XIT][8];
+    half8 xq[SPLIT_IN ? XIT : 1];
     unsigned xoff[XIT];
-    int xslot[XIT];   // LDS item index of plane (h, hi) for this item, or -1
+    int xslot[XIT];   // LDS item index, or -1
     bool xok[XIT];
-    int xh[XIT];
+    int xh[XIT];      // fp32: channel half (0/1); split: plane index (h*2 + pl) in 0..3
 #pragma unroll
     for (int e = 0; e < XIT; ++e) {
         const int i = tid + e * 256;
-        const int h = i >= spanp ? 1 : 0;
+        const int h = i / spanp;              // spanp is a multiple of 64: cheap shifts would do, this runs once
         const int p = i - h * spanp;
         const int pos = lo + p;
         xok[e] = pos >= 0 && pos < lin;
@@ -289,35 +321,60 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
         pc = pc < 0 ? 0 : pc;
         xoff[e] = (unsigned)pc;
         xh[e] = h;
-        xslot[e] = (p < a.span && i < 2 * spanp) ? (h * 2) * a.span_pad + p : -1;
+        if (SPLIT_IN)
+            xslot[e] = (p < a.span && h < 4) ? h * a.span_pad + p : -1;
+        else
+            xslot[e] = (p < a.span && h < 2) ? (h * 2) * a.span_pad + p : -1;
     }
+    const half8* xsb = reinterpret_cast<const half8*>(a.xs) + (size_t)b * (a.Cin >> 3) * 2 * a.Lin;
     auto x_issue = [&](int c) {
+        if (SPLIT_IN) {
+            // plane (h, pl) of chunk c = 8-channel group (2c + h), plane pl: a wave-uniform row base + per-lane position
 #pragma unroll
-        for (int ch = 0; ch < 8; ++ch) {
-            // the two channel rows (h = 0 / 1) of this step are wave-uniform scalars: loads use sgpr base + vgpr offset
-            const int c0 = c * 16 + ch, c1 = c * 16 + 8 + ch;
-            const float* r0 = xb + (size_t)(c0 < a.Cin ? c0 : a.Cin - 1) * a.Lin;
-            const float* r1 = xb + (size_t)(c1 < a.Cin ? c1 : a.Cin - 1) * a.Lin;
+            for (int e = 0; e < XIT; ++e) {
+                const int hp = xh[e] < 4 ? xh[e] : 3;
+                int c8 = 2 * c + (hp >> 1);
+                c8 = c8 < (a.Cin >> 3) ? c8 : (a.Cin >> 3) - 1;
+                xq[SPLIT_IN ? e : 0] = xsb[((size_t)c8 * 2 + (hp & 1)) * a.Lin + xoff[e]];
+            }
+        } else {
 #pragma unroll
-            for (int e = 0; e < XIT; ++e) xr[e][ch] = (xh[e] ? r1 : r0)[xoff[e]];
+            for (int ch = 0; ch < 8; ++ch) {
+                // the two channel rows (h = 0 / 1) of this step are wave-uniform scalars: sgpr base + vgpr offset
+                const int c0 = c * 16 + ch, c1 = c * 16 + 8 + ch;
+                const float* r0 = xb + (size_t)(c0 < a.Cin ? c0 : a.Cin - 1) * a.Lin;
+                const float* r1 = xb + (size_t)(c1 < a.Cin ? c1 : a.Cin - 1) * a.Lin;
+#pragma unroll
+                for (int e = 0; e < XIT; ++e) xr[SPLIT_IN ? 0 : e][ch] = (xh[e] ? r1 : r0)[xoff[e]];
+            }
         }
     };
     auto x_commit = [&](int c) {
 #pragma unroll
         for (int e = 0; e < XIT; ++e) {
             if (xslot[e] >= 0) {
-                const int cb = c * 16 + xh[e] * 8;
-                half8 vh, vl;
+                if (SPLIT_IN) {
+                    const int c8 = 2 * c + (xh[e] >> 1);
+                    half8 v = xq[SPLIT_IN ? e : 0];
+                    if (!(xok[e] && c8 < (a.Cin >> 3))) {
 #pragma unroll
-                for (int ch = 0; ch < 8; ++ch) {
-                    float v = (xok[e] && cb + ch < a.Cin) ? xr[e][ch] * a.in_scale : 0.f;
-                    v = fmaxf(v, v * a.in_slope);   // leaky-relu for slopes in [0,1] (1 = identity)
-                    const _Float16 hh = (_Float16)v;
-                    vh[ch] = hh;
-                    vl[ch] = (_Float16)(v - (float)hh);
+                        for (int ch = 0; ch < 8; ++ch) v[ch] = (_Float16)0.f;
+                    }
+                    Xp[xslot[e]] = v;
+                } else {
+                    const int cb = c * 16 + xh[e] * 8;
+                    half8 vh, vl;
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch) {
+                        float v = (xok[e] && cb + ch < a.Cin) ? xr[SPLIT_IN ? 0 : e][ch] * a.in_scale : 0.f;
+                        v = fmaxf(v, v * a.in_slope);   // leaky-relu for slopes in [0,1] (1 = identity)
+                        const _Float16 hh = (_Float16)v;
+                        vh[ch] = hh;
+                        vl[ch] = (_Float16)(v - (float)hh);
+                    }
+                    Xp[xslot[e]] = vh;
+                    Xp[xslot[e] + a.span_pad] = vl;
                 }
-                Xp[xslot[e]] = vh;
-                Xp[xslot[e] + a.span_pad] = vl;
             }
         }
     };
@@ -563,6 +620,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 2)) void respair32_f16x3_ke
     ea.out_scale = 1.f;
     ea.out_act = TTSC_ACT_NONE;
     ea.accumulate = a.accumulate;
+    ea.xs = nullptr;
+    ea.ys = nullptr;
+    ea.ys_scale = 1.f;
+    ea.ys_slope = 1.f;
+    ea.write_f32 = 1;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int col = wv * 64 + n * 32 + l31;
@@ -572,7 +634,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 2)) void respair32_f16x3_ke
     }
 }
 
-template <int MI, int NJ, int TMAX>
+template <int MI, int NJ, int TMAX, bool SPLIT_IN>
 static int launch_f16_t(const ConvArgs& a, int B, hipStream_t s) {
     constexpr int NT = 4 * NJ * 32;
     constexpr int MT = MI * 32;
@@ -580,10 +642,10 @@ static int launch_f16_t(const ConvArgs& a, int B, hipStream_t s) {
     const size_t lds = (size_t)a.span_pad * 4 * 16 + (size_t)a.ntaps * MI * 2 * 64 * 16;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv_f16x3_kernel<MI, NJ, TMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_f16x3_kernel<MI, NJ, TMAX, SPLIT_IN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL((conv_f16x3_kernel<MI, NJ, TMAX>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_f16x3_kernel<MI, NJ, TMAX, SPLIT_IN>), grid, dim3(256), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("conv_f16x3_kernel launch failed: %s", hipGetErrorString(e));
@@ -592,12 +654,17 @@ static int launch_f16_t(const ConvArgs& a, int B, hipStream_t s) {
     return TTSC_OK;
 }
 
+template <int MI, int NJ, bool SPLIT_IN>
+static int launch_f16_s(const ConvArgs& a, int B, hipStream_t s) {
+    if (a.ntaps <= 3) return launch_f16_t<MI, NJ, 3, SPLIT_IN>(a, B, s);
+    if (a.ntaps <= 7) return launch_f16_t<MI, NJ, 7, SPLIT_IN>(a, B, s);
+    if (a.ntaps <= 11) return launch_f16_t<MI, NJ, 11, SPLIT_IN>(a, B, s);
+    return launch_f16_t<MI, NJ, 16, SPLIT_IN>(a, B, s);
+}
+
 template <int MI, int NJ>
 static int launch_f16(const ConvArgs& a, int B, hipStream_t s) {
-    if (a.ntaps <= 3) return launch_f16_t<MI, NJ, 3>(a, B, s);
-    if (a.ntaps <= 7) return launch_f16_t<MI, NJ, 7>(a, B, s);
-    if (a.ntaps <= 11) return launch_f16_t<MI, NJ, 11>(a, B, s);
-    return launch_f16_t<MI, NJ, 16>(a, B, s);
+    return a.xs ? launch_f16_s<MI, NJ, true>(a, B, s) : launch_f16_s<MI, NJ, false>(a, B, s);
 }
 
 template <int MI, int NJ, int WM, int WN>
@@ -858,7 +925,25 @@ extern "C" int ttsc_conv1d_forward(const ttsc_conv1d* c, const float* x, int32_t
 extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, int32_t B, int64_t Lin, float* y,
                                           const float* resid, const ttsc_conv1d_epilogue* ep, const int32_t* in_len_dev,
                                           const int32_t* out_len_dev, void* stream) {
-    TTSC_REQUIRE(c && x && y, "ttsc_conv1d_forward: null argument");
+    return ttsc_conv1d_forward_split(c, x, nullptr, B, Lin, y, nullptr, 1.f, 1.f, resid, ep, in_len_dev, out_len_dev, stream);
+}
+
+extern "C" int32_t ttsc_conv1d_in_channels(const ttsc_conv1d* c) { return c ? c->cfg.in_channels : 0; }
+
+extern "C" size_t ttsc_split_bytes(int32_t B, int32_t C, int64_t L) { return (size_t)B * (size_t)((C + 7) / 8) * 2 * (size_t)L * 16; }
+
+extern "C" int ttsc_conv1d_forward_split(const ttsc_conv1d* c, const float* x, const void* x_split, int32_t B, int64_t Lin, float* y,
+                                         void* y_split, float ys_scale, float ys_slope, const float* resid,
+                                         const ttsc_conv1d_epilogue* ep, const int32_t* in_len_dev, const int32_t* out_len_dev,
+                                         void* stream) {
+    TTSC_REQUIRE(c && (x || x_split) && (y || y_split), "ttsc_conv1d_forward: null argument");
+    if (x_split || y_split) {
+        TTSC_REQUIRE(c->precision == TTSC_PREC_F16X3, "split activation tensors need TTSC_PREC_F16X3");
+        TTSC_REQUIRE(!x_split || c->cfg.in_channels % 16 == 0, "split input needs in_channels %% 16 == 0");
+        TTSC_REQUIRE(!y_split || c->cfg.out_channels % 8 == 0, "split output needs out_channels %% 8 == 0");
+        TTSC_REQUIRE(ys_slope >= 0.f && ys_slope <= 1.f, "ys_slope must be in [0,1]");
+        TTSC_REQUIRE(y || !(ep && ep->accumulate), "accumulate needs the fp32 output");
+    }
     if (!c->has_weight) {
         set_error("ttsc_conv1d_forward: weights not set");
         return TTSC_ESTATE;
@@ -881,6 +966,11 @@ extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, 
         a.bias = c->bias_dev;
         a.in_len = in_len_dev;
         a.out_len = out_len_dev;
+        a.xs = x_split;
+        a.ys = y_split;
+        a.ys_scale = ys_scale;
+        a.ys_slope = ys_slope;
+        a.write_f32 = y ? 1 : 0;
         a.Cin = g.in_channels;
         a.CinP = c->CinP;
         a.Cout = g.out_channels;

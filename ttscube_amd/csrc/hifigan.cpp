@@ -41,6 +41,8 @@ struct ttsc_hifigan {
     std::map<std::string, std::unique_ptr<Layer>> layers;
     std::vector<int> stage_ch;  // channels after upsample i
     bool use_fused = true;      // env TTSC_HIFIGAN_FUSED=0 disables the fused residual-pair kernel (A/B measurements)
+    bool use_split = true;      // env TTSC_HIFIGAN_SPLIT=0 disables the producer-side split-activation flow
+    int precision = TTSC_PREC_FP32;
     // pack + upload every layer whose host copy changed; returns the name of the first incomplete layer (or "")
     int flush_weights(std::string* missing) {
         for (auto& kv : layers) {
@@ -84,6 +86,7 @@ extern "C" int ttsc_hifigan_create(const ttsc_hifigan_cfg* cfg, ttsc_hifigan** o
     std::unique_ptr<ttsc_hifigan> g(new ttsc_hifigan());
     g->cfg = *cfg;
     if (const char* ev = getenv("TTSC_HIFIGAN_FUSED")) g->use_fused = atoi(ev) != 0;
+    if (const char* ev = getenv("TTSC_HIFIGAN_SPLIT")) g->use_split = atoi(ev) != 0;
     int rc = add_layer(g.get(), "conv_pre", cfg->num_mels, cfg->upsample_initial_channel, 7, 1, 3, 1, 0);
     if (rc) return rc;
     int ch = cfg->upsample_initial_channel;
@@ -128,6 +131,7 @@ extern "C" int ttsc_hifigan_set_precision(ttsc_hifigan* g, int32_t precision) {
         int rc = ttsc_conv1d_set_precision(kv.second->c, precision);
         if (rc) return rc;
     }
+    g->precision = precision;
     return TTSC_OK;
 }
 
@@ -192,7 +196,7 @@ static size_t len_table_bytes(const ttsc_hifigan* g, int32_t B) {
 
 extern "C" size_t ttsc_hifigan_workspace_bytes(const ttsc_hifigan* g, int32_t B, int64_t T) {
     if (!g || B <= 0 || T <= 0) return 0;
-    return 4 * buf_elems(g, B, T) * sizeof(float) + len_table_bytes(g, B);
+    return 7 * buf_elems(g, B, T) * sizeof(float) + len_table_bytes(g, B);
 }
 
 extern "C" int ttsc_hifigan_algorithmic_flops(const ttsc_hifigan* g, int32_t B, int64_t T, double* out) {
@@ -257,7 +261,7 @@ extern "C" int ttsc_hifigan_forward_ragged(ttsc_hifigan* g, const float* mel, in
                 tab[(size_t)(i + 1) * B + b] = (int32_t)Lb;
             }
         }
-        int32_t* dtab = (int32_t*)(S + be);
+        int32_t* dtab = (int32_t*)(S + 4 * be);
         TTSC_HIP_CHECK(hipMemcpyAsync(dtab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, (hipStream_t)stream));
         TTSC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));  // `tab` is pageable host memory going out of scope
         for (int i = 0; i <= c.num_upsamples; ++i) lens[i] = dtab + (size_t)i * B;
@@ -265,33 +269,65 @@ extern "C" int ttsc_hifigan_forward_ragged(ttsc_hifigan* g, const float* mel, in
     auto layer = [&](const std::string& n) -> const ttsc_conv1d* { return g->layers.at(n)->c; };
     int rc;
 
+    // ---- split-activation flow (TTSC_PREC_F16X3, ResBlock1) ------------------------------------------------------
+    // Every conv input of the generator passes through a leaky-relu, so the producer writes split(lrelu(.)) of its output
+    // once (fp16 hi|lo planes, see conv1d.hip) and consumers stage plain 16-byte copies.  fp32 copies are kept only where
+    // a residual add or the running block sum needs them.  Xs/Rs/Ss are the split twins of X/R/S; XT only exists split.
+    float* Xs = S + be;   // (the length table of ragged batches lives behind the 7th buffer)
+    float* Rs = Xs + be;
+    float* Ss = Rs + be;
+    const bool split_ok = g->use_split && c.resblock == 1 && g->precision == TTSC_PREC_F16X3;
+    auto in16 = [&](const ttsc_conv1d* l) { return ttsc_conv1d_in_channels(l) % 16 == 0; };
+    auto conv = [&](const ttsc_conv1d* l, const float* x, const void* xs, int64_t Lin, float* y, void* ys, float ys_scale,
+                    float ys_slope, const float* resid, const ttsc_conv1d_epilogue& e, const int32_t* il, const int32_t* ol) {
+        return ttsc_conv1d_forward_split(l, xs ? nullptr : x, xs, B, Lin, y, ys, ys_scale, ys_slope, resid, &e, il, ol, stream);
+    };
+    const float inv_nk = 1.f / (float)c.num_kernels;
     ttsc_conv1d_epilogue ep{1.f, 1.f, 1.f, TTSC_ACT_NONE, 0};
-    rc = ttsc_conv1d_forward_ragged(layer("conv_pre"), mel, B, T, S, nullptr, &ep, lens[0], lens[0], stream);
-    if (rc) return rc;
     int64_t L = T;
-    float sum_scale = 1.f;  // pending division by nk of the previous stage's block sum
+    float sum_scale = 1.f;   // pending division by nk of the previous stage's block sum (fp32 consumers)
+    bool s_split = false;    // Ss holds split(lrelu(S * scale, 0.1)) for the next upsampler
+    {
+        const ttsc_conv1d* up0 = layer("ups.0");
+        s_split = split_ok && in16(up0) && c.upsample_initial_channel % 8 == 0;
+        rc = conv(layer("conv_pre"), mel, nullptr, T, s_split ? nullptr : S, s_split ? (void*)Ss : nullptr, 1.f, 0.1f, nullptr, ep, lens[0], lens[0]);
+        if (rc) return rc;
+    }
     for (int i = 0; i < c.num_upsamples; ++i) {
-        // x = ups[i](lrelu(x / nk_prev, 0.1))
-        ttsc_conv1d_epilogue eu{sum_scale, 0.1f, 1.f, TTSC_ACT_NONE, 0};
+        const int ch = g->stage_ch[i];
         const ttsc_conv1d* up = layer("ups." + std::to_string(i));
-        rc = ttsc_conv1d_forward_ragged(up, S, B, L, X, nullptr, &eu, lens[i], lens[i + 1], stream);
+        // is this stage's ResBlock1 chain run by the fused 32-channel pair kernel?
+        bool fused_stage = (c.resblock == 1) && g->use_fused;
+        for (int j = 0; fused_stage && j < c.num_kernels; ++j)
+            for (int m = 0; fused_stage && m < c.num_dilations[j]; ++m) {
+                const std::string rb = "resblocks." + std::to_string(i * c.num_kernels + j);
+                fused_stage = ttsc_respair_supported(layer(rb + ".convs1." + std::to_string(m)), layer(rb + ".convs2." + std::to_string(m))) != 0;
+            }
+        const bool stage_split = split_ok && !fused_stage && ch % 16 == 0;
+        // x = ups[i](lrelu(x / nk_prev, 0.1)); the stage input is needed in fp32 (residual of the first pair) and, in the
+        // split flow, as split(lrelu(x, 0.1)) for the three first convs
+        ttsc_conv1d_epilogue eu{sum_scale, 0.1f, 1.f, TTSC_ACT_NONE, 0};
+        rc = conv(up, S, s_split ? (const void*)Ss : nullptr, L, X, stage_split ? (void*)Xs : nullptr, 1.f, 0.1f, nullptr, eu, lens[i], lens[i + 1]);
         if (rc) return rc;
         L = ttsc_conv1d_out_len(up, L);
+        const int32_t* ln = lens[i + 1];
+        // who consumes this stage's block mean: the next upsampler (slope 0.1) or conv_post (slope 0.01)
+        const bool last_stage = (i == c.num_upsamples - 1);
+        const ttsc_conv1d* nxt = last_stage ? layer("conv_post") : layer("ups." + std::to_string(i + 1));
+        const bool next_split = stage_split && in16(nxt);
+        const float next_slope = last_stage ? 0.01f : 0.1f;
         for (int j = 0; j < c.num_kernels; ++j) {
             const std::string rb = "resblocks." + std::to_string(i * c.num_kernels + j);
             const int nd = c.num_dilations[j];
-            // 32-channel ResBlock1 pairs run as ONE fused launch each (inner activation stays in LDS); the residual
-            // stream then ping-pongs between R and XT because a fused tile reads its neighbours' halo of the input.
-            bool fused = (c.resblock == 1) && g->use_fused;
-            for (int m = 0; fused && m < nd; ++m)
-                fused = ttsc_respair_supported(layer(rb + ".convs1." + std::to_string(m)), layer(rb + ".convs2." + std::to_string(m))) != 0;
-            if (fused) {
+            if (fused_stage) {
+                // ONE fused launch per pair (inner activation stays in LDS); the residual stream ping-pongs between R and
+                // XT because a fused tile reads its neighbours' halo of the input.
                 const float* src = X;
                 for (int m = 0; m < nd; ++m) {
                     const bool last = (m == nd - 1);
                     float* dst = last ? S : (src == R ? XT : R);
                     rc = ttsc_respair_forward(layer(rb + ".convs1." + std::to_string(m)), layer(rb + ".convs2." + std::to_string(m)), src, B,
-                                              L, dst, (last && j > 0) ? 1 : 0, lens[i + 1], stream);
+                                              L, dst, (last && j > 0) ? 1 : 0, ln, stream);
                     if (rc) return rc;
                     src = dst;
                 }
@@ -299,29 +335,46 @@ extern "C" int ttsc_hifigan_forward_ragged(ttsc_hifigan* g, const float* mel, in
             }
             for (int m = 0; m < nd; ++m) {
                 const float* src = (m == 0) ? X : R;
+                const void* src_s = stage_split ? (const void*)((m == 0) ? Xs : Rs) : nullptr;
                 const bool last = (m == nd - 1);
                 float* dst = last ? S : R;
                 ttsc_conv1d_epilogue e2{1.f, 0.1f, 1.f, TTSC_ACT_NONE, (last && j > 0) ? 1 : 0};
                 if (c.resblock == 1) {
                     ttsc_conv1d_epilogue e1{1.f, 0.1f, 1.f, TTSC_ACT_NONE, 0};
-                    rc = ttsc_conv1d_forward_ragged(layer(rb + ".convs1." + std::to_string(m)), src, B, L, XT, nullptr, &e1, lens[i + 1], lens[i + 1], stream);
+                    // conv1: its output only feeds conv2 -> split form only (XT's memory holds the split tensor)
+                    rc = conv(layer(rb + ".convs1." + std::to_string(m)), src, src_s, L, stage_split ? nullptr : XT,
+                              stage_split ? (void*)XT : nullptr, 1.f, 0.1f, nullptr, e1, ln, ln);
                     if (rc) return rc;
-                    rc = ttsc_conv1d_forward_ragged(layer(rb + ".convs2." + std::to_string(m)), XT, B, L, dst, src, &e2, lens[i + 1], lens[i + 1], stream);
+                    // conv2 (+ residual): fp32 for the residual stream / block sum, split twin for the next consumer:
+                    //   not last      -> split(lrelu(r, 0.1)) for the next pair's conv1
+                    //   last, j==nk-1 -> split(lrelu(sum/nk, slope_next)) for the next upsampler / conv_post
+                    void* ys = nullptr;
+                    float yscale = 1.f, yslope = 0.1f;
+                    if (stage_split && !last) ys = Rs;
+                    if (next_split && last && j == c.num_kernels - 1) {
+                        ys = Ss;
+                        yscale = inv_nk;
+                        yslope = next_slope;
+                    }
+                    rc = conv(layer(rb + ".convs2." + std::to_string(m)), XT, stage_split ? (const void*)XT : nullptr, L, dst, ys, yscale,
+                              yslope, src, e2, ln, ln);
                     if (rc) return rc;
                 } else {
                     // ResBlock2 reads src both as conv input and residual; dst != src unless m>0 && !last (R->R),
                     // where an in-place update would race with neighbouring tiles' halo reads -> ping-pong via XT.
                     float* d2 = dst;
                     if (dst == src) d2 = XT;
-                    rc = ttsc_conv1d_forward_ragged(layer(rb + ".convs." + std::to_string(m)), src, B, L, d2, src, &e2, lens[i + 1], lens[i + 1], stream);
+                    rc = ttsc_conv1d_forward_ragged(layer(rb + ".convs." + std::to_string(m)), src, B, L, d2, src, &e2, ln, ln, stream);
                     if (rc) return rc;
                     if (d2 != dst) std::swap(R, XT);
                 }
             }
         }
-        sum_scale = 1.f / (float)c.num_kernels;
+        sum_scale = inv_nk;
+        s_split = next_split;
     }
     ttsc_conv1d_epilogue epost{sum_scale, 0.01f, 1.f, TTSC_ACT_TANH, 0};
-    rc = ttsc_conv1d_forward_ragged(layer("conv_post"), S, B, L, wav, nullptr, &epost, lens[c.num_upsamples], lens[c.num_upsamples], stream);
-    return rc;
+    return conv(layer("conv_post"), S, s_split ? (const void*)Ss : nullptr, L, wav, nullptr, 1.f, 1.f, nullptr, epost, lens[c.num_upsamples],
+                lens[c.num_upsamples]);
 }
+
