@@ -16,6 +16,7 @@
 // 256-byte wave load that hits L2.  Epilogue fuses bias, residual add, scaling, tanh and the running
 // sum over residual blocks.
 #include <cmath>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -50,6 +51,7 @@ struct ConvArgs {
     void* ys;         // split output or null
     float ys_scale, ys_slope;
     int write_f32;    // 0: only the split output is written
+    int dbg;          // ablation switches (env TTSC_CONV_DBG): 1 skip LDS commits, 2 skip MFMA loop, 4 skip epilogue, 8 skip global prefetch
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -383,13 +385,16 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
     a_issue(0);
     for (int c = 0; c < nchunks; ++c) {
         if (c) __syncthreads();  // everyone finished reading chunk c-1 from LDS
-        x_commit(c);
-        a_commit();
+        if (!(a.dbg & 1)) {
+            x_commit(c);
+            a_commit();
+        }
         __syncthreads();
-        if (c + 1 < nchunks) {
+        if (c + 1 < nchunks && !(a.dbg & 8)) {
             x_issue(c + 1);
             a_issue(c + 1);
         }
+        if (a.dbg & 2) continue;
         // per-lane LDS bases are loop invariants; inside the tap loop only `shift` / the tap's block offset are added
         // (32-bit LDS addressing, immediate offsets for the fragment index) — VALU work per MFMA matters here because
         // VALU and MFMA issue from the same in-order wave
@@ -427,6 +432,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
     }
 
     const int q_hi = a.q_lo + a.q_cnt;
+    if (a.dbg & 4) {
+        if (acc[0][0][0] == 12345.678f) a.y[0] = 1.f;  // keep the accumulators alive
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -625,6 +634,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 2)) void respair32_f16x3_ke
     ea.ys_scale = 1.f;
     ea.ys_slope = 1.f;
     ea.write_f32 = 1;
+    ea.dbg = 0;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int col = wv * 64 + n * 32 + l31;
@@ -971,6 +981,8 @@ extern "C" int ttsc_conv1d_forward_split(const ttsc_conv1d* c, const float* x, c
         a.ys_scale = ys_scale;
         a.ys_slope = ys_slope;
         a.write_f32 = y ? 1 : 0;
+        a.dbg = 0;
+        if (const char* ev = getenv("TTSC_CONV_DBG")) a.dbg = atoi(ev);
         a.Cin = g.in_channels;
         a.CinP = c->CinP;
         a.Cout = g.out_channels;
