@@ -68,77 +68,76 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // C/D layout of v_mfma_*_32x32: column (time) = lane & 31, row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 __device__ __forceinline__ void epilogue_tile(const f32x16& acc, const ConvArgs& a, int b, int co_base, long o, bool qok,
                                               int half, float acc_scale) {
-    // NOTE: the optional operands are tested ONCE per tile (wave-uniform branches around straight-line load groups).
-    // A per-element `ptr ? ptr[i] : 0` makes hipcc branch around every single load and wait for each one in turn.
-    float rv[16], yv[16], bv[16];
+    // NOTE: the optional operands are tested once per row group (wave-uniform branches around straight-line load
+    // groups).  A per-element `ptr ? ptr[i] : 0` makes hipcc branch around every single load and wait for each one in turn.
+    // The tile is processed as four groups of four rows (= the four 8-channel items a lane contributes to): all loads
+    // of a group are issued before its stores, and only ~4 values per operand are live at a time (register pressure).
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
     const long o_c = qok ? o : 0;
-    size_t idx[16];
+    const size_t c8n = (size_t)(a.Cout >> 3);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int co_c = co < a.Cout ? co : a.Cout - 1;
-        idx[r] = ((size_t)b * a.Cout + co_c) * a.Lout + o_c;
-    }
-    if (a.bias) {
+    for (int g = 0; g < 4; ++g) {
+        float rv[4], yv[4], bv[4], res[4];
+        size_t idx[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * half;
-            bv[r] = a.bias[co < a.Cout ? co : a.Cout - 1];
+        for (int e = 0; e < 4; ++e) {
+            const int co = co_base + 8 * g + 4 * half + e;
+            const int co_c = co < a.Cout ? co : a.Cout - 1;
+            idx[e] = ((size_t)b * a.Cout + co_c) * a.Lout + o_c;
         }
-    } else {
+        if (a.bias) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bv[r] = 0.f;
-    }
-    if (a.resid) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rv[r] = a.resid[idx[r]];
-    } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rv[r] = 0.f;
-    }
-    if (a.accumulate) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) yv[r] = a.y[idx[r]];
-    } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) yv[r] = 0.f;
-    }
-    float res[16];
-    if (a.out_act == TTSC_ACT_NONE) {   // the common case gets its own straight-line copy (no inlined tanh/exp bodies)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) res[r] = (acc[r] * acc_scale + bv[r] + rv[r]) * a.out_scale + yv[r];
-    } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) res[r] = apply_act((acc[r] * acc_scale + bv[r] + rv[r]) * a.out_scale, a.out_act) + yv[r];
-    }
-    if (a.write_f32) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (qok && co < a.Cout) a.y[idx[r]] = res[r];
-        }
-    }
-    if (a.ys && qok) {
-        // this lane owns channels {8g + 4*half + e} of its column: four 8-byte pieces, one per 8-channel item
-        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-        const size_t c8n = (size_t)(a.Cout >> 3);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (co_base + 8 * g + 4 * half < a.Cout) {
-                half4 vh, vl;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = res[4 * g + e] * a.ys_scale;
-                    v = fmaxf(v, v * a.ys_slope);
-                    const _Float16 hh = (_Float16)v;
-                    vh[e] = hh;
-                    vl[e] = (_Float16)(v - (float)hh);
-                }
-                const size_t item = (((size_t)b * c8n + (size_t)((co_base >> 3) + g)) * 2) * a.Lout + (size_t)o;
-                _Float16* ph = reinterpret_cast<_Float16*>(a.ys) + item * 8 + 4 * half;
-                *reinterpret_cast<half4*>(ph) = vh;
-                *reinterpret_cast<half4*>(ph + (size_t)a.Lout * 8) = vl;
+            for (int e = 0; e < 4; ++e) {
+                const int co = co_base + 8 * g + 4 * half + e;
+                bv[e] = a.bias[co < a.Cout ? co : a.Cout - 1];
             }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = 0.f;
+        }
+        if (a.resid) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rv[e] = a.resid[idx[e]];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rv[e] = 0.f;
+        }
+        if (a.accumulate) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) yv[e] = a.y[idx[e]];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) yv[e] = 0.f;
+        }
+        if (a.out_act == TTSC_ACT_NONE) {   // the common case gets its own straight-line copy (no inlined tanh/exp bodies)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) res[e] = (acc[4 * g + e] * acc_scale + bv[e] + rv[e]) * a.out_scale + yv[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) res[e] = apply_act((acc[4 * g + e] * acc_scale + bv[e] + rv[e]) * a.out_scale, a.out_act) + yv[e];
+        }
+        if (a.write_f32) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = co_base + 8 * g + 4 * half + e;
+                if (qok && co < a.Cout) a.y[idx[e]] = res[e];
+            }
+        }
+        if (a.ys && qok && co_base + 8 * g + 4 * half < a.Cout) {
+            // split(lrelu(ys_scale * y, ys_slope)) of this lane's 4 channels of 8-channel item (co_base/8 + g)
+            half4 vh, vl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = res[e] * a.ys_scale;
+                v = fmaxf(v, v * a.ys_slope);
+                const _Float16 hh = (_Float16)v;
+                vh[e] = hh;
+                vl[e] = (_Float16)(v - (float)hh);
+            }
+            const size_t item = (((size_t)b * c8n + (size_t)((co_base >> 3) + g)) * 2) * a.Lout + (size_t)o;
+            _Float16* ph = reinterpret_cast<_Float16*>(a.ys) + item * 8 + 4 * half;
+            *reinterpret_cast<half4*>(ph) = vh;
+            *reinterpret_cast<half4*>(ph + (size_t)a.Lout * 8) = vl;
         }
     }
 }
