@@ -41,7 +41,8 @@ struct ttsc_hifigan {
     std::map<std::string, std::unique_ptr<Layer>> layers;
     std::vector<int> stage_ch;  // channels after upsample i
     bool use_fused = true;      // env TTSC_HIFIGAN_FUSED=0 disables the fused residual-pair kernel (A/B measurements)
-    bool use_split = true;      // env TTSC_HIFIGAN_SPLIT=0 disables the producer-side split-activation flow
+    bool use_split = false;     // env TTSC_HIFIGAN_SPLIT=1 enables the producer-side split-activation flow (measured: no gain —
+                                // the consumer-side conversion hides behind the MFMA loop, the extra tensors cost HBM traffic)
     int precision = TTSC_PREC_FP32;
     // pack + upload every layer whose host copy changed; returns the name of the first incomplete layer (or "")
     int flush_weights(std::string* missing) {
