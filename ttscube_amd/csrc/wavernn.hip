@@ -105,24 +105,63 @@ __global__ __launch_bounds__(256) void wr_cond_kernel(const float* __restrict__ 
 template <int BT, int NG, int UN>
 __device__ __forceinline__ void chain_matvec(float (&acc)[BT][NG], const float* __restrict__ wp, int rows, int gstride, int row,
                                              const float* v, int vstride, int K) {
+    // Weight stream with EXPLICIT software pipelining: the 16-byte loads of a whole batch (UN k-blocks x NG rows) are
+    // issued back to back into one register set while the fmaf chain consumes the other set.  Left to itself hipcc
+    // places each load right before its use and waits vmcnt(0) per load, i.e. one L2 round trip per 16 bytes.
+    // The chain order (k ascending, one fmaf per term) is unchanged.
     const float4* w4 = reinterpret_cast<const float4*>(wp) + row;
     const int KB = K >> 2;
-#pragma unroll UN
-    for (int kb = 0; kb < KB; ++kb) {
-        float4 w[NG];
+    auto load = [&](float4 (&w)[UN][NG], int kb0) {
 #pragma unroll
-        for (int g = 0; g < NG; ++g) w[g] = w4[(size_t)kb * rows + g * gstride];
+        for (int q = 0; q < UN; ++q)
 #pragma unroll
-        for (int u = 0; u < BT; ++u) {
-            const float4 hv = *reinterpret_cast<const float4*>(v + u * vstride + 4 * kb);
+            for (int g = 0; g < NG; ++g) w[q][g] = w4[(size_t)(kb0 + q) * rows + g * gstride];
+    };
+    auto fma_batch = [&](const float4 (&w)[UN][NG], int kb0) {
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                float x = acc[u][g];
-                x = fmaf(w[g].x, hv.x, x);
-                x = fmaf(w[g].y, hv.y, x);
-                x = fmaf(w[g].z, hv.z, x);
-                x = fmaf(w[g].w, hv.w, x);
-                acc[u][g] = x;
+        for (int q = 0; q < UN; ++q) {
+#pragma unroll
+            for (int u = 0; u < BT; ++u) {
+                const float4 hv = *reinterpret_cast<const float4*>(v + u * vstride + 4 * (kb0 + q));
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    float x = acc[u][g];
+                    x = fmaf(w[q][g].x, hv.x, x);
+                    x = fmaf(w[q][g].y, hv.y, x);
+                    x = fmaf(w[q][g].z, hv.z, x);
+                    x = fmaf(w[q][g].w, hv.w, x);
+                    acc[u][g] = x;
+                }
+            }
+        }
+    };
+    if (KB % UN == 0) {
+        float4 wa[UN][NG], wb[UN][NG];
+        const int NB = KB / UN;
+        load(wa, 0);
+        for (int bi = 0; bi < NB; bi += 2) {
+            if (bi + 1 < NB) load(wb, (bi + 1) * UN);
+            fma_batch(wa, bi * UN);
+            if (bi + 2 < NB) load(wa, (bi + 2) * UN);
+            if (bi + 1 < NB) fma_batch(wb, (bi + 1) * UN);
+        }
+    } else {
+        for (int kb = 0; kb < KB; ++kb) {
+            float4 w[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) w[g] = w4[(size_t)kb * rows + g * gstride];
+#pragma unroll
+            for (int u = 0; u < BT; ++u) {
+                const float4 hv = *reinterpret_cast<const float4*>(v + u * vstride + 4 * kb);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    float x = acc[u][g];
+                    x = fmaf(w[g].x, hv.x, x);
+                    x = fmaf(w[g].y, hv.y, x);
+                    x = fmaf(w[g].z, hv.z, x);
+                    x = fmaf(w[g].w, hv.w, x);
+                    acc[u][g] = x;
+                }
             }
         }
     }
@@ -251,13 +290,13 @@ __global__ __launch_bounds__(WR_THREADS) void wr_decode_kernel(WrArgs a) {
                     for (int u = 0; u < BT; ++u)
 #pragma unroll
                         for (int g = 0; g < 3; ++g) gi[u][g] = a.b_ih[l][g * H + j];
-                    chain_matvec<BT, 3, (BT == 1 ? 4 : 2)>(gi, a.wt_ih[l], H3, H, j, hp, H, H);
+                    chain_matvec<BT, 3, 2>(gi, a.wt_ih[l], H3, H, j, hp, H, H);
                 }
 #pragma unroll
                 for (int u = 0; u < BT; ++u)
 #pragma unroll
                     for (int g = 0; g < 3; ++g) gh[u][g] = a.b_hh[l][g * H + j];
-                chain_matvec<BT, 3, (BT == 1 ? 4 : 2)>(gh, a.wt_hh[l], H3, H, j, hc, H, H);
+                chain_matvec<BT, 3, 2>(gh, a.wt_hh[l], H3, H, j, hc, H, H);
 #pragma unroll
                 for (int u = 0; u < BT; ++u) {
                     const float r = ttsc_sigmoidf(gi[u][0] + gh[u][0]);
@@ -277,7 +316,7 @@ __global__ __launch_bounds__(WR_THREADS) void wr_decode_kernel(WrArgs a) {
             const int row = tid & 255;
             for (int u = tid >> 8; u < BT; u += WR_THREADS / 256) {
                 float acc[1][1] = {{a.b_pre[row]}};
-                chain_matvec<1, 1, 16>(acc, a.wt_pre, 256, 0, row, ht + u * H, H, H);
+                chain_matvec<1, 1, 4>(acc, a.wt_pre, 256, 0, row, ht + u * H, H, H);
                 pre[u * 256 + row] = ttsc_tanhf(acc[0][0]);
             }
         }
@@ -288,7 +327,7 @@ __global__ __launch_bounds__(WR_THREADS) void wr_decode_kernel(WrArgs a) {
             for (int u = tid >> 8; u < BT; u += WR_THREADS / 256) {
                 if (row < S) {
                     float accv[1][1] = {{a.b_out[row]}};
-                    chain_matvec<1, 1, 16>(accv, a.wt_out, S, 0, row, pre + u * 256, 256, 256);
+                    chain_matvec<1, 1, 4>(accv, a.wt_out, S, 0, row, pre + u * 256, 256, 256);
                     const float acc = accv[0][0];
                     const size_t o = ((size_t)BIDX(u) * a.L + t) * S + row;
                     if (a.out_logits && BOK(u)) a.out_logits[o] = acc;
