@@ -51,6 +51,7 @@ struct ConvArgs {
     void* ys;         // split output or null
     float ys_scale, ys_slope;
     int write_f32;    // 0: only the split output is written
+    int vphase;       // fused ConvTranspose1d phases: GEMM row v = r * vphase + co (vphase = real Cout), output o += r; 0 = off
     int dbg;          // ablation switches (env TTSC_CONV_DBG): 1 skip LDS commits, 2 skip MFMA loop, 4 skip epilogue, 8 skip global prefetch
 };
 
@@ -224,7 +225,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
             const int q = q0 + wn * (NJ * 32) + n * 32 + l31;
             const long o = (long)q * a.out_stride + a.out_off;
             const bool qok = (q < q_hi) && (o >= 0) && (o < a.Lout);
-            epilogue_tile(acc[i][n], a, b, (cot0 + i) * 32, o, qok, half, 1.f);
+            int cb = (cot0 + i) * 32;
+            long oo = o;
+            bool ok = qok;
+            if (a.vphase) {   // virtual row tile -> (phase r, real channel tile); tiles never straddle phases (Cout % 32 == 0)
+                const int r = cb / a.vphase;
+                cb -= r * a.vphase;
+                oo += r;
+                ok = (q < q_hi) && (oo >= 0) && (oo < a.Lout) && (r < a.out_stride);
+            }
+            epilogue_tile(acc[i][n], a, b, cb, oo, ok, half, 1.f);
         }
     }
 }
@@ -442,7 +452,16 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
             const int q = q0 + wn * (NJ * 32) + n * 32 + l31;
             const long o = (long)q * a.out_stride + a.out_off;
             const bool qok = (q < q_hi) && (o >= 0) && (o < a.Lout);
-            epilogue_tile(acc[i][n], a, b, (cot0 + i) * 32, o, qok, half, a.w_unscale);
+            int cb = (cot0 + i) * 32;
+            long oo = o;
+            bool ok = qok;
+            if (a.vphase) {   // virtual row tile -> (phase r, real channel tile); tiles never straddle phases (Cout % 32 == 0)
+                const int r = cb / a.vphase;
+                cb -= r * a.vphase;
+                oo += r;
+                ok = (q < q_hi) && (oo >= 0) && (oo < a.Lout) && (r < a.out_stride);
+            }
+            epilogue_tile(acc[i][n], a, b, cb, oo, ok, half, a.w_unscale);
         }
     }
 }
@@ -634,6 +653,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 2)) void respair32_f16x3_ke
     ea.ys_slope = 1.f;
     ea.write_f32 = 1;
     ea.dbg = 0;
+    ea.vphase = 0;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int col = wv * 64 + n * 32 + l31;
@@ -723,6 +743,8 @@ struct ttsc_conv1d {
     float* bias_dev = nullptr;
     bool has_weight = false;
     int precision = TTSC_PREC_FP32;
+    bool vfused = false;   // ConvTranspose1d with Cout % 32 == 0: all `stride` phases as extra GEMM rows of ONE launch
+    int CoutV = 0;         // stride * Cout when vfused
     float w_unscale = 1.f;
     std::vector<float> w_host, b_host;  // kept so that the precision can be switched (repack) at any time
     bool has_bias = false;
@@ -741,10 +763,12 @@ extern "C" int ttsc_conv1d_create(const ttsc_conv1d_cfg* cfg, ttsc_conv1d** out)
     }
     ttsc_conv1d* c = new ttsc_conv1d();
     c->cfg = *cfg;
-    c->MT = pick_mt(cfg->out_channels);
+    c->vfused = cfg->transposed && (cfg->out_channels % 32 == 0) && cfg->stride > 1;
+    c->CoutV = c->vfused ? cfg->stride * cfg->out_channels : cfg->out_channels;
+    c->MT = pick_mt(c->CoutV);
     c->NT = c->MT == 128 ? 128 : (c->MT == 64 ? 256 : 512);
     c->CinP = (int)round_up(cfg->in_channels, KC);
-    c->CoutP = (int)round_up(cfg->out_channels, c->MT);
+    c->CoutP = (int)round_up(c->CoutV, c->MT);
     *out = c;
     return TTSC_OK;
 }
@@ -782,11 +806,18 @@ static void pack_phase(const ttsc_conv1d* c, const float* w, const std::vector<i
         for (int cip = 0; cip < cipN; ++cip)
             for (int cot = 0; cot < cotN; ++cot)
                 for (int lane = 0; lane < 64; ++lane) {
-                    const int co = cot * 32 + (lane & 31);
+                    int co = cot * 32 + (lane & 31);
                     const int ci = 2 * cip + (lane >> 5);
+                    int kk = k;
+                    bool ok = co < c->CoutV && ci < Cin;
+                    if (c->vfused) {   // virtual row = phase r * Cout + co, tap index k -> kernel tap r + k*stride
+                        const int r = co / Cout;
+                        co -= r * Cout;
+                        kk = r + k * g.stride;
+                        ok = ok && kk < K;
+                    }
                     float v = 0.f;
-                    if (co < Cout && ci < Cin)
-                        v = g.transposed ? w[((size_t)ci * Cout + co) * K + k] : w[((size_t)co * Cin + ci) * K + k];
+                    if (ok) v = g.transposed ? w[((size_t)ci * Cout + co) * K + kk] : w[((size_t)co * Cin + ci) * K + kk];
                     out[(((size_t)j * cipN + cip) * cotN + cot) * 64 + lane] = v;
                 }
     }
@@ -806,11 +837,18 @@ static void pack_phase_f16(const ttsc_conv1d* c, const float* w, const std::vect
             for (int cot = 0; cot < cotN; ++cot)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int e = 0; e < 8; ++e) {
-                        const int co = cot * 32 + (lane & 31);
+                        int co = cot * 32 + (lane & 31);
                         const int ci = ch * 16 + 8 * (lane >> 5) + e;
+                        int kk = k;
+                        bool ok = co < c->CoutV && ci < Cin;
+                        if (c->vfused) {
+                            const int r = co / Cout;
+                            co -= r * Cout;
+                            kk = r + k * g.stride;
+                            ok = ok && kk < K;
+                        }
                         float v = 0.f;
-                        if (co < Cout && ci < Cin)
-                            v = g.transposed ? w[((size_t)ci * Cout + co) * K + k] : w[((size_t)co * Cin + ci) * K + k];
+                        if (ok) v = g.transposed ? w[((size_t)ci * Cout + co) * K + kk] : w[((size_t)co * Cin + ci) * K + kk];
                         v *= scale;
                         const _Float16 hi = (_Float16)v;
                         const _Float16 lo = (_Float16)(v - (float)hi);
@@ -895,6 +933,21 @@ static int conv_repack(ttsc_conv1d* c) {
         int rc = upload(ph);
         if (rc) return rc;
         c->phases.push_back(ph);
+    } else if (c->vfused) {
+        ConvPhase ph;
+        std::vector<int> taps;
+        const int J = (g.kernel_size + g.stride - 1) / g.stride;
+        for (int j = 0; j < J; ++j) taps.push_back(j);   // tap INDEX; the packers map (phase, index) -> kernel tap
+        ph.r = -1;
+        ph.ntaps = J;
+        ph.tap_base = 0;
+        ph.tap_step = -1;
+        ph.out_stride = g.stride;
+        ph.out_off = -g.padding;
+        cur_taps = taps;
+        int rc = upload(ph);
+        if (rc) return rc;
+        c->phases.push_back(ph);
     } else {
         for (int r = 0; r < g.stride; ++r) {
             ConvPhase ph;
@@ -913,6 +966,9 @@ static int conv_repack(ttsc_conv1d* c) {
             c->phases.push_back(ph);
         }
         TTSC_REQUIRE((int)c->phases.size() == g.stride, "ConvTranspose1d with kernel_size < stride is not supported");
+    }
+    if (g.transposed) {
+        TTSC_REQUIRE(g.kernel_size >= g.stride, "ConvTranspose1d with kernel_size < stride is not supported");
     }
     if (c->bias_dev) {
         (void)hipFree(c->bias_dev);
@@ -982,6 +1038,7 @@ extern "C" int ttsc_conv1d_forward_split(const ttsc_conv1d* c, const float* x, c
         a.write_f32 = y ? 1 : 0;
         a.dbg = 0;
         if (const char* ev = getenv("TTSC_CONV_DBG")) a.dbg = atoi(ev);
+        a.vphase = c->vfused ? g.out_channels : 0;
         a.Cin = g.in_channels;
         a.CinP = c->CinP;
         a.Cout = g.out_channels;
@@ -996,6 +1053,13 @@ extern "C" int ttsc_conv1d_forward_split(const ttsc_conv1d* c, const float* x, c
         if (!g.transposed) {
             a.q_lo = 0;
             a.q_cnt = (int)Lout;
+        } else if (c->vfused) {
+            // union over the phases r = 0..s-1 of  o = q*s + r - p in [0, Lout); per-element validity is checked in the epilogue
+            int64_t qlo = -floor_div((g.stride - 1) - g.padding, g.stride);
+            int64_t qhi = floor_div(Lout - 1 + g.padding, g.stride) + 1;
+            if (qhi <= qlo) continue;
+            a.q_lo = (int)qlo;
+            a.q_cnt = (int)(qhi - qlo);
         } else {
             // o = q*s + r - p in [0, Lout)
             int64_t qlo = -floor_div(ph.r - g.padding, g.stride);  // ceil((p - r) / s)
