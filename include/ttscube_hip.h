@@ -216,6 +216,23 @@ int ttsc_lstm_seq_forward(const float* xg_dev, const float* whh_packed_dev, floa
 /* frees a device buffer returned by a ttsc_*_pack_* function */
 void ttsc_device_free(void* p);
 
+/* ------------------------------------------------------------------------------------------------
+ * Autoregressive mel decoder loop of CubenetTextcoder as one persistent kernel.  Replaces the python loop at
+ * cube/networks/textcoder.py:174-185: per step PreNet (modules.py:159-164, dropout p=0.5 always on) -> 2-layer LSTM step
+ * -> Linear H->O (three 80-bin frames) -> feedback of the last frame.  The caller hoists the overlay part of the layer-1
+ * input projection: xg1_dev [B,S,4H] = overlay . W_ih1[:, :overlay]^T + b_ih1 + b_hh1 (ttsc_linear_forward).
+ * masks_dev: {0,1} floats [B,S,2,P] (injected dropout masks) or NULL (Bernoulli(0.5) from Philox(seed)); steps_dev int32
+ * [B] or NULL (all S); y_dev [B,S,O] pre-postnet mel (zeros beyond an utterance's steps).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ttsc_melar ttsc_melar;
+int ttsc_melar_create(int32_t H, int32_t P, int32_t M, int32_t O, ttsc_melar** out);
+int ttsc_melar_set_weights(ttsc_melar* m, const float* w_ih1, int64_t ld1, const float* w_hh1, const float* w_ih2,
+                           const float* w_hh2, const float* b_ih2, const float* b_hh2, const float* w_out, const float* b_out,
+                           const float* pn_w1, const float* pn_b1, const float* pn_w2, const float* pn_b2);
+int ttsc_melar_decode(const ttsc_melar* m, const float* xg1_dev, int32_t B, int32_t S, const float* masks_dev, uint64_t seed,
+                      const int32_t* steps_dev, float* y_dev, void* stream);
+void ttsc_melar_destroy(ttsc_melar* m);
+
 #ifdef __cplusplus
 }
 #endif

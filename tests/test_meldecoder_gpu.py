@@ -74,6 +74,20 @@ def test_textcoder_matches_reference_golden(golden_dir):
     mel = net.inference(dict(X), dropout_masks=torch.from_numpy(z['masks']).unsqueeze(2)).cpu()
     assert mel.shape == z['mel'].shape
     assert float((mel - torch.from_numpy(z['mel'])).pow(2).mean().sqrt()) < 1e-4
+    # persistent AR kernel == step-wise launches (same masks), and the Philox-dropout production path runs
+    with torch.no_grad():
+        h, out_dur = net._text_stack(X['x_char'].cuda(), X['x_speaker'].cuda(), None)
+        durs = torch.argmax(out_dur, dim=-1).cpu().numpy().reshape(-1)
+        from ttscube_amd.networks.modules import _expand_rows
+        f2p = [p for p, d in enumerate(durs) for _ in range(int(d))]
+        h, _ = _expand_rows(h, [f2p], stride=3)
+        h = net._lstm('_rnn_overlay')(h)
+        mk = torch.from_numpy(z['masks']).unsqueeze(2)
+        a = net._ar_decode(h, mk)
+        b = net._ar_decode_stepwise(h, mk)
+        assert float((a - b).abs().max()) < 1e-4
+        free = net.inference(dict(X))
+        assert free.shape == mel.shape and bool(torch.isfinite(free).all())
     Xt = dict(X)
     Xt['y_frame2phone'] = [list(z['f2p_tf'])]
     Xt['y_mgc'] = torch.from_numpy(z['y_mgc'])

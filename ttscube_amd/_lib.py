@@ -95,6 +95,11 @@ SIGNATURES = {
                                         C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
     'ttsc_device_free': (None, [C.c_void_p]),
+    'ttsc_melar_create': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    'ttsc_melar_set_weights': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 11),
+    'ttsc_melar_decode': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
+    'ttsc_melar_destroy': (None, [C.c_void_p]),
 }
 
 

@@ -1,6 +1,8 @@
 """Mirror of cube/networks/textcoder.py: ``CubenetTextcoder`` — phonemes -> log10-mel (two-stage path of
 cube/io_utils/runtime.py:41-80).  Same constructor / state_dict keys; `inference` and the teacher-forced `forward` run
 on the HIP conv / GEMM / LSTM kernels."""
+import ctypes as C
+
 import torch
 import torch.nn as nn
 
@@ -76,19 +78,68 @@ class CubenetTextcoder(nn.Module):
             if h.shape[1] == 0:
                 return torch.zeros((1, 0, 80), device=dev)
             h = self._lstm('_rnn_overlay')(h)
-            last = torch.full((1, 1, 80), -5.0, device=dev)
-            hx = None
-            outs = []
-            rnn = self._lstm('_mel_rnn')
-            for t in range(h.shape[1]):
-                m = None if dropout_masks is None else [dropout_masks[t][0].to(dev), dropout_masks[t][1].to(dev)]
-                pn = self._prenet(last, masks=m)
-                y, hx = rnn(torch.cat([h[:, t:t + 1], pn], dim=-1).contiguous(), hx=hx, return_state=True)
-                o = linear_hip(y, self._mel_output.linear_layer.weight, self._mel_output.linear_layer.bias)
-                outs.append(o)
-                last = o[:, :, -80:].contiguous()
-            mel = torch.cat(outs, dim=1).reshape(1, -1, 80).contiguous()
+            mel = self._ar_decode(h, dropout_masks)
             return self._postnet(mel, add_residual=True)
+
+    def _melar_handle(self):
+        """(re)build the persistent AR-decoder handle when a parameter changed"""
+        mods = [self._mel_rnn, self._mel_output, self._prenet]
+        sig = tuple((p.data_ptr(), p._version) for m in mods for p in m.parameters())
+        if self._hip.get('_melar_sig') == sig:
+            return self._hip['_melar']
+        L = _lib.lib()
+        _lib.require_gpu()
+        if '_melar' in self._hip:
+            L.ttsc_melar_destroy(self._hip['_melar'])
+        hnd = C.c_void_p()
+        _lib.check(L.ttsc_melar_create(self._mel_rnn.hidden_size, 256, 80, 80 * self._pframes, C.byref(hnd)), 'ttsc_melar_create')
+        g = lambda t: t.detach().float().cpu().contiguous()
+        r = self._mel_rnn
+        ts = [g(r.weight_ih_l0), g(r.weight_hh_l0), g(r.weight_ih_l1), g(r.weight_hh_l1), g(r.bias_ih_l1), g(r.bias_hh_l1),
+              g(self._mel_output.linear_layer.weight), g(self._mel_output.linear_layer.bias),
+              g(self._prenet.layers_h[0].linear_layer.weight), g(self._prenet.layers_h[0].linear_layer.bias),
+              g(self._prenet.layers_h[1].linear_layer.weight), g(self._prenet.layers_h[1].linear_layer.bias)]
+        P = lambda t: C.c_void_p(t.data_ptr())
+        _lib.check(L.ttsc_melar_set_weights(hnd, P(ts[0]), ts[0].shape[1], *[P(t) for t in ts[1:]]), 'ttsc_melar_set_weights')
+        self._hip['_melar'] = hnd
+        self._hip['_melar_sig'] = sig
+        return hnd
+
+    def _ar_decode(self, h, dropout_masks=None, steps=None, seed=None):
+        """textcoder.py:174-185 as ONE persistent kernel launch (csrc/melar.hip).  h: overlay states [B, S, 1024]."""
+        hnd = self._melar_handle()
+        B, S, _ = h.shape
+        r = self._mel_rnn
+        n_ov = r.weight_ih_l0.shape[1] - 256
+        xg1 = linear_hip(h, r.weight_ih_l0[:, :n_ov].contiguous(), r.bias_ih_l0 + r.bias_hh_l0)    # hoisted input projection
+        y = torch.empty((B, S, 80 * self._pframes), dtype=torch.float32, device=h.device)
+        m = None
+        if dropout_masks is not None:
+            m = torch.as_tensor(dropout_masks).to(h.device).float().reshape(S, 2, B, 256).permute(2, 0, 1, 3).contiguous()
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        st = torch.as_tensor(steps, dtype=torch.int32, device=h.device) if steps is not None else None
+        with torch.cuda.device(h.device):
+            _lib.check(_lib.lib().ttsc_melar_decode(hnd, _lib.dev_ptr(xg1), B, S, _lib.dev_ptr(m) if m is not None else None,
+                                                    C.c_uint64(seed), _lib.dev_ptr(st) if st is not None else None, _lib.dev_ptr(y),
+                                                    _lib.current_stream()), 'ttsc_melar_decode')
+        return y.reshape(B, S * self._pframes, 80).contiguous()
+
+    def _ar_decode_stepwise(self, h, dropout_masks=None):
+        """The same loop as one kernel launch per layer and step (kept for A/B tests of the persistent kernel)."""
+        dev = h.device
+        last = torch.full((1, 1, 80), -5.0, device=dev)
+        hx = None
+        outs = []
+        rnn = self._lstm('_mel_rnn')
+        for t in range(h.shape[1]):
+            m = None if dropout_masks is None else [dropout_masks[t][0].to(dev), dropout_masks[t][1].to(dev)]
+            pn = self._prenet(last, masks=m)
+            y, hx = rnn(torch.cat([h[:, t:t + 1], pn], dim=-1).contiguous(), hx=hx, return_state=True)
+            o = linear_hip(y, self._mel_output.linear_layer.weight, self._mel_output.linear_layer.bias)
+            outs.append(o)
+            last = o[:, :, -80:].contiguous()
+        return torch.cat(outs, dim=1).reshape(1, -1, 80).contiguous()
 
     def forward(self, X, dropout_masks=None):
         """Teacher-forced path (textcoder.py:100-138), inference numerics (no autograd): returns
