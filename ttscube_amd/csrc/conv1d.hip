@@ -51,7 +51,6 @@ struct ConvArgs {
     void* ys;         // split output or null
     float ys_scale, ys_slope;
     int write_f32;    // 0: only the split output is written
-    int tpw;          // f16x3 kernel: consecutive time tiles per workgroup (cross-tile prefetch)
     int vphase;       // fused ConvTranspose1d phases: GEMM row v = r * vphase + co (vphase = real Cout), output o += r; 0 = off
     int dbg;          // ablation switches (env TTSC_CONV_DBG): 1 skip LDS commits, 2 skip MFMA loop, 4 skip epilogue, 8 skip global prefetch
 };
@@ -267,32 +266,30 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.z;
+    const int q0 = a.q_lo + blockIdx.x * NT;
     const int lin = a.in_len ? a.in_len[b] : a.Lin;
+    if (a.out_len && (long)q0 * a.out_stride + a.out_off >= a.out_len[b]) return;
     const int cot0 = blockIdx.y * MI;
     const int cotN = a.CoutP >> 5;
     const int nchunks = a.CinP >> 4;
-    // A workgroup walks a RUN of `tpw` consecutive time tiles: the loads of the next tile's first channel chunk are
-    // issued before the last MFMA loop of the current tile (cross-tile prefetch) and the epilogue's stores drain while
-    // the next tile computes, so the per-tile prologue/epilogue latency is paid once per run instead of once per tile.
-    const int tiles_total = (a.q_cnt + NT - 1) / NT;
-    const int tile_first = blockIdx.x * a.tpw;
-    int ntile = tiles_total - tile_first;
-    ntile = ntile < a.tpw ? ntile : a.tpw;
-    if (a.out_len) {   // ragged batch: drop the tiles wholly beyond this utterance's output
-        const long ol = a.out_len[b];
-        while (ntile > 0 && (long)(a.q_lo + (tile_first + ntile - 1) * NT) * a.out_stride + a.out_off >= ol) --ntile;
-    }
-    if (ntile <= 0) return;
 
     f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
     const float* xb = a.x + (size_t)b * a.Cin * a.Lin;
+    const int lo = q0 + a.min_shift;
     const half8* wsrc = reinterpret_cast<const half8*>(a.wph);
 
-    // Both operands are software-pipelined through registers ONE CHANNEL CHUNK ahead: the global loads of the next
-    // chunk (activation window and the weight fragments of all taps) are issued before the MFMA loop of the current
-    // one and committed to LDS after it, so their latency hides behind ntaps*MI*NJ*3 MFMAs and the tap loop itself has
-    // no barrier and no global access.  Addresses are clamped and loads unconditional (selects zero the padding) so
-    // the compiler never branches around a load.
+    // Both operands are software-pipelined through registers ONE CHANNEL CHUNK ahead: the global loads of chunk c+1
+    // (activation window and the weight fragments of all taps) are issued before the MFMA loop of chunk c and
+    // committed to LDS after it, so their latency hides behind ntaps*MI*NJ*3 MFMAs and the tap loop itself has no
+    // barrier and no global access.  Addresses are clamped and loads unconditional (selects zero the padding) so the
+    // compiler never branches around a load.
     constexpr int APT = (TMAX * AFR + 255) / 256;  // weight items per thread per chunk
     const int a_items = a.ntaps * AFR;
     half8 areg[APT];
@@ -325,32 +322,25 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
     bool xok[XIT];
     int xh[XIT];      // fp32: channel half (0/1); split: plane index (h*2 + pl) in 0..3
 #pragma unroll
-    for (int e = 0; e < XIT; ++e) {   // tile-independent part of the per-item invariants
+    for (int e = 0; e < XIT; ++e) {
         const int i = tid + e * 256;
-        const int h = i / spanp;
+        const int h = i / spanp;              // spanp is a multiple of 64: cheap shifts would do, this runs once
         const int p = i - h * spanp;
+        const int pos = lo + p;
+        xok[e] = pos >= 0 && pos < lin;
+        int pc = pos > lin - 1 ? lin - 1 : pos;
+        pc = pc < 0 ? 0 : pc;
+        xoff[e] = (unsigned)pc;
         xh[e] = h;
         if (SPLIT_IN)
             xslot[e] = (p < a.span && h < 4) ? h * a.span_pad + p : -1;
         else
             xslot[e] = (p < a.span && h < 2) ? (h * 2) * a.span_pad + p : -1;
     }
-    auto x_setup = [&](int tile) {    // position window of `tile`: clamped load offsets and validity
-        const int lo = a.q_lo + tile * NT + a.min_shift;
-#pragma unroll
-        for (int e = 0; e < XIT; ++e) {
-            const int i = tid + e * 256;
-            const int p = i - xh[e] * spanp;
-            const int pos = lo + p;
-            xok[e] = pos >= 0 && pos < lin;
-            int pc = pos > lin - 1 ? lin - 1 : pos;
-            pc = pc < 0 ? 0 : pc;
-            xoff[e] = (unsigned)pc;
-        }
-    };
     const half8* xsb = reinterpret_cast<const half8*>(a.xs) + (size_t)b * (a.Cin >> 3) * 2 * a.Lin;
     auto x_issue = [&](int c) {
         if (SPLIT_IN) {
+            // plane (h, pl) of chunk c = 8-channel group (2c + h), plane pl: a wave-uniform row base + per-lane position
 #pragma unroll
             for (int e = 0; e < XIT; ++e) {
                 const int hp = xh[e] < 4 ? xh[e] : 3;
@@ -370,8 +360,6 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
             }
         }
     };
-    // NOTE: x_commit(c) runs BEFORE x_setup of a following tile is applied (see the loop), so xok[] still describes
-    // the tile the registers were loaded for.
     auto x_commit = [&](int c) {
 #pragma unroll
         for (int e = 0; e < XIT; ++e) {
@@ -402,94 +390,78 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
         }
     };
 
-    // per-lane LDS bases are loop invariants; inside the tap loop only `shift` / the tap's block offset are added
-    const half8* xh_base = Xp + (unsigned)((half * 2 + 0) * a.span_pad + wn * (NJ * 32) + l31);
-    const half8* xl_base = Xp + (unsigned)((half * 2 + 1) * a.span_pad + wn * (NJ * 32) + l31);
-    const half8* al_base = Ap + lane;
-    const int q_hi = a.q_lo + a.q_cnt;
-
-    x_setup(tile_first);
     x_issue(0);
     a_issue(0);
-    bool first = true;
-    for (int tl = 0; tl < ntile; ++tl) {
-        const int q0 = a.q_lo + (tile_first + tl) * NT;
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        for (int c = 0; c < nchunks; ++c) {
-            if (!first) __syncthreads();  // everyone finished reading the previous chunk from LDS
-            first = false;
-            if (!(a.dbg & 1)) {
-                x_commit(c);
-                if (!(a.dbg & 32)) a_commit();
-            }
-            __syncthreads();
-            if (!(a.dbg & 8)) {
-                if (c + 1 < nchunks) {
-                    x_issue(c + 1);
-                    a_issue(c + 1);
-                } else if (tl + 1 < ntile) {   // cross-tile prefetch: first chunk of the next tile of this run
-                    x_setup(tile_first + tl + 1);
-                    x_issue(0);
-                    a_issue(0);
-                }
-            }
-            if (a.dbg & 2) continue;
-            int shift = a.tap_base - a.min_shift;
-            for (int j = 0; j < a.ntaps; ++j, shift += a.tap_step) {
-                const half8* Ab = al_base + ((a.dbg & 16) ? 0 : j * AFR);
-                half8 ah[MI], al[MI], bh[NJ], bl[NJ];
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    ah[i] = Ab[(i * 2 + 0) * 64];
-                    al[i] = Ab[(i * 2 + 1) * 64];
-                }
-#pragma unroll
-                for (int n = 0; n < NJ; ++n) {
-                    bh[n] = xh_base[shift + n * 32];
-                    bl[n] = xl_base[shift + n * 32];
-                }
-                // three product terms; consecutive MFMAs go to DIFFERENT accumulators (no back-to-back dependency)
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[n], acc[i][n], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[n], acc[i][n], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[n], acc[i][n], 0, 0, 0);
-            }
+    for (int c = 0; c < nchunks; ++c) {
+        if (c) __syncthreads();  // everyone finished reading chunk c-1 from LDS
+        if (!(a.dbg & 1)) {
+            x_commit(c);
+            a_commit();
         }
-        if (a.dbg & 4) {
-            if (acc[0][0][0] == 12345.678f) a.y[0] = 1.f;  // keep the accumulators alive
-            continue;
+        __syncthreads();
+        if (c + 1 < nchunks && !(a.dbg & 8)) {
+            x_issue(c + 1);
+            a_issue(c + 1);
         }
+        if (a.dbg & 2) continue;
+        // per-lane LDS bases are loop invariants; inside the tap loop only `shift` / the tap's block offset are added
+        // (32-bit LDS addressing, immediate offsets for the fragment index) — VALU work per MFMA matters here because
+        // VALU and MFMA issue from the same in-order wave
+        const half8* xh = Xp + (unsigned)((half * 2 + 0) * a.span_pad + wn * (NJ * 32) + l31);
+        const half8* xl = Xp + (unsigned)((half * 2 + 1) * a.span_pad + wn * (NJ * 32) + l31);
+        const half8* al_base = Ap + lane;
+        int shift = a.tap_base - a.min_shift;
+        for (int j = 0; j < a.ntaps; ++j, shift += a.tap_step) {
+            const half8* Ab = al_base + j * AFR;
+            half8 ah[MI], al[MI], bh[NJ], bl[NJ];
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+            for (int i = 0; i < MI; ++i) {
+                ah[i] = Ab[(i * 2 + 0) * 64];
+                al[i] = Ab[(i * 2 + 1) * 64];
+            }
 #pragma unroll
             for (int n = 0; n < NJ; ++n) {
-                const int q = q0 + wn * (NJ * 32) + n * 32 + l31;
-                const long o = (long)q * a.out_stride + a.out_off;
-                const bool qok = (q < q_hi) && (o >= 0) && (o < a.Lout);
-                int cb = (cot0 + i) * 32;
-                long oo = o;
-                bool ok = qok;
-                if (a.vphase) {   // virtual row tile -> (phase r, real channel tile); tiles never straddle phases (Cout % 32 == 0)
-                    const int r = cb / a.vphase;
-                    cb -= r * a.vphase;
-                    oo += r;
-                    ok = (q < q_hi) && (oo >= 0) && (oo < a.Lout) && (r < a.out_stride);
-                }
-                epilogue_tile(acc[i][n], a, b, cb, oo, ok, half, a.w_unscale);
+                bh[n] = xh[shift + n * 32];
+                bl[n] = xl[shift + n * 32];
             }
+            // three product terms; consecutive MFMAs go to DIFFERENT accumulators (no back-to-back dependency)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[n], acc[i][n], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[n], acc[i][n], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[n], acc[i][n], 0, 0, 0);
+        }
+    }
+
+    const int q_hi = a.q_lo + a.q_cnt;
+    if (a.dbg & 4) {
+        if (acc[0][0][0] == 12345.678f) a.y[0] = 1.f;  // keep the accumulators alive
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int n = 0; n < NJ; ++n) {
+            const int q = q0 + wn * (NJ * 32) + n * 32 + l31;
+            const long o = (long)q * a.out_stride + a.out_off;
+            const bool qok = (q < q_hi) && (o >= 0) && (o < a.Lout);
+            int cb = (cot0 + i) * 32;
+            long oo = o;
+            bool ok = qok;
+            if (a.vphase) {   // virtual row tile -> (phase r, real channel tile); tiles never straddle phases (Cout % 32 == 0)
+                const int r = cb / a.vphase;
+                cb -= r * a.vphase;
+                oo += r;
+                ok = (q < q_hi) && (oo >= 0) && (oo < a.Lout) && (r < a.out_stride);
+            }
+            epilogue_tile(acc[i][n], a, b, cb, oo, ok, half, a.w_unscale);
         }
     }
 }
@@ -682,7 +654,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 2)) void respair32_f16x3_ke
     ea.write_f32 = 1;
     ea.dbg = 0;
     ea.vphase = 0;
-    ea.tpw = 1;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int col = wv * 64 + n * 32 + l31;
@@ -696,22 +667,14 @@ template <int MI, int NJ, int TMAX, bool SPLIT_IN>
 static int launch_f16_t(const ConvArgs& a, int B, hipStream_t s) {
     constexpr int NT = 4 * NJ * 32;
     constexpr int MT = MI * 32;
-    // tiles per workgroup: long enough runs to amortise the per-run prologue, still >= ~8 workgroups per CU in flight
-    ConvArgs aa = a;
-    const long tiles = ceil_div(a.q_cnt, NT);
-    const long wgs1 = tiles * (a.CoutP / MT) * B;
-    int tpw = (int)(wgs1 / 2048);
-    tpw = tpw < 1 ? 1 : (tpw > 8 ? 8 : tpw);
-    if (const char* ev = getenv("TTSC_CONV_TPW")) tpw = atoi(ev) > 0 ? atoi(ev) : tpw;
-    aa.tpw = tpw;
-    dim3 grid((unsigned)ceil_div(tiles, tpw), (unsigned)(a.CoutP / MT), (unsigned)B);
+    dim3 grid((unsigned)ceil_div(a.q_cnt, NT), (unsigned)(a.CoutP / MT), (unsigned)B);
     const size_t lds = (size_t)a.span_pad * 4 * 16 + (size_t)a.ntaps * MI * 2 * 64 * 16;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)conv_f16x3_kernel<MI, NJ, TMAX, SPLIT_IN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL((conv_f16x3_kernel<MI, NJ, TMAX, SPLIT_IN>), grid, dim3(256), lds, s, aa);
+    hipLaunchKernelGGL((conv_f16x3_kernel<MI, NJ, TMAX, SPLIT_IN>), grid, dim3(256), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("conv_f16x3_kernel launch failed: %s", hipGetErrorString(e));
@@ -1076,7 +1039,6 @@ extern "C" int ttsc_conv1d_forward_split(const ttsc_conv1d* c, const float* x, c
         a.dbg = 0;
         if (const char* ev = getenv("TTSC_CONV_DBG")) a.dbg = atoi(ev);
         a.vphase = c->vfused ? g.out_channels : 0;
-        a.tpw = 1;
         a.Cin = g.in_channels;
         a.CinP = c->CinP;
         a.Cout = g.out_channels;
