@@ -90,3 +90,31 @@ def test_cubegan_load_is_non_strict_and_device_checked(tmp_path):
     m.load(base + '.model')
     with pytest.raises(TTSCError):
         m.inference({'x_char': torch.tensor([[1, 2]]), 'x_speaker': torch.tensor([[1]])})   # parameters on CPU
+
+
+def test_zero_frame_guard_and_single_phoneme(tmp_path):
+    """Cubegan.inference (cubegan.py:81-82): when every predicted duration is 0 the generator still gets ONE zero frame.
+    Forced here by zeroing the duration head so that argmax == 0 for every phoneme."""
+    from ttscube_amd.io_utils.io_cubegan import CubeganEncodings
+    from ttscube_amd.networks.cubegan import Cubegan
+    base, _, _ = _make_model_dir(tmp_path)
+    enc = CubeganEncodings(base + '.encodings')
+    m = Cubegan(enc, conditioning=None, train=False)
+    m.load(base + '.model')
+    with torch.no_grad():
+        m._languasito._dur_output.linear_layer.weight.zero_()
+        b = torch.full_like(m._languasito._dur_output.linear_layer.bias, -1.0)
+        b[0] = 1.0
+        m._languasito._dur_output.linear_layer.bias.copy_(b)
+    m = m.cuda().eval()
+    X = {'x_char': torch.tensor([[3, 1, 4]]), 'x_speaker': torch.tensor([[1]])}
+    wav = m.inference(X)
+    assert X['y_frame2phone'] == [[]]
+    assert wav.shape == (1, 1, 240 * 1 + 64) and bool(torch.isfinite(wav).all())
+    # a one-phoneme sentence with a non-zero duration runs through the ragged path too
+    with torch.no_grad():
+        b[0] = -1.0
+        b[2] = 1.0
+        m._languasito._dur_output.linear_layer.bias.copy_(b)
+    wav = m.inference({'x_char': torch.tensor([[5]]), 'x_speaker': torch.tensor([[2]])})
+    assert wav.shape == (1, 1, 240 * 2 + 64)
