@@ -189,6 +189,10 @@ int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel_dev, const float* xlow
                         int32_t mode, const float* noise_dev, uint64_t seed, const float* forced_x_dev,
                         uint8_t* idx_dev, float* wav_dev, float* logits_dev, void* workspace_dev, size_t workspace_bytes,
                         void* stream);
+/* Synchronises `stream`, then: 0 = last decode finished normally; 1 = the cluster (weight-stationary) kernel gave up on an
+ * inter-workgroup hand-off (bounded spin timed out; outputs invalid; rerun with env TTSC_WR_CLUSTER=0); -1 = the last decode
+ * used the single-workgroup streaming kernel. */
+int ttsc_wavernn_last_status(ttsc_wavernn* w, void* stream);
 void ttsc_wavernn_destroy(ttsc_wavernn* w);
 
 /* ------------------------------------------------------------------------------------------------

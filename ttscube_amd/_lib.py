@@ -87,6 +87,7 @@ SIGNATURES = {
     'ttsc_wavernn_decode': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
                                       C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_size_t, C.c_void_p]),
+    'ttsc_wavernn_last_status': (C.c_int, [C.c_void_p, C.c_void_p]),
     'ttsc_wavernn_destroy': (None, [C.c_void_p]),
     'ttsc_linear_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                       C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),

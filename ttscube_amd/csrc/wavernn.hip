@@ -25,6 +25,7 @@
 #include "common.hpp"
 #include "../../include/ttscube_math.h"
 #include "../../include/ttscube_mulaw_lut.h"
+#include "wavernn_cluster.hip"
 
 namespace ttsc {
 
@@ -403,6 +404,12 @@ struct ttsc_wavernn {
     float *wt_pre = nullptr, *b_pre = nullptr, *wt_out = nullptr, *b_out = nullptr, *lut = nullptr;
     float* lc_w[3] = {nullptr, nullptr, nullptr};
     float* lc_b[3] = {nullptr, nullptr, nullptr};
+    // host copies (torch layout) kept for the cluster kernel's per-member packing
+    std::vector<float> h_wih0, h_whh0, h_bih0, h_bhh0, h_wpre, h_bpre, h_wout, h_bout;
+    float *c_whh = nullptr, *c_wih = nullptr, *c_bih = nullptr, *c_bhh = nullptr, *c_wpre = nullptr, *c_bpre = nullptr, *c_wout = nullptr,
+          *c_bout = nullptr;
+    bool cluster_dirty = true;
+    unsigned* last_abort_word = nullptr;   // device word set by the cluster kernel when a hand-off timed out
     std::vector<std::string> have;
     bool has(const std::string& n) const {
         for (auto& s : have)
@@ -464,7 +471,8 @@ extern "C" void ttsc_wavernn_destroy(ttsc_wavernn* w) {
         if (w->b_ih[l]) (void)hipFree(w->b_ih[l]);
         if (w->b_hh[l]) (void)hipFree(w->b_hh[l]);
     }
-    for (float* p : {w->wt_pre, w->b_pre, w->wt_out, w->b_out, w->lut, w->lc_w[0], w->lc_w[1], w->lc_w[2], w->lc_b[0], w->lc_b[1], w->lc_b[2]})
+    for (float* p : {w->wt_pre, w->b_pre, w->wt_out, w->b_out, w->lut, w->lc_w[0], w->lc_w[1], w->lc_w[2], w->lc_b[0], w->lc_b[1], w->lc_b[2],
+                     w->c_whh, w->c_wih, w->c_bih, w->c_bhh, w->c_wpre, w->c_bpre, w->c_wout, w->c_bout})
         if (p) (void)hipFree(p);
     delete w;
 }
@@ -492,15 +500,19 @@ extern "C" int ttsc_wavernn_set_weight(ttsc_wavernn* w, const char* name, const 
         if (k == "weight_ih_l0") {
             TTSC_REQUIRE(shape_is(shape, nd, {3 * H, in_l}), "ttsc_wavernn_set_weight: '%s' expects [%d,%d]", name, 3 * H, in_l);
             rc = (l == 0) ? upload_transposed(&w->wt_ih[l], host, 3 * H, in_l) : upload_packed4(&w->wt_ih[l], host, 3 * H, in_l);
+            if (l == 0) w->h_wih0.assign(host, host + (size_t)3 * H * in_l);
         } else if (k == "weight_hh_l0") {
             TTSC_REQUIRE(shape_is(shape, nd, {3 * H, H}), "ttsc_wavernn_set_weight: '%s' expects [%d,%d]", name, 3 * H, H);
             rc = upload_packed4(&w->wt_hh[l], host, 3 * H, H);
+            if (l == 0) w->h_whh0.assign(host, host + (size_t)3 * H * H);
         } else if (k == "bias_ih_l0") {
             TTSC_REQUIRE(shape_is(shape, nd, {3 * H}), "ttsc_wavernn_set_weight: '%s' expects [%d]", name, 3 * H);
             rc = upload(&w->b_ih[l], host, 3 * H);
+            if (l == 0) w->h_bih0.assign(host, host + 3 * H);
         } else if (k == "bias_hh_l0") {
             TTSC_REQUIRE(shape_is(shape, nd, {3 * H}), "ttsc_wavernn_set_weight: '%s' expects [%d]", name, 3 * H);
             rc = upload(&w->b_hh[l], host, 3 * H);
+            if (l == 0) w->h_bhh0.assign(host, host + 3 * H);
         } else {
             TTSC_REQUIRE(false, "ttsc_wavernn_set_weight: unknown key '%s'", name);
         }
@@ -517,20 +529,83 @@ extern "C" int ttsc_wavernn_set_weight(ttsc_wavernn* w, const char* name, const 
     } else if (n == "_preoutput.linear_layer.weight") {
         TTSC_REQUIRE(shape_is(shape, nd, {256, H}), "ttsc_wavernn_set_weight: '%s' expects [256,%d]", name, H);
         rc = upload_packed4(&w->wt_pre, host, 256, H);
+        w->h_wpre.assign(host, host + (size_t)256 * H);
     } else if (n == "_preoutput.linear_layer.bias") {
         TTSC_REQUIRE(shape_is(shape, nd, {256}), "ttsc_wavernn_set_weight: '%s' expects [256]", name);
         rc = upload(&w->b_pre, host, 256);
+        w->h_bpre.assign(host, host + 256);
     } else if (n == "_output.linear_layer.weight") {
         TTSC_REQUIRE(shape_is(shape, nd, {S, 256}), "ttsc_wavernn_set_weight: '%s' expects [%d,256]", name, S);
         rc = upload_packed4(&w->wt_out, host, S, 256);
+        w->h_wout.assign(host, host + (size_t)S * 256);
     } else if (n == "_output.linear_layer.bias") {
         TTSC_REQUIRE(shape_is(shape, nd, {S}), "ttsc_wavernn_set_weight: '%s' expects [%d]", name, S);
         rc = upload(&w->b_out, host, S);
+        w->h_bout.assign(host, host + S);
     } else {
         TTSC_REQUIRE(false, "ttsc_wavernn_set_weight: unknown key '%s'", name);
     }
     if (rc == TTSC_OK && !w->has(n)) w->have.push_back(n);
+    w->cluster_dirty = true;
     return rc;
+}
+
+// ---- cluster (weight-stationary) path ---------------------------------------------------------------------------
+static bool cluster_supported(const ttsc_wavernn* w, int B) {
+    const auto& c = w->cfg;
+    if (const char* ev = getenv("TTSC_WR_CLUSTER"))
+        if (atoi(ev) == 0) return false;
+    if (c.num_layers != 1 || c.H % WC_NC != 0 || c.H > 512 || c.S % WC_NC != 0 || c.S > 256) return false;
+    const int G = (int)ceil_div(B, WC_BU);
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    return G * WC_NC <= cus;   // every member must be resident (one workgroup per CU): otherwise the exchange deadlocks
+}
+
+static size_t cluster_exchange_bytes(const ttsc_wavernn* w, int B) {
+    const int G = (int)ceil_div(B, WC_BU);
+    const auto& c = w->cfg;
+    const size_t per = ((size_t)2 * c.H * WC_BU + (size_t)2 * 256 * WC_BU + (size_t)2 * WC_BU * c.S + 2 * WC_BU) * sizeof(float);
+    return (size_t)G * per + ((size_t)G * 4 + 64) * sizeof(unsigned) + 256;
+}
+
+// member m owns hidden units [m*UPW, (m+1)*UPW), pre rows [8m, 8m+8), output rows [m*SR, (m+1)*SR); packed [K/4][rows][4]
+static int cluster_pack(ttsc_wavernn* w) {
+    const auto& c = w->cfg;
+    const int H = c.H, UPW = H / WC_NC, R3 = 3 * UPW, I0 = w->in0, I0P = (int)round_up(I0, 4), S = c.S, SR = S / WC_NC;
+    std::vector<float> whh((size_t)WC_NC * H * R3, 0.f), wih((size_t)WC_NC * I0P * R3, 0.f), bih((size_t)WC_NC * R3), bhh((size_t)WC_NC * R3);
+    std::vector<float> wpre((size_t)WC_NC * H * 8), bpre((size_t)WC_NC * 8), wout((size_t)WC_NC * 256 * SR), bout((size_t)WC_NC * SR);
+    for (int m = 0; m < WC_NC; ++m) {
+        for (int q = 0; q < 3; ++q)
+            for (int j = 0; j < UPW; ++j) {
+                const int row = q * H + m * UPW + j, lr = q * UPW + j;
+                for (int k = 0; k < H; ++k) whh[(size_t)m * H * R3 + ((size_t)(k >> 2) * R3 + lr) * 4 + (k & 3)] = w->h_whh0[(size_t)row * H + k];
+                for (int k = 0; k < I0; ++k) wih[(size_t)m * I0P * R3 + ((size_t)(k >> 2) * R3 + lr) * 4 + (k & 3)] = w->h_wih0[(size_t)row * I0 + k];
+                bih[(size_t)m * R3 + lr] = w->h_bih0[row];
+                bhh[(size_t)m * R3 + lr] = w->h_bhh0[row];
+            }
+        for (int r = 0; r < 8; ++r) {
+            const int row = m * 8 + r;
+            for (int k = 0; k < H; ++k) wpre[(size_t)m * H * 8 + ((size_t)(k >> 2) * 8 + r) * 4 + (k & 3)] = w->h_wpre[(size_t)row * H + k];
+            bpre[(size_t)m * 8 + r] = w->h_bpre[row];
+        }
+        for (int r = 0; r < SR; ++r) {
+            const int row = m * SR + r;
+            for (int k = 0; k < 256; ++k) wout[(size_t)m * 256 * SR + ((size_t)(k >> 2) * SR + r) * 4 + (k & 3)] = w->h_wout[(size_t)row * 256 + k];
+            bout[(size_t)m * SR + r] = w->h_bout[row];
+        }
+    }
+    int rc;
+    if ((rc = upload(&w->c_whh, whh.data(), whh.size()))) return rc;
+    if ((rc = upload(&w->c_wih, wih.data(), wih.size()))) return rc;
+    if ((rc = upload(&w->c_bih, bih.data(), bih.size()))) return rc;
+    if ((rc = upload(&w->c_bhh, bhh.data(), bhh.size()))) return rc;
+    if ((rc = upload(&w->c_wpre, wpre.data(), wpre.size()))) return rc;
+    if ((rc = upload(&w->c_bpre, bpre.data(), bpre.size()))) return rc;
+    if ((rc = upload(&w->c_wout, wout.data(), wout.size()))) return rc;
+    if ((rc = upload(&w->c_bout, bout.data(), bout.size()))) return rc;
+    w->cluster_dirty = false;
+    return TTSC_OK;
 }
 
 extern "C" int64_t ttsc_wavernn_out_len(const ttsc_wavernn* w, int64_t T, int64_t Tl) {
@@ -543,9 +618,14 @@ extern "C" int64_t ttsc_wavernn_out_len(const ttsc_wavernn* w, int64_t T, int64_
     return L;
 }
 
+static size_t cond_bytes(const ttsc_wavernn* w, int32_t B, int64_t Tl) {
+    if (!w->cfg.use_lowres) return 256;
+    return (size_t)round_up((int64_t)(((size_t)B * Tl * w->cfg.upsample_low + 2 * (size_t)B * 20 * Tl) * sizeof(float)) + 256, 256);
+}
+
 extern "C" size_t ttsc_wavernn_workspace_bytes(const ttsc_wavernn* w, int32_t B, int64_t T, int64_t Tl) {
-    if (!w || !w->cfg.use_lowres) return 256;
-    return ((size_t)B * Tl * w->cfg.upsample_low + 2 * (size_t)B * 20 * Tl) * sizeof(float) + 256;
+    if (!w) return 0;
+    return cond_bytes(w, B, Tl) + cluster_exchange_bytes(w, B);
 }
 
 extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const float* x_low, int32_t B, int64_t T, int64_t Tl,
@@ -624,6 +704,51 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
     }
     a.seed = seed;
     TTSC_REQUIRE(a.L > 0, "ttsc_wavernn_decode: nothing to decode (L=%d)", a.L);
+    if (cluster_supported(w, B)) {
+        if (w->cluster_dirty) {
+            int prc = cluster_pack(w);
+            if (prc) return prc;
+        }
+        const size_t need_all = ttsc_wavernn_workspace_bytes(w, B, T, Tl);
+        if (!ws || ws_bytes < need_all) {
+            set_error("ttsc_wavernn_decode: workspace %zu < required %zu bytes", ws_bytes, need_all);
+            return TTSC_ENOMEM;
+        }
+        const int G = (int)ceil_div(B, WC_BU);
+        char* xbase = (char*)ws + cond_bytes(w, B, Tl);
+        WcArgs ca;
+        memset(&ca, 0, sizeof(ca));
+        ca.mel = mel; ca.interp = a.interp; ca.feats = a.feats;
+        ca.whh = w->c_whh; ca.wih = w->c_wih; ca.bih = w->c_bih; ca.bhh = w->c_bhh;
+        ca.wpre = w->c_wpre; ca.bpre = w->c_bpre; ca.wout = w->c_wout; ca.bout = w->c_bout;
+        ca.lut = w->lut; ca.noise = noise; ca.forced_x = forced_x; ca.out_idx = idx; ca.out_wav = wav; ca.out_logits = logits;
+        float* f = (float*)xbase;
+        ca.xh = f; f += (size_t)G * 2 * c.H * WC_BU;
+        ca.xpre = f; f += (size_t)G * 2 * 256 * WC_BU;
+        ca.xlog = f; f += (size_t)G * 2 * WC_BU * c.S;
+        ca.xlx = f; f += (size_t)G * 2 * WC_BU;
+        ca.cnt = (unsigned*)f;
+        ca.B = B; ca.T = (int)T; ca.Tl = (int)Tl; ca.H = c.H; ca.UPW = c.H / WC_NC; ca.I0 = w->in0; ca.I0P = (int)round_up(w->in0, 4);
+        ca.use_lowres = c.use_lowres; ca.up = c.upsample; ca.up_low = c.upsample_low; ca.S = c.S; ca.SR = c.S / WC_NC; ca.n_mel = c.n_mel;
+        ca.out_kind = c.out_kind; ca.mode = mode; ca.L = a.L; ca.G = G; ca.seed = seed;
+        TTSC_HIP_CHECK(hipMemsetAsync(ca.cnt, 0, ((size_t)G * 4 + 64) * sizeof(unsigned), s));
+        const size_t lds = ((size_t)c.H * 3 * ca.UPW + (size_t)ca.I0P * 3 * ca.UPW + (size_t)c.H * 8 + (size_t)256 * ca.SR + c.S + 64) * sizeof(float);
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)wr_cluster_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr = true;
+        }
+        hipLaunchKernelGGL(wr_cluster_kernel, dim3(G * WC_NC), dim3(WC_THREADS), lds, s, ca);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            set_error("wr_cluster_kernel launch failed: %s", hipGetErrorString(e));
+            return TTSC_EHIP;
+        }
+        // the abort word is checked by the caller-visible helper below (no host sync here)
+        w->last_abort_word = ca.cnt + (size_t)G * 4;
+        return TTSC_OK;
+    }
+    w->last_abort_word = nullptr;
     // Utterances per workgroup (BT).  Measured on MI355X (H=512, 1 layer): one utterance per workgroup is fastest
     // per step (60 us) while the batch fits the 256 CUs; beyond that a tile of 2/4 utterances shares one weight
     // stream (74 / 98 us per step) and raises throughput (B=1024, BT=4: 9.6 M samples/s).
@@ -647,4 +772,17 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
         return TTSC_EHIP;
     }
     return TTSC_OK;
+}
+
+
+// After the stream has executed the last decode: 0 = ok, 1 = the cluster kernel aborted on a hand-off timeout (results
+// invalid), -1 = last decode did not use the cluster kernel.  Synchronises the stream.
+extern "C" int ttsc_wavernn_last_status(ttsc_wavernn* w, void* stream) {
+    if (!w) return TTSC_EINVAL;
+    if (!w->last_abort_word) return -1;
+    unsigned v = 0;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return TTSC_EHIP;
+    if (hipMemcpy(&v, w->last_abort_word, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return TTSC_EHIP;
+    if (v) set_error("wr_cluster_kernel: inter-workgroup hand-off timed out (not all members resident?)");
+    return v ? 1 : 0;
 }

@@ -154,6 +154,10 @@ class WaveRNN(nn.Module):
                                              P(fx) if fx is not None else None, P(idx), P(wav),
                                              P(logits) if logits is not None else None, P(self._ws), self._ws.numel() * 4,
                                              _lib.current_stream()), 'ttsc_wavernn_decode')
+            st = L.ttsc_wavernn_last_status(self._handle, _lib.current_stream())
+            if st == 1:
+                raise _lib.TTSCError('WaveRNN cluster kernel aborted on a hand-off timeout: ' + L.ttsc_last_error().decode())
+            self.last_kernel = 'cluster' if st == 0 else 'stream'
         return idx, wav, logits
 
     def forward(self, X):
