@@ -732,7 +732,7 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
         ca.use_lowres = c.use_lowres; ca.up = c.upsample; ca.up_low = c.upsample_low; ca.S = c.S; ca.SR = c.S / WC_NC; ca.n_mel = c.n_mel;
         ca.out_kind = c.out_kind; ca.mode = mode; ca.L = a.L; ca.G = G; ca.seed = seed;
         TTSC_HIP_CHECK(hipMemsetAsync(ca.cnt, 0, ((size_t)G * 4 + 64) * sizeof(unsigned), s));
-        const size_t lds = ((size_t)c.H * 3 * ca.UPW + (size_t)ca.I0P * 3 * ca.UPW + (size_t)c.H * 8 + (size_t)256 * ca.SR + c.S + 64) * sizeof(float);
+        const size_t lds = ((size_t)c.H * 3 * ca.UPW + (size_t)ca.I0P * 3 * ca.UPW + (size_t)c.H * 8 + (size_t)256 * ca.SR + c.S + 4096 + 64) * sizeof(float);
         // (the kernel also has a few bytes of static LDS, so ask for exactly what is needed rather than the 160 KiB maximum)
         TTSC_HIP_CHECK(hipFuncSetAttribute((const void*)wr_cluster_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(wr_cluster_kernel, dim3(G * WC_NC), dim3(WC_THREADS), lds, s, ca);

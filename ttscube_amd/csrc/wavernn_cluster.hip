@@ -97,6 +97,64 @@ __device__ __forceinline__ void publish(unsigned* cnt) {
     if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// acc[r] <- k-ordered fmaf chain over K inputs of an EXCHANGED vector (global, layout [K/2][BU][2], written by other
+// workgroups with write-through stores) for NR weight rows held in LDS (row r at wr[r] + (k>>2)*kstride + (k&3)).
+// Every (k-pair, utterance) item is fetched ONCE per workgroup: all 512 threads issue 8-byte sc1 loads (4 chunks = 8 loads
+// per thread in flight), park them in a double-buffered LDS staging tile of 32 k-pairs x 32 utterances, and the owner
+// threads (`active`) read their utterance's pairs back as conflict-free 8-byte LDS reads.  One barrier per chunk.
+template <int NR>
+__device__ __forceinline__ void wc_stage_chain(float (&acc)[NR], const float* const (&wr)[NR], int kstride, bool active, int u,
+                                               const float* __restrict__ src, int K, float* stage) {
+    constexpr int CK2 = 32, PD = 4;                    // k-pairs per chunk, prefetch depth (chunks)
+    const int K2 = K >> 1;
+    const int nch = (K2 + CK2 - 1) / CK2;
+    const int tid = threadIdx.x;
+    // this thread's two items of a chunk: item i = tid + e*512 -> (k2 = i / 32, utterance = i % 32); contiguous in memory
+    u64 pf[PD][2];
+    auto issue = [&](int c, u64 (&dst)[2]) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            int k2 = c * CK2 + ((tid + e * WC_THREADS) >> 5);
+            k2 = k2 < K2 ? k2 : K2 - 1;
+            dst[e] = __hip_atomic_load(reinterpret_cast<const u64*>(src) + (size_t)k2 * WC_BU + (tid & 31), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    u64* st64 = reinterpret_cast<u64*>(stage);         // [2][CK2*BU]
+#pragma unroll
+    for (int d = 0; d < PD; ++d)
+        if (d < nch) issue(d, pf[d]);
+    for (int c0 = 0; c0 < nch; c0 += PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            const int c = c0 + d;
+            if (c < nch) {
+                u64* sb = st64 + (size_t)(c & 1) * (CK2 * WC_BU);
+                sb[tid] = pf[d][0];
+                sb[tid + WC_THREADS] = pf[d][1];
+                if (c + PD < nch) issue(c + PD, pf[d]);
+                __syncthreads();
+                if (active) {
+                    const int kn = min(CK2, K2 - c * CK2);
+                    const float2* sv = reinterpret_cast<const float2*>(sb) + u;
+#pragma unroll 8
+                    for (int q = 0; q < kn; ++q) {
+                        const float2 hv = sv[q * WC_BU];
+                        const int k = 2 * (c * CK2 + q);
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) {
+                            const float* w = wr[r] + (k >> 2) * kstride + (k & 3);
+                            acc[r] = fmaf(w[0], hv.x, acc[r]);
+                            acc[r] = fmaf(w[1], hv.y, acc[r]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();   // the staging tile may be rewritten by the next caller
+}
+
 __global__ __launch_bounds__(WC_THREADS) void wr_cluster_kernel(WcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int H = a.H, UPW = a.UPW, S = a.S, SR = a.SR, NM = a.n_mel, I0P = a.I0P;
@@ -109,6 +167,7 @@ __global__ __launch_bounds__(WC_THREADS) void wr_cluster_kernel(WcArgs a) {
     float* Wpre = Wih + (size_t)I0P * R3;     // [H/4][8][4]
     float* Wout = Wpre + (size_t)H * 8;       // [64][SR][4]
     float* scr = Wout + (size_t)256 * SR;     // [S] sampling scratch
+    float* stage = scr + S;                   // [2][32 k-pairs][32 utterances][2] staging tile of exchanged vectors (16 KB)
     const int tid = threadIdx.x;
     // ---- load this member's weight slices into LDS (once) ----
     {
@@ -179,8 +238,14 @@ __global__ __launch_bounds__(WC_THREADS) void wr_cluster_kernel(WcArgs a) {
             if (!wait_count(cnt + 0, (unsigned)t * WC_NC, abort_word)) return;
             if (!wait_count(cnt + 3, (unsigned)t * (unsigned)nu, abort_word)) return;
         }
+        float gh[3] = {bhh[0], bhh[1], bhh[2]};
+        if (t > 0) {   // h_{-1} = 0: fmaf(w, 0, acc) == acc, the chain over zeros is skipped at t = 0
+            const float* const wr[3] = {Whh + (0 * UPW + (gru_thr ? j : 0)) * 4, Whh + (1 * UPW + (gru_thr ? j : 0)) * 4,
+                                        Whh + (2 * UPW + (gru_thr ? j : 0)) * 4};
+            wc_stage_chain<3>(gh, wr, R3 * 4, gru_thr, u, xh + (size_t)(par ^ 1) * H * WC_BU, H, stage);
+        }
         if (gru_thr) {
-            float gi[3], gh[3];
+            float gi[3];
             const float lx = (t > 0) ? ld_f32(xlx + (par ^ 1) * WC_BU + u) : 0.f;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
@@ -191,30 +256,6 @@ __global__ __launch_bounds__(WC_THREADS) void wr_cluster_kernel(WcArgs a) {
                 }
                 const int k = a.I0 - 1;
                 gi[q] = fmaf(Wih[((k >> 2) * R3 + q * UPW + j) * 4 + (k & 3)], lx, acc);
-                gh[q] = bhh[q];
-            }
-            if (t > 0) {
-                const float* hp = xh + (size_t)(par ^ 1) * H * WC_BU + u * 2;   // item (k/2, u): 2 floats
-                // two consecutive k per 8-byte write-through load; weights as LDS broadcasts (all 32 lanes of a half-wave
-                // share the row); loads are software-pipelined by hand (8 pairs in flight)
-                constexpr int UN = 8;
-                for (int k2 = 0; k2 < H / 2; k2 += UN) {
-                    float2 hv[UN];
-#pragma unroll
-                    for (int e = 0; e < UN; ++e) hv[e] = ld_f32x2(hp + (size_t)(k2 + e) * WC_BU * 2);
-#pragma unroll
-                    for (int e = 0; e < UN; ++e) {
-                        const int k = 2 * (k2 + e);
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) {
-                            const float* w = Whh + ((k >> 2) * R3 + q * UPW + j) * 4 + (k & 3);
-                            gh[q] = fmaf(w[0], hv[e].x, gh[q]);
-                            gh[q] = fmaf(w[1], hv[e].y, gh[q]);
-                        }
-                    }
-                }
-            } else {
-                // h_{-1} = 0: the chain still runs over zeros in the reference arithmetic; fmaf(w, 0, acc) == acc exactly
             }
             const float r = ttsc_sigmoidf(gi[0] + gh[0]);
             const float z = ttsc_sigmoidf(gi[1] + gh[1]);
@@ -228,47 +269,27 @@ __global__ __launch_bounds__(WC_THREADS) void wr_cluster_kernel(WcArgs a) {
         publish(cnt + 0);
         // ---- phase B: pre-output slice (8 rows) over the full h_t ----
         if (!wait_count(cnt + 0, (unsigned)(t + 1) * WC_NC, abort_word)) return;
-        if (j < 8) {
-            float acc = bpre;
-            const float* hp = xh + (size_t)par * H * WC_BU + u * 2;
-            constexpr int UN = 8;
-            for (int k2 = 0; k2 < H / 2; k2 += UN) {
-                float2 hv[UN];
-#pragma unroll
-                for (int e = 0; e < UN; ++e) hv[e] = ld_f32x2(hp + (size_t)(k2 + e) * WC_BU * 2);
-#pragma unroll
-                for (int e = 0; e < UN; ++e) {
-                    const int k = 2 * (k2 + e);
-                    const float* w = Wpre + ((k >> 2) * 8 + j) * 4 + (k & 3);
-                    acc = fmaf(w[0], hv[e].x, acc);
-                    acc = fmaf(w[1], hv[e].y, acc);
-                }
+        {
+            float acc[1] = {bpre};
+            const float* const wr[1] = {Wpre + ((j < 8) ? j : 0) * 4};
+            wc_stage_chain<1>(acc, wr, 8 * 4, j < 8, u, xh + (size_t)par * H * WC_BU, H, stage);
+            if (j < 8) {
+                const int row = m * 8 + j;
+                st_f32(xpre + (size_t)par * 256 * WC_BU + ((size_t)(row >> 1) * WC_BU + u) * 2 + (row & 1), ttsc_tanhf(acc[0]));
             }
-            const int row = m * 8 + j;
-            st_f32(xpre + (size_t)par * 256 * WC_BU + ((size_t)(row >> 1) * WC_BU + u) * 2 + (row & 1), ttsc_tanhf(acc));
         }
         publish(cnt + 1);
         // ---- phase C: output slice (SR rows) over the full pre-output ----
         if (!wait_count(cnt + 1, (unsigned)(t + 1) * WC_NC, abort_word)) return;
-        if (j < SR) {
-            float acc = bout;
-            const float* pp = xpre + (size_t)par * 256 * WC_BU + u * 2;
-            constexpr int UN = 8;
-            for (int k2 = 0; k2 < 128; k2 += UN) {
-                float2 pv[UN];
-#pragma unroll
-                for (int e = 0; e < UN; ++e) pv[e] = ld_f32x2(pp + (size_t)(k2 + e) * WC_BU * 2);
-#pragma unroll
-                for (int e = 0; e < UN; ++e) {
-                    const int k = 2 * (k2 + e);
-                    const float* w = Wout + ((k >> 2) * SR + j) * 4 + (k & 3);
-                    acc = fmaf(w[0], pv[e].x, acc);
-                    acc = fmaf(w[1], pv[e].y, acc);
-                }
+        {
+            float acc[1] = {bout};
+            const float* const wr[1] = {Wout + ((j < SR) ? j : 0) * 4};
+            wc_stage_chain<1>(acc, wr, SR * 4, j < SR, u, xpre + (size_t)par * 256 * WC_BU, 256, stage);
+            if (j < SR) {
+                const int s_ = m * SR + j;
+                st_f32(xlog + ((size_t)par * WC_BU + u) * S + s_, acc[0]);
+                if (a.out_logits && uok) a.out_logits[((size_t)bu * a.L + t) * S + s_] = acc[0];
             }
-            const int s = m * SR + j;
-            st_f32(xlog + ((size_t)par * WC_BU + u) * S + s, acc);
-            if (a.out_logits && uok) a.out_logits[((size_t)bu * a.L + t) * S + s] = acc;
         }
         publish(cnt + 2);
         // ---- phase D: member m samples utterance m of the cluster ----
