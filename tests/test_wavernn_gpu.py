@@ -124,3 +124,32 @@ def test_cubenet_vocoder_fold_and_decode(golden_dir):
     assert x_lr.shape == (1, 960, 1) and x_hr.shape == (1, 6800)  # T=40 -> lr 960, hr 6800
     assert np.array_equal(x_lr[:, :, 0], r_lr)
     assert np.array_equal(x_hr, O.compose_batched_inference(r_hr))
+
+
+def test_cluster_kernel_bit_exact(monkeypatch):
+    """Weight-stationary 32-workgroup cluster kernel (csrc/wavernn_cluster.hip, env TTSC_WR_CLUSTER=1): LDS-resident weight
+    slices, four L2 hand-offs per step with bounded spins — same fmaf chains, so indices/logits stay bit-exact."""
+    monkeypatch.setenv('TTSC_WR_CLUSTER', '1')
+    for H, lowres, B, T, mode in [(512, True, 40, 1, 'noise'), (64, True, 5, 2, 'philox'), (128, False, 33, 4, 'argmax')]:
+        sd = O.synthetic_state_dict(H=H, num_layers=1, use_lowres=lowres, seed=300 + H)
+        net = _net(H, 1, lowres, sd)
+        up = 240 if lowres else 24
+        mel, x_low = O.synthetic_inputs(B, T, seed=11 + T, upsample=up)
+        X = {'mel': torch.from_numpy(mel)}
+        if lowres:
+            X['x_low'] = torch.from_numpy(x_low)
+        L = T * up
+        noise = None
+        if mode == 'noise':
+            uu = np.random.RandomState(6).uniform(1e-6, 1 - 1e-6, size=(B, L, 256))
+            noise = (-np.log(-np.log(uu))).astype(np.float32)
+        omode = {'noise': O.MODE_NOISE, 'philox': O.MODE_PHILOX, 'argmax': O.MODE_ARGMAX}[mode]
+        ridx, rwav, rlog = O.decode(sd, mel, x_low if lowres else None, num_layers=1, H=H, use_lowres=lowres, upsample=up,
+                                    mode=omode, noise=noise, seed=77, want_logits=True)
+        idx, wav, logits = net.decode(X, mode=mode, noise=noise, seed=77, want_logits=True)
+        assert net.last_kernel == 'cluster'
+        assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(wav.cpu().numpy(), rwav)
+        assert np.array_equal(logits.cpu().numpy(), rlog)
+    monkeypatch.setenv('TTSC_WR_CLUSTER', '0')
+    net.decode(X, mode='argmax')
+    assert net.last_kernel == 'stream'

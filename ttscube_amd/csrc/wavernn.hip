@@ -553,8 +553,11 @@ extern "C" int ttsc_wavernn_set_weight(ttsc_wavernn* w, const char* name, const 
 // ---- cluster (weight-stationary) path ---------------------------------------------------------------------------
 static bool cluster_supported(const ttsc_wavernn* w, int B) {
     const auto& c = w->cfg;
-    if (const char* ev = getenv("TTSC_WR_CLUSTER"))
-        if (atoi(ev) == 0) return false;
+    // OFF by default: measured on MI355X (H=512, B=1..256) the four all-to-all hand-offs per step cost as much as the
+    // weight stream they remove (48 us/step vs 45 us/step for the single-workgroup kernel); kept, bit-exact and tested,
+    // as the starting point for a cheaper exchange (env TTSC_WR_CLUSTER=1 enables it).
+    const char* ev = getenv("TTSC_WR_CLUSTER");
+    if (!ev || atoi(ev) == 0) return false;
     if (c.num_layers != 1 || c.H % WC_NC != 0 || c.H > 512 || c.S % WC_NC != 0 || c.S > 256) return false;
     const int G = (int)ceil_div(B, WC_BU);
     int dev = 0, cus = 0;
