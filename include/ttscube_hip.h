@@ -69,11 +69,18 @@ typedef struct {
     float out_scale;     /* y = act((conv + bias + resid) * out_scale)  */
     int32_t out_act;     /* TTSC_ACT_* */
     int32_t accumulate;  /* 1: y += result (running sum of residual blocks) */
+    /* data-gradient launches (training, row a9): gate_dev = the pre-activation [B,Cout,Lout] the forward layer read through its
+     * leaky-relu prologue; then y = ((conv + bias) * (gate > 0 ? 1 : gate_slope) + resid) * out_scale.  NULL = off. */
+    const float* gate_dev;
+    float gate_slope;
 } ttsc_conv1d_epilogue;
 
 int ttsc_conv1d_create(const ttsc_conv1d_cfg* cfg, ttsc_conv1d** out);
 /* weight: host fp32 in torch layout (already weight-norm folded); bias: host [Cout] or NULL */
 int ttsc_conv1d_set_weight(ttsc_conv1d* c, const float* weight_host, const float* bias_host);
+/* training: (re)pack the weights from DEVICE memory (torch parameter layout, fp32) on `stream`, no host round trip;
+ * TTSC_PREC_FP32 handles only.  bias_dev NULL = no bias. */
+int ttsc_conv1d_set_weight_device(ttsc_conv1d* c, const float* weight_dev, const float* bias_dev, void* stream);
 /* switch the arithmetic (TTSC_PREC_*); weights are re-packed from the host copy kept by set_weight */
 int ttsc_conv1d_set_precision(ttsc_conv1d* c, int32_t precision);
 int64_t ttsc_conv1d_out_len(const ttsc_conv1d* c, int64_t Lin);
@@ -104,6 +111,15 @@ int ttsc_respair_supported(const ttsc_conv1d* conv1, const ttsc_conv1d* conv2);
 int ttsc_respair_forward(const ttsc_conv1d* conv1, const ttsc_conv1d* conv2, const float* x_dev, int32_t B, int64_t L,
                          float* y_dev, int32_t accumulate, const int32_t* len_dev, void* stream);
 void ttsc_conv1d_destroy(ttsc_conv1d* c);
+
+/* Weight gradient of the generator's convolutions (training: `Cubegan.training_step`, cube/networks/cubegan.py:85-189,
+ * where torch autograd differentiates Generator.forward):
+ *   G[a, b, j] += sum_n sum_t P[n,a,t] * leaky_relu(q_scale * Q[n,b,t + base + j*step], q_slope)       (zero outside [0,LQ))
+ * Conv1d(weight [Co,Ci,K], dilation d, padding p): P = dL/dy [N,Co,Lout], Q = layer input [N,Ci,Lin], base = -p, step = d,
+ * G = dL/dW [Co,Ci,K].  G (device, [A,B,J] fp32) must be zeroed by the caller; partial sums are added with fp32 atomics
+ * (summation order, hence the last bits, vary from run to run).  |(J-1)*step| <= 64 per group of 12 taps. */
+int ttsc_conv_wgrad(const float* p_dev, const float* q_dev, float* g_dev, int32_t N, int32_t A, int32_t B, int64_t LP, int64_t LQ,
+                    int32_t J, int32_t base, int32_t step, float q_scale, float q_slope, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * HiFi-GAN generator.  Replaces `hifigan.models.Generator(h)` [EXTERNAL submodule]:

@@ -19,7 +19,7 @@ class Conv1dCfg(C.Structure):
 
 class Conv1dEpilogue(C.Structure):
     _fields_ = [('in_scale', C.c_float), ('in_slope', C.c_float), ('out_scale', C.c_float),
-                ('out_act', C.c_int32), ('accumulate', C.c_int32)]
+                ('out_act', C.c_int32), ('accumulate', C.c_int32), ('gate_dev', C.c_void_p), ('gate_slope', C.c_float)]
 
 
 MAX_UPS, MAX_RB, MAX_DIL = 8, 8, 8
@@ -69,6 +69,9 @@ SIGNATURES = {
     'ttsc_respair_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int32,
                                        C.c_void_p, C.c_void_p]),
     'ttsc_conv1d_destroy': (None, [C.c_void_p]),
+    'ttsc_conv1d_set_weight_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ttsc_conv_wgrad': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
+                                  C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p]),
     'ttsc_hifigan_create': (C.c_int, [C.POINTER(HifiganCfg), C.POINTER(C.c_void_p)]),
     'ttsc_hifigan_set_weight': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
     'ttsc_hifigan_set_precision': (C.c_int, [C.c_void_p, C.c_int32]),

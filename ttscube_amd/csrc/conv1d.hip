@@ -53,6 +53,8 @@ struct ConvArgs {
     int write_f32;    // 0: only the split output is written
     int vphase;       // fused ConvTranspose1d phases: GEMM row v = r * vphase + co (vphase = real Cout), output o += r; 0 = off
     int dbg;          // ablation switches (env TTSC_CONV_DBG): 1 skip LDS commits, 2 skip MFMA loop, 4 skip epilogue, 8 skip global prefetch
+    const float* gate;  // data-gradient launches: [B,Cout,Lout] pre-activation saved by the forward; the conv result is
+    float gate_slope;   // multiplied by d lrelu/dx = (gate > 0 ? 1 : gate_slope) BEFORE the residual is added; null = off
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -110,7 +112,14 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& acc, const ConvArgs&
 #pragma unroll
             for (int e = 0; e < 4; ++e) yv[e] = 0.f;
         }
-        if (a.out_act == TTSC_ACT_NONE) {   // the common case gets its own straight-line copy (no inlined tanh/exp bodies)
+        if (a.gate) {   // backward of the fused leaky-relu prologue (training only)
+            float gv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gv[e] = a.gate[idx[e]];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                res[e] = ((acc[4 * g + e] * acc_scale + bv[e]) * (gv[e] > 0.f ? 1.f : a.gate_slope) + rv[e]) * a.out_scale + yv[e];
+        } else if (a.out_act == TTSC_ACT_NONE) {   // the common case gets its own straight-line copy (no inlined tanh/exp bodies)
 #pragma unroll
             for (int e = 0; e < 4; ++e) res[e] = (acc[4 * g + e] * acc_scale + bv[e] + rv[e]) * a.out_scale + yv[e];
         } else {
@@ -653,6 +662,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 2)) void respair32_f16x3_ke
     ea.ys_slope = 1.f;
     ea.write_f32 = 1;
     ea.dbg = 0;
+    ea.gate = nullptr;
+    ea.gate_slope = 1.f;
     ea.vphase = 0;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
@@ -734,6 +745,7 @@ struct ConvPhase {
     int ntaps = 0, tap_base = 0, tap_step = 0;
     int out_stride = 1, out_off = 0;
     int r = 0;  // phase index (transposed)
+    std::vector<int> taps;  // kernel taps (or tap indices when vfused) of this phase, in GEMM order
 };
 
 struct ttsc_conv1d {
@@ -748,6 +760,7 @@ struct ttsc_conv1d {
     float w_unscale = 1.f;
     std::vector<float> w_host, b_host;  // kept so that the precision can be switched (repack) at any time
     bool has_bias = false;
+    bool dev_weights = false;  // weights were last written by ttsc_conv1d_set_weight_device (host copy is stale)
 };
 
 extern "C" int ttsc_conv1d_create(const ttsc_conv1d_cfg* cfg, ttsc_conv1d** out) {
@@ -871,6 +884,7 @@ extern "C" int ttsc_conv1d_set_precision(ttsc_conv1d* c, int32_t precision) {
     const int taps = c->cfg.transposed ? (c->cfg.kernel_size + c->cfg.stride - 1) / c->cfg.stride : c->cfg.kernel_size;
     if (precision == TTSC_PREC_F16X3 && (halo > 64 || taps > 16)) precision = TTSC_PREC_FP32;
     if (precision == c->precision) return TTSC_OK;
+    TTSC_REQUIRE(!c->dev_weights, "ttsc_conv1d_set_precision: weights were set from device memory; switch the precision first");
     c->precision = precision;
     return c->has_weight ? conv_repack(c) : TTSC_OK;
 }
@@ -881,7 +895,85 @@ extern "C" int ttsc_conv1d_set_weight(ttsc_conv1d* c, const float* w, const floa
     c->w_host.assign(w, w + (size_t)g0.in_channels * g0.out_channels * g0.kernel_size);
     c->has_bias = bias != nullptr;
     if (bias) c->b_host.assign(bias, bias + g0.out_channels);
+    c->dev_weights = false;
     return conv_repack(c);
+}
+
+// Device-side packing for training: the weights change every optimizer step, so the fragment order is produced by a
+// gather kernel straight from the torch parameter (same mapping as pack_phase above), no host round trip.
+namespace ttsc {
+struct PackArgs {
+    const float* w;
+    float* out;
+    int Cin, Cout, K, CoutV, cipN, cotN, ntaps, k0, kstep, transposed, vfused, stride;
+};
+__global__ void pack_w_kernel(PackArgs p) {
+    const long total = (long)p.ntaps * p.cipN * p.cotN * 64;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        long t = i >> 6;
+        const int cot = (int)(t % p.cotN);
+        t /= p.cotN;
+        const int cip = (int)(t % p.cipN);
+        const int j = (int)(t / p.cipN);
+        int co = cot * 32 + (lane & 31);
+        const int ci = 2 * cip + (lane >> 5);
+        int kk = p.k0 + j * p.kstep;
+        bool ok = co < p.CoutV && ci < p.Cin;
+        if (p.vfused) {
+            const int r = co / p.Cout;
+            co -= r * p.Cout;
+            kk = r + (p.k0 + j * p.kstep) * p.stride;
+            ok = ok && kk < p.K;
+        }
+        float v = 0.f;
+        if (ok) v = p.transposed ? p.w[((size_t)ci * p.Cout + co) * p.K + kk] : p.w[((size_t)co * p.Cin + ci) * p.K + kk];
+        p.out[i] = v;
+    }
+}
+}  // namespace ttsc
+
+extern "C" int ttsc_conv1d_set_weight_device(ttsc_conv1d* c, const float* w_dev, const float* bias_dev, void* stream) {
+    TTSC_REQUIRE(c && w_dev, "ttsc_conv1d_set_weight_device: null argument");
+    TTSC_REQUIRE(c->precision == TTSC_PREC_FP32, "ttsc_conv1d_set_weight_device: only TTSC_PREC_FP32 handles take device weights");
+    const auto& g = c->cfg;
+    if (c->phases.empty() || (bias_dev != nullptr) != (c->bias_dev != nullptr)) {
+        // first call: lay out the phase buffers (zero weights), later calls only overwrite them
+        c->w_host.assign((size_t)g.in_channels * g.out_channels * g.kernel_size, 0.f);
+        c->has_bias = bias_dev != nullptr;
+        c->b_host.assign(g.out_channels, 0.f);
+        int rc = conv_repack(c);
+        if (rc) return rc;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    for (auto& ph : c->phases) {
+        PackArgs p;
+        p.w = w_dev;
+        p.out = ph.wp_dev;
+        p.Cin = g.in_channels;
+        p.Cout = g.out_channels;
+        p.K = g.kernel_size;
+        p.CoutV = c->CoutV;
+        p.cipN = c->CinP / 2;
+        p.cotN = c->CoutP / 32;
+        p.ntaps = ph.ntaps;
+        p.k0 = ph.taps.empty() ? 0 : ph.taps[0];
+        p.kstep = ph.taps.size() > 1 ? ph.taps[1] - ph.taps[0] : 1;
+        p.transposed = g.transposed;
+        p.vfused = c->vfused ? 1 : 0;
+        p.stride = g.stride;
+        const long total = (long)p.ntaps * p.cipN * p.cotN * 64;
+        const int blocks = (int)std::min<long>((total + 255) / 256, 2048);
+        hipLaunchKernelGGL(pack_w_kernel, dim3(blocks), dim3(256), 0, s, p);
+    }
+    if (bias_dev) TTSC_HIP_CHECK(hipMemcpyAsync(c->bias_dev, bias_dev, g.out_channels * sizeof(float), hipMemcpyDeviceToDevice, s));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("pack_w_kernel launch failed: %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    c->dev_weights = true;
+    return TTSC_OK;
 }
 
 static int conv_repack(ttsc_conv1d* c) {
@@ -930,6 +1022,7 @@ static int conv_repack(ttsc_conv1d* c) {
         ph.out_stride = 1;
         ph.out_off = 0;
         cur_taps = taps;
+        ph.taps = taps;
         int rc = upload(ph);
         if (rc) return rc;
         c->phases.push_back(ph);
@@ -945,6 +1038,7 @@ static int conv_repack(ttsc_conv1d* c) {
         ph.out_stride = g.stride;
         ph.out_off = -g.padding;
         cur_taps = taps;
+        ph.taps = taps;
         int rc = upload(ph);
         if (rc) return rc;
         c->phases.push_back(ph);
@@ -961,6 +1055,7 @@ static int conv_repack(ttsc_conv1d* c) {
             ph.out_stride = g.stride;
             ph.out_off = r - g.padding;
             cur_taps = taps;
+            ph.taps = taps;
             int rc = upload(ph);
             if (rc) return rc;
             c->phases.push_back(ph);
@@ -1077,6 +1172,8 @@ extern "C" int ttsc_conv1d_forward_split(const ttsc_conv1d* c, const float* x, c
         a.out_scale = ep ? ep->out_scale : 1.f;
         a.out_act = ep ? ep->out_act : TTSC_ACT_NONE;
         a.accumulate = ep ? ep->accumulate : 0;
+        a.gate = ep ? ep->gate_dev : nullptr;
+        a.gate_slope = ep ? ep->gate_slope : 1.f;
         int rc;
         if (c->precision == TTSC_PREC_F16X3) {
             // the split kernel's N tile is fixed by its 4-waves-along-N shape

@@ -1,0 +1,220 @@
+// Weight gradient of Conv1d / ConvTranspose1d (training) as an fp32-MFMA correlation — gfx950.
+//
+//   G[a, b, j] += sum_n sum_t  P[n, a, t] * lrelu(q_scale * Q[n, b, t + base + j*step], q_slope)
+//
+// Conv1d (weight [Co,Ci,K], dilation d, padding p):  P = dL/dy [N,Co,Lout], Q = the layer input x [N,Ci,Lin] read through
+// the same leaky-relu prologue as the forward, base = -p, step = d  ->  G = dL/dW.  ConvTranspose1d is expressed in the
+// same form on the phase-de-interleaved output gradient (see hifigan/autograd.py).
+//
+// GEMM view: M = a (32 rows per wave), N = b (32 columns per wave), K = the N*L positions — a reduction that is 10^5..10^6
+// long while M x N is at most 512 x 256, so the parallelism is in K: every WAVE is an independent worker that owns one
+// 32 x 32 (a, b) tile with ALL taps (J accumulators; the P fragment is shared by the J taps) over a contiguous run of
+// 64-position chunks of one batch item, and adds its partial sums into G with hardware fp32 atomics.  Chunks are staged
+// through a per-wave LDS tile (row pitch = 2 mod 64 words: the 32-row x 2-position fragment reads are conflict-free) with
+// the global loads of the next chunk issued before the MFMA loop of the current one (explicit register double buffer).
+#include "common.hpp"
+
+namespace ttsc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgArgs {
+    const float* P;
+    const float* Q;
+    float* G;
+    int N, A, Bc, LP, LQ;
+    int J, Jtot, j0;   // taps handled by this launch: j0 .. j0+J-1 of Jtot
+    int base, step;
+    float q_scale, q_slope;
+    int chunks;        // 64-position chunks per batch item = ceil(LP / 64)
+    int CH;            // chunks per wave
+    int groups;        // position groups per batch item = ceil(chunks / CH)
+    int minoff, span;  // Q window of one chunk: positions t0 + minoff .. t0 + minoff + 64 + span
+};
+
+constexpr int WG_TK = 64;
+constexpr int WG_PP = 66;    // P tile pitch (words)
+constexpr int WG_QP = 130;   // Q tile pitch: 64 + span (<= 64) + pad
+
+template <int JT>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    float* pl = sm + wave * (32 * WG_PP + 32 * WG_QP);
+    float* ql = pl + 32 * WG_PP;
+    const int tb_n = (a.Bc + 31) >> 5;
+    const int a0 = (blockIdx.y / tb_n) * 32, b0 = (blockIdx.y % tb_n) * 32;
+    const int grp = blockIdx.x * 4 + wave;            // position group of this wave
+    const bool live = grp < a.N * a.groups;
+    const int n = live ? grp / a.groups : 0;
+    const int c_beg = live ? (grp % a.groups) * a.CH : 0;
+    const int c_end = live ? min(c_beg + a.CH, a.chunks) : 0;
+    const bool two = a.span > 0;                      // Q window wider than 64 positions
+
+    f32x16 acc[JT];
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const float* Pn = a.P + (size_t)n * a.A * a.LP;
+    const float* Qn = a.Q + (size_t)n * a.Bc * a.LQ;
+    float pr[32], q0r[32], q1r[32];
+    auto load = [&](int c) {
+        const int t0 = c * WG_TK;
+        const int tp = t0 + lane;
+        const bool pok = tp < a.LP;
+        const int tpc = pok ? tp : a.LP - 1;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const int row = a0 + r;
+            const float v = Pn[(size_t)(row < a.A ? row : a.A - 1) * a.LP + tpc];
+            pr[r] = (pok && row < a.A) ? v : 0.f;
+        }
+        const int q_a = t0 + a.minoff + lane;
+        const bool qa_ok = q_a >= 0 && q_a < a.LQ;
+        const int qa_c = qa_ok ? q_a : 0;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const int row = b0 + r;
+            float v = Qn[(size_t)(row < a.Bc ? row : a.Bc - 1) * a.LQ + qa_c] * a.q_scale;
+            v = v > 0.f ? v : v * a.q_slope;
+            q0r[r] = (qa_ok && row < a.Bc) ? v : 0.f;
+        }
+        if (two) {
+            const int q_b = q_a + 64;
+            const bool qb_ok = q_b >= 0 && q_b < a.LQ && lane < a.span;
+            const int qb_c = qb_ok ? q_b : 0;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                const int row = b0 + r;
+                float v = Qn[(size_t)(row < a.Bc ? row : a.Bc - 1) * a.LQ + qb_c] * a.q_scale;
+                v = v > 0.f ? v : v * a.q_slope;
+                q1r[r] = (qb_ok && row < a.Bc) ? v : 0.f;
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) pl[r * WG_PP + lane] = pr[r];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) ql[r * WG_QP + lane] = q0r[r];
+        if (two) {
+#pragma unroll
+            for (int r = 0; r < 32; ++r) ql[r * WG_QP + 64 + lane] = q1r[r];
+        }
+    };
+
+    // every wave of the workgroup runs the same number of iterations (workgroup barriers inside); idle ones add zeros
+    if (c_beg < c_end) load(c_beg);
+    for (int it = 0; it < a.CH; ++it) {
+        const int c = c_beg + it;
+        const bool on = c < c_end;
+        if (on) commit();
+        __syncthreads();
+        if (c + 1 < c_end) load(c + 1);
+        if (on) {
+            const float* pa = pl + l31 * WG_PP + half;
+            const float* qb = ql + l31 * WG_QP + half;
+#pragma unroll 4
+            for (int kk = 0; kk < WG_TK / 2; ++kk) {
+                const float af = pa[2 * kk];
+#pragma unroll
+                for (int j = 0; j < JT; ++j) {
+                    if (j < a.J) {
+                        const int sh = a.base + (a.j0 + j) * a.step - a.minoff;
+                        const float bf = qb[2 * kk + sh];
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!live) return;
+    // C/D layout: column (= b) = lane & 31, row (= a) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int bcol = b0 + l31;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+        if (j < a.J) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int arow = a0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (arow < a.A && bcol < a.Bc) unsafeAtomicAdd(a.G + ((size_t)arow * a.Bc + bcol) * a.Jtot + a.j0 + j, acc[j][r]);
+            }
+        }
+    }
+}
+
+template <int JT>
+static int launch_wgrad(const WgArgs& a, hipStream_t s) {
+    const int tiles = ((a.A + 31) / 32) * ((a.Bc + 31) / 32);
+    const int wgs_x = (a.N * a.groups + 3) / 4;
+    const size_t lds = (size_t)4 * (32 * WG_PP + 32 * WG_QP) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        TTSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<JT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad_kernel<JT>, dim3(wgs_x, tiles), dim3(256), lds, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("conv_wgrad_kernel launch failed: %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    return TTSC_OK;
+}
+
+}  // namespace ttsc
+
+using namespace ttsc;
+
+extern "C" int ttsc_conv_wgrad(const float* p_dev, const float* q_dev, float* g_dev, int32_t N, int32_t A, int32_t Bc, int64_t LP,
+                               int64_t LQ, int32_t J, int32_t base, int32_t step, float q_scale, float q_slope, void* stream) {
+    TTSC_REQUIRE(p_dev && q_dev && g_dev, "ttsc_conv_wgrad: null argument");
+    TTSC_REQUIRE(N > 0 && A > 0 && Bc > 0 && LP > 0 && LQ > 0 && J > 0, "ttsc_conv_wgrad: bad shape N=%d A=%d B=%d LP=%lld LQ=%lld J=%d", N, A, Bc,
+                 (long long)LP, (long long)LQ, J);
+    TTSC_REQUIRE(LP < (1ll << 30) && LQ < (1ll << 30), "ttsc_conv_wgrad: length too large");
+    TTSC_REQUIRE(q_slope >= 0.f && q_slope <= 1.f, "ttsc_conv_wgrad: q_slope must be in [0,1]");
+    hipStream_t s = (hipStream_t)stream;
+    WgArgs a;
+    a.P = p_dev;
+    a.Q = q_dev;
+    a.G = g_dev;
+    a.N = N;
+    a.A = A;
+    a.Bc = Bc;
+    a.LP = (int)LP;
+    a.LQ = (int)LQ;
+    a.Jtot = J;
+    a.base = base;
+    a.step = step;
+    a.q_scale = q_scale;
+    a.q_slope = q_slope;
+    a.chunks = (int)ceil_div(LP, WG_TK);
+    const int tiles = ((A + 31) / 32) * ((Bc + 31) / 32);
+    // ~4096 waves (4 rounds of one wave per SIMD), but at least 2 chunks per wave so the atomics stay a minor cost
+    long ch = ((long)N * a.chunks * tiles + 4095) / 4096;
+    if (ch < 2) ch = 2;
+    if (ch > a.chunks) ch = a.chunks;
+    a.CH = (int)ch;
+    a.groups = (int)ceil_div(a.chunks, a.CH);
+    for (int j0 = 0; j0 < J; j0 += 12) {
+        a.j0 = j0;
+        a.J = J - j0 < 12 ? J - j0 : 12;
+        const int off_first = base + j0 * step, off_last = base + (j0 + a.J - 1) * step;
+        a.minoff = off_first < off_last ? off_first : off_last;
+        a.span = (off_first < off_last ? off_last : off_first) - a.minoff;
+        TTSC_REQUIRE(a.span <= 64, "ttsc_conv_wgrad: tap window (%d positions) exceeds 64", a.span);
+        int rc;
+        if (a.J <= 4)
+            rc = launch_wgrad<4>(a, s);
+        else if (a.J <= 8)
+            rc = launch_wgrad<8>(a, s);
+        else
+            rc = launch_wgrad<12>(a, s);
+        if (rc) return rc;
+    }
+    return TTSC_OK;
+}

@@ -1,6 +1,217 @@
-"""Training path of the Generator: differentiable forward on torch-ROCm ops (see networks/training.py)."""
+"""Native training path of the HiFi-GAN generator.
+
+The reference trains the generator through torch autograd over torch convolutions (`Cubegan.training_step`,
+cube/networks/cubegan.py:85-189; `Generator.forward` [EXTERNAL hifigan/models.py]).  Here every convolution of the
+generator is one `torch.autograd.Function` whose three legs are hand-written HIP kernels behind the C ABI:
+
+  forward   ttsc_conv1d_forward      implicit-GEMM fp32 MFMA, leaky-relu prologue / bias / residual epilogue fused
+  dgrad     ttsc_conv1d_forward      the SAME kernel on the transposed+flipped weights; the epilogue multiplies by the
+                                     leaky-relu derivative of the saved pre-activation (`gate_dev`) and adds the gradient
+                                     of the residual branch
+  wgrad     ttsc_conv_wgrad          fp32 MFMA correlation over all positions with atomically reduced partial sums
+
+Weights live in torch parameters (weight-norm g, v stay torch leaves so the four AdamW optimizers of
+cubegan.py:275-311 see the usual gradients); `ttsc_conv1d_set_weight_device` re-packs the MFMA fragments from the live
+tensors on the stream every step.  ConvTranspose1d backward runs on the phase-de-interleaved output gradient
+dyP[b, r*Co+co, q] = dy[b, co, q*u + r], which turns both legs into stride-1 problems of the same kernels.
+Arithmetic: fp32 MFMA throughout (gradients span too many orders of magnitude for the fp16 split path)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..hip_layers import Conv1dHip
+
+
+class TrainConv:
+    """Per-layer state of the native training path: forward handle, data-gradient handle, index maps."""
+
+    def __init__(self, Cin, Cout, K, stride=1, padding=0, dilation=1, transposed=False):
+        self.Cin, self.Cout, self.K = Cin, Cout, K
+        self.stride, self.padding, self.dilation, self.transposed = stride, padding, dilation, transposed
+        self.fwd = Conv1dHip(Cin, Cout, K, stride=stride, padding=padding, dilation=dilation, transposed=transposed)
+        self._dgrad = None
+        self._maps = None
+
+    # ---- Conv1d ----------------------------------------------------------------------------------------------------
+    def dgrad_handle(self):
+        if self._dgrad is None:
+            if not self.transposed:
+                pd = self.dilation * (self.K - 1) - self.padding
+                if pd < 0:
+                    raise _lib.TTSCError('TrainConv: padding larger than the receptive field is not supported')
+                self._dgrad = Conv1dHip(self.Cout, self.Cin, self.K, padding=pd, dilation=self.dilation)
+            else:
+                self._dgrad = Conv1dHip(self.stride * self.Cout, self.Cin, self.taps_t()[2], padding=0)
+        return self._dgrad
+
+    # ---- ConvTranspose1d: phase decomposition ------------------------------------------------------------------------
+    def taps_t(self):
+        u, p, K = self.stride, self.padding, self.K
+        m_lo = (0 - p) // u
+        m_hi = (K - 1 - p) // u
+        return m_lo, m_hi, m_hi - m_lo + 1
+
+    def maps_t(self, device):
+        """gather maps (device long tensors): w[Ci,Co,K] -> W'[Ci, u*Co, M]  and  G[u*Co, Ci, M] -> dW[Ci,Co,K]."""
+        if self._maps is None:
+            u, p, K, Ci, Co = self.stride, self.padding, self.K, self.Cin, self.Cout
+            m_lo, _, M = self.taps_t()
+            ci = np.arange(Ci)[:, None, None, None]
+            r = np.arange(u)[None, :, None, None]
+            co = np.arange(Co)[None, None, :, None]
+            j = np.arange(M)[None, None, None, :]
+            k = (m_lo + j) * u + r + p
+            src = (ci * Co + co) * K + k
+            src = np.where((k >= 0) & (k < K), src, Ci * Co * K)          # last slot = appended zero
+            w_map = np.broadcast_to(src, (Ci, u, Co, M)).reshape(Ci, u * Co, M)
+            ci = np.arange(Ci)[:, None, None]
+            co = np.arange(Co)[None, :, None]
+            k = np.arange(K)[None, None, :]
+            r = (k - p) % u
+            jj = (k - p - r) // u - m_lo
+            g_map = ((r * Co + co) * Ci + ci) * M + jj
+            self._maps = (torch.from_numpy(np.ascontiguousarray(w_map)).long().to(device),
+                          torch.from_numpy(np.ascontiguousarray(np.broadcast_to(g_map, (Ci, Co, K)))).long().to(device))
+        return self._maps
+
+    def deinterleave(self, dy, Lin):
+        """dy [B,Co,Lo] -> dyP [B, u*Co, Lin+M-1] with dyP[b, r*Co+co, i] = dy[b, co, (i+m_lo)*u + r] (zero outside)."""
+        u = self.stride
+        m_lo, _, M = self.taps_t()
+        B, Co, Lo = dy.shape
+        Lq = -(-Lo // u)
+        if Lq * u != Lo:
+            dy = torch.nn.functional.pad(dy, (0, Lq * u - Lo))
+        ph = dy.view(B, Co, Lq, u).permute(0, 3, 1, 2).reshape(B, u * Co, Lq)
+        out = torch.zeros((B, u * Co, Lin + M - 1), dtype=dy.dtype, device=dy.device)
+        # out index i <-> q = i + m_lo
+        q0, q1 = max(0, m_lo), min(Lq, Lin + M - 1 + m_lo)
+        if q1 > q0:
+            out[:, :, q0 - m_lo:q1 - m_lo] = ph[:, :, q0:q1]
+        return out
+
+
+def _wgrad(P, Q, A, Bc, J, base, step, q_scale, q_slope):
+    G = torch.zeros((A, Bc, J), dtype=torch.float32, device=P.device)
+    N, _, LP = P.shape
+    LQ = Q.shape[2]
+    with torch.cuda.device(P.device):
+        _lib.check(_lib.lib().ttsc_conv_wgrad(_lib.dev_ptr(P), _lib.dev_ptr(Q), _lib.dev_ptr(G), N, A, Bc, LP, LQ, J, base, step,
+                                              q_scale, q_slope, _lib.current_stream()), 'ttsc_conv_wgrad')
+    return G
+
+
+class HipConvFn(torch.autograd.Function):
+    """y = conv(leaky_relu(in_scale * x, in_slope); w) + b [+ resid]  with HIP forward / dgrad / wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, resid, tc, in_scale, in_slope):
+        x = x.contiguous()
+        wd = w.detach().contiguous()
+        tc.fwd.set_weight_device(wd, b.detach() if b is not None else None)
+        y = tc.fwd(x, resid=resid, in_scale=in_scale, in_slope=in_slope)
+        ctx.save_for_backward(x, wd)
+        ctx.tc, ctx.in_scale, ctx.in_slope = tc, in_scale, in_slope
+        ctx.has_b, ctx.has_r = b is not None, resid is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        tc, sc, sl = ctx.tc, ctx.in_scale, ctx.in_slope
+        dy = dy.contiguous()
+        B, _, Lin = x.shape
+        dx = dw = db = None
+        if not tc.transposed:
+            if ctx.needs_input_grad[0]:
+                h = tc.dgrad_handle()
+                h.set_weight_device(w.flip(2).transpose(0, 1).contiguous())
+                dx = h(dy, out_scale=sc, gate=x if sl != 1.0 else None, gate_slope=sl)
+            if ctx.needs_input_grad[1]:
+                dw = _wgrad(dy, x, tc.Cout, tc.Cin, tc.K, -tc.padding, tc.dilation, sc, sl)
+        else:
+            m_lo, _, M = tc.taps_t()
+            dyp = tc.deinterleave(dy, Lin)
+            w_map, g_map = tc.maps_t(dy.device)
+            if ctx.needs_input_grad[0]:
+                h = tc.dgrad_handle()
+                wz = torch.cat([w.reshape(-1), w.new_zeros(1)])
+                h.set_weight_device(wz[w_map].contiguous())
+                dx = h(dyp, out_scale=sc, gate=x if sl != 1.0 else None, gate_slope=sl)
+            if ctx.needs_input_grad[1]:
+                G = _wgrad(dyp, x, tc.stride * tc.Cout, tc.Cin, M, 0, -1, sc, sl)
+                dw = G.reshape(-1)[g_map]
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = dy.sum(dim=(0, 2))
+        dr = dy if (ctx.has_r and ctx.needs_input_grad[3]) else None
+        return dx, dw, db, dr, None, None, None
+
+
+def hip_conv(tc, x, w, b=None, resid=None, in_scale=1.0, in_slope=1.0):
+    return HipConvFn.apply(x, w, b, resid, tc, float(in_scale), float(in_slope))
+
+
+def _wn(l):
+    """live weight-norm: w = g * v / ||v|| (so that gradients reach weight_g and weight_v)."""
+    if hasattr(l, 'weight'):
+        return l.weight
+    v, g = l.weight_v, l.weight_g
+    return g * v / v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, 1, 1)
+
+
+def _train_convs(gen):
+    tcs = getattr(gen, '_train_convs_cache', None)
+    if tcs is not None:
+        return tcs
+    from .models import ResBlock1
+    h = gen.h
+    tcs = {}
+    c0 = h['upsample_initial_channel']
+    tcs['conv_pre'] = TrainConv(h.get('num_mels', 80), c0, 7, padding=3)
+    nk = gen.num_kernels
+    ch = c0
+    for i, (u, k) in enumerate(zip(h['upsample_rates'], h['upsample_kernel_sizes'])):
+        tcs['ups.%d' % i] = TrainConv(ch, ch // 2, k, stride=u, padding=(k - u) // 2, transposed=True)
+        ch //= 2
+        for j in range(nk):
+            rb = gen.resblocks[i * nk + j]
+            kr, ds = h['resblock_kernel_sizes'][j], h['resblock_dilation_sizes'][j]
+            for m, d in enumerate(ds):
+                if isinstance(rb, ResBlock1):
+                    tcs['rb.%d.c1.%d' % (i * nk + j, m)] = TrainConv(ch, ch, kr, padding=d * (kr - 1) // 2, dilation=d)
+                    tcs['rb.%d.c2.%d' % (i * nk + j, m)] = TrainConv(ch, ch, kr, padding=(kr - 1) // 2)
+                else:
+                    tcs['rb.%d.c.%d' % (i * nk + j, m)] = TrainConv(ch, ch, kr, padding=d * (kr - 1) // 2, dilation=d)
+    tcs['conv_post'] = TrainConv(ch, 1, 7, padding=3)
+    object.__setattr__(gen, '_train_convs_cache', tcs)
+    return tcs
 
 
 def generator_forward_with_grad(gen, x):
-    from ..networks.training import generator_forward_train
-    return generator_forward_train(gen, x)
+    """Differentiable HiFi-GAN generator forward on the HIP kernels (same math as `ttsc_hifigan_forward`)."""
+    from .models import ResBlock1
+    if not x.is_cuda:
+        raise _lib.TTSCError('generator training needs a HIP device; no CPU path')
+    h = gen.h
+    T = _train_convs(gen)
+    nk = gen.num_kernels
+    x = hip_conv(T['conv_pre'], x.float(), _wn(gen.conv_pre), gen.conv_pre.bias)
+    for i in range(len(h['upsample_rates'])):
+        x = hip_conv(T['ups.%d' % i], x, _wn(gen.ups[i]), gen.ups[i].bias, in_scale=(1.0 / nk) if i > 0 else 1.0, in_slope=0.1)
+        xs = None
+        for j in range(nk):
+            rb = gen.resblocks[i * nk + j]
+            r = x
+            if isinstance(rb, ResBlock1):
+                for m, (c1, c2) in enumerate(zip(rb.convs1, rb.convs2)):
+                    xt = hip_conv(T['rb.%d.c1.%d' % (i * nk + j, m)], r, _wn(c1), c1.bias, in_slope=0.1)
+                    r = hip_conv(T['rb.%d.c2.%d' % (i * nk + j, m)], xt, _wn(c2), c2.bias, resid=r, in_slope=0.1)
+            else:
+                for m, c in enumerate(rb.convs):
+                    r = hip_conv(T['rb.%d.c.%d' % (i * nk + j, m)], r, _wn(c), c.bias, resid=r, in_slope=0.1)
+            xs = r if xs is None else xs + r
+        x = xs
+    x = hip_conv(T['conv_post'], x, _wn(gen.conv_post), gen.conv_post.bias, in_scale=1.0 / nk, in_slope=0.01)
+    return torch.tanh(x)

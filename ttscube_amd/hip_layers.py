@@ -42,10 +42,24 @@ class Conv1dHip:
                                                      C.c_void_p(b.data_ptr()) if b is not None else None),
                    'ttsc_conv1d_set_weight')
 
+    def set_weight_device(self, weight, bias=None):
+        """Training: (re)pack the fragments from the live fp32 device tensors on the current stream (no host copy)."""
+        exp = ((self.cfg.in_channels, self.cfg.out_channels) if self.cfg.transposed else
+               (self.cfg.out_channels, self.cfg.in_channels)) + (self.cfg.kernel_size,)
+        if tuple(weight.shape) != exp or not weight.is_cuda or weight.dtype != torch.float32 or not weight.is_contiguous():
+            raise _lib.TTSCError('Conv1dHip.set_weight_device: need a contiguous fp32 device tensor of shape %s' % (exp,))
+        if bias is not None and (bias.numel() != self.cfg.out_channels or not bias.is_cuda or bias.dtype != torch.float32):
+            raise _lib.TTSCError('Conv1dHip.set_weight_device: bias must be an fp32 device tensor with %d elements' % self.cfg.out_channels)
+        with torch.cuda.device(weight.device):
+            _lib.check(_lib.lib().ttsc_conv1d_set_weight_device(self._h, _lib.dev_ptr(weight),
+                                                                _lib.dev_ptr(bias.contiguous()) if bias is not None else None,
+                                                                _lib.current_stream()), 'ttsc_conv1d_set_weight_device')
+
     def out_len(self, Lin):
         return int(_lib.lib().ttsc_conv1d_out_len(self._h, Lin))
 
-    def __call__(self, x, resid=None, out=None, in_scale=1.0, in_slope=1.0, out_scale=1.0, act=None, accumulate=False):
+    def __call__(self, x, resid=None, out=None, in_scale=1.0, in_slope=1.0, out_scale=1.0, act=None, accumulate=False,
+                 gate=None, gate_slope=1.0):
         if not x.is_cuda:
             raise _lib.TTSCError('Conv1dHip: input must live on a HIP device; no CPU path')
         x = x.float().contiguous()
@@ -61,7 +75,10 @@ class Conv1dHip:
         if resid is not None:
             resid = resid.float().contiguous()
             assert tuple(resid.shape) == tuple(out.shape)
-        ep = _lib.Conv1dEpilogue(in_scale, in_slope, out_scale, ACT[act], int(accumulate))
+        if gate is not None:
+            assert gate.is_contiguous() and gate.dtype == torch.float32 and tuple(gate.shape) == tuple(out.shape)
+        ep = _lib.Conv1dEpilogue(in_scale, in_slope, out_scale, ACT[act], int(accumulate),
+                                 gate.data_ptr() if gate is not None else None, gate_slope)
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().ttsc_conv1d_forward(self._h, _lib.dev_ptr(x), B, Lin, _lib.dev_ptr(out),
                                                       _lib.dev_ptr(resid) if resid is not None else None,

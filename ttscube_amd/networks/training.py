@@ -48,10 +48,12 @@ def wavernn_loss(net, X):
 # =====================================================================================================================
 # Training steps (torch-ROCm autograd + explicit RCCL gradient exchange).
 #
-# Status (round 1): the backward pass runs through torch-ROCm (MIOpen) ops on the SAME parameter tensors the HIP
-# inference kernels read, exactly like the reference trains on a GPU (pl.Trainer -> torch autograd); what is new is
-# the explicit flat-bucket RCCL exchange (ttscube_amd/distributed.py) replacing Lightning's implicit DDP.  The
-# training forward is checked against the HIP inference path in tests/test_training_gpu.py (<= 1e-4 RMS).
+# Status (round 1): the GENERATOR trains on the hand-written HIP kernels (hifigan/autograd.py: forward, data gradient
+# and weight gradient of every convolution behind `torch.autograd.Function`); `generator_forward_train` below is the
+# torch-op formulation of the same network, kept as the gradient reference for tests/test_training_gpu.py.  The
+# discriminators, the mel decoder stacks and the teacher-forced WaveRNN still differentiate through torch-ROCm ops on
+# the SAME parameter tensors the HIP inference kernels read.  The explicit flat-bucket RCCL exchange
+# (ttscube_amd/distributed.py) replaces Lightning's implicit DDP.
 # =====================================================================================================================
 import itertools
 import random
@@ -59,6 +61,7 @@ import random
 import torch.nn.functional as F
 
 from ..hifigan.models import ResBlock1
+from ..hifigan.autograd import generator_forward_with_grad
 
 
 def _wn(l):
@@ -70,7 +73,7 @@ def _wn(l):
 
 
 def generator_forward_train(gen, x):
-    """Differentiable HiFi-GAN generator forward (same math as `ttsc_hifigan_forward`), torch-ROCm ops."""
+    """HiFi-GAN generator forward as torch ops: the autograd REFERENCE the native path (hifigan/autograd.py) is tested against."""
     h = gen.h
     x = F.conv1d(x, _wn(gen.conv_pre), gen.conv_pre.bias, padding=3)
     nk = gen.num_kernels
@@ -190,7 +193,7 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
         y = torch.cat(ys, dim=0)
         conditioning = torch.cat(cs, dim=0)
     y = y.unsqueeze(1)
-    y_g_hat = generator_forward_train(model._generator, conditioning.permute(0, 2, 1))
+    y_g_hat = generator_forward_with_grad(model._generator, conditioning.permute(0, 2, 1).contiguous())
     m = min(y.shape[2], y_g_hat.shape[2])
     y, y_g_hat = y[:, :, :m], y_g_hat[:, :, :m]
     y_mel = mel_spectrogram(y.squeeze(1), 1024, 80, 24000, 240, 1024, 0, 12000)
