@@ -116,10 +116,12 @@ void ttsc_conv1d_destroy(ttsc_conv1d* c);
  * where torch autograd differentiates Generator.forward):
  *   G[a, b, j] += sum_n sum_t P[n,a,t] * leaky_relu(q_scale * Q[n,b,t + base + j*step], q_slope)       (zero outside [0,LQ))
  * Conv1d(weight [Co,Ci,K], dilation d, padding p): P = dL/dy [N,Co,Lout], Q = layer input [N,Ci,Lin], base = -p, step = d,
- * G = dL/dW [Co,Ci,K].  G (device, [A,B,J] fp32) must be zeroed by the caller; partial sums are added with fp32 atomics
- * (summation order, hence the last bits, vary from run to run).  |(J-1)*step| <= 64 per group of 12 taps. */
+ * G = dL/dW [Co,Ci,K].  G (device, [A,B,J] fp32) is overwritten.  The position axis is split over ~2048 waves whose partial
+ * tiles go through `ws_dev` (>= ttsc_conv_wgrad_workspace_bytes) and are added in a fixed order (deterministic).
+ * |(J-1)*step| <= 64 per group of 12 taps. */
+size_t ttsc_conv_wgrad_workspace_bytes(int32_t N, int32_t A, int32_t B, int64_t LP, int32_t J);
 int ttsc_conv_wgrad(const float* p_dev, const float* q_dev, float* g_dev, int32_t N, int32_t A, int32_t B, int64_t LP, int64_t LQ,
-                    int32_t J, int32_t base, int32_t step, float q_scale, float q_slope, void* stream);
+                    int32_t J, int32_t base, int32_t step, float q_scale, float q_slope, void* ws_dev, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * HiFi-GAN generator.  Replaces `hifigan.models.Generator(h)` [EXTERNAL submodule]:

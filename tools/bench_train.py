@@ -17,6 +17,7 @@ def main():
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--frames', type=int, default=50)
     ap.add_argument('--iters', type=int, default=10)
+    ap.add_argument('--only', default='')
     a = ap.parse_args()
     from ttscube_amd.hifigan.env import AttrDict
     from ttscube_amd.hifigan.models import Generator
@@ -31,6 +32,8 @@ def main():
     samples = a.batch * a.frames * 240
     flops = 3 * 1168559.0 * samples
     for name, fn in (('hip', generator_forward_with_grad), ('torch', generator_forward_train)):
+        if a.only and a.only != name:
+            continue
         def step():
             y = fn(g, mel)
             torch.autograd.grad(y.abs().mean(), [mel] + params)

@@ -1185,12 +1185,29 @@ extern "C" int ttsc_conv1d_forward_split(const ttsc_conv1d* c, const float* x, c
                 rc = launch_f16<2, 2>(a, B, s);   // 64 x 256 tile (MT=128 layers run as two M tiles)
             else
                 rc = launch_f16<1, 4>(a, B, s);   // 32 x 512 tile
-        } else if (c->MT == 128)
-            rc = launch_cfg<2, 2, 2, 2>(a, B, s);
-        else if (c->MT == 64)
-            rc = launch_cfg<2, 2, 1, 4>(a, B, s);
-        else
-            rc = launch_cfg<1, 4, 1, 4>(a, B, s);
+        } else {
+            // fp32 tile by machine fill: the largest tile that still gives >= 2 workgroups per CU (training crops and
+            // single short utterances are small problems: a 128 x 128 tile would leave most of the 256 CUs idle)
+            auto wgs = [&](int mt, int nt) { return (long)ceil_div(a.q_cnt, nt) * (c->CoutP / mt) * B; };
+            auto set_nt = [&](int nt) {
+                a.span = nt + (last < 0 ? -last : last);
+                a.span_pad = a.span + 1;
+            };
+            const long want = 512;
+            if (c->MT == 128) {
+                if (wgs(128, 128) >= want) { set_nt(128); rc = launch_cfg<2, 2, 2, 2>(a, B, s); }
+                else if (wgs(64, 128) >= want) { set_nt(128); rc = launch_cfg<1, 2, 2, 2>(a, B, s); }
+                else { set_nt(64); rc = launch_cfg<1, 1, 2, 2>(a, B, s); }
+            } else if (c->MT == 64) {
+                if (wgs(64, 256) >= want) { set_nt(256); rc = launch_cfg<2, 2, 1, 4>(a, B, s); }
+                else if (wgs(64, 128) >= want) { set_nt(128); rc = launch_cfg<1, 2, 2, 2>(a, B, s); }
+                else { set_nt(64); rc = launch_cfg<1, 1, 2, 2>(a, B, s); }
+            } else {
+                if (wgs(32, 512) >= want) { set_nt(512); rc = launch_cfg<1, 4, 1, 4>(a, B, s); }
+                else if (wgs(32, 256) >= want) { set_nt(256); rc = launch_cfg<1, 2, 1, 4>(a, B, s); }
+                else { set_nt(128); rc = launch_cfg<1, 1, 1, 4>(a, B, s); }
+            }
+        }
         if (rc) return rc;
     }
     return TTSC_OK;

@@ -8,7 +8,7 @@ generator is one `torch.autograd.Function` whose three legs are hand-written HIP
   dgrad     ttsc_conv1d_forward      the SAME kernel on the transposed+flipped weights; the epilogue multiplies by the
                                      leaky-relu derivative of the saved pre-activation (`gate_dev`) and adds the gradient
                                      of the residual branch
-  wgrad     ttsc_conv_wgrad          fp32 MFMA correlation over all positions with atomically reduced partial sums
+  wgrad     ttsc_conv_wgrad          fp32 MFMA correlation over all positions, split-K partials reduced in a fixed order
 
 Weights live in torch parameters (weight-norm g, v stay torch leaves so the four AdamW optimizers of
 cubegan.py:275-311 see the usual gradients); `ttsc_conv1d_set_weight_device` re-packs the MFMA fragments from the live
@@ -72,8 +72,8 @@ class TrainConv:
             r = (k - p) % u
             jj = (k - p - r) // u - m_lo
             g_map = ((r * Co + co) * Ci + ci) * M + jj
-            self._maps = (torch.from_numpy(np.ascontiguousarray(w_map)).long().to(device),
-                          torch.from_numpy(np.ascontiguousarray(np.broadcast_to(g_map, (Ci, Co, K)))).long().to(device))
+            self._maps = (torch.from_numpy(np.array(w_map)).long().to(device),
+                          torch.from_numpy(np.array(np.broadcast_to(g_map, (Ci, Co, K)))).long().to(device))
         return self._maps
 
     def deinterleave(self, dy, Lin):
@@ -94,12 +94,15 @@ class TrainConv:
 
 
 def _wgrad(P, Q, A, Bc, J, base, step, q_scale, q_slope):
-    G = torch.zeros((A, Bc, J), dtype=torch.float32, device=P.device)
+    G = torch.empty((A, Bc, J), dtype=torch.float32, device=P.device)
     N, _, LP = P.shape
     LQ = Q.shape[2]
+    L = _lib.lib()
+    nbytes = int(L.ttsc_conv_wgrad_workspace_bytes(N, A, Bc, LP, J))
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=P.device)
     with torch.cuda.device(P.device):
-        _lib.check(_lib.lib().ttsc_conv_wgrad(_lib.dev_ptr(P), _lib.dev_ptr(Q), _lib.dev_ptr(G), N, A, Bc, LP, LQ, J, base, step,
-                                              q_scale, q_slope, _lib.current_stream()), 'ttsc_conv_wgrad')
+        _lib.check(L.ttsc_conv_wgrad(_lib.dev_ptr(P), _lib.dev_ptr(Q), _lib.dev_ptr(G), N, A, Bc, LP, LQ, J, base, step,
+                                     q_scale, q_slope, _lib.dev_ptr(ws), nbytes, _lib.current_stream()), 'ttsc_conv_wgrad')
     return G
 
 
