@@ -153,11 +153,15 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& acc, const ConvArgs&
 }
 
 template <int MI, int NJ, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];  // [KC][span_pad]
+__global__ __launch_bounds__(WM* WN * 64, 2) void conv_mfma_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [2][KC][span_pad]  (double-buffered activation chunk)
     constexpr int NT = WN * NJ * 32;
     constexpr int NTHREADS = WM * WN * 64;
+    constexpr int SPC = NT + 64;                                   // staged positions per channel covered by the register prefetch
     constexpr int NWAVES = WM * WN;
+    constexpr int SMAIN = KC * NT / NTHREADS;                      // prefetch registers per thread: tile columns
+    constexpr int SHALO = KC / NWAVES;                             //                                halo strip
+    static_assert(KC * NT % NTHREADS == 0 && KC % NWAVES == 0, "staging split");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -184,45 +188,127 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a) {
     const float* xb = a.x + (size_t)b * a.Cin * a.Lin;
     const int lo = q0 + a.min_shift;  // x position of LDS column 0
     const int cipN = a.CinP >> 1;
+    const int nchunks = a.CinP / KC;
+    const int bufsz = KC * a.span_pad;
+    const bool wide = a.span > SPC;   // receptive field beyond the prefetch window: extra columns are staged synchronously
 
-    for (int cc = 0; cc < a.CinP; cc += KC) {
-        __syncthreads();
-        // ---- stage x[b, cc:cc+KC, lo:lo+span] -> LDS, leaky-relu prologue fused -------------------
-        for (int c = wave; c < KC; c += NWAVES) {
-            const int ci = cc + c;
-            const float* xr = xb + (size_t)ci * a.Lin;
-            float* dst = xs + c * a.span_pad;
-            const bool cok = ci < a.Cin;
-            for (int p = lane; p < a.span; p += 64) {
-                const int pos = lo + p;
-                float v = 0.f;
-                if (cok && pos >= 0 && pos < lin) {
-                    v = xr[pos] * a.in_scale;
-                    v = v > 0.f ? v : v * a.in_slope;
+    // ---- software pipeline -------------------------------------------------------------------------------------
+    // Left to itself hipcc issues every global load right before its use and waits vmcnt(0) for it: one L2 round trip
+    // per MFMA and per staged element, which only many resident workgroups can hide.  Training crops and short
+    // utterances run at <= 1 workgroup per CU, so both operand streams are pipelined explicitly:
+    //   * activations: chunk c+1 is fetched into registers (sreg) while chunk c is multiplied; LDS is double-buffered,
+    //     one barrier per chunk;
+    //   * weights: the 8*MI fragments of (chunk, tap) g+1 are in flight while (chunk, tap) g is multiplied (wa / wb).
+    // The fmaf chain order (chunk, tap, channel pair) is unchanged, results stay bit-identical.
+    // prefetch registers: the NT tile columns of the 16 channels (e = tid + i*NTHREADS -> channel e / NT, column e % NT,
+    // powers of two) plus a 64-column halo strip (channel = wave + i*NWAVES, column = NT + lane)
+    float sreg[SMAIN + SHALO];
+    auto sload = [&](int cc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < SMAIN; ++i) {
+            const int e = tid + i * NTHREADS;
+            const int c = e / NT, p = e % NT;
+            const int ci = cc + c, pos = lo + p;
+            const bool ok = p < a.span && ci < a.Cin && pos >= 0 && pos < lin;
+            float v = xb[ok ? (unsigned)(ci * a.Lin + pos) : 0u] * a.in_scale;
+            v = v > 0.f ? v : v * a.in_slope;
+            sreg[i] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < SHALO; ++i) {
+            const int c = wave + i * NWAVES, p = NT + lane;
+            const int ci = cc + c, pos = lo + p;
+            const bool ok = p < a.span && ci < a.Cin && pos >= 0 && pos < lin;
+            float v = xb[ok ? (unsigned)(ci * a.Lin + pos) : 0u] * a.in_scale;
+            v = v > 0.f ? v : v * a.in_slope;
+            sreg[SMAIN + i] = ok ? v : 0.f;
+        }
+    };
+    auto scommit = [&](float* buf, int cc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < SMAIN; ++i) {
+            const int e = tid + i * NTHREADS;
+            const int c = e / NT, p = e % NT;
+            if (p < a.span) buf[c * a.span_pad + p] = sreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < SHALO; ++i) {
+            const int c = wave + i * NWAVES, p = NT + lane;
+            if (p < a.span) buf[c * a.span_pad + p] = sreg[SMAIN + i];
+        }
+        if (wide) {
+            for (int c = wave; c < KC; c += NWAVES) {
+                const int ci = cc + c;
+                for (int p = SPC + lane; p < a.span; p += 64) {
+                    const int pos = lo + p;
+                    float v = 0.f;
+                    if (ci < a.Cin && pos >= 0 && pos < lin) {
+                        v = xb[(size_t)ci * a.Lin + pos] * a.in_scale;
+                        v = v > 0.f ? v : v * a.in_slope;
+                    }
+                    buf[c * a.span_pad + p] = v;
                 }
-                dst[p] = v;
             }
         }
-        __syncthreads();
-        // ---- MFMA over taps x channel pairs --------------------------------------------------
-        for (int j = 0; j < a.ntaps; ++j) {
-            const int shift = a.tap_base + j * a.tap_step - a.min_shift;  // >= 0
-            const float* wj = a.wp + ((size_t)(j * cipN + (cc >> 1)) * cotN + cot0) * 64 + lane;
-            const float* bj = xs + half * a.span_pad + wn * (NJ * 32) + l31 + shift;
+    };
+    auto loadA = [&](float (&w)[KC / 2][MI], int ch, int j) __attribute__((always_inline)) {
+        const float* wj = a.wp + ((size_t)(j * cipN + ch * (KC / 2)) * cotN + cot0) * 64 + lane;
 #pragma unroll
-            for (int cp = 0; cp < KC / 2; ++cp) {
-                float af[MI], bf[NJ];
+        for (int cp = 0; cp < KC / 2; ++cp)
 #pragma unroll
-                for (int i = 0; i < MI; ++i) af[i] = wj[((size_t)cp * cotN + i) * 64];
-#pragma unroll
-                for (int n = 0; n < NJ; ++n) bf[n] = bj[(2 * cp) * a.span_pad + n * 32];
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int n = 0; n < NJ; ++n)
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[n], acc[i][n], 0, 0, 0);
-            }
+            for (int i = 0; i < MI; ++i) w[cp][i] = wj[((size_t)cp * cotN + i) * 64];
+    };
+    int chC = 0, jC = 0;   // compute cursor
+    auto step = [&](const float (&w)[KC / 2][MI]) __attribute__((always_inline)) {
+        if (jC == 0 && chC > 0) {   // chunk switch: publish the prefetched activations, fetch the chunk after
+            scommit(xs + (chC & 1) * bufsz, chC * KC);
+            __syncthreads();
+            if (chC + 1 < nchunks) sload((chC + 1) * KC);
         }
+        const int shift = a.tap_base + jC * a.tap_step - a.min_shift;  // >= 0
+        const float* bj = xs + (chC & 1) * bufsz + half * a.span_pad + wn * (NJ * 32) + l31 + shift;
+#pragma unroll
+        for (int cp = 0; cp < KC / 2; ++cp) {
+            float bf[NJ];
+#pragma unroll
+            for (int n = 0; n < NJ; ++n) bf[n] = bj[(2 * cp) * a.span_pad + n * 32];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int n = 0; n < NJ; ++n)
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cp][i], bf[n], acc[i][n], 0, 0, 0);
+        }
+        if (++jC == a.ntaps) {
+            jC = 0;
+            ++chC;
+        }
+    };
+    int chL = 0, jL = 0;   // weight-load cursor (one (chunk, tap) ahead of the compute cursor)
+    auto advL = [&]() __attribute__((always_inline)) {
+        if (++jL == a.ntaps) {
+            jL = 0;
+            ++chL;
+        }
+    };
+    float wa[KC / 2][MI], wb[KC / 2][MI];
+    const int total = nchunks * a.ntaps;
+    loadA(wa, 0, 0);
+    advL();
+    sload(0);
+    scommit(xs, 0);
+    __syncthreads();
+    if (nchunks > 1) sload(KC);
+    for (int g = 0; g < total; g += 2) {
+        if (g + 1 < total) {
+            loadA(wb, chL, jL);
+            advL();
+        }
+        step(wa);
+        if (g + 2 < total) {
+            loadA(wa, chL, jL);
+            advL();
+        }
+        if (g + 1 < total) step(wb);
     }
 
     // ---- epilogue: bias + residual + scale + activation (+ running sum) --------------------------
@@ -713,7 +799,15 @@ static int launch_cfg(const ConvArgs& a, int B, hipStream_t s) {
     constexpr int MT = WM * MI * 32;
     dim3 grid((unsigned)ceil_div(a.q_cnt, NT), (unsigned)(a.CoutP / MT), (unsigned)B);
     dim3 block(WM * WN * 64);
-    size_t lds = (size_t)KC * a.span_pad * sizeof(float);
+    size_t lds = (size_t)2 * KC * a.span_pad * sizeof(float);
+    TTSC_REQUIRE(lds <= 160 * 1024, "conv_mfma_kernel: receptive field too large for LDS (%zu bytes)", lds);
+    if (lds > 64 * 1024) {
+        static size_t attr_set = 0;
+        if (lds > attr_set) {
+            TTSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<MI, NJ, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = lds;
+        }
+    }
     hipLaunchKernelGGL((conv_mfma_kernel<MI, NJ, WM, WN>), grid, block, lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
