@@ -110,6 +110,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgArgs a) {
         }
     };
 
+    const float* qj[JT];   // per-tap fragment base inside the Q tile
+#pragma unroll
+    for (int j = 0; j < JT; ++j) qj[j] = ql + l31 * WG_QP + half + (a.base + (a.j0 + j) * a.step - a.minoff);
+
     // every wave of the workgroup runs the same number of iterations (workgroup barriers inside); idle ones add zeros
     if (c_beg < c_end) load(c_beg);
     for (int it = 0; it < a.CH; ++it) {
@@ -120,18 +124,21 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgArgs a) {
         if (c + 1 < c_end) load(c + 1);
         if (on) {
             const float* pa = pl + l31 * WG_PP + half;
-            const float* qb = ql + l31 * WG_QP + half;
-#pragma unroll 4
-            for (int kk = 0; kk < WG_TK / 2; ++kk) {
-                const float af = pa[2 * kk];
+#pragma unroll 2
+            for (int kk0 = 0; kk0 < WG_TK / 2; kk0 += 4) {
+                // all fragment reads of four k-steps first (the LDS returns them in order, the MFMAs start as they land);
+                // a read placed right before its MFMA costs one LDS round trip per MFMA
+                float af[4], bf[4][JT];
 #pragma unroll
-                for (int j = 0; j < JT; ++j) {
-                    if (j < a.J) {
-                        const int sh = a.base + (a.j0 + j) * a.step - a.minoff;
-                        const float bf = qb[2 * kk + sh];
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[j], 0, 0, 0);
-                    }
+                for (int u = 0; u < 4; ++u) {
+                    af[u] = pa[2 * (kk0 + u)];
+#pragma unroll
+                    for (int j = 0; j < JT; ++j) bf[u][j] = qj[j][2 * (kk0 + u)];
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < JT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u], bf[u][j], acc[j], 0, 0, 0);
             }
         }
         __syncthreads();
@@ -142,20 +149,18 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgArgs a) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
-        if (j < a.J) {
-            __syncthreads();
+        __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[j][r];
-            __syncthreads();
-            float* dst = a.part + ((size_t)blockIdx.x * a.Jtot + a.j0 + j) * a.A * a.Bc;
+        for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[j][r];
+        __syncthreads();
+        float* dst = a.part + ((size_t)blockIdx.x * a.Jtot + a.j0 + j) * a.A * a.Bc;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int e = tid + 256 * i;
-                const float v = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
-                const int r = e >> 6, ln = e & 63;
-                const int arow = a0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), bcol = b0 + (ln & 31);
-                if (arow < a.A && bcol < a.Bc) dst[(size_t)arow * a.Bc + bcol] = v;
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            const float v = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+            const int r = e >> 6, ln = e & 63;
+            const int arow = a0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), bcol = b0 + (ln & 31);
+            if (arow < a.A && bcol < a.Bc) dst[(size_t)arow * a.Bc + bcol] = v;
         }
     }
 }
@@ -253,12 +258,20 @@ extern "C" int ttsc_conv_wgrad(const float* p_dev, const float* q_dev, float* g_
         a.span = (off_first < off_last ? off_last : off_first) - a.minoff;
         TTSC_REQUIRE(a.span <= 64, "ttsc_conv_wgrad: tap window (%d positions) exceeds 64", a.span);
         int rc;
-        if (a.J <= 4)
-            rc = launch_wgrad<4>(a, s);
-        else if (a.J <= 8)
-            rc = launch_wgrad<8>(a, s);
-        else
-            rc = launch_wgrad<12>(a, s);
+        switch (a.J) {   // one instance per tap count: no per-tap branch in the MFMA loop
+            case 1: rc = launch_wgrad<1>(a, s); break;
+            case 2: rc = launch_wgrad<2>(a, s); break;
+            case 3: rc = launch_wgrad<3>(a, s); break;
+            case 4: rc = launch_wgrad<4>(a, s); break;
+            case 5: rc = launch_wgrad<5>(a, s); break;
+            case 6: rc = launch_wgrad<6>(a, s); break;
+            case 7: rc = launch_wgrad<7>(a, s); break;
+            case 8: rc = launch_wgrad<8>(a, s); break;
+            case 9: rc = launch_wgrad<9>(a, s); break;
+            case 10: rc = launch_wgrad<10>(a, s); break;
+            case 11: rc = launch_wgrad<11>(a, s); break;
+            default: rc = launch_wgrad<12>(a, s); break;
+        }
         if (rc) return rc;
     }
     const long AB = (long)A * Bc;
