@@ -203,25 +203,21 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_mfma_kernel(ConvArgs a) {
     // prefetch registers: the NT tile columns of the 16 channels (e = tid + i*NTHREADS -> channel e / NT, column e % NT,
     // powers of two) plus a 64-column halo strip (channel = wave + i*NWAVES, column = NT + lane)
     float sreg[SMAIN + SHALO];
+    // sload only ISSUES the loads (clamped addresses); masking, scaling and the leaky-relu happen in scommit, so that no
+    // use of a loaded value sits between the loads (hipcc would wait for each one in turn)
     auto sload = [&](int cc) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < SMAIN; ++i) {
             const int e = tid + i * NTHREADS;
             const int c = e / NT, p = e % NT;
-            const int ci = cc + c, pos = lo + p;
-            const bool ok = p < a.span && ci < a.Cin && pos >= 0 && pos < lin;
-            float v = xb[ok ? (unsigned)(ci * a.Lin + pos) : 0u] * a.in_scale;
-            v = v > 0.f ? v : v * a.in_slope;
-            sreg[i] = ok ? v : 0.f;
+            const int ci = min(cc + c, a.Cin - 1), pos = min(max(lo + p, 0), a.Lin - 1);
+            sreg[i] = xb[(unsigned)(ci * a.Lin + pos)];
         }
 #pragma unroll
         for (int i = 0; i < SHALO; ++i) {
             const int c = wave + i * NWAVES, p = NT + lane;
-            const int ci = cc + c, pos = lo + p;
-            const bool ok = p < a.span && ci < a.Cin && pos >= 0 && pos < lin;
-            float v = xb[ok ? (unsigned)(ci * a.Lin + pos) : 0u] * a.in_scale;
-            v = v > 0.f ? v : v * a.in_slope;
-            sreg[SMAIN + i] = ok ? v : 0.f;
+            const int ci = min(cc + c, a.Cin - 1), pos = min(max(lo + p, 0), a.Lin - 1);
+            sreg[SMAIN + i] = xb[(unsigned)(ci * a.Lin + pos)];
         }
     };
     auto scommit = [&](float* buf, int cc) __attribute__((always_inline)) {
@@ -229,12 +225,18 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_mfma_kernel(ConvArgs a) {
         for (int i = 0; i < SMAIN; ++i) {
             const int e = tid + i * NTHREADS;
             const int c = e / NT, p = e % NT;
-            if (p < a.span) buf[c * a.span_pad + p] = sreg[i];
+            const int ci = cc + c, pos = lo + p;
+            float v = sreg[i] * a.in_scale;
+            v = v > 0.f ? v : v * a.in_slope;
+            if (p < a.span) buf[c * a.span_pad + p] = (ci < a.Cin && pos >= 0 && pos < lin) ? v : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < SHALO; ++i) {
             const int c = wave + i * NWAVES, p = NT + lane;
-            if (p < a.span) buf[c * a.span_pad + p] = sreg[SMAIN + i];
+            const int ci = cc + c, pos = lo + p;
+            float v = sreg[SMAIN + i] * a.in_scale;
+            v = v > 0.f ? v : v * a.in_slope;
+            if (p < a.span) buf[c * a.span_pad + p] = (ci < a.Cin && pos >= 0 && pos < lin) ? v : 0.f;
         }
         if (wide) {
             for (int c = wave; c < KC; c += NWAVES) {

@@ -64,49 +64,46 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgArgs a) {
 
     const float* Pn = a.P + (size_t)n * a.A * a.LP;
     const float* Qn = a.Q + (size_t)n * a.Bc * a.LQ;
+    // `load` only ISSUES the global loads (clamped addresses, no use of the values): any arithmetic on a loaded value placed
+    // here makes hipcc wait for that load before issuing the next ones.  Masking and the leaky-relu prologue happen in
+    // `commit`, one MFMA phase later.
     float pr[32], q0r[32], q1r[32];
-    auto load = [&](int c) {
+    auto load = [&](int c) __attribute__((always_inline)) {
         const int t0 = c * WG_TK;
-        const int tp = t0 + lane;
-        const bool pok = tp < a.LP;
-        const int tpc = pok ? tp : a.LP - 1;
+        const int tp = min(t0 + lane, a.LP - 1);
 #pragma unroll
-        for (int r = 0; r < 32; ++r) {
-            const int row = a0 + r;
-            const float v = Pn[(size_t)(row < a.A ? row : a.A - 1) * a.LP + tpc];
-            pr[r] = (pok && row < a.A) ? v : 0.f;
+        for (int r = 0; r < 32; ++r) pr[r] = Pn[(unsigned)(min(a0 + r, a.A - 1) * a.LP + tp)];
+        const int q_a = min(max(t0 + a.minoff + lane, 0), a.LQ - 1);
+#pragma unroll
+        for (int r = 0; r < 32; ++r) q0r[r] = Qn[(unsigned)(min(b0 + r, a.Bc - 1) * a.LQ + q_a)];
+        if (two) {
+            const int q_b = min(max(t0 + a.minoff + lane + 64, 0), a.LQ - 1);
+#pragma unroll
+            for (int r = 0; r < 32; ++r) q1r[r] = Qn[(unsigned)(min(b0 + r, a.Bc - 1) * a.LQ + q_b)];
         }
+    };
+    auto commit = [&](int c) __attribute__((always_inline)) {
+        const int t0 = c * WG_TK;
+        const bool pok = t0 + lane < a.LP;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) pl[r * WG_PP + lane] = (pok && a0 + r < a.A) ? pr[r] : 0.f;
         const int q_a = t0 + a.minoff + lane;
         const bool qa_ok = q_a >= 0 && q_a < a.LQ;
-        const int qa_c = qa_ok ? q_a : 0;
 #pragma unroll
         for (int r = 0; r < 32; ++r) {
-            const int row = b0 + r;
-            float v = Qn[(size_t)(row < a.Bc ? row : a.Bc - 1) * a.LQ + qa_c] * a.q_scale;
+            float v = q0r[r] * a.q_scale;
             v = v > 0.f ? v : v * a.q_slope;
-            q0r[r] = (qa_ok && row < a.Bc) ? v : 0.f;
+            ql[r * WG_QP + lane] = (qa_ok && b0 + r < a.Bc) ? v : 0.f;
         }
         if (two) {
             const int q_b = q_a + 64;
             const bool qb_ok = q_b >= 0 && q_b < a.LQ && lane < a.span;
-            const int qb_c = qb_ok ? q_b : 0;
 #pragma unroll
             for (int r = 0; r < 32; ++r) {
-                const int row = b0 + r;
-                float v = Qn[(size_t)(row < a.Bc ? row : a.Bc - 1) * a.LQ + qb_c] * a.q_scale;
+                float v = q1r[r] * a.q_scale;
                 v = v > 0.f ? v : v * a.q_slope;
-                q1r[r] = (qb_ok && row < a.Bc) ? v : 0.f;
+                ql[r * WG_QP + 64 + lane] = (qb_ok && b0 + r < a.Bc) ? v : 0.f;
             }
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int r = 0; r < 32; ++r) pl[r * WG_PP + lane] = pr[r];
-#pragma unroll
-        for (int r = 0; r < 32; ++r) ql[r * WG_QP + lane] = q0r[r];
-        if (two) {
-#pragma unroll
-            for (int r = 0; r < 32; ++r) ql[r * WG_QP + 64 + lane] = q1r[r];
         }
     };
 
@@ -119,7 +116,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgArgs a) {
     for (int it = 0; it < a.CH; ++it) {
         const int c = c_beg + it;
         const bool on = c < c_end;
-        if (on) commit();
+        if (on) commit(c);
         __syncthreads();
         if (c + 1 < c_end) load(c + 1);
         if (on) {
