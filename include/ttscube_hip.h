@@ -81,6 +81,9 @@ int ttsc_conv1d_set_weight(ttsc_conv1d* c, const float* weight_host, const float
 /* training: (re)pack the weights from DEVICE memory (torch parameter layout, fp32) on `stream`, no host round trip;
  * TTSC_PREC_FP32 handles only.  bias_dev NULL = no bias. */
 int ttsc_conv1d_set_weight_device(ttsc_conv1d* c, const float* weight_dev, const float* bias_dev, void* stream);
+/* same, reading the weight of the FORWARD layer this handle is the data gradient of: a Conv1d(Ci -> Co, K) forward weight
+ * [Co,Ci,K] is packed as the flipped, transposed Conv1d(Co -> Ci, K) weight  W'[ci,co,k] = W[co,ci,K-1-k]. */
+int ttsc_conv1d_set_weight_device_dgrad(ttsc_conv1d* c, const float* fwd_weight_dev, void* stream);
 /* switch the arithmetic (TTSC_PREC_*); weights are re-packed from the host copy kept by set_weight */
 int ttsc_conv1d_set_precision(ttsc_conv1d* c, int32_t precision);
 int64_t ttsc_conv1d_out_len(const ttsc_conv1d* c, int64_t Lin);
@@ -119,6 +122,16 @@ void ttsc_conv1d_destroy(ttsc_conv1d* c);
  * G = dL/dW [Co,Ci,K].  G (device, [A,B,J] fp32) is overwritten.  The position axis is split over ~2048 waves whose partial
  * tiles go through `ws_dev` (>= ttsc_conv_wgrad_workspace_bytes) and are added in a fixed order (deterministic).
  * |(J-1)*step| <= 64 per group of 12 taps. */
+/* torch.nn.utils.weight_norm(dim=0) of the generator convolutions [EXTERNAL hifigan/models.py], fused: v [rows, cols] (cols =
+ * product of the other dims), g [rows];  forward: w = v * g / ||v||_row, norm = ||v||_row;  backward: dv, dg from dw. */
+int ttsc_weight_norm_forward(const float* v_dev, const float* g_dev, float* w_dev, float* norm_dev, int32_t rows, int64_t cols, void* stream);
+int ttsc_weight_norm_backward(const float* dw_dev, const float* v_dev, const float* g_dev, const float* norm_dev, float* dv_dev,
+                              float* dg_dev, int32_t rows, int64_t cols, void* stream);
+/* bias gradient db[c] = sum_{b,t} dy[b,c,t] (fixed summation order).  ws_is_fresh = 1 when the workspace was not left by a
+ * previous ttsc_bias_grad call with the same shape (its ticket counters are then zeroed on the stream first). */
+size_t ttsc_bias_grad_workspace_bytes(int32_t B, int32_t C, int64_t L);
+int ttsc_bias_grad(const float* dy_dev, float* db_dev, int32_t B, int32_t C, int64_t L, void* ws_dev, size_t ws_bytes, int32_t ws_is_fresh,
+                   void* stream);
 size_t ttsc_conv_wgrad_workspace_bytes(int32_t N, int32_t A, int32_t B, int64_t LP, int32_t J);
 int ttsc_conv_wgrad(const float* p_dev, const float* q_dev, float* g_dev, int32_t N, int32_t A, int32_t B, int64_t LP, int64_t LQ,
                     int32_t J, int32_t base, int32_t step, float q_scale, float q_slope, void* ws_dev, size_t ws_bytes, void* stream);

@@ -190,3 +190,23 @@ def test_vocoder_training_step_and_teacher_forced_logits_agree():
     assert abs(float(v['hr']) - T.wavernn_train_loss(net, {k: t.cuda() for k, t in batch.items()}).item()) < 1e-3
     sd = voc.state_dict()
     assert any(k.startswith('_wavernn_hr._rnns.0.') for k in sd) and any(k.startswith('_wavernn_lr._skip.') for k in sd)
+
+
+def test_fused_weight_norm_and_bias_grad_match_torch():
+    from ttscube_amd.hifigan.autograd import HipWeightNormFn, TrainConv, _bias_grad
+    g_ = torch.Generator().manual_seed(9)
+    for shape in [(512, 256, 16), (32, 32, 11), (1, 32, 7), (7, 3, 1)]:
+        v = torch.randn(shape, generator=g_).cuda().requires_grad_(True)
+        g = (torch.rand(shape[0], 1, 1, generator=g_) + 0.5).cuda().requires_grad_(True)
+        gw = torch.randn(shape, generator=g_).cuda()
+        w0 = g * v / v.reshape(shape[0], -1).norm(dim=1).reshape(-1, 1, 1)
+        r0 = torch.autograd.grad(w0, (v, g), gw)
+        w1 = HipWeightNormFn.apply(v, g)
+        r1 = torch.autograd.grad(w1, (v, g), gw)
+        assert _rel(w1, w0) < 1e-6 and _rel(r1[0], r0[0]) < 1e-5 and _rel(r1[1], r0[1]) < 1e-5
+    tc = TrainConv(4, 4, 1)
+    for B, C_, L in [(16, 32, 12064), (3, 5, 17), (16, 512, 50), (2, 1, 100000)]:
+        dy = torch.randn(B, C_, L, generator=g_).cuda()
+        for rep in range(2):          # second call re-uses the ticket workspace
+            db = _bias_grad(tc, dy)
+            assert _rel(db, dy.double().sum(dim=(0, 2)).float()) < 1e-5

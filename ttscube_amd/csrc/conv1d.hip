@@ -857,6 +857,7 @@ struct ttsc_conv1d {
     std::vector<float> w_host, b_host;  // kept so that the precision can be switched (repack) at any time
     bool has_bias = false;
     bool dev_weights = false;  // weights were last written by ttsc_conv1d_set_weight_device (host copy is stale)
+    const float* bias_ext = nullptr;  // device-weight mode: the caller's bias tensor
 };
 
 extern "C" int ttsc_conv1d_create(const ttsc_conv1d_cfg* cfg, ttsc_conv1d** out) {
@@ -1002,6 +1003,7 @@ struct PackArgs {
     const float* w;
     float* out;
     int Cin, Cout, K, CoutV, cipN, cotN, ntaps, k0, kstep, transposed, vfused, stride;
+    int flipT;   // source is the forward weight [Cin(this), Cout(this), K] of the layer this handle differentiates
 };
 __global__ void pack_w_kernel(PackArgs p) {
     const long total = (long)p.ntaps * p.cipN * p.cotN * 64;
@@ -1023,13 +1025,29 @@ __global__ void pack_w_kernel(PackArgs p) {
             ok = ok && kk < p.K;
         }
         float v = 0.f;
-        if (ok) v = p.transposed ? p.w[((size_t)ci * p.Cout + co) * p.K + kk] : p.w[((size_t)co * p.Cin + ci) * p.K + kk];
+        if (ok) {
+            if (p.flipT)
+                v = p.w[((size_t)ci * p.Cout + co) * p.K + (p.K - 1 - kk)];
+            else
+                v = p.transposed ? p.w[((size_t)ci * p.Cout + co) * p.K + kk] : p.w[((size_t)co * p.Cin + ci) * p.K + kk];
+        }
         p.out[i] = v;
     }
 }
 }  // namespace ttsc
 
+static int set_weight_device_impl(ttsc_conv1d* c, const float* w_dev, const float* bias_dev, int flipT, void* stream);
+
 extern "C" int ttsc_conv1d_set_weight_device(ttsc_conv1d* c, const float* w_dev, const float* bias_dev, void* stream) {
+    return set_weight_device_impl(c, w_dev, bias_dev, 0, stream);
+}
+
+extern "C" int ttsc_conv1d_set_weight_device_dgrad(ttsc_conv1d* c, const float* fwd_weight_dev, void* stream) {
+    TTSC_REQUIRE(c && !c->cfg.transposed, "ttsc_conv1d_set_weight_device_dgrad: the data-gradient handle must be a Conv1d");
+    return set_weight_device_impl(c, fwd_weight_dev, nullptr, 1, stream);
+}
+
+static int set_weight_device_impl(ttsc_conv1d* c, const float* w_dev, const float* bias_dev, int flipT, void* stream) {
     TTSC_REQUIRE(c && w_dev, "ttsc_conv1d_set_weight_device: null argument");
     TTSC_REQUIRE(c->precision == TTSC_PREC_FP32, "ttsc_conv1d_set_weight_device: only TTSC_PREC_FP32 handles take device weights");
     const auto& g = c->cfg;
@@ -1058,11 +1076,12 @@ extern "C" int ttsc_conv1d_set_weight_device(ttsc_conv1d* c, const float* w_dev,
         p.transposed = g.transposed;
         p.vfused = c->vfused ? 1 : 0;
         p.stride = g.stride;
+        p.flipT = flipT;
         const long total = (long)p.ntaps * p.cipN * p.cotN * 64;
         const int blocks = (int)std::min<long>((total + 255) / 256, 2048);
         hipLaunchKernelGGL(pack_w_kernel, dim3(blocks), dim3(256), 0, s, p);
     }
-    if (bias_dev) TTSC_HIP_CHECK(hipMemcpyAsync(c->bias_dev, bias_dev, g.out_channels * sizeof(float), hipMemcpyDeviceToDevice, s));
+    c->bias_ext = bias_dev;   // read straight from the caller's tensor by the launches that follow (no copy)
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("pack_w_kernel launch failed: %s", hipGetErrorString(e));
@@ -1219,7 +1238,7 @@ extern "C" int ttsc_conv1d_forward_split(const ttsc_conv1d* c, const float* x, c
         a.wp = ph.wp_dev;
         a.wph = ph.wph_dev;
         a.w_unscale = c->w_unscale;
-        a.bias = c->bias_dev;
+        a.bias = (c->dev_weights && c->bias_ext) ? c->bias_ext : c->bias_dev;
         a.in_len = in_len_dev;
         a.out_len = out_len_dev;
         a.xs = x_split;

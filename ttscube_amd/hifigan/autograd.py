@@ -33,6 +33,7 @@ class TrainConv:
         self.fwd = Conv1dHip(Cin, Cout, K, stride=stride, padding=padding, dilation=dilation, transposed=transposed)
         self._dgrad = None
         self._maps = None
+        self._bg_ws = {}
 
     # ---- Conv1d ----------------------------------------------------------------------------------------------------
     def dgrad_handle(self):
@@ -93,6 +94,24 @@ class TrainConv:
         return out
 
 
+def _bias_grad(tc, dy):
+    """db[c] = sum_{b,t} dy[b,c,t] — one launch (ttsc_bias_grad); the ticket workspace is kept per layer and shape."""
+    B, Cc, L = dy.shape
+    Lb = _lib.lib()
+    key = (B, Cc, L, dy.device)
+    ws = tc._bg_ws.get(key)
+    fresh = ws is None
+    nbytes = int(Lb.ttsc_bias_grad_workspace_bytes(B, Cc, L))
+    if fresh:
+        ws = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=dy.device)
+        tc._bg_ws = {key: ws}
+    db = torch.empty(Cc, dtype=torch.float32, device=dy.device)
+    with torch.cuda.device(dy.device):
+        _lib.check(Lb.ttsc_bias_grad(_lib.dev_ptr(dy), _lib.dev_ptr(db), B, Cc, L, _lib.dev_ptr(ws), nbytes, int(fresh),
+                                     _lib.current_stream()), 'ttsc_bias_grad')
+    return db
+
+
 def _wgrad(P, Q, A, Bc, J, base, step, q_scale, q_slope):
     G = torch.empty((A, Bc, J), dtype=torch.float32, device=P.device)
     N, _, LP = P.shape
@@ -130,7 +149,7 @@ class HipConvFn(torch.autograd.Function):
         if not tc.transposed:
             if ctx.needs_input_grad[0]:
                 h = tc.dgrad_handle()
-                h.set_weight_device(w.flip(2).transpose(0, 1).contiguous())
+                h.set_weight_device_dgrad(w)
                 dx = h(dy, out_scale=sc, gate=x if sl != 1.0 else None, gate_slope=sl)
             if ctx.needs_input_grad[1]:
                 dw = _wgrad(dy, x, tc.Cout, tc.Cin, tc.K, -tc.padding, tc.dilation, sc, sl)
@@ -147,7 +166,7 @@ class HipConvFn(torch.autograd.Function):
                 G = _wgrad(dyp, x, tc.stride * tc.Cout, tc.Cin, M, 0, -1, sc, sl)
                 dw = G.reshape(-1)[g_map]
         if ctx.has_b and ctx.needs_input_grad[2]:
-            db = dy.sum(dim=(0, 2))
+            db = _bias_grad(tc, dy)
         dr = dy if (ctx.has_r and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dr, None, None, None
 
@@ -156,12 +175,43 @@ def hip_conv(tc, x, w, b=None, resid=None, in_scale=1.0, in_slope=1.0):
     return HipConvFn.apply(x, w, b, resid, tc, float(in_scale), float(in_slope))
 
 
+class HipWeightNormFn(torch.autograd.Function):
+    """w = g * v / ||v||  (weight_norm dim=0) as one kernel forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, v, g):
+        v = v.contiguous()
+        g = g.contiguous()
+        R = v.shape[0]
+        Cc = v.numel() // R
+        w = torch.empty_like(v)
+        n = torch.empty(R, dtype=torch.float32, device=v.device)
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().ttsc_weight_norm_forward(_lib.dev_ptr(v), _lib.dev_ptr(g), _lib.dev_ptr(w), _lib.dev_ptr(n), R, Cc,
+                                                           _lib.current_stream()), 'ttsc_weight_norm_forward')
+        ctx.save_for_backward(v, g, n)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        v, g, n = ctx.saved_tensors
+        dw = dw.contiguous()
+        R = v.shape[0]
+        Cc = v.numel() // R
+        dv = torch.empty_like(v)
+        dg = torch.empty_like(g)
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().ttsc_weight_norm_backward(_lib.dev_ptr(dw), _lib.dev_ptr(v), _lib.dev_ptr(g), _lib.dev_ptr(n),
+                                                            _lib.dev_ptr(dv), _lib.dev_ptr(dg), R, Cc, _lib.current_stream()),
+                       'ttsc_weight_norm_backward')
+        return dv, dg
+
+
 def _wn(l):
     """live weight-norm: w = g * v / ||v|| (so that gradients reach weight_g and weight_v)."""
     if hasattr(l, 'weight'):
         return l.weight
-    v, g = l.weight_v, l.weight_g
-    return g * v / v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, 1, 1)
+    return HipWeightNormFn.apply(l.weight_v, l.weight_g)
 
 
 def _train_convs(gen):

@@ -55,6 +55,16 @@ class Conv1dHip:
                                                                 _lib.dev_ptr(bias.contiguous()) if bias is not None else None,
                                                                 _lib.current_stream()), 'ttsc_conv1d_set_weight_device')
 
+    def set_weight_device_dgrad(self, fwd_weight):
+        """Training: this handle is the data gradient of a Conv1d whose weight is `fwd_weight` [Cin(this), Cout(this), K]; the
+        flipped / transposed view is read directly by the packing kernel."""
+        exp = (self.cfg.in_channels, self.cfg.out_channels, self.cfg.kernel_size)
+        if tuple(fwd_weight.shape) != exp or not fwd_weight.is_cuda or fwd_weight.dtype != torch.float32 or not fwd_weight.is_contiguous():
+            raise _lib.TTSCError('Conv1dHip.set_weight_device_dgrad: need a contiguous fp32 device tensor of shape %s' % (exp,))
+        with torch.cuda.device(fwd_weight.device):
+            _lib.check(_lib.lib().ttsc_conv1d_set_weight_device_dgrad(self._h, _lib.dev_ptr(fwd_weight), _lib.current_stream()),
+                       'ttsc_conv1d_set_weight_device_dgrad')
+
     def out_len(self, Lin):
         return int(_lib.lib().ttsc_conv1d_out_len(self._h, Lin))
 
