@@ -162,19 +162,33 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgArgs a) {
     }
 }
 
-// G[a][b][j] = sum over splits of part[sp][j][a][b]   (fixed order)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ G, int splits, int J, long AB) {
+// G[a][b][j] = sum over splits of part[sp][j][a][b]   (fixed order).  Block = 32 consecutive elements x 8 split lanes: lane q adds
+// the splits q, q+8, ... with four loads in flight, then the 8 lanes are added in index order through LDS.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ G, int splits, int J, long AB) {
+    __shared__ float red[8][32];
     const long total = (long)J * AB;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        float s0 = 0.f, s1 = 0.f;
-        int sp = 0;
-        for (; sp + 1 < splits; sp += 2) {
-            s0 += part[(size_t)sp * total + i];
-            s1 += part[(size_t)(sp + 1) * total + i];
+    const int ex = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const long i = (long)blockIdx.x * 32 + ex;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < total) {
+        const float* p = part + i;
+        int sp = q;
+        for (; sp + 24 < splits; sp += 32) {
+            s0 += p[(size_t)sp * total];
+            s1 += p[(size_t)(sp + 8) * total];
+            s2 += p[(size_t)(sp + 16) * total];
+            s3 += p[(size_t)(sp + 24) * total];
         }
-        if (sp < splits) s0 += part[(size_t)sp * total + i];
+        for (; sp < splits; sp += 8) s0 += p[(size_t)sp * total];
+    }
+    red[q][ex] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q == 0 && i < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][ex];
         const long j = i / AB, ab = i - j * AB;
-        G[ab * J + j] = s0 + s1;
+        G[ab * J + j] = t;
     }
 }
 
@@ -272,8 +286,9 @@ extern "C" int ttsc_conv_wgrad(const float* p_dev, const float* q_dev, float* g_
         if (rc) return rc;
     }
     const long AB = (long)A * Bc;
-    const int blocks = (int)std::min<long>((AB * J + 255) / 256, 1024);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws_dev, g_dev, splits, (int)J, AB);
+    const long blocks = (AB * J + 31) / 32;
+    TTSC_REQUIRE(blocks < (1l << 31), "ttsc_conv_wgrad: weight tensor too large");
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)ws_dev, g_dev, splits, (int)J, AB);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("wgrad_reduce_kernel launch failed: %s", hipGetErrorString(e));

@@ -60,14 +60,23 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
     __shared__ float red[4];
     __shared__ bool last;
     const int c = blockIdx.x, s = blockIdx.y;
-    const long total = (long)B * L;
-    const long per = (total + S - 1) / S;
-    const long i0 = (long)s * per, i1 = min(i0 + per, total);
-    float acc = 0.f;
-    for (long i = i0 + threadIdx.x; i < i1; i += 256) {
-        const long b = i / L, t = i - b * L;
-        acc += dy[((size_t)b * C + c) * L + t];
+    // block s owns the time slice [t0, t1) of every batch item: rows of contiguous floats, no index division, four
+    // independent accumulators so the loads of a row overlap
+    const int per = (L + S - 1) / S;
+    const int t0 = s * per, t1 = min(t0 + per, L);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* row = dy + ((size_t)b * C + c) * L;
+        int t = t0 + threadIdx.x;
+        for (; t + 768 < t1; t += 1024) {
+            a0 += row[t];
+            a1 += row[t + 256];
+            a2 += row[t + 512];
+            a3 += row[t + 768];
+        }
+        for (; t < t1; t += 256) a0 += row[t];
     }
+    float acc = (a0 + a1) + (a2 + a3);
     acc = block_sum(acc, red);
     if (threadIdx.x == 0) {
         __hip_atomic_store(&part[(size_t)c * S + s], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -114,7 +123,7 @@ extern "C" int ttsc_weight_norm_backward(const float* dw_dev, const float* v_dev
 }
 
 static int bias_grad_splits(int32_t B, int32_t C, int64_t L) {
-    long s = ((long)B * L + 8191) / 8192;        // >= 8192 positions per block
+    long s = (L + 1023) / 1024;                  // >= 1024 positions of every batch item per block
     const long cap = (1024 + C - 1) / C;         // ~1024 blocks in all
     if (s > cap) s = cap;
     if (s < 1) s = 1;
