@@ -64,18 +64,23 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
     // independent accumulators so the loads of a row overlap
     const int per = (L + S - 1) / S;
     const int t0 = s * per, t1 = min(t0 + per, L);
+    // flattened (batch item, position of the slice) index space, four independent loads per thread and trip
+    const int w = t1 - t0;
+    const int n = B * w;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float* row = dy + ((size_t)b * C + c) * L;
-        int t = t0 + threadIdx.x;
-        for (; t + 768 < t1; t += 1024) {
-            a0 += row[t];
-            a1 += row[t + 256];
-            a2 += row[t + 512];
-            a3 += row[t + 768];
-        }
-        for (; t < t1; t += 256) a0 += row[t];
+    auto at = [&](int i) {
+        const int b = i / w, t = t0 + (i - b * w);
+        return dy[((size_t)b * C + c) * L + t];
+    };
+    int i = threadIdx.x;
+    for (; i + 768 < n; i += 1024) {
+        const float v0 = at(i), v1 = at(i + 256), v2 = at(i + 512), v3 = at(i + 768);
+        a0 += v0;
+        a1 += v1;
+        a2 += v2;
+        a3 += v3;
     }
+    for (; i < n; i += 256) a0 += at(i);
     float acc = (a0 + a1) + (a2 + a3);
     acc = block_sum(acc, red);
     if (threadIdx.x == 0) {
