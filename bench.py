@@ -105,6 +105,11 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
+        # setup (not a step): the first forward packs + uploads the weights and allocates the workspace; a second one
+        # brings the clocks up so that a small --warmup does not time the power ramp
+        for _ in range(2):
+            out = g(mel)
+        barrier()
         for _ in range(args.warmup):
             out = g(mel)
         barrier()
