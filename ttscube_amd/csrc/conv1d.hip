@@ -1296,10 +1296,36 @@ extern "C" int ttsc_conv1d_forward_split(const ttsc_conv1d* c, const float* x, c
             a.span = nt + (last < 0 ? -last : last);
             a.span_pad = a.span;
             TTSC_REQUIRE(ph.ntaps <= 16, "f16x3 path supports at most 16 taps per phase (got %d)", ph.ntaps);
-            if (c->MT >= 64)
-                rc = launch_f16<2, 2>(a, B, s);   // 64 x 256 tile (MT=128 layers run as two M tiles)
-            else
-                rc = launch_f16<1, 4>(a, B, s);   // 32 x 512 tile
+            // tile by machine fill (same rule as the fp32 path): a single short utterance (the reference API's B=1 case)
+            // has only a few thousand positions per layer, so the big tiles would occupy a fraction of the 256 CUs
+            auto wgs16 = [&](int mt, int nt) { return (long)ceil_div(a.q_cnt, nt) * (c->CoutP / mt) * B; };
+            auto set_nt16 = [&](int n) {
+                a.span = n + (last < 0 ? -last : last);
+                a.span_pad = a.span;
+            };
+            static const bool big_only = getenv("TTSC_F16_TILE") && atoi(getenv("TTSC_F16_TILE")) == 0;
+            const long want16 = 512;
+            if (c->MT >= 64) {
+                if (a.xs || big_only || wgs16(64, 256) >= want16)
+                    rc = launch_f16<2, 2>(a, B, s);   // 64 x 256 tile (MT=128 layers run as two M tiles)
+                else if (wgs16(64, 128) >= want16) {
+                    set_nt16(128);
+                    rc = launch_f16_s<2, 1, false>(a, B, s);
+                } else {
+                    set_nt16(128);
+                    rc = launch_f16_s<1, 1, false>(a, B, s);
+                }
+            } else {
+                if (a.xs || big_only || wgs16(32, 512) >= want16)
+                    rc = launch_f16<1, 4>(a, B, s);   // 32 x 512 tile
+                else if (wgs16(32, 256) >= want16) {
+                    set_nt16(256);
+                    rc = launch_f16_s<1, 2, false>(a, B, s);
+                } else {
+                    set_nt16(128);
+                    rc = launch_f16_s<1, 1, false>(a, B, s);
+                }
+            }
         } else {
             // fp32 tile by machine fill: the largest tile that still gives >= 2 workgroups per CU (training crops and
             // single short utterances are small problems: a 128 x 128 tile would leave most of the 256 CUs idle)

@@ -211,11 +211,21 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
     opt_d.step()
     opt_g.zero_grad()
     loss_mel = F.l1_loss(y_mel, y_g_hat_mel) * 45
-    y_df_hat_r, y_df_hat_g, fmap_f_r, fmap_f_g = model._mpd(y, y_g_hat)
-    y_ds_hat_r, y_ds_hat_g, fmap_s_r, fmap_s_g = model._msd(y, y_g_hat)
-    loss_gen_all = (generator_loss(y_ds_hat_g)[0] + generator_loss(y_df_hat_g)[0] + feature_loss(fmap_s_r, fmap_s_g)
-                    + feature_loss(fmap_f_r, fmap_f_g) + loss_mel)
-    loss_gen_all.backward(retain_graph=True)
+    # the generator step only needs the discriminators' DATA gradients: the reference also accumulates their weight
+    # gradients here and throws them away at the next opt_d.zero_grad() (cubegan.py:137,157-170); freezing the
+    # discriminator parameters for this pass skips a third of its backward work with identical updates
+    d_params = [p for p in itertools.chain(model._mpd.parameters(), model._msd.parameters()) if p.requires_grad]
+    for p in d_params:
+        p.requires_grad_(False)
+    try:
+        y_df_hat_r, y_df_hat_g, fmap_f_r, fmap_f_g = model._mpd(y, y_g_hat)
+        y_ds_hat_r, y_ds_hat_g, fmap_s_r, fmap_s_g = model._msd(y, y_g_hat)
+        loss_gen_all = (generator_loss(y_ds_hat_g)[0] + generator_loss(y_df_hat_g)[0] + feature_loss(fmap_s_r, fmap_s_g)
+                        + feature_loss(fmap_f_r, fmap_f_g) + loss_mel)
+        loss_gen_all.backward(retain_graph=True)
+    finally:
+        for p in d_params:
+            p.requires_grad_(True)
     if reducers:
         reducers[0].reduce()
     opt_g.step()
