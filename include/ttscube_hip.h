@@ -248,6 +248,22 @@ int ttsc_lstm_pack_whh(const float* whh_host, int32_t ndir, int32_t H, float** w
 int ttsc_lstm_seq_forward(const float* xg_dev, const float* whh_packed_dev, float* y_dev, const int32_t* lengths_dev,
                           int32_t B, int32_t T, int32_t H, int32_t ndir, int64_t ldy, int32_t yoff, const float* h0_dev,
                           const float* c0_dev, float* hn_dev, float* cn_dev, void* stream);
+/* Training of the mel-decoder stacks (Languasito2 / CubenetTextcoder LSTMs inside `Cubegan.training_step`, cubegan.py:85-189;
+ * the reference differentiates torch.nn.LSTM):
+ *   ttsc_lstm_pack_whh_device   weight_hh [ndir,4H,H] on the DEVICE -> out_dev [ndir*4H*H]: the forward packing (transpose = 0) or
+ *                               the W_hh^T packing the backward kernel streams (transpose = 1); no host round trip
+ *   ttsc_lstm_seq_forward_train same recurrence, additionally saves the post-activation gates [B,T,ndir*4H] (i,f,g,o) and the
+ *                               cell states [B,T,ndir*H]
+ *   ttsc_lstm_seq_backward      backward through time: dy [B,T,ldy] (columns yoff + d*H ...) -> gradient wrt the pre-activation
+ *                               gates dgates [B,T,ndir*4H] (zero beyond lengths).  The caller finishes with plain GEMMs:
+ *                               dx = dgates W_ih, dW_ih = dgates^T x, dW_hh = dgates^T h_prev, db = sum dgates. */
+int ttsc_lstm_pack_whh_device(const float* whh_dev, int32_t ndir, int32_t H, int32_t transpose, float* out_dev, void* stream);
+int ttsc_lstm_seq_forward_train(const float* xg_dev, const float* whh_packed_dev, float* y_dev, const int32_t* lengths_dev,
+                                int32_t B, int32_t T, int32_t H, int32_t ndir, int64_t ldy, int32_t yoff, float* gates_dev,
+                                float* c_dev, void* stream);
+int ttsc_lstm_seq_backward(const float* dy_dev, const float* gates_dev, const float* c_dev, const float* whhT_packed_dev,
+                           float* dgates_dev, const int32_t* lengths_dev, int32_t B, int32_t T, int32_t H, int32_t ndir,
+                           int64_t ldy, int32_t yoff, void* stream);
 /* frees a device buffer returned by a ttsc_*_pack_* function */
 void ttsc_device_free(void* p);
 

@@ -210,3 +210,22 @@ def test_fused_weight_norm_and_bias_grad_match_torch():
         for rep in range(2):          # second call re-uses the ticket workspace
             db = _bias_grad(tc, dy)
             assert _rel(db, dy.double().sum(dim=(0, 2)).float()) < 1e-5
+
+
+@pytest.mark.parametrize('cfg', [(2, True, 64, 37, 3, 9), (1, False, 32, 20, 2, 5), (2, True, 256, 641, 2, 30)])
+def test_hip_lstm_autograd_matches_torch(cfg):
+    """forward + backward-through-time kernels of a stacked (bi)LSTM vs torch.nn.LSTM autograd (same parameters)."""
+    from ttscube_amd.networks.lstm_autograd import lstm_forward_train
+    layers, bi, H, nin, B, T = cfg
+    torch.manual_seed(3)
+    m = torch.nn.LSTM(nin, H, num_layers=layers, bidirectional=bi, batch_first=True).cuda()
+    x = torch.randn(B, T, nin, device='cuda', requires_grad=True)
+    gy = torch.randn(B, T, H * (2 if bi else 1), device='cuda')
+    params = list(m.parameters())
+    y0, _ = m(x)
+    g0 = torch.autograd.grad(y0, [x] + params, gy)
+    y1 = lstm_forward_train(m, x)
+    g1 = torch.autograd.grad(y1, [x] + params, gy)
+    assert _rel(y1, y0) < 1e-5
+    for a_, b_, p in zip(g1, g0, [x] + params):
+        assert a_.shape == b_.shape and _rel(a_, b_) < 1e-4, (tuple(p.shape), _rel(a_, b_))

@@ -10,6 +10,8 @@
 // h lives in LDS double-buffered) — no inter-workgroup communication, one workgroup barrier per step.
 // Ragged batches: `lengths[b]` gives pack_padded_sequence semantics (reverse direction starts at len-1, outputs
 // beyond len are zero), so a padded batch reproduces the per-utterance results exactly.
+#include <algorithm>
+
 #include "common.hpp"
 #include "../../include/ttscube_math.h"
 
@@ -25,6 +27,8 @@ struct LstmArgs {
     const float* h_0;    // optional initial state [ndir, B, H]
     const float* c_0;
     int B, T, H, ndir, ldy, yoff;
+    float* gates_out;    // training: post-activation gates [B, T, ndir*4H] (i,f,g,o) saved for the backward kernel, or null
+    float* c_out;        // training: cell states [B, T, ndir*H], or null
 };
 
 template <int BT, int NG, int UN>
@@ -140,6 +144,14 @@ __global__ __launch_bounds__(512) void lstm_seq_kernel(LstmArgs a) {
                     c[u] = cn;
                     hn[u * H + j] = hv;
                     a.y[((size_t)bi[u] * a.T + tpos[u]) * a.ldy + a.yoff + dir * H + j] = hv;
+                    if (a.gates_out) {
+                        float* gp = a.gates_out + ((size_t)bi[u] * a.T + tpos[u]) * ((size_t)a.ndir * H4) + (size_t)dir * H4 + j;
+                        gp[0] = ig;
+                        gp[H] = fg;
+                        gp[2 * H] = gg;
+                        gp[3 * H] = og;
+                        a.c_out[((size_t)bi[u] * a.T + tpos[u]) * ((size_t)a.ndir * H) + (size_t)dir * H + j] = cn;
+                    }
                 } else {
                     hn[u * H + j] = hc[u * H + j];
                     // padded positions read as zeros (pad_packed_sequence); each padded t is written exactly once:
@@ -159,6 +171,114 @@ __global__ __launch_bounds__(512) void lstm_seq_kernel(LstmArgs a) {
                 if (a.c_n) a.c_n[((size_t)dir * a.B + bi[u]) * H + j] = c[u];
             }
         }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward through time (training of the mel-decoder stacks): one persistent workgroup per
+// (utterance, direction) walks the steps in reverse.  Thread k owns hidden unit k: it turns (dy_t + dh_rec, dc_next) into
+// the four pre-activation gate gradients from the gates / cell states the forward saved, publishes them in LDS, and then
+// evaluates its own dh_rec[k] = sum_r W_hh[r,k] * dgates[r] as one chain over the 4H gate rows (W_hh^T packed
+// [4H/4][H][4], the same 16-byte streaming as the forward).  The gate gradients of all steps go to HBM; the weight /
+// input gradients are three plain GEMMs over them afterwards (dW_ih = dG^T x, dW_hh = dG^T h_prev, dx = dG W_ih).
+struct LstmBwdArgs {
+    const float* dy;      // [B, T, ldy]; direction d reads columns [yoff + d*H, yoff + (d+1)*H)
+    const float* gates;   // [B, T, ndir*4H]
+    const float* cst;     // [B, T, ndir*H]
+    const float* whhT;    // [ndir][4H/4][H][4]
+    float* dgates;        // [B, T, ndir*4H]
+    const int* lengths;
+    int B, T, H, ndir, ldy, yoff;
+};
+
+__global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // dg[4H]
+    const int H = a.H, H4 = 4 * H;
+    const int j = threadIdx.x;
+    const bool unit = j < H;
+    const int b = blockIdx.x, dir = blockIdx.y;
+    const int len = a.lengths ? a.lengths[b] : a.T;
+    const float* whhT = a.whhT + (size_t)dir * H * H4;
+    const size_t gstride = (size_t)a.ndir * H4, cstride = (size_t)a.ndir * H;
+    const float* gb = a.gates + (size_t)b * a.T * gstride + (size_t)dir * H4 + j;
+    const float* cb = a.cst + (size_t)b * a.T * cstride + (size_t)dir * H + j;
+    const float* dyb = a.dy + (size_t)b * a.T * a.ldy + a.yoff + dir * H + j;
+    float* dgb = a.dgates + (size_t)b * a.T * gstride + (size_t)dir * H4 + j;
+    if (unit)
+        for (int t = len; t < a.T; ++t) {   // padded positions contribute nothing to the GEMMs that follow
+            float* p = dgb + (size_t)t * gstride;
+            p[0] = 0.f;
+            p[H] = 0.f;
+            p[2 * H] = 0.f;
+            p[3 * H] = 0.f;
+        }
+    float dh_rec = 0.f, dc_next = 0.f;
+    // saved values of the step about to be processed (prefetched during the previous step's chain)
+    float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, ct = 0.f, cp = 0.f, dyv = 0.f;
+    auto fetch = [&](int s) __attribute__((always_inline)) {
+        const int tpos = dir == 0 ? s : (len - 1 - s);
+        const int tprev = dir == 0 ? tpos - 1 : tpos + 1;
+        const float* g = gb + (size_t)tpos * gstride;
+        ig = g[0];
+        fg = g[H];
+        gg = g[2 * H];
+        og = g[3 * H];
+        ct = cb[(size_t)tpos * cstride];
+        cp = s > 0 ? cb[(size_t)tprev * cstride] : 0.f;
+        dyv = dyb[(size_t)tpos * a.ldy];
+    };
+    if (unit && len > 0) fetch(len - 1);
+    for (int s = len - 1; s >= 0; --s) {
+        if (unit) {
+            const int tpos = dir == 0 ? s : (len - 1 - s);
+            const float dh = dyv + dh_rec;
+            const float tc = ttsc_tanhf(ct);
+            const float d_o = dh * tc * og * (1.f - og);
+            const float dc = dc_next + dh * og * (1.f - tc * tc);
+            const float d_i = dc * gg * ig * (1.f - ig);
+            const float d_g = dc * ig * (1.f - gg * gg);
+            const float d_f = dc * cp * fg * (1.f - fg);
+            dc_next = dc * fg;
+            float* p = dgb + (size_t)tpos * gstride;
+            p[0] = d_i;
+            p[H] = d_f;
+            p[2 * H] = d_g;
+            p[3 * H] = d_o;
+            sm[j] = d_i;
+            sm[H + j] = d_f;
+            sm[2 * H + j] = d_g;
+            sm[3 * H + j] = d_o;
+        }
+        __syncthreads();
+        if (unit) {
+            if (s > 0) fetch(s - 1);
+            float acc[1][1] = {{0.f}};
+            lstm_chain<1, 1, 4>(acc, whhT, H, 0, j, sm, H4, H4);
+            dh_rec = acc[0][0];
+        }
+        __syncthreads();
+    }
+}
+
+// [ndir][4H][H] (torch weight_hh layout, device)  ->  forward pack [ndir][H/4][4H][4]  or  transposed pack [ndir][4H/4][H][4]
+__global__ void lstm_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int ndir, int H, int transpose) {
+    const long per = (long)4 * H * H;
+    const long total = per * ndir;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(i / per);
+        const long e = i - (long)d * per;
+        const int q = (int)(e & 3);
+        const long t = e >> 2;
+        float v;
+        if (!transpose) {   // out[d][k/4][r][k%4] = w[d][r][k]
+            const int r = (int)(t % (4 * H)), k4 = (int)(t / (4 * H));
+            v = w[(size_t)d * per + (size_t)r * H + 4 * k4 + q];
+        } else {            // out[d][r/4][k][r%4] = w[d][r][k]
+            const int k = (int)(t % H), r4 = (int)(t / H);
+            v = w[(size_t)d * per + (size_t)(4 * r4 + q) * H + k];
+        }
+        out[i] = v;
     }
 }
 
@@ -186,13 +306,63 @@ extern "C" void ttsc_device_free(void* p) {
     if (p) (void)hipFree(p);
 }
 
+static int lstm_forward_impl(const float* xg_dev, const float* whh_packed_dev, float* y_dev, const int32_t* lengths_dev,
+                             int32_t B, int32_t T, int32_t H, int32_t ndir, int64_t ldy, int32_t yoff, const float* h0_dev,
+                             const float* c0_dev, float* hn_dev, float* cn_dev, float* gates_dev, float* c_dev, void* stream);
+
 extern "C" int ttsc_lstm_seq_forward(const float* xg_dev, const float* whh_packed_dev, float* y_dev, const int32_t* lengths_dev,
                                      int32_t B, int32_t T, int32_t H, int32_t ndir, int64_t ldy, int32_t yoff, const float* h0_dev,
                                      const float* c0_dev, float* hn_dev, float* cn_dev, void* stream) {
+    return lstm_forward_impl(xg_dev, whh_packed_dev, y_dev, lengths_dev, B, T, H, ndir, ldy, yoff, h0_dev, c0_dev, hn_dev, cn_dev,
+                             nullptr, nullptr, stream);
+}
+
+extern "C" int ttsc_lstm_seq_forward_train(const float* xg_dev, const float* whh_packed_dev, float* y_dev, const int32_t* lengths_dev,
+                                           int32_t B, int32_t T, int32_t H, int32_t ndir, int64_t ldy, int32_t yoff, float* gates_dev,
+                                           float* c_dev, void* stream) {
+    TTSC_REQUIRE(gates_dev && c_dev, "ttsc_lstm_seq_forward_train: null argument");
+    return lstm_forward_impl(xg_dev, whh_packed_dev, y_dev, lengths_dev, B, T, H, ndir, ldy, yoff, nullptr, nullptr, nullptr, nullptr,
+                             gates_dev, c_dev, stream);
+}
+
+extern "C" int ttsc_lstm_pack_whh_device(const float* whh_dev, int32_t ndir, int32_t H, int32_t transpose, float* out_dev, void* stream) {
+    TTSC_REQUIRE(whh_dev && out_dev, "ttsc_lstm_pack_whh_device: null argument");
+    TTSC_REQUIRE(ndir >= 1 && ndir <= 2 && H >= 4 && H <= 512 && H % 4 == 0, "ttsc_lstm_pack_whh_device: need ndir in {1,2}, H %% 4 == 0, H <= 512 (got %d, %d)", ndir, H);
+    const long total = (long)4 * H * H * ndir;
+    hipLaunchKernelGGL(lstm_pack_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream, whh_dev, out_dev,
+                       ndir, H, transpose);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("lstm_pack_kernel launch failed: %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    return TTSC_OK;
+}
+
+extern "C" int ttsc_lstm_seq_backward(const float* dy_dev, const float* gates_dev, const float* c_dev, const float* whhT_packed_dev,
+                                      float* dgates_dev, const int32_t* lengths_dev, int32_t B, int32_t T, int32_t H, int32_t ndir,
+                                      int64_t ldy, int32_t yoff, void* stream) {
+    TTSC_REQUIRE(dy_dev && gates_dev && c_dev && whhT_packed_dev && dgates_dev, "ttsc_lstm_seq_backward: null argument");
+    TTSC_REQUIRE(B > 0 && T > 0 && ndir >= 1 && ndir <= 2 && H >= 4 && H <= 512 && H % 4 == 0, "ttsc_lstm_seq_backward: bad shape B=%d T=%d H=%d ndir=%d", B, T, H, ndir);
+    TTSC_REQUIRE(ldy >= (int64_t)yoff + (int64_t)ndir * H, "ttsc_lstm_seq_backward: ldy too small");
+    LstmBwdArgs a{dy_dev, gates_dev, c_dev, whhT_packed_dev, dgates_dev, lengths_dev, B, T, H, ndir, (int)ldy, yoff};
+    const int threads = (int)round_up(H, 64);
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)B, (unsigned)ndir), dim3(threads), (size_t)4 * H * sizeof(float), (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("lstm_bwd_kernel launch failed: %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    return TTSC_OK;
+}
+
+static int lstm_forward_impl(const float* xg_dev, const float* whh_packed_dev, float* y_dev, const int32_t* lengths_dev,
+                             int32_t B, int32_t T, int32_t H, int32_t ndir, int64_t ldy, int32_t yoff, const float* h0_dev,
+                             const float* c0_dev, float* hn_dev, float* cn_dev, float* gates_dev, float* c_dev, void* stream) {
     TTSC_REQUIRE(xg_dev && whh_packed_dev && y_dev, "ttsc_lstm_seq_forward: null argument");
     TTSC_REQUIRE(B > 0 && T > 0 && ndir >= 1 && ndir <= 2 && H >= 4 && H <= 512 && H % 4 == 0, "ttsc_lstm_seq_forward: bad shape B=%d T=%d H=%d ndir=%d", B, T, H, ndir);
     TTSC_REQUIRE(ldy >= (int64_t)yoff + (int64_t)ndir * H, "ttsc_lstm_seq_forward: ldy too small");
-    LstmArgs a{xg_dev, whh_packed_dev, y_dev, lengths_dev, hn_dev, cn_dev, h0_dev, c0_dev, B, T, H, ndir, (int)ldy, yoff};
+    LstmArgs a{xg_dev, whh_packed_dev, y_dev, lengths_dev, hn_dev, cn_dev, h0_dev, c0_dev, B, T, H, ndir, (int)ldy, yoff, gates_dev, c_dev};
     const int threads = (int)round_up(H, 64);
     const int bt = B * ndir > 512 ? 2 : 1;
     dim3 grid((unsigned)ceil_div(B, bt), (unsigned)ndir);

@@ -1,0 +1,96 @@
+"""Native training path of the mel-decoder LSTMs (SURVEY.md §8 rows a5/a6 inside a9).
+
+The reference trains `Languasito2` / `CubenetTextcoder` through torch.nn.LSTM (cube/networks/modules.py:873-905,
+textcoder.py:55-92), which on ROCm is MIOpen's per-time-step kernel chain: ~8 000 launches per Cubegan step at the GAN
+crop sizes.  Here one layer (both directions) is one `torch.autograd.Function`:
+
+  forward   ttsc_linear_forward            x W_ih^T + (b_ih + b_hh) for all steps (fp32 MFMA GEMM)
+            ttsc_lstm_seq_forward_train    persistent recurrence kernel, saves gates + cell states
+  backward  ttsc_lstm_seq_backward         persistent backward-through-time kernel -> gate gradients of all steps
+            three library GEMMs            dx = dG W_ih,  dW_ih = dG^T x,  dW_hh = dG^T h_prev   (+ column sums for the biases)
+
+W_hh is re-packed on the device every step (`ttsc_lstm_pack_whh_device`, forward and transposed layouts)."""
+import torch
+
+from .. import _lib
+from ..hip_layers import linear_hip
+
+
+def _pack(whh, transpose):
+    nd, H4, H = whh.shape
+    out = torch.empty(nd * H4 * H, dtype=torch.float32, device=whh.device)
+    with torch.cuda.device(whh.device):
+        _lib.check(_lib.lib().ttsc_lstm_pack_whh_device(_lib.dev_ptr(whh), nd, H, int(transpose), _lib.dev_ptr(out),
+                                                        _lib.current_stream()), 'ttsc_lstm_pack_whh_device')
+    return out
+
+
+class HipLSTMLayerFn(torch.autograd.Function):
+    """One (bi)directional LSTM layer over a padded batch: x [B,T,in] -> y [B,T,ndir*H].
+    params = (w_ih, w_hh, b_ih, b_hh) per direction, torch.nn.LSTM layout (gate order i,f,g,o)."""
+
+    @staticmethod
+    def forward(ctx, x, nd, *params):
+        x = x.contiguous().float()
+        B, T, _ = x.shape
+        w_ih = [params[4 * d].detach() for d in range(nd)]
+        w_hh = [params[4 * d + 1].detach() for d in range(nd)]
+        bias = torch.cat([params[4 * d + 2].detach() + params[4 * d + 3].detach() for d in range(nd)])
+        H = w_hh[0].shape[1]
+        wih = torch.cat(w_ih, dim=0).contiguous()                      # [nd*4H, in]
+        whh = torch.stack(w_hh, dim=0).contiguous()                    # [nd, 4H, H]
+        xg = linear_hip(x, wih, bias)                                  # [B, T, nd*4H]
+        y = torch.empty((B, T, nd * H), dtype=torch.float32, device=x.device)
+        gates = torch.empty((B, T, nd * 4 * H), dtype=torch.float32, device=x.device)
+        cst = torch.empty((B, T, nd * H), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ttsc_lstm_seq_forward_train(_lib.dev_ptr(xg), _lib.dev_ptr(_pack(whh, False)), _lib.dev_ptr(y), None,
+                                                              B, T, H, nd, nd * H, 0, _lib.dev_ptr(gates), _lib.dev_ptr(cst),
+                                                              _lib.current_stream()), 'ttsc_lstm_seq_forward_train')
+        ctx.save_for_backward(x, wih, whh, gates, cst, y)
+        ctx.nd, ctx.H = nd, H
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wih, whh, gates, cst, y = ctx.saved_tensors
+        nd, H = ctx.nd, ctx.H
+        B, T, _ = x.shape
+        dy = dy.contiguous()
+        dG = torch.empty_like(gates)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ttsc_lstm_seq_backward(_lib.dev_ptr(dy), _lib.dev_ptr(gates), _lib.dev_ptr(cst),
+                                                         _lib.dev_ptr(_pack(whh, True)), _lib.dev_ptr(dG), None, B, T, H, nd, nd * H, 0,
+                                                         _lib.current_stream()), 'ttsc_lstm_seq_backward')
+        dG2 = dG.reshape(B * T, nd * 4 * H)
+        dx = (dG2 @ wih).reshape(x.shape) if ctx.needs_input_grad[0] else None
+        dwih = dG2.t() @ x.reshape(B * T, -1)                          # [nd*4H, in]
+        db = dG2.sum(dim=0)
+        grads = []
+        for d in range(nd):
+            sl = slice(d * 4 * H, (d + 1) * 4 * H)
+            hy = y[:, :, d * H:(d + 1) * H]
+            hprev = torch.zeros_like(hy)
+            if d == 0:
+                hprev[:, 1:] = hy[:, :-1]          # forward direction: h_{t-1}
+            else:
+                hprev[:, :-1] = hy[:, 1:]          # reverse direction: the previous step is t+1
+            dwhh = dG2[:, sl].t() @ hprev.reshape(B * T, H)
+            grads += [dwih[sl], dwhh, db[sl], db[sl]]
+        return (dx, None) + tuple(grads)
+
+
+def lstm_forward_train(m, x):
+    """Differentiable forward of a torch.nn.LSTM parameter set `m` (batch_first, zero initial state) on the HIP kernels."""
+    if not x.is_cuda:
+        raise _lib.TTSCError('LSTM training needs a HIP device; no CPU path')
+    nd = 2 if m.bidirectional else 1
+    assert m.batch_first and float(m.dropout) == 0.0
+    h = x
+    for l in range(m.num_layers):
+        ps = []
+        for sfx in ['', '_reverse'][:nd]:
+            ps += [getattr(m, 'weight_ih_l%d%s' % (l, sfx)), getattr(m, 'weight_hh_l%d%s' % (l, sfx)),
+                   getattr(m, 'bias_ih_l%d%s' % (l, sfx)), getattr(m, 'bias_hh_l%d%s' % (l, sfx))]
+        h = HipLSTMLayerFn.apply(h, nd, *ps)
+    return h

@@ -62,6 +62,7 @@ import torch.nn.functional as F
 
 from ..hifigan.models import ResBlock1
 from ..hifigan.autograd import generator_forward_with_grad
+from .lstm_autograd import lstm_forward_train
 
 
 def _wn(l):
@@ -109,7 +110,7 @@ def languasito_forward_train(lang, X):
         h = getattr(lang, '_phon_emb_' + which)(x_char).permute(0, 2, 1)
         for layer in getattr(lang, '_char_cnn_' + which):
             h = torch.tanh(F.conv1d(h, layer.conv.weight, layer.conv.bias, padding=1)) if hasattr(layer, 'conv') else h
-        h, _ = getattr(lang, '_char_rnn_' + which)(h.permute(0, 2, 1))
+        h = lstm_forward_train(getattr(lang, '_char_rnn_' + which), h.permute(0, 2, 1))
         spk = getattr(lang, '_speaker_emb_' + which)(x_speaker)
         return torch.cat([h, spk.repeat(1, h.shape[1], 1)], dim=-1)
 
@@ -122,14 +123,14 @@ def languasito_forward_train(lang, X):
         return torch.gather(x, 1, idx.to(x.device)[:, :, None].expand(-1, -1, x.shape[2]))
 
     hcs = stack('t')
-    hd, _ = lang._dur_rnn(hcs)
+    hd = lstm_forward_train(lang._dur_rnn, hcs)
     out_dur = F.linear(hd, lang._dur_output.linear_layer.weight, lang._dur_output.linear_layer.bias)
-    hp, _ = lang._pitch_rnn(expand(hcs, X['y_frame2phone']))
+    hp = lstm_forward_train(lang._pitch_rnn, expand(hcs, X['y_frame2phone']))
     op = F.linear(hp, lang._pitch_output.linear_layer.weight, lang._pitch_output.linear_layer.bias)
     g = expand(stack('g'), X['y_frame2phone'])
     pitch = X['y_pitch'].to(dev).float().unsqueeze(2) / lang._max_pitch
     m = min(g.shape[1], pitch.shape[1])
-    g, _ = lang._cond_rnn(torch.cat([g[:, :m], pitch[:, :m]], dim=-1))
+    g = lstm_forward_train(lang._cond_rnn, torch.cat([g[:, :m], pitch[:, :m]], dim=-1))
     cond = F.linear(g, lang._cond_output.linear_layer.weight, lang._cond_output.linear_layer.bias)
     return out_dur, torch.sigmoid(op[:, :, 0]), torch.sigmoid(op[:, :, 1]), cond
 
