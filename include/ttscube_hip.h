@@ -264,6 +264,17 @@ int ttsc_lstm_seq_forward_train(const float* xg_dev, const float* whh_packed_dev
 int ttsc_lstm_seq_backward(const float* dy_dev, const float* gates_dev, const float* c_dev, const float* whhT_packed_dev,
                            float* dgates_dev, const int32_t* lengths_dev, int32_t B, int32_t T, int32_t H, int32_t ndir,
                            int64_t ldy, int32_t yoff, void* stream);
+/* Training of the WaveRNN vocoder (`WaveRNN._train_forward` cube/networks/modules.py:505-539 + `training_step` 553-563: torch.nn.GRU
+ * over the teacher-forced sequence, differentiated by torch autograd).  Gate order r,z,n; one layer, unidirectional:
+ *   ttsc_gru_pack_whh_device  weight_hh [3H,H] (device) -> out_dev [3H*H]: forward (transpose=0) / backward (transpose=1) packing
+ *   ttsc_gru_seq_forward      xg = W_ih x + b_ih [B,T,3H] -> y [B,T,H]; saved_dev [B,T,4H] (r,z,n,W_hn h + b_hn) or NULL (inference)
+ *   ttsc_gru_seq_backward     dy [B,T,H] -> dgi [B,T,3H] (grad wrt W_ih x + b_ih), dgh [B,T,3H] (grad wrt W_hh h + b_hh);
+ *                             the caller finishes with GEMMs: dx = dgi W_ih, dW_ih = dgi^T x, dW_hh = dgh^T h_prev, biases = sums */
+int ttsc_gru_pack_whh_device(const float* whh_dev, int32_t H, int32_t transpose, float* out_dev, void* stream);
+int ttsc_gru_seq_forward(const float* xg_dev, const float* whh_packed_dev, const float* bhh_dev, float* y_dev, float* saved_dev,
+                         const float* h0_dev, int32_t B, int32_t T, int32_t H, void* stream);
+int ttsc_gru_seq_backward(const float* dy_dev, const float* saved_dev, const float* y_dev, const float* h0_dev,
+                          const float* whhT_packed_dev, float* dgi_dev, float* dgh_dev, int32_t B, int32_t T, int32_t H, void* stream);
 /* frees a device buffer returned by a ttsc_*_pack_* function */
 void ttsc_device_free(void* p);
 

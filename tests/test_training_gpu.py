@@ -229,3 +229,22 @@ def test_hip_lstm_autograd_matches_torch(cfg):
     assert _rel(y1, y0) < 1e-5
     for a_, b_, p in zip(g1, g0, [x] + params):
         assert a_.shape == b_.shape and _rel(a_, b_) < 1e-4, (tuple(p.shape), _rel(a_, b_))
+
+
+@pytest.mark.parametrize('cfg', [(64, 102, 3, 50), (512, 81, 2, 33), (128, 7, 1, 300)])
+def test_hip_gru_autograd_matches_torch(cfg):
+    """forward + backward-through-time GRU kernels vs torch.nn.GRU autograd (same parameters)."""
+    from ttscube_amd.networks.gru_autograd import gru_forward_train
+    H, nin, B, T = cfg
+    torch.manual_seed(4)
+    m = torch.nn.GRU(nin, H, num_layers=1, batch_first=True).cuda()
+    x = torch.randn(B, T, nin, device='cuda', requires_grad=True)
+    gy = torch.randn(B, T, H, device='cuda')
+    params = list(m.parameters())
+    y0, _ = m(x)
+    g0 = torch.autograd.grad(y0, [x] + params, gy)
+    y1 = gru_forward_train(m, x)
+    g1 = torch.autograd.grad(y1, [x] + params, gy)
+    assert _rel(y1, y0) < 1e-5
+    for a_, b_, p in zip(g1, g0, [x] + params):
+        assert a_.shape == b_.shape and _rel(a_, b_) < 1e-4, (tuple(p.shape), _rel(a_, b_))

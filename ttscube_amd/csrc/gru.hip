@@ -1,0 +1,207 @@
+// GRU sequence recurrence + backward through time for TRAINING the WaveRNN vocoder (SURVEY.md §8 row a9:
+// `WaveRNN._train_forward` cube/networks/modules.py:505-539 runs torch.nn.GRU over the whole teacher-forced sequence,
+// 24 000 steps per utterance; `training_step` 553-563 differentiates it) — gfx950.
+//
+// torch.nn.GRU semantics (gate order r,z,n):  r = s(xr + W_hr h + b_hr), z = s(xz + W_hz h + b_hz),
+// n = tanh(xn + r * (W_hn h + b_hn)), h' = (1 - z) * n + z * h, with x* = W_i* x + b_i* hoisted into one GEMM for all steps.
+// Same shape as lstm.hip: one persistent workgroup per utterance, thread j owns hidden unit j (its three gate rows are
+// streamed from L2 as 16-byte packed loads, h lives in LDS double-buffered), one barrier per step.  The training forward
+// saves r, z, n and the linear part hn = W_hn h + b_hn; the backward kernel walks the steps in reverse, publishes the three
+// hidden-side gate gradients in LDS and evaluates its own dh_prev[k] = z*dh + sum_r W_hh[r,k] * dGh[r] as one chain over
+// 3H rows of the transposed packing.  Weight / input gradients are plain GEMMs over the saved per-step gate gradients.
+#include <algorithm>
+
+#include "common.hpp"
+#include "../../include/ttscube_math.h"
+#include "rnn_chain.hpp"
+
+namespace ttsc {
+
+struct GruArgs {
+    const float* xg;     // [B, T, 3H]   W_ih x + b_ih
+    const float* whh;    // [H/4][3H][4]
+    const float* bhh;    // [3H]
+    float* y;            // [B, T, H]
+    float* saved;        // [B, T, 4H]   r, z, n, hn  (training) or null
+    const float* h_0;    // [B, H] or null
+    int B, T, H;
+};
+
+__global__ __launch_bounds__(512) void gru_seq_kernel(GruArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // h[2][H]
+    const int H = a.H, H3 = 3 * H;
+    const int j = threadIdx.x;
+    const bool unit = j < H;
+    const int b = blockIdx.x;
+    if (unit) sm[j] = a.h_0 ? a.h_0[(size_t)b * H + j] : 0.f;
+    float br = 0.f, bz = 0.f, bn = 0.f;
+    if (unit) {
+        br = a.bhh[j];
+        bz = a.bhh[H + j];
+        bn = a.bhh[2 * H + j];
+    }
+    __syncthreads();
+    int cur = 0;
+    const float* xb = a.xg + (size_t)b * a.T * H3 + j;
+    float xr = 0.f, xz = 0.f, xn = 0.f;
+    if (unit) {
+        xr = xb[0];
+        xz = xb[H];
+        xn = xb[2 * H];
+    }
+    for (int t = 0; t < a.T; ++t) {
+        const float* hc = sm + cur * H;
+        float* hn = sm + (cur ^ 1) * H;
+        if (unit) {
+            float acc[1][3] = {{br, bz, bn}};
+            const float cxr = xr, cxz = xz, cxn = xn;
+            if (t + 1 < a.T) {   // next step's input projection, in flight during the chain
+                const float* xp = xb + (size_t)(t + 1) * H3;
+                xr = xp[0];
+                xz = xp[H];
+                xn = xp[2 * H];
+            }
+            lstm_chain<1, 3, 2>(acc, a.whh, H3, H, j, hc, H, H);
+            const float r = ttsc_sigmoidf(cxr + acc[0][0]);
+            const float z = ttsc_sigmoidf(cxz + acc[0][1]);
+            const float n = ttsc_tanhf(fmaf(r, acc[0][2], cxn));
+            const float hv = fmaf(z, hc[j] - n, n);   // (1 - z) * n + z * h
+            hn[j] = hv;
+            a.y[((size_t)b * a.T + t) * H + j] = hv;
+            if (a.saved) {
+                float* sp = a.saved + ((size_t)b * a.T + t) * (4 * (size_t)H) + j;
+                sp[0] = r;
+                sp[H] = z;
+                sp[2 * H] = n;
+                sp[3 * H] = acc[0][2];
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+struct GruBwdArgs {
+    const float* dy;      // [B, T, H]
+    const float* saved;   // [B, T, 4H]
+    const float* y;       // [B, T, H]  (h_t; h_{-1} = h_0 or zero)
+    const float* h_0;     // [B, H] or null
+    const float* whhT;    // [3H/4][H][4]
+    float* dgi;           // [B, T, 3H]  gradient wrt (W_ih x + b_ih):  dr_pre, dz_pre, dn_pre
+    float* dgh;           // [B, T, 3H]  gradient wrt (W_hh h + b_hh):  dr_pre, dz_pre, dn_pre * r
+    int B, T, H;
+};
+
+__global__ __launch_bounds__(512) void gru_bwd_kernel(GruBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // dGh[3H]
+    const int H = a.H, H3 = 3 * H;
+    const int j = threadIdx.x;
+    const bool unit = j < H;
+    const int b = blockIdx.x;
+    const float* sb = a.saved + (size_t)b * a.T * (4 * (size_t)H) + j;
+    const float* yb = a.y + (size_t)b * a.T * H + j;
+    const float* dyb = a.dy + (size_t)b * a.T * H + j;
+    float* gib = a.dgi + (size_t)b * a.T * H3 + j;
+    float* ghb = a.dgh + (size_t)b * a.T * H3 + j;
+    const float h0 = (unit && a.h_0) ? a.h_0[(size_t)b * H + j] : 0.f;
+    float dh_rec = 0.f;
+    float r = 0.f, z = 0.f, n = 0.f, hl = 0.f, hp = 0.f, dyv = 0.f;
+    auto fetch = [&](int t) __attribute__((always_inline)) {
+        const float* s = sb + (size_t)t * (4 * (size_t)H);
+        r = s[0];
+        z = s[H];
+        n = s[2 * H];
+        hl = s[3 * H];
+        hp = t > 0 ? yb[(size_t)(t - 1) * H] : h0;
+        dyv = dyb[(size_t)t * H];
+    };
+    if (unit) fetch(a.T - 1);
+    for (int t = a.T - 1; t >= 0; --t) {
+        float dh_direct = 0.f;
+        if (unit) {
+            const float dh = dyv + dh_rec;
+            const float dn_pre = dh * (1.f - z) * (1.f - n * n);
+            const float dz_pre = dh * (hp - n) * z * (1.f - z);
+            const float dr_pre = dn_pre * hl * r * (1.f - r);
+            const float dhn = dn_pre * r;
+            dh_direct = dh * z;
+            float* gi = gib + (size_t)t * H3;
+            gi[0] = dr_pre;
+            gi[H] = dz_pre;
+            gi[2 * H] = dn_pre;
+            float* gh = ghb + (size_t)t * H3;
+            gh[0] = dr_pre;
+            gh[H] = dz_pre;
+            gh[2 * H] = dhn;
+            sm[j] = dr_pre;
+            sm[H + j] = dz_pre;
+            sm[2 * H + j] = dhn;
+        }
+        __syncthreads();
+        if (unit) {
+            if (t > 0) fetch(t - 1);
+            float acc[1][1] = {{dh_direct}};
+            lstm_chain<1, 1, 4>(acc, a.whhT, H, 0, j, sm, H3, H3);
+            dh_rec = acc[0][0];
+        }
+        __syncthreads();
+    }
+}
+
+// weight_hh [3H][H] (device) -> forward pack [H/4][3H][4] (transpose = 0) or transposed pack [3H/4][H][4] (transpose = 1)
+__global__ void gru_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int H, int transpose) {
+    const long total = (long)3 * H * H;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(i & 3);
+        const long t = i >> 2;
+        float v;
+        if (!transpose) {
+            const int r = (int)(t % (3 * H)), k4 = (int)(t / (3 * H));
+            v = w[(size_t)r * H + 4 * k4 + q];
+        } else {
+            const int k = (int)(t % H), r4 = (int)(t / H);
+            v = w[(size_t)(4 * r4 + q) * H + k];
+        }
+        out[i] = v;
+    }
+}
+
+}  // namespace ttsc
+
+using namespace ttsc;
+
+static int gru_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s launch failed: %s", what, hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    return TTSC_OK;
+}
+
+extern "C" int ttsc_gru_pack_whh_device(const float* whh_dev, int32_t H, int32_t transpose, float* out_dev, void* stream) {
+    TTSC_REQUIRE(whh_dev && out_dev, "ttsc_gru_pack_whh_device: null argument");
+    TTSC_REQUIRE(H >= 4 && H <= 512 && H % 4 == 0, "ttsc_gru_pack_whh_device: need H %% 4 == 0, H <= 512 (got %d)", H);
+    const long total = (long)3 * H * H;
+    hipLaunchKernelGGL(gru_pack_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream, whh_dev, out_dev, H,
+                       transpose);
+    return gru_check_launch("gru_pack_kernel");
+}
+
+extern "C" int ttsc_gru_seq_forward(const float* xg_dev, const float* whh_packed_dev, const float* bhh_dev, float* y_dev, float* saved_dev,
+                                    const float* h0_dev, int32_t B, int32_t T, int32_t H, void* stream) {
+    TTSC_REQUIRE(xg_dev && whh_packed_dev && bhh_dev && y_dev, "ttsc_gru_seq_forward: null argument");
+    TTSC_REQUIRE(B > 0 && T > 0 && H >= 4 && H <= 512 && H % 4 == 0, "ttsc_gru_seq_forward: bad shape B=%d T=%d H=%d", B, T, H);
+    GruArgs a{xg_dev, whh_packed_dev, bhh_dev, y_dev, saved_dev, h0_dev, B, T, H};
+    hipLaunchKernelGGL(gru_seq_kernel, dim3((unsigned)B), dim3((unsigned)round_up(H, 64)), (size_t)2 * H * sizeof(float), (hipStream_t)stream, a);
+    return gru_check_launch("gru_seq_kernel");
+}
+
+extern "C" int ttsc_gru_seq_backward(const float* dy_dev, const float* saved_dev, const float* y_dev, const float* h0_dev,
+                                     const float* whhT_packed_dev, float* dgi_dev, float* dgh_dev, int32_t B, int32_t T, int32_t H, void* stream) {
+    TTSC_REQUIRE(dy_dev && saved_dev && y_dev && whhT_packed_dev && dgi_dev && dgh_dev, "ttsc_gru_seq_backward: null argument");
+    TTSC_REQUIRE(B > 0 && T > 0 && H >= 4 && H <= 512 && H % 4 == 0, "ttsc_gru_seq_backward: bad shape B=%d T=%d H=%d", B, T, H);
+    GruBwdArgs a{dy_dev, saved_dev, y_dev, h0_dev, whhT_packed_dev, dgi_dev, dgh_dev, B, T, H};
+    hipLaunchKernelGGL(gru_bwd_kernel, dim3((unsigned)B), dim3((unsigned)round_up(H, 64)), (size_t)3 * H * sizeof(float), (hipStream_t)stream, a);
+    return gru_check_launch("gru_bwd_kernel");
+}

@@ -1,0 +1,73 @@
+// Shared matvec chain of the persistent recurrent kernels (lstm.hip, gru.hip): thread `row` accumulates NG gate rows over K
+// inputs from a weight matrix packed [K/4][rows][4] (one 16-byte load per row per 4 inputs), for BT input vectors in LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ttsc {
+
+template <int BT, int NG, int UN>
+__device__ __forceinline__ void lstm_chain(float (&acc)[BT][NG], const float* __restrict__ wp, int rows, int gstride, int row,
+                                             const float* v, int vstride, int K) {
+    // Weight stream with EXPLICIT software pipelining: the 16-byte loads of a whole batch (UN k-blocks x NG rows) are
+    // issued back to back into one register set while the fmaf chain consumes the other set.  Left to itself hipcc
+    // places each load right before its use and waits vmcnt(0) per load, i.e. one L2 round trip per 16 bytes.
+    // The chain order (k ascending, one fmaf per term) is unchanged.
+    const float4* w4 = reinterpret_cast<const float4*>(wp) + row;
+    const int KB = K >> 2;
+    auto load = [&](float4 (&w)[UN][NG], int kb0) {
+#pragma unroll
+        for (int q = 0; q < UN; ++q)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) w[q][g] = w4[(size_t)(kb0 + q) * rows + g * gstride];
+    };
+    auto fma_batch = [&](const float4 (&w)[UN][NG], int kb0) {
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+#pragma unroll
+            for (int u = 0; u < BT; ++u) {
+                const float4 hv = *reinterpret_cast<const float4*>(v + u * vstride + 4 * (kb0 + q));
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    float x = acc[u][g];
+                    x = fmaf(w[q][g].x, hv.x, x);
+                    x = fmaf(w[q][g].y, hv.y, x);
+                    x = fmaf(w[q][g].z, hv.z, x);
+                    x = fmaf(w[q][g].w, hv.w, x);
+                    acc[u][g] = x;
+                }
+            }
+        }
+    };
+    if (KB % UN == 0) {
+        float4 wa[UN][NG], wb[UN][NG];
+        const int NB = KB / UN;
+        load(wa, 0);
+        for (int bi = 0; bi < NB; bi += 2) {
+            if (bi + 1 < NB) load(wb, (bi + 1) * UN);
+            fma_batch(wa, bi * UN);
+            if (bi + 2 < NB) load(wa, (bi + 2) * UN);
+            if (bi + 1 < NB) fma_batch(wb, (bi + 1) * UN);
+        }
+    } else {
+        for (int kb = 0; kb < KB; ++kb) {
+            float4 w[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) w[g] = w4[(size_t)kb * rows + g * gstride];
+#pragma unroll
+            for (int u = 0; u < BT; ++u) {
+                const float4 hv = *reinterpret_cast<const float4*>(v + u * vstride + 4 * kb);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    float x = acc[u][g];
+                    x = fmaf(w[g].x, hv.x, x);
+                    x = fmaf(w[g].y, hv.y, x);
+                    x = fmaf(w[g].z, hv.z, x);
+                    x = fmaf(w[g].w, hv.w, x);
+                    acc[u][g] = x;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace ttsc

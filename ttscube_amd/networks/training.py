@@ -63,6 +63,7 @@ import torch.nn.functional as F
 from ..hifigan.models import ResBlock1
 from ..hifigan.autograd import generator_forward_with_grad
 from .lstm_autograd import lstm_forward_train
+from .gru_autograd import gru_forward_train
 
 
 def _wn(l):
@@ -246,7 +247,8 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
 
 
 def wavernn_logits_train(net, X):
-    """Differentiable WaveRNN._train_forward (modules.py:505-539) on torch-ROCm ops (full-sequence nn.GRU)."""
+    """Differentiable WaveRNN._train_forward (modules.py:505-539): the GRU(s) run on the persistent HIP forward / backward
+    kernels (gru_autograd.py); conditioning build and the two output Linears are torch-ROCm ops."""
     mel, gs_x = X['mel'], X['x']
     up = mel.repeat_interleave(net._upsample, dim=1)
     if net._use_lowres:
@@ -262,7 +264,7 @@ def wavernn_logits_train(net, X):
         m = min(up.shape[1], gs_x.shape[1])
         hidden = torch.cat([up[:, :m], gs_x[:, :m].unsqueeze(2)], dim=-1)
     for rnn in net._rnns:
-        hidden, _ = rnn(hidden)
+        hidden = gru_forward_train(rnn, hidden)
     pre = torch.tanh(F.linear(hidden, net._preoutput.linear_layer.weight, net._preoutput.linear_layer.bias))
     return F.linear(pre, net._output.linear_layer.weight, net._output.linear_layer.bias)
 
