@@ -270,6 +270,10 @@ int ttsc_lstm_seq_backward(const float* dy_dev, const float* gates_dev, const fl
  *   ttsc_gru_seq_forward      xg = W_ih x + b_ih [B,T,3H] -> y [B,T,H]; saved_dev [B,T,4H] (r,z,n,W_hn h + b_hn) or NULL (inference)
  *   ttsc_gru_seq_backward     dy [B,T,H] -> dgi [B,T,3H] (grad wrt W_ih x + b_ih), dgh [B,T,3H] (grad wrt W_hh h + b_hh);
  *                             the caller finishes with GEMMs: dx = dgi W_ih, dW_ih = dgi^T x, dW_hh = dgh^T h_prev, biases = sums */
+/* With few utterances (B * G <= number of CUs) both recurrences split every utterance over G workgroups (env TTSC_GRU_SPLIT caps
+ * G, default 8, 1 = off) that exchange the state through y / dgh once per step; launches of one process must then be
+ * stream-ordered (shared hand-off counters).  ttsc_gru_split_status: 0 = all hand-offs of the last launch completed. */
+int32_t ttsc_gru_split_status(void);
 int ttsc_gru_pack_whh_device(const float* whh_dev, int32_t H, int32_t transpose, float* out_dev, void* stream);
 int ttsc_gru_seq_forward(const float* xg_dev, const float* whh_packed_dev, const float* bhh_dev, float* y_dev, float* saved_dev,
                          const float* h0_dev, int32_t B, int32_t T, int32_t H, void* stream);

@@ -231,10 +231,12 @@ def test_hip_lstm_autograd_matches_torch(cfg):
         assert a_.shape == b_.shape and _rel(a_, b_) < 1e-4, (tuple(p.shape), _rel(a_, b_))
 
 
-@pytest.mark.parametrize('cfg', [(64, 102, 3, 50), (512, 81, 2, 33), (128, 7, 1, 300)])
+@pytest.mark.parametrize('cfg', [(64, 102, 3, 50), (512, 81, 2, 33), (128, 7, 1, 300), (512, 102, 16, 40), (256, 20, 300, 5)])
 def test_hip_gru_autograd_matches_torch(cfg):
-    """forward + backward-through-time GRU kernels vs torch.nn.GRU autograd (same parameters)."""
+    """forward + backward-through-time GRU kernels vs torch.nn.GRU autograd (same parameters): single-workgroup kernels
+    (H=64, or B=300 > CUs / 2) and the split kernels (2..8 workgroups per utterance exchanging the state every step)."""
     from ttscube_amd.networks.gru_autograd import gru_forward_train
+    from ttscube_amd import _lib
     H, nin, B, T = cfg
     torch.manual_seed(4)
     m = torch.nn.GRU(nin, H, num_layers=1, batch_first=True).cuda()
@@ -244,7 +246,9 @@ def test_hip_gru_autograd_matches_torch(cfg):
     y0, _ = m(x)
     g0 = torch.autograd.grad(y0, [x] + params, gy)
     y1 = gru_forward_train(m, x)
+    assert _lib.lib().ttsc_gru_split_status() == 0
     g1 = torch.autograd.grad(y1, [x] + params, gy)
+    assert _lib.lib().ttsc_gru_split_status() == 0
     assert _rel(y1, y0) < 1e-5
     for a_, b_, p in zip(g1, g0, [x] + params):
         assert a_.shape == b_.shape and _rel(a_, b_) < 1e-4, (tuple(p.shape), _rel(a_, b_))

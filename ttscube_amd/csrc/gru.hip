@@ -148,6 +148,177 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(GruBwdArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Split recurrence: G workgroups ("members") per utterance.  With B = 16 utterances the kernels above keep 16 of the 256
+// CUs busy, each bound by ONE CU's L2 load path (3 MB of W_hh per step ~ 20 us).  Here member m owns H/G hidden units and
+// streams only its 1/G of the rows; the 512 threads of a member are (unit u, k-slice ks) pairs whose partial sums meet in
+// LDS.  Per step the members exchange the full state through the output tensors themselves (y for the forward, dgh for the
+// backward: write-through agent-scope stores, one monotonic counter per utterance, bounded spins with a shared abort word —
+// the hand-off protocol of wavernn_cluster.hip).  All G*B workgroups must be co-resident: the host only takes this path
+// when G*B <= number of CUs.
+typedef unsigned long long u64_t;
+__device__ __forceinline__ void g_st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float g_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+constexpr unsigned GS_SPIN_LIMIT = 1u << 22;
+
+__device__ __forceinline__ bool g_wait(unsigned* cnt, unsigned want, unsigned* abort_word, int* ok_s) {
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        unsigned spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            if (++spins > GS_SPIN_LIMIT || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        *ok_s = ok;
+    }
+    __syncthreads();
+    return *ok_s != 0;
+}
+__device__ __forceinline__ void g_publish(unsigned* cnt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct GruSplitArgs {
+    GruArgs f;
+    GruBwdArgs bw;
+    unsigned* cnt;     // [B] monotonic counters (zeroed by the host before the launch)
+    unsigned* abort_word;
+    int G, HU, KS;     // members per utterance, units per member, k-slices per unit (HU * KS = 512 threads)
+};
+
+__global__ __launch_bounds__(512) void gru_seq_split_kernel(GruSplitArgs s) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // h[H] | part[KS][3][HU]
+    __shared__ int ok_s;
+    const GruArgs& a = s.f;
+    const int H = a.H, H3 = 3 * H, HU = s.HU, KS = s.KS;
+    const int tid = threadIdx.x, u = tid % HU, ks = tid / HU;
+    const int m = blockIdx.x, b = blockIdx.y;
+    const int j = m * HU + u;                 // hidden unit of this thread
+    const int KL = H / KS;                    // inputs per k-slice
+    float* hs = sm;
+    float* part = sm + H;
+    unsigned* cnt = s.cnt + b;
+    const bool owner = ks == 0;
+    float br = 0.f, bz = 0.f, bn = 0.f;
+    if (owner) {
+        br = a.bhh[j];
+        bz = a.bhh[H + j];
+        bn = a.bhh[2 * H + j];
+    }
+    const float* xb = a.xg + (size_t)b * a.T * H3 + j;
+    float* yb = a.y + (size_t)b * a.T * H;
+    for (int t = 0; t < a.T; ++t) {
+        float xr = 0.f, xz = 0.f, xn = 0.f;
+        if (owner) {   // issued before the wait: in flight while the other members finish step t-1
+            const float* xp = xb + (size_t)t * H3;
+            xr = xp[0];
+            xz = xp[H];
+            xn = xp[2 * H];
+        }
+        if (t > 0) {
+            if (!g_wait(cnt, (unsigned)t * (unsigned)s.G, s.abort_word, &ok_s)) return;
+            for (int i = tid; i < H; i += 512) hs[i] = g_ld(yb + (size_t)(t - 1) * H + i);
+        } else {
+            for (int i = tid; i < H; i += 512) hs[i] = a.h_0 ? a.h_0[(size_t)b * H + i] : 0.f;
+        }
+        __syncthreads();
+        float acc[1][3] = {{0.f, 0.f, 0.f}};
+        lstm_chain<1, 3, 2>(acc, a.whh + (size_t)(ks * KL / 4) * H3 * 4, H3, H, j, hs + ks * KL, H, KL);
+        part[(ks * 3 + 0) * HU + u] = acc[0][0];
+        part[(ks * 3 + 1) * HU + u] = acc[0][1];
+        part[(ks * 3 + 2) * HU + u] = acc[0][2];
+        __syncthreads();
+        if (owner) {
+            float hr = br, hz = bz, hl = bn;
+            for (int q = 0; q < KS; ++q) {
+                hr += part[(q * 3 + 0) * HU + u];
+                hz += part[(q * 3 + 1) * HU + u];
+                hl += part[(q * 3 + 2) * HU + u];
+            }
+            const float r = ttsc_sigmoidf(xr + hr);
+            const float z = ttsc_sigmoidf(xz + hz);
+            const float n = ttsc_tanhf(fmaf(r, hl, xn));
+            const float hv = fmaf(z, hs[j] - n, n);
+            g_st(yb + (size_t)t * H + j, hv);
+            if (a.saved) {
+                float* sp = a.saved + ((size_t)b * a.T + t) * (4 * (size_t)H) + j;
+                sp[0] = r;
+                sp[H] = z;
+                sp[2 * H] = n;
+                sp[3 * H] = hl;
+            }
+        }
+        g_publish(cnt);
+    }
+}
+
+__global__ __launch_bounds__(512) void gru_bwd_split_kernel(GruSplitArgs s) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // dGh[3H] | part[KS][HU]
+    __shared__ int ok_s;
+    const GruBwdArgs& a = s.bw;
+    const int H = a.H, H3 = 3 * H, HU = s.HU, KS = s.KS;
+    const int tid = threadIdx.x, u = tid % HU, ks = tid / HU;
+    const int m = blockIdx.x, b = blockIdx.y;
+    const int j = m * HU + u;
+    const int KL = H3 / KS;
+    float* dg = sm;
+    float* part = sm + H3;
+    unsigned* cnt = s.cnt + b;
+    const bool owner = ks == 0;
+    const float* sb = a.saved + (size_t)b * a.T * (4 * (size_t)H) + j;
+    const float* yb = a.y + (size_t)b * a.T * H + j;
+    const float* dyb = a.dy + (size_t)b * a.T * H + j;
+    float* gib = a.dgi + (size_t)b * a.T * H3;
+    float* ghb = a.dgh + (size_t)b * a.T * H3;
+    const float h0 = (owner && a.h_0) ? a.h_0[(size_t)b * H + j] : 0.f;
+    float dh_rec = 0.f;
+    unsigned step = 0;
+    for (int t = a.T - 1; t >= 0; --t) {
+        float dh_direct = 0.f;
+        if (owner) {
+            const float* sv = sb + (size_t)t * (4 * (size_t)H);
+            const float r = sv[0], z = sv[H], n = sv[2 * H], hl = sv[3 * H];
+            const float hp = t > 0 ? yb[(size_t)(t - 1) * H] : h0;
+            const float dh = dyb[(size_t)t * H] + dh_rec;
+            const float dn_pre = dh * (1.f - z) * (1.f - n * n);
+            const float dz_pre = dh * (hp - n) * z * (1.f - z);
+            const float dr_pre = dn_pre * hl * r * (1.f - r);
+            dh_direct = dh * z;
+            float* gi = gib + (size_t)t * H3 + j;
+            gi[0] = dr_pre;
+            gi[H] = dz_pre;
+            gi[2 * H] = dn_pre;
+            float* gh = ghb + (size_t)t * H3 + j;
+            g_st(gh, dr_pre);
+            g_st(gh + H, dz_pre);
+            g_st(gh + 2 * H, dn_pre * r);
+        }
+        g_publish(cnt);
+        ++step;
+        if (t == 0) break;   // dh_{-1} is not needed
+        if (!g_wait(cnt, step * (unsigned)s.G, s.abort_word, &ok_s)) return;
+        for (int i = tid; i < H3; i += 512) dg[i] = g_ld(ghb + (size_t)t * H3 + i);
+        __syncthreads();
+        float acc[1][1] = {{0.f}};
+        lstm_chain<1, 1, 4>(acc, a.whhT + (size_t)(ks * KL / 4) * H * 4, H, 0, j, dg + ks * KL, H3, KL);
+        part[ks * HU + u] = acc[0][0];
+        __syncthreads();
+        if (owner) {
+            float v = dh_direct;
+            for (int q = 0; q < KS; ++q) v += part[q * HU + u];
+            dh_rec = v;
+        }
+        __syncthreads();   // part / dg are rewritten in the next step
+    }
+}
+
 // weight_hh [3H][H] (device) -> forward pack [H/4][3H][4] (transpose = 0) or transposed pack [3H/4][H][4] (transpose = 1)
 __global__ void gru_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int H, int transpose) {
     const long total = (long)3 * H * H;
@@ -179,6 +350,47 @@ static int gru_check_launch(const char* what) {
     return TTSC_OK;
 }
 
+
+// members per utterance for the split kernels: power of two, units per member >= 32, all workgroups co-resident
+static int gru_split_members(int B, int H) {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess)
+            cus = 0;
+        else
+            cus = p.multiProcessorCount;
+    }
+    int gmax = 8;
+    if (const char* ev = getenv("TTSC_GRU_SPLIT")) gmax = atoi(ev);
+    int G = 1;
+    while (G * 2 <= gmax && (long)G * 2 * B <= cus && H % (G * 2) == 0 && H / (G * 2) >= 32 && 512 % (H / (G * 2)) == 0) {
+        const int HU = H / (G * 2), KS = 512 / HU;
+        if (H % KS != 0 || (H / KS) % 8 != 0 || (3 * H / KS) % 16 != 0) break;   // chain batches: K slice multiple of 4*UN
+        G *= 2;
+    }
+    return G;
+}
+
+static unsigned* g_gru_words = nullptr;   // [0..4095] per-utterance counters, [4096] abort word
+
+static unsigned* gru_sync_words(int B, hipStream_t s) {
+    if (B > 4096) return nullptr;
+    if (!g_gru_words && hipMalloc((void**)&g_gru_words, 4097 * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemsetAsync(g_gru_words, 0, 4097 * sizeof(unsigned), s) != hipSuccess) return nullptr;
+    return g_gru_words;
+}
+
+// 0 = every hand-off of the most recent split launch completed; 1 = a bounded spin timed out (that launch's results are
+// invalid).  Synchronises the device; meant for tests and debugging.
+extern "C" int32_t ttsc_gru_split_status(void) {
+    if (!g_gru_words) return 0;
+    unsigned v = 0;
+    if (hipMemcpy(&v, g_gru_words + 4096, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int32_t)v;
+}
+
 extern "C" int ttsc_gru_pack_whh_device(const float* whh_dev, int32_t H, int32_t transpose, float* out_dev, void* stream) {
     TTSC_REQUIRE(whh_dev && out_dev, "ttsc_gru_pack_whh_device: null argument");
     TTSC_REQUIRE(H >= 4 && H <= 512 && H % 4 == 0, "ttsc_gru_pack_whh_device: need H %% 4 == 0, H <= 512 (got %d)", H);
@@ -193,6 +405,21 @@ extern "C" int ttsc_gru_seq_forward(const float* xg_dev, const float* whh_packed
     TTSC_REQUIRE(xg_dev && whh_packed_dev && bhh_dev && y_dev, "ttsc_gru_seq_forward: null argument");
     TTSC_REQUIRE(B > 0 && T > 0 && H >= 4 && H <= 512 && H % 4 == 0, "ttsc_gru_seq_forward: bad shape B=%d T=%d H=%d", B, T, H);
     GruArgs a{xg_dev, whh_packed_dev, bhh_dev, y_dev, saved_dev, h0_dev, B, T, H};
+    const int G = gru_split_members(B, H);
+    if (G > 1) {
+        unsigned* words = gru_sync_words(B, (hipStream_t)stream);
+        TTSC_REQUIRE(words, "ttsc_gru_seq_forward: cannot allocate the hand-off counters");
+        GruSplitArgs sa{};
+        sa.f = a;
+        sa.cnt = words;
+        sa.abort_word = words + 4096;
+        sa.G = G;
+        sa.HU = H / G;
+        sa.KS = 512 / sa.HU;
+        const size_t lds = ((size_t)H + (size_t)sa.KS * 3 * sa.HU) * sizeof(float);
+        hipLaunchKernelGGL(gru_seq_split_kernel, dim3((unsigned)G, (unsigned)B), dim3(512), lds, (hipStream_t)stream, sa);
+        return gru_check_launch("gru_seq_split_kernel");
+    }
     hipLaunchKernelGGL(gru_seq_kernel, dim3((unsigned)B), dim3((unsigned)round_up(H, 64)), (size_t)2 * H * sizeof(float), (hipStream_t)stream, a);
     return gru_check_launch("gru_seq_kernel");
 }
@@ -202,6 +429,21 @@ extern "C" int ttsc_gru_seq_backward(const float* dy_dev, const float* saved_dev
     TTSC_REQUIRE(dy_dev && saved_dev && y_dev && whhT_packed_dev && dgi_dev && dgh_dev, "ttsc_gru_seq_backward: null argument");
     TTSC_REQUIRE(B > 0 && T > 0 && H >= 4 && H <= 512 && H % 4 == 0, "ttsc_gru_seq_backward: bad shape B=%d T=%d H=%d", B, T, H);
     GruBwdArgs a{dy_dev, saved_dev, y_dev, h0_dev, whhT_packed_dev, dgi_dev, dgh_dev, B, T, H};
+    const int G = gru_split_members(B, H);
+    if (G > 1) {
+        unsigned* words = gru_sync_words(B, (hipStream_t)stream);
+        TTSC_REQUIRE(words, "ttsc_gru_seq_backward: cannot allocate the hand-off counters");
+        GruSplitArgs sa{};
+        sa.bw = a;
+        sa.cnt = words;
+        sa.abort_word = words + 4096;
+        sa.G = G;
+        sa.HU = H / G;
+        sa.KS = 512 / sa.HU;
+        const size_t lds = ((size_t)3 * H + (size_t)sa.KS * sa.HU) * sizeof(float);
+        hipLaunchKernelGGL(gru_bwd_split_kernel, dim3((unsigned)G, (unsigned)B), dim3(512), lds, (hipStream_t)stream, sa);
+        return gru_check_launch("gru_bwd_split_kernel");
+    }
     hipLaunchKernelGGL(gru_bwd_kernel, dim3((unsigned)B), dim3((unsigned)round_up(H, 64)), (size_t)3 * H * sizeof(float), (hipStream_t)stream, a);
     return gru_check_launch("gru_bwd_kernel");
 }
