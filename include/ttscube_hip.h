@@ -271,7 +271,7 @@ int ttsc_lstm_seq_backward(const float* dy_dev, const float* gates_dev, const fl
  *   ttsc_gru_seq_backward     dy [B,T,H] -> dgi [B,T,3H] (grad wrt W_ih x + b_ih), dgh [B,T,3H] (grad wrt W_hh h + b_hh);
  *                             the caller finishes with GEMMs: dx = dgi W_ih, dW_ih = dgi^T x, dW_hh = dgh^T h_prev, biases = sums */
 /* With few utterances (B * G <= number of CUs) both recurrences split every utterance over G workgroups (env TTSC_GRU_SPLIT caps
- * G, default 8, 1 = off) that exchange the state through y / dgh once per step; launches of one process must then be
+ * G, default 4, 1 = off) that exchange the state through y / dgh once per step; launches of one process must then be
  * stream-ordered (shared hand-off counters).  ttsc_gru_split_status: 0 = all hand-offs of the last launch completed. */
 int32_t ttsc_gru_split_status(void);
 int ttsc_gru_pack_whh_device(const float* whh_dev, int32_t H, int32_t transpose, float* out_dev, void* stream);

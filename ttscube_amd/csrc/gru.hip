@@ -362,7 +362,7 @@ static int gru_split_members(int B, int H) {
         else
             cus = p.multiProcessorCount;
     }
-    int gmax = 8;
+    int gmax = 4;   // measured on MI355X (H=512, B=16, T=24000): G=2.. see DESIGN.md; 4 is the best trade between row stream and hand-off cost
     if (const char* ev = getenv("TTSC_GRU_SPLIT")) gmax = atoi(ev);
     int G = 1;
     while (G * 2 <= gmax && (long)G * 2 * B <= cus && H % (G * 2) == 0 && H / (G * 2) >= 32 && 512 % (H / (G * 2)) == 0) {
