@@ -220,9 +220,11 @@ int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel_dev, const float* xlow
                         int32_t mode, const float* noise_dev, uint64_t seed, const float* forced_x_dev,
                         uint8_t* idx_dev, float* wav_dev, float* logits_dev, void* workspace_dev, size_t workspace_bytes,
                         void* stream);
-/* Synchronises `stream`, then: 0 = last decode finished normally; 1 = the cluster (weight-stationary) kernel gave up on an
- * inter-workgroup hand-off (bounded spin timed out; outputs invalid; rerun with env TTSC_WR_CLUSTER=0); -1 = the last decode
- * used the single-workgroup streaming kernel. */
+/* Which kernel ran the last decode and whether its hand-offs completed.  Synchronises `stream`, then: -1 = single-workgroup
+ * streaming kernel; 2 = quad kernel (4 workgroups step 4 utterances, each streaming a quarter of the weight rows; default
+ * whenever ceil(B/4)*4 <= number of CUs, 1 layer, H <= 512; env TTSC_WR_QUAD=0 disables); 0 = 32-member weight-stationary
+ * cluster kernel (env TTSC_WR_CLUSTER=1); 1 = a multi-workgroup kernel gave up on an inter-workgroup hand-off (bounded spin
+ * timed out; outputs invalid). */
 int ttsc_wavernn_last_status(ttsc_wavernn* w, void* stream);
 void ttsc_wavernn_destroy(ttsc_wavernn* w);
 

@@ -10,6 +10,16 @@ from oracle import wavernn_ref as O
 
 pytestmark = pytest.mark.gpu
 
+
+
+@pytest.fixture(params=['quad', 'stream'], autouse=True)
+def wr_kernel(request, monkeypatch):
+    """Every test runs twice: with the default multi-workgroup quad kernel (one-layer nets, small batches) and with the
+    single-workgroup streaming kernel that larger batches / stacked GRUs use — both must be bit-exact."""
+    monkeypatch.setenv('TTSC_WR_QUAD', '1' if request.param == 'quad' else '0')
+    return request.param
+
+
 CASES = ['wavernn_hr_h64_n1', 'wavernn_hr_h64_n2', 'wavernn_lr_h64_n1', 'wavernn_hr_h512_n1', 'wavernn_hr_h64_raw']
 
 
@@ -47,9 +57,9 @@ def test_reference_goldens_bit_exact(golden_dir, name):
 
 @pytest.mark.parametrize('H,N,lowres,B,T,mode', [
     (512, 1, True, 3, 2, 'noise'), (512, 2, True, 2, 1, 'noise'), (512, 1, False, 4, 8, 'noise'),
-    (64, 1, True, 5, 3, 'philox'), (512, 1, True, 2, 1, 'philox'), (128, 2, False, 2, 5, 'argmax'), (512, 1, True, 2, 1, 'argmax'),
+    (64, 1, True, 5, 3, 'philox'), (512, 1, True, 2, 1, 'philox'), (512, 1, True, 9, 1, 'noise'), (256, 1, False, 6, 4, 'philox'), (128, 2, False, 2, 5, 'argmax'), (512, 1, True, 2, 1, 'argmax'),
 ])
-def test_matches_oracle_bit_exact(H, N, lowres, B, T, mode):
+def test_matches_oracle_bit_exact(H, N, lowres, B, T, mode, wr_kernel):
     sd = O.synthetic_state_dict(H=H, num_layers=N, use_lowres=lowres, seed=100 + H + N)
     net = _net(H, N, lowres, sd)
     mel, x_low = O.synthetic_inputs(B, T, seed=7 + T, upsample=240 if lowres else 24)
@@ -66,6 +76,7 @@ def test_matches_oracle_bit_exact(H, N, lowres, B, T, mode):
     ridx, rwav, rlog = O.decode(sd, mel, x_low if lowres else None, num_layers=N, H=H, use_lowres=lowres, upsample=up,
                                 mode=omode, noise=noise, seed=0xC0FFEE12345, want_logits=True)
     idx, wav, logits = net.decode(X, mode=mode, noise=noise, seed=0xC0FFEE12345, want_logits=True)
+    assert net.last_kernel == ('quad' if (wr_kernel == 'quad' and N == 1) else 'stream')
     assert np.array_equal(idx.cpu().numpy(), ridx), 'first index mismatch at %s' % (np.argwhere(idx.cpu().numpy() != ridx)[:3],)
     assert np.array_equal(wav.cpu().numpy(), rwav)
     assert np.array_equal(logits.cpu().numpy(), rlog)  # logits themselves are bit-exact
@@ -151,5 +162,8 @@ def test_cluster_kernel_bit_exact(monkeypatch):
         assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(wav.cpu().numpy(), rwav)
         assert np.array_equal(logits.cpu().numpy(), rlog)
     monkeypatch.setenv('TTSC_WR_CLUSTER', '0')
+    net.decode(X, mode='argmax')
+    assert net.last_kernel == 'quad'
+    monkeypatch.setenv('TTSC_WR_QUAD', '0')
     net.decode(X, mode='argmax')
     assert net.last_kernel == 'stream'

@@ -26,6 +26,7 @@
 #include "../../include/ttscube_math.h"
 #include "../../include/ttscube_mulaw_lut.h"
 #include "wavernn_cluster.hip"
+#include "wavernn_quad.hip"
 
 namespace ttsc {
 
@@ -409,6 +410,10 @@ struct ttsc_wavernn {
     float *c_whh = nullptr, *c_wih = nullptr, *c_bih = nullptr, *c_bhh = nullptr, *c_wpre = nullptr, *c_bpre = nullptr, *c_wout = nullptr,
           *c_bout = nullptr;
     bool cluster_dirty = true;
+    float *q_whh = nullptr, *q_wih = nullptr, *q_bih = nullptr, *q_bhh = nullptr, *q_wpre = nullptr, *q_bpre = nullptr, *q_wout = nullptr,
+          *q_bout = nullptr;   // quad kernel (wavernn_quad.hip): 4 row slices of every matrix
+    bool quad_dirty = true;
+    int last_kind = 0;         // 0 streaming kernel, 1 cluster kernel, 2 quad kernel
     unsigned* last_abort_word = nullptr;   // device word set by the cluster kernel when a hand-off timed out
     std::vector<std::string> have;
     bool has(const std::string& n) const {
@@ -547,6 +552,7 @@ extern "C" int ttsc_wavernn_set_weight(ttsc_wavernn* w, const char* name, const 
     }
     if (rc == TTSC_OK && !w->has(n)) w->have.push_back(n);
     w->cluster_dirty = true;
+    w->quad_dirty = true;
     return rc;
 }
 
@@ -611,6 +617,64 @@ static int cluster_pack(ttsc_wavernn* w) {
     return TTSC_OK;
 }
 
+
+// ---- quad path (wavernn_quad.hip): 4 workgroups step 4 utterances, each streaming a quarter of the rows -------------
+static bool quad_supported(const ttsc_wavernn* w, int B) {
+    const auto& c = w->cfg;
+    if (const char* ev = getenv("TTSC_WR_QUAD"))
+        if (atoi(ev) == 0) return false;
+    if (c.num_layers != 1 || c.H % (4 * WQ_NC) != 0 || c.H > 512 || c.S % WQ_NC != 0 || c.S > 256) return false;
+    const int G = (int)ceil_div(B, WQ_BU);
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    return G * WQ_NC <= cus;   // every member must be resident, otherwise the exchange cannot complete
+}
+
+static size_t quad_exchange_bytes(const ttsc_wavernn* w, int B) {
+    const int G = (int)ceil_div(B, WQ_BU);
+    const auto& c = w->cfg;
+    const size_t per = ((size_t)2 * WQ_BU * c.H + (size_t)2 * WQ_BU * 256 + (size_t)2 * WQ_BU * c.S + 2 * WQ_BU) * sizeof(float);
+    return (size_t)G * per + ((size_t)G * 4 + 64) * sizeof(unsigned) + 256;
+}
+
+static int quad_pack(ttsc_wavernn* w) {
+    const auto& c = w->cfg;
+    const int NC = WQ_NC, H = c.H, UPW = H / NC, R3 = 3 * UPW, I0 = w->in0, I0P = (int)round_up(I0, 4), S = c.S, SR = S / NC, PR = 256 / NC;
+    std::vector<float> whh((size_t)NC * H * R3, 0.f), wih((size_t)NC * I0P * R3, 0.f), bih((size_t)NC * R3), bhh((size_t)NC * R3);
+    std::vector<float> wpre((size_t)NC * H * PR), bpre((size_t)NC * PR), wout((size_t)NC * 256 * SR), bout((size_t)NC * SR);
+    for (int m = 0; m < NC; ++m) {
+        for (int q = 0; q < 3; ++q)
+            for (int j = 0; j < UPW; ++j) {
+                const int row = q * H + m * UPW + j, lr = q * UPW + j;
+                for (int k = 0; k < H; ++k) whh[(size_t)m * H * R3 + ((size_t)(k >> 2) * R3 + lr) * 4 + (k & 3)] = w->h_whh0[(size_t)row * H + k];
+                for (int k = 0; k < I0; ++k) wih[(size_t)m * I0P * R3 + ((size_t)(k >> 2) * R3 + lr) * 4 + (k & 3)] = w->h_wih0[(size_t)row * I0 + k];
+                bih[(size_t)m * R3 + lr] = w->h_bih0[row];
+                bhh[(size_t)m * R3 + lr] = w->h_bhh0[row];
+            }
+        for (int r = 0; r < PR; ++r) {
+            const int row = m * PR + r;
+            for (int k = 0; k < H; ++k) wpre[(size_t)m * H * PR + ((size_t)(k >> 2) * PR + r) * 4 + (k & 3)] = w->h_wpre[(size_t)row * H + k];
+            bpre[(size_t)m * PR + r] = w->h_bpre[row];
+        }
+        for (int r = 0; r < SR; ++r) {
+            const int row = m * SR + r;
+            for (int k = 0; k < 256; ++k) wout[(size_t)m * 256 * SR + ((size_t)(k >> 2) * SR + r) * 4 + (k & 3)] = w->h_wout[(size_t)row * 256 + k];
+            bout[(size_t)m * SR + r] = w->h_bout[row];
+        }
+    }
+    int rc;
+    if ((rc = upload(&w->q_whh, whh.data(), whh.size()))) return rc;
+    if ((rc = upload(&w->q_wih, wih.data(), wih.size()))) return rc;
+    if ((rc = upload(&w->q_bih, bih.data(), bih.size()))) return rc;
+    if ((rc = upload(&w->q_bhh, bhh.data(), bhh.size()))) return rc;
+    if ((rc = upload(&w->q_wpre, wpre.data(), wpre.size()))) return rc;
+    if ((rc = upload(&w->q_bpre, bpre.data(), bpre.size()))) return rc;
+    if ((rc = upload(&w->q_wout, wout.data(), wout.size()))) return rc;
+    if ((rc = upload(&w->q_bout, bout.data(), bout.size()))) return rc;
+    w->quad_dirty = false;
+    return TTSC_OK;
+}
+
 extern "C" int64_t ttsc_wavernn_out_len(const ttsc_wavernn* w, int64_t T, int64_t Tl) {
     if (!w) return TTSC_EINVAL;
     int64_t L = T * w->cfg.upsample;
@@ -628,7 +692,7 @@ static size_t cond_bytes(const ttsc_wavernn* w, int32_t B, int64_t Tl) {
 
 extern "C" size_t ttsc_wavernn_workspace_bytes(const ttsc_wavernn* w, int32_t B, int64_t T, int64_t Tl) {
     if (!w) return 0;
-    return cond_bytes(w, B, Tl) + cluster_exchange_bytes(w, B);
+    return cond_bytes(w, B, Tl) + std::max(cluster_exchange_bytes(w, B), quad_exchange_bytes(w, B));
 }
 
 extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const float* x_low, int32_t B, int64_t T, int64_t Tl,
@@ -746,9 +810,50 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
         }
         // the abort word is checked by the caller-visible helper below (no host sync here)
         w->last_abort_word = ca.cnt + (size_t)G * 4;
+        w->last_kind = 1;
+        return TTSC_OK;
+    }
+    if (!cluster_supported(w, B) && quad_supported(w, B)) {
+        if (w->quad_dirty) {
+            int prc = quad_pack(w);
+            if (prc) return prc;
+        }
+        const size_t need_all = ttsc_wavernn_workspace_bytes(w, B, T, Tl);
+        if (!ws || ws_bytes < need_all) {
+            set_error("ttsc_wavernn_decode: workspace %zu < required %zu bytes", ws_bytes, need_all);
+            return TTSC_ENOMEM;
+        }
+        const int G = (int)ceil_div(B, WQ_BU);
+        char* xbase = (char*)ws + cond_bytes(w, B, Tl);
+        WqArgs qa;
+        memset(&qa, 0, sizeof(qa));
+        qa.mel = mel; qa.interp = a.interp; qa.feats = a.feats;
+        qa.whh = w->q_whh; qa.wih = w->q_wih; qa.bih = w->q_bih; qa.bhh = w->q_bhh;
+        qa.wpre = w->q_wpre; qa.bpre = w->q_bpre; qa.wout = w->q_wout; qa.bout = w->q_bout;
+        qa.lut = w->lut; qa.noise = noise; qa.forced_x = forced_x; qa.out_idx = idx; qa.out_wav = wav; qa.out_logits = logits;
+        float* f = (float*)xbase;
+        qa.xh = f; f += (size_t)G * 2 * WQ_BU * c.H;
+        qa.xpre = f; f += (size_t)G * 2 * WQ_BU * 256;
+        qa.xlog = f; f += (size_t)G * 2 * WQ_BU * c.S;
+        qa.xlx = f; f += (size_t)G * 2 * WQ_BU;
+        qa.cnt = (unsigned*)f;
+        qa.B = B; qa.T = (int)T; qa.Tl = (int)Tl; qa.H = c.H; qa.UPW = c.H / WQ_NC; qa.I0 = w->in0; qa.I0P = (int)round_up(w->in0, 4);
+        qa.use_lowres = c.use_lowres; qa.up = c.upsample; qa.up_low = c.upsample_low; qa.S = c.S; qa.SR = c.S / WQ_NC; qa.PR = 256 / WQ_NC;
+        qa.n_mel = c.n_mel; qa.out_kind = c.out_kind; qa.mode = mode; qa.L = a.L; qa.G = G; qa.seed = seed;
+        TTSC_HIP_CHECK(hipMemsetAsync(qa.cnt, 0, ((size_t)G * 4 + 64) * sizeof(unsigned), s));
+        const size_t lds = ((size_t)WQ_BU * (c.H > 256 ? c.H : 256) + c.S + 64) * sizeof(float);
+        hipLaunchKernelGGL(wr_quad_kernel, dim3(G * WQ_NC), dim3(WQ_THREADS), lds, s, qa);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            set_error("wr_quad_kernel launch failed: %s", hipGetErrorString(e));
+            return TTSC_EHIP;
+        }
+        w->last_abort_word = qa.cnt + (size_t)G * 4;
+        w->last_kind = 2;
         return TTSC_OK;
     }
     w->last_abort_word = nullptr;
+    w->last_kind = 0;
     // Utterances per workgroup (BT).  Measured on MI355X (H=512, 1 layer): one utterance per workgroup is fastest
     // per step (60 us) while the batch fits the 256 CUs; beyond that a tile of 2/4 utterances shares one weight
     // stream (74 / 98 us per step) and raises throughput (B=1024, BT=4: 9.6 M samples/s).
@@ -775,14 +880,14 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
 }
 
 
-// After the stream has executed the last decode: 0 = ok, 1 = the cluster kernel aborted on a hand-off timeout (results
-// invalid), -1 = last decode did not use the cluster kernel.  Synchronises the stream.
+// After the stream has executed the last decode: -1 = streaming kernel (nothing to check), 0 = cluster kernel ok, 2 = quad
+// kernel ok, 1 = a multi-workgroup kernel aborted on a hand-off timeout (results invalid).  Synchronises the stream.
 extern "C" int ttsc_wavernn_last_status(ttsc_wavernn* w, void* stream) {
     if (!w) return TTSC_EINVAL;
     if (!w->last_abort_word) return -1;
     unsigned v = 0;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return TTSC_EHIP;
     if (hipMemcpy(&v, w->last_abort_word, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return TTSC_EHIP;
-    if (v) set_error("wr_cluster_kernel: inter-workgroup hand-off timed out (not all members resident?)");
-    return v ? 1 : 0;
+    if (v) set_error("WaveRNN multi-workgroup kernel: inter-workgroup hand-off timed out (not all members resident?)");
+    return v ? 1 : (w->last_kind == 2 ? 2 : 0);
 }
