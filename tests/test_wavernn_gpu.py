@@ -162,6 +162,7 @@ def test_cluster_kernel_bit_exact(monkeypatch):
         assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(wav.cpu().numpy(), rwav)
         assert np.array_equal(logits.cpu().numpy(), rlog)
     monkeypatch.setenv('TTSC_WR_CLUSTER', '0')
+    monkeypatch.setenv('TTSC_WR_QUAD', '1')
     net.decode(X, mode='argmax')
     assert net.last_kernel == 'quad'
     monkeypatch.setenv('TTSC_WR_QUAD', '0')
