@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(params=['quad', 'stream'], autouse=True)
 def wr_kernel(request, monkeypatch):
-    """Every test runs twice: with the default multi-workgroup quad kernel (one-layer nets, small batches) and with the
-    single-workgroup streaming kernel that larger batches / stacked GRUs use — both must be bit-exact."""
+    """Every test runs twice: with the multi-workgroup quad kernel (opt-in, one-layer nets) and with the default
+    single-workgroup streaming kernel — both must be bit-exact."""
     monkeypatch.setenv('TTSC_WR_QUAD', '1' if request.param == 'quad' else '0')
     return request.param
 

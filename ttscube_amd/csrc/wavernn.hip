@@ -621,8 +621,11 @@ static int cluster_pack(ttsc_wavernn* w) {
 // ---- quad path (wavernn_quad.hip): 4 workgroups step 4 utterances, each streaming a quarter of the rows -------------
 static bool quad_supported(const ttsc_wavernn* w, int B) {
     const auto& c = w->cfg;
-    if (const char* ev = getenv("TTSC_WR_QUAD"))
-        if (atoi(ev) == 0) return false;
+    // OFF by default (env TTSC_WR_QUAD=1): bit-exact and tested, but measured 41 us/step at any batch size against 36..45 us
+    // for the streaming kernel — the four hand-offs + three LDS stagings per step cost what the shorter weight stream saves,
+    // and lanes that share a weight address do not shorten the CU's address path.
+    const char* evq = getenv("TTSC_WR_QUAD");
+    if (!evq || atoi(evq) == 0) return false;
     if (c.num_layers != 1 || c.H % (4 * WQ_NC) != 0 || c.H > 512 || c.S % WQ_NC != 0 || c.S > 256) return false;
     const int G = (int)ceil_div(B, WQ_BU);
     int dev = 0, cus = 0;

@@ -3,10 +3,8 @@
 // The single-workgroup kernel (wavernn.hip) streams the whole fp32 weight set (3.8 MB for H=512) from L2 every step and is
 // bound by ONE CU's load path (~64 B/clk): 45 us per step at B = 256.  Here a quad of NC = 4 workgroups steps BU = 4
 // utterances together; member m owns a quarter of the rows of every matrix (H/4 hidden units x 3 gates, 64 rows of the
-// pre-output layer, S/4 rows of the output layer) and streams ONLY those rows: the GRU thread of unit j keeps the 16-byte
-// weight word in registers for all four utterances (the address path of a CU retires 64 lanes x 16 B per 16 clocks whether
-// or not lanes share an address, so the reuse has to happen in registers, not across lanes).  A member thus issues a
-// quarter of the loads per step while B = 256 still fills all 256 CUs (64 quads).
+// pre-output layer, S/4 rows of the output layer) and streams ONLY those rows — each 16-byte weight word is used for
+// four utterances, so a member moves a quarter of the bytes per step while B = 256 still fills all 256 CUs (64 quads).
 // Per step the members exchange four small vectors (h_t, pre, logits, last_x) with the hand-off protocol of
 // wavernn_cluster.hip (write-through payload, monotonic counters, bounded spins + abort word); with 4 members a hand-off
 // costs ~1 us (measured on the GRU training kernels, gru.hip), against ~8 us for the 32-member cluster.
@@ -59,16 +57,14 @@ __global__ __launch_bounds__(WQ_THREADS) void wr_quad_kernel(WqArgs a) {
     float* vec = sm;
     float* scr = sm + (size_t)WQ_BU * VW;
     const int tid = threadIdx.x;
-    // phase A (GRU): thread j < UPW owns hidden unit j of this member for ALL four utterances
-    // phases B / C:   thread (row = tid >> 1, pair = tid & 1) owns one row for utterances 2*pair, 2*pair + 1
-    const int j = tid;
+    const int u = tid & (WQ_BU - 1);   // utterance slot
+    const int j = tid >> 2;            // local hidden unit (GRU) / local row (pre, out)
+    const int bu = g * WQ_BU + u;
+    const bool uok = bu < a.B;
+    const int bc = uok ? bu : a.B - 1;
+    const int nu = min(WQ_BU, a.B - g * WQ_BU);
     const bool gru_thr = j < UPW;
     const int jc = gru_thr ? j : 0;
-    const int row2 = tid >> 1, pair = tid & 1;
-    const int nu = min(WQ_BU, a.B - g * WQ_BU);
-    int bcu[WQ_BU];
-#pragma unroll
-    for (int u = 0; u < WQ_BU; ++u) bcu[u] = min(g * WQ_BU + u, a.B - 1);
     const float* Whh = a.whh + (size_t)m * H * R3;
     const float* Wih = a.wih + (size_t)m * I0P * R3;
     const float* Wpre = a.wpre + (size_t)m * H * PR;
@@ -82,16 +78,10 @@ __global__ __launch_bounds__(WQ_THREADS) void wr_quad_kernel(WqArgs a) {
         w_lx[q] = Wih[((size_t)(k1 >> 2) * R3 + q * UPW + jc) * 4 + (k1 & 3)];
         w_int[q] = Wih[((size_t)(k2 >> 2) * R3 + q * UPW + jc) * 4 + (k2 & 3)];
     }
-    const float bpre = a.bpre[m * PR + (row2 < PR ? row2 : 0)];
-    const float bout = a.bout[m * SR + (row2 < SR ? row2 : 0)];
-    float pmel[WQ_BU][3], plow[WQ_BU][3];
-    float hprev[WQ_BU];   // h_{t-1}[unit m*UPW + j][utterance u]: each (unit, utterance) has exactly one owner thread
-#pragma unroll
-    for (int u = 0; u < WQ_BU; ++u) {
-        hprev[u] = 0.f;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) pmel[u][q] = plow[u][q] = 0.f;
-    }
+    const float bpre = a.bpre[m * PR + (j < PR ? j : 0)];
+    const float bout = a.bout[m * SR + (j < SR ? j : 0)];
+    float pmel[3] = {0, 0, 0}, plow[3] = {0, 0, 0};
+    float hprev = 0.f;   // h_{t-1}[unit m*UPW + j][utterance u]: each (unit, utterance) has exactly one owner thread
     unsigned* cnt = a.cnt + (size_t)g * 4;
     unsigned* abort_word = a.cnt + (size_t)a.G * 4;
     float* xh = a.xh + (size_t)g * 2 * WQ_BU * H;
@@ -106,37 +96,22 @@ __global__ __launch_bounds__(WQ_THREADS) void wr_quad_kernel(WqArgs a) {
         if (gru_thr) {
             if (fr_phase == 0) {
 #pragma unroll
-                for (int u = 0; u < WQ_BU; ++u)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) pmel[u][q] = bih[q];
+                for (int q = 0; q < 3; ++q) pmel[q] = bih[q];
+                const float* mf = a.mel + ((size_t)bc * a.T + fr) * NM;
                 for (int k = 0; k < NM; ++k) {
-                    float wq[3];
+                    const float v = mf[k];
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) wq[q] = Wih[((size_t)(k >> 2) * R3 + q * UPW + j) * 4 + (k & 3)];
-#pragma unroll
-                    for (int u = 0; u < WQ_BU; ++u) {
-                        const float v = a.mel[((size_t)bcu[u] * a.T + fr) * NM + k];
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) pmel[u][q] = fmaf(wq[q], v, pmel[u][q]);
-                    }
+                    for (int q = 0; q < 3; ++q) pmel[q] = fmaf(Wih[((size_t)(k >> 2) * R3 + q * UPW + j) * 4 + (k & 3)], v, pmel[q]);
                 }
             }
             if (a.use_lowres && lo_phase == 0) {
 #pragma unroll
-                for (int u = 0; u < WQ_BU; ++u)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) plow[u][q] = pmel[u][q];
+                for (int q = 0; q < 3; ++q) plow[q] = pmel[q];
                 for (int f = 0; f < 20; ++f) {
                     const int k = NM + f;
-                    float wq[3];
+                    const float v = a.feats[((size_t)bc * 20 + f) * a.Tl + lo];
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) wq[q] = Wih[((size_t)(k >> 2) * R3 + q * UPW + j) * 4 + (k & 3)];
-#pragma unroll
-                    for (int u = 0; u < WQ_BU; ++u) {
-                        const float v = a.feats[((size_t)bcu[u] * 20 + f) * a.Tl + lo];
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) plow[u][q] = fmaf(wq[q], v, plow[u][q]);
-                    }
+                    for (int q = 0; q < 3; ++q) plow[q] = fmaf(Wih[((size_t)(k >> 2) * R3 + q * UPW + j) * 4 + (k & 3)], v, plow[q]);
                 }
             }
         }
@@ -151,30 +126,23 @@ __global__ __launch_bounds__(WQ_THREADS) void wr_quad_kernel(WqArgs a) {
         }
         __syncthreads();
         if (gru_thr) {
-            float gh[WQ_BU][3];
+            float gh[1][3] = {{bhh[0], bhh[1], bhh[2]}};
+            lstm_chain<1, 3, 2>(gh, Whh, R3, UPW, j, vec + u * VW, VW, H);
+            const float lx = (t > 0) ? ld_f32(xlx + (par ^ 1) * WQ_BU + u) : 0.f;
+            float gi[3];
 #pragma unroll
-            for (int u = 0; u < WQ_BU; ++u)
-#pragma unroll
-                for (int q = 0; q < 3; ++q) gh[u][q] = bhh[q];
-            lstm_chain<WQ_BU, 3, 4>(gh, Whh, R3, UPW, j, vec, VW, H);
-#pragma unroll
-            for (int u = 0; u < WQ_BU; ++u) {
-                const float lx = (t > 0) ? ld_f32(xlx + (par ^ 1) * WQ_BU + u) : 0.f;
-                float gi[3];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    float acc = a.use_lowres ? plow[u][q] : pmel[u][q];
-                    if (a.use_lowres) acc = fmaf(w_int[q], a.interp[(size_t)bcu[u] * ((size_t)a.Tl * a.up_low) + t], acc);
-                    gi[q] = fmaf(w_lx[q], lx, acc);
-                }
-                const float r = ttsc_sigmoidf(gi[0] + gh[u][0]);
-                const float z = ttsc_sigmoidf(gi[1] + gh[u][1]);
-                const float rg = r * gh[u][2];
-                const float nn = ttsc_tanhf(gi[2] + rg);
-                const float d = hprev[u] - nn;
-                hprev[u] = fmaf(z, d, nn);
-                st_f32(xh + ((size_t)par * WQ_BU + u) * H + m * UPW + j, hprev[u]);
+            for (int q = 0; q < 3; ++q) {
+                float acc = a.use_lowres ? plow[q] : pmel[q];
+                if (a.use_lowres) acc = fmaf(w_int[q], a.interp[(size_t)bc * ((size_t)a.Tl * a.up_low) + t], acc);
+                gi[q] = fmaf(w_lx[q], lx, acc);
             }
+            const float r = ttsc_sigmoidf(gi[0] + gh[0][0]);
+            const float z = ttsc_sigmoidf(gi[1] + gh[0][1]);
+            const float rg = r * gh[0][2];
+            const float nn = ttsc_tanhf(gi[2] + rg);
+            const float d = hprev - nn;
+            hprev = fmaf(z, d, nn);
+            st_f32(xh + ((size_t)par * WQ_BU + u) * H + m * UPW + j, hprev);
         }
         publish(cnt + 0);
         // ---- phase B: pre-output slice (PR rows) over the full h_t ----
@@ -184,11 +152,10 @@ __global__ __launch_bounds__(WQ_THREADS) void wr_quad_kernel(WqArgs a) {
             for (int i = tid; i < WQ_BU * H; i += WQ_THREADS) vec[(i / H) * VW + (i % H)] = ld_f32(src + i);
         }
         __syncthreads();
-        if (row2 < PR) {
-            float acc[2][1] = {{bpre}, {bpre}};
-            lstm_chain<2, 1, 4>(acc, Wpre, PR, 0, row2, vec + 2 * pair * VW, VW, H);
-            st_f32(xpre + ((size_t)par * WQ_BU + 2 * pair) * 256 + m * PR + row2, ttsc_tanhf(acc[0][0]));
-            st_f32(xpre + ((size_t)par * WQ_BU + 2 * pair + 1) * 256 + m * PR + row2, ttsc_tanhf(acc[1][0]));
+        if (j < PR) {
+            float acc[1][1] = {{bpre}};
+            lstm_chain<1, 1, 4>(acc, Wpre, PR, 0, j, vec + u * VW, VW, H);
+            st_f32(xpre + ((size_t)par * WQ_BU + u) * 256 + m * PR + j, ttsc_tanhf(acc[0][0]));
         }
         publish(cnt + 1);
         // ---- phase C: output slice (SR rows) over the full pre-output ----
@@ -198,16 +165,12 @@ __global__ __launch_bounds__(WQ_THREADS) void wr_quad_kernel(WqArgs a) {
             for (int i = tid; i < WQ_BU * 256; i += WQ_THREADS) vec[(i >> 8) * VW + (i & 255)] = ld_f32(src + i);
         }
         __syncthreads();
-        if (row2 < SR) {
-            float acc[2][1] = {{bout}, {bout}};
-            lstm_chain<2, 1, 4>(acc, Wout, SR, 0, row2, vec + 2 * pair * VW, VW, 256);
-            const int s_ = m * SR + row2;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int u = 2 * pair + e, bu = g * WQ_BU + u;
-                st_f32(xlog + ((size_t)par * WQ_BU + u) * S + s_, acc[e][0]);
-                if (a.out_logits && bu < a.B) a.out_logits[((size_t)bu * a.L + t) * S + s_] = acc[e][0];
-            }
+        if (j < SR) {
+            float acc[1][1] = {{bout}};
+            lstm_chain<1, 1, 4>(acc, Wout, SR, 0, j, vec + u * VW, VW, 256);
+            const int s_ = m * SR + j;
+            st_f32(xlog + ((size_t)par * WQ_BU + u) * S + s_, acc[0][0]);
+            if (a.out_logits && uok) a.out_logits[((size_t)bu * a.L + t) * S + s_] = acc[0][0];
         }
         publish(cnt + 2);
         // ---- phase D: member m samples utterance m of the quad ----
