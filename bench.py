@@ -144,6 +144,11 @@ def main():
         else:
             peak, kname = PEAK_FP32_MFMA_TFLOPS, 'conv_mfma_kernel (v_mfma_f32_32x32x2_f32 implicit-GEMM conv; all launches of one forward)'
             executed = achieved
+        # HBM traffic of ONE forward of this exact workload, from the rocprofv3 PMC passes committed in
+        # profiles/r01_bench_f16x3_hbm_pmc.csv (FETCH_SIZE 64.5 GB + WRITE_SIZE 62.1 GB, separate passes, KiB units; the
+        # kernels stage with 4 B/lane loads, for which the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md — x2 for
+        # 16 B/lane streams — does not apply).  Only reported for the configuration it was measured on.
+        traffic = 126.6e9 if (precision == 'f16x3' and B == 64 and T == 800) else None
         res = {
             'metric': 'audio samples/sec (HiFi-GAN vocoder inference)', 'value': value, 'unit': 'samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
@@ -157,7 +162,8 @@ def main():
             'rtf_24k': value / world / 24000.0, 'rtf_22k05': value / world / 22050.0,
             'per_gpu_samples_s': value / world,
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak, 'traffic': None, 'kernel': kname,
+                         'frac': achieved / peak, 'traffic': traffic, 'traffic_unit': 'bytes per step (PMC, profiles/r01_bench_f16x3_hbm_pmc.csv)',
+                         'kernel': kname,
                          'flops_per_step': flops_step, 'device_ms_per_step': dev_ms / args.steps,
                          'mfma_executed_tflops': executed, 'mfma_dense_peak_tflops': PEAK_F16_MFMA_TFLOPS if precision == 'f16x3' else PEAK_FP32_MFMA_TFLOPS,
                          'x_fp32_mfma_peak': achieved / PEAK_FP32_MFMA_TFLOPS,
