@@ -170,7 +170,7 @@ def main():
                          'hbm_compulsory_GBs': alg_bytes * args.steps / (dev_ms * 1e-3) / 1e9,
                          'hbm_frac_compulsory': alg_bytes * args.steps / (dev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
         }
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:   # reported baseline: rank 0 at N=1 only
             res['cpu_baseline'] = cpu_baseline(h, sd)
         else:
             res['cpu_baseline'] = None
