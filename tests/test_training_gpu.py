@@ -212,10 +212,14 @@ def test_fused_weight_norm_and_bias_grad_match_torch():
             assert _rel(db, dy.double().sum(dim=(0, 2)).float()) < 1e-5
 
 
-@pytest.mark.parametrize('cfg', [(2, True, 64, 37, 3, 9), (1, False, 32, 20, 2, 5), (2, True, 256, 641, 2, 30)])
+@pytest.mark.parametrize('cfg', [(2, True, 64, 37, 3, 9), (1, False, 32, 20, 2, 5), (2, True, 256, 641, 2, 30), (2, True, 256, 80, 16, 24),
+                                 (1, False, 512, 96, 3, 17), (1, True, 128, 40, 200, 4)])
 def test_hip_lstm_autograd_matches_torch(cfg):
-    """forward + backward-through-time kernels of a stacked (bi)LSTM vs torch.nn.LSTM autograd (same parameters)."""
+    """forward + backward-through-time kernels of a stacked (bi)LSTM vs torch.nn.LSTM autograd (same parameters): the
+    single-workgroup kernels (H = 64 / 32, or too many sequences for the CUs) and the split kernels (2..4 workgroups per
+    (utterance, direction) exchanging the state every step)."""
     from ttscube_amd.networks.lstm_autograd import lstm_forward_train
+    from ttscube_amd import _lib
     layers, bi, H, nin, B, T = cfg
     torch.manual_seed(3)
     m = torch.nn.LSTM(nin, H, num_layers=layers, bidirectional=bi, batch_first=True).cuda()
@@ -225,7 +229,9 @@ def test_hip_lstm_autograd_matches_torch(cfg):
     y0, _ = m(x)
     g0 = torch.autograd.grad(y0, [x] + params, gy)
     y1 = lstm_forward_train(m, x)
+    assert _lib.lib().ttsc_lstm_split_status() == 0
     g1 = torch.autograd.grad(y1, [x] + params, gy)
+    assert _lib.lib().ttsc_lstm_split_status() == 0
     assert _rel(y1, y0) < 1e-5
     for a_, b_, p in zip(g1, g0, [x] + params):
         assert a_.shape == b_.shape and _rel(a_, b_) < 1e-4, (tuple(p.shape), _rel(a_, b_))

@@ -101,6 +101,7 @@ SIGNATURES = {
     'ttsc_wavernn_destroy': (None, [C.c_void_p]),
     'ttsc_linear_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                       C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    'ttsc_lstm_split_status': (C.c_int32, []),
     'ttsc_lstm_pack_whh_device': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     'ttsc_lstm_seq_forward_train': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                               C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -197,6 +197,163 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Split recurrences (same scheme as gru.hip): when B * ndir is small the kernels above leave most CUs idle while each
+// workgroup is bound by ONE CU's L2 load path (W_hh: 1 MB for H = 256, 4 MB for H = 512, per step).  Here G workgroups share
+// one (utterance, direction): member m owns H/G hidden units and streams only their gate rows, its 512 threads are (unit,
+// k-slice) pairs whose partial sums meet in LDS, and the members exchange h_t (forward, through y) / the gate gradients
+// (backward, through dgates) once per step.  Results differ from the single-workgroup kernels only in summation order.
+// All G * B * ndir workgroups must be co-resident: the host takes this path only when they fit the CUs.
+struct LstmSplitArgs {
+    LstmArgs f;
+    LstmBwdArgs bw;
+    unsigned* cnt;        // [B * ndir] monotonic counters (zeroed by the host before the launch)
+    unsigned* abort_word;
+    int G, HU, KS;        // members, hidden units per member, k-slices (HU * KS = 512 threads)
+};
+
+__global__ __launch_bounds__(512) void lstm_seq_split_kernel(LstmSplitArgs s) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // h[H] | part[KS][4][HU]
+    __shared__ int ok_s;
+    const LstmArgs& a = s.f;
+    const int H = a.H, H4 = 4 * H, HU = s.HU, KS = s.KS;
+    const int tid = threadIdx.x, u = tid % HU, ks = tid / HU;
+    const int m = blockIdx.x, b = blockIdx.y, dir = blockIdx.z;
+    const int j = m * HU + u;
+    const int KL = H / KS;
+    float* hs = sm;
+    float* part = sm + H;
+    unsigned* cnt = s.cnt + (b * a.ndir + dir);
+    const bool owner = ks == 0;
+    const int len = a.lengths ? a.lengths[b] : a.T;
+    const float* whh = a.whh + (size_t)dir * H * H4;
+    float* yb = a.y + (size_t)b * a.T * a.ldy + a.yoff + dir * H;
+    float c = (owner && a.c_0) ? a.c_0[((size_t)dir * a.B + b) * H + j] : 0.f;
+    float hlast = (owner && a.h_0) ? a.h_0[((size_t)dir * a.B + b) * H + j] : 0.f;
+    if (owner)
+        for (int t = len; t < a.T; ++t) yb[(size_t)t * a.ldy + j] = 0.f;   // pad_packed_sequence: zeros beyond the length
+    for (int st = 0; st < len; ++st) {
+        const int tpos = dir == 0 ? st : (len - 1 - st);
+        const int tprev = dir == 0 ? tpos - 1 : tpos + 1;
+        float xv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (owner) {   // in flight while the other members finish the previous step
+            const float* xr = a.xg + ((size_t)b * a.T + tpos) * ((size_t)a.ndir * H4) + (size_t)dir * H4 + j;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xv[g] = xr[g * H];
+        }
+        if (st > 0) {
+            if (!g_wait(cnt, (unsigned)st * (unsigned)s.G, s.abort_word, &ok_s)) return;
+            for (int i = tid; i < H; i += 512) hs[i] = g_ld(yb + (size_t)tprev * a.ldy + i);
+        } else {
+            for (int i = tid; i < H; i += 512) hs[i] = a.h_0 ? a.h_0[((size_t)dir * a.B + b) * H + i] : 0.f;
+        }
+        __syncthreads();
+        float acc[1][4] = {{0.f, 0.f, 0.f, 0.f}};
+        lstm_chain<1, 4, 2>(acc, whh + (size_t)(ks * KL / 4) * H4 * 4, H4, H, j, hs + ks * KL, H, KL);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) part[(ks * 4 + g) * HU + u] = acc[0][g];
+        __syncthreads();
+        if (owner) {
+            float gs[4] = {xv[0], xv[1], xv[2], xv[3]};
+            for (int q = 0; q < KS; ++q)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gs[g] += part[(q * 4 + g) * HU + u];
+            const float ig = ttsc_sigmoidf(gs[0]);
+            const float fg = ttsc_sigmoidf(gs[1]);
+            const float gg = ttsc_tanhf(gs[2]);
+            const float og = ttsc_sigmoidf(gs[3]);
+            c = fmaf(fg, c, ig * gg);
+            hlast = og * ttsc_tanhf(c);
+            g_st(yb + (size_t)tpos * a.ldy + j, hlast);
+            if (a.gates_out) {
+                float* gp = a.gates_out + ((size_t)b * a.T + tpos) * ((size_t)a.ndir * H4) + (size_t)dir * H4 + j;
+                gp[0] = ig;
+                gp[H] = fg;
+                gp[2 * H] = gg;
+                gp[3 * H] = og;
+                a.c_out[((size_t)b * a.T + tpos) * ((size_t)a.ndir * H) + (size_t)dir * H + j] = c;
+            }
+        }
+        g_publish(cnt);
+    }
+    if (owner) {
+        if (a.h_n) a.h_n[((size_t)dir * a.B + b) * H + j] = hlast;
+        if (a.c_n) a.c_n[((size_t)dir * a.B + b) * H + j] = c;
+    }
+}
+
+__global__ __launch_bounds__(512) void lstm_bwd_split_kernel(LstmSplitArgs s) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // dg[4H] | part[KS][HU]
+    __shared__ int ok_s;
+    const LstmBwdArgs& a = s.bw;
+    const int H = a.H, H4 = 4 * H, HU = s.HU, KS = s.KS;
+    const int tid = threadIdx.x, u = tid % HU, ks = tid / HU;
+    const int m = blockIdx.x, b = blockIdx.y, dir = blockIdx.z;
+    const int j = m * HU + u;
+    const int KL = H4 / KS;
+    float* dg = sm;
+    float* part = sm + H4;
+    unsigned* cnt = s.cnt + (b * a.ndir + dir);
+    const bool owner = ks == 0;
+    const int len = a.lengths ? a.lengths[b] : a.T;
+    const float* whhT = a.whhT + (size_t)dir * H * H4;
+    const size_t gstride = (size_t)a.ndir * H4, cstride = (size_t)a.ndir * H;
+    const float* gb = a.gates + (size_t)b * a.T * gstride + (size_t)dir * H4 + j;
+    const float* cb = a.cst + (size_t)b * a.T * cstride + (size_t)dir * H + j;
+    const float* dyb = a.dy + (size_t)b * a.T * a.ldy + a.yoff + dir * H + j;
+    float* dgrow = a.dgates + (size_t)b * a.T * gstride + (size_t)dir * H4;
+    if (owner)
+        for (int t = len; t < a.T; ++t) {
+            float* p = dgrow + (size_t)t * gstride + j;
+            p[0] = 0.f;
+            p[H] = 0.f;
+            p[2 * H] = 0.f;
+            p[3 * H] = 0.f;
+        }
+    float dh_rec = 0.f, dc_next = 0.f;
+    unsigned step = 0;
+    for (int st = len - 1; st >= 0; --st) {
+        const int tpos = dir == 0 ? st : (len - 1 - st);
+        const int tprev = dir == 0 ? tpos - 1 : tpos + 1;
+        if (owner) {
+            const float* g = gb + (size_t)tpos * gstride;
+            const float ig = g[0], fg = g[H], gg = g[2 * H], og = g[3 * H];
+            const float ct = cb[(size_t)tpos * cstride];
+            const float cp = st > 0 ? cb[(size_t)tprev * cstride] : 0.f;
+            const float dh = dyb[(size_t)tpos * a.ldy] + dh_rec;
+            const float tc = ttsc_tanhf(ct);
+            const float d_o = dh * tc * og * (1.f - og);
+            const float dc = dc_next + dh * og * (1.f - tc * tc);
+            const float d_i = dc * gg * ig * (1.f - ig);
+            const float d_g = dc * ig * (1.f - gg * gg);
+            const float d_f = dc * cp * fg * (1.f - fg);
+            dc_next = dc * fg;
+            float* p = dgrow + (size_t)tpos * gstride + j;
+            g_st(p, d_i);
+            g_st(p + H, d_f);
+            g_st(p + 2 * H, d_g);
+            g_st(p + 3 * H, d_o);
+        }
+        g_publish(cnt);
+        ++step;
+        if (st == 0) break;
+        if (!g_wait(cnt, step * (unsigned)s.G, s.abort_word, &ok_s)) return;
+        for (int i = tid; i < H4; i += 512) dg[i] = g_ld(dgrow + (size_t)tpos * gstride + i);
+        __syncthreads();
+        float acc[1][1] = {{0.f}};
+        lstm_chain<1, 1, 4>(acc, whhT + (size_t)(ks * KL / 4) * H * 4, H, 0, j, dg + ks * KL, H4, KL);
+        part[ks * HU + u] = acc[0][0];
+        __syncthreads();
+        if (owner) {
+            float v = 0.f;
+            for (int q = 0; q < KS; ++q) v += part[q * HU + u];
+            dh_rec = v;
+        }
+        __syncthreads();
+    }
+}
+
 // [ndir][4H][H] (torch weight_hh layout, device)  ->  forward pack [ndir][H/4][4H][4]  or  transposed pack [ndir][4H/4][H][4]
 __global__ void lstm_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int ndir, int H, int transpose) {
     const long per = (long)4 * H * H;
@@ -242,6 +399,42 @@ extern "C" void ttsc_device_free(void* p) {
     if (p) (void)hipFree(p);
 }
 
+
+// members per (utterance, direction) for the split kernels: power of two <= 4, >= 32 units per member, all workgroups resident
+static int lstm_split_members(int B, int ndir, int H) {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    }
+    int gmax = 4;
+    if (const char* ev = getenv("TTSC_LSTM_SPLIT")) gmax = atoi(ev);
+    int G = 1;
+    while (G * 2 <= gmax && (long)G * 2 * B * ndir <= cus && H % (G * 2) == 0 && H / (G * 2) >= 32 && 512 % (H / (G * 2)) == 0) {
+        const int HU = H / (G * 2), KS = 512 / HU;
+        if (H % KS != 0 || (H / KS) % 8 != 0 || (4 * H / KS) % 16 != 0) break;
+        G *= 2;
+    }
+    return G;
+}
+
+static unsigned* g_lstm_words = nullptr;   // [0..8191] per-(utterance, direction) counters, [8192] abort word
+
+static unsigned* lstm_sync_words(int n, hipStream_t s) {
+    if (n > 8192) return nullptr;
+    if (!g_lstm_words && hipMalloc((void**)&g_lstm_words, 8193 * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemsetAsync(g_lstm_words, 0, 8193 * sizeof(unsigned), s) != hipSuccess) return nullptr;
+    return g_lstm_words;
+}
+
+// 0 = every hand-off of the most recent split LSTM launch completed, 1 = a bounded spin timed out.  Synchronises the device.
+extern "C" int32_t ttsc_lstm_split_status(void) {
+    if (!g_lstm_words) return 0;
+    unsigned v = 0;
+    if (hipMemcpy(&v, g_lstm_words + 8192, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int32_t)v;
+}
+
 static int lstm_forward_impl(const float* xg_dev, const float* whh_packed_dev, float* y_dev, const int32_t* lengths_dev,
                              int32_t B, int32_t T, int32_t H, int32_t ndir, int64_t ldy, int32_t yoff, const float* h0_dev,
                              const float* c0_dev, float* hn_dev, float* cn_dev, float* gates_dev, float* c_dev, void* stream);
@@ -282,6 +475,26 @@ extern "C" int ttsc_lstm_seq_backward(const float* dy_dev, const float* gates_de
     TTSC_REQUIRE(B > 0 && T > 0 && ndir >= 1 && ndir <= 2 && H >= 4 && H <= 512 && H % 4 == 0, "ttsc_lstm_seq_backward: bad shape B=%d T=%d H=%d ndir=%d", B, T, H, ndir);
     TTSC_REQUIRE(ldy >= (int64_t)yoff + (int64_t)ndir * H, "ttsc_lstm_seq_backward: ldy too small");
     LstmBwdArgs a{dy_dev, gates_dev, c_dev, whhT_packed_dev, dgates_dev, lengths_dev, B, T, H, ndir, (int)ldy, yoff};
+    const int G = lstm_split_members(B, ndir, H);
+    if (G > 1) {
+        unsigned* words = lstm_sync_words(B * ndir, (hipStream_t)stream);
+        TTSC_REQUIRE(words, "ttsc_lstm_seq_backward: cannot allocate the hand-off counters");
+        LstmSplitArgs sa{};
+        sa.bw = a;
+        sa.cnt = words;
+        sa.abort_word = words + 8192;
+        sa.G = G;
+        sa.HU = H / G;
+        sa.KS = 512 / sa.HU;
+        const size_t lds = ((size_t)4 * H + (size_t)sa.KS * sa.HU) * sizeof(float);
+        hipLaunchKernelGGL(lstm_bwd_split_kernel, dim3((unsigned)G, (unsigned)B, (unsigned)ndir), dim3(512), lds, (hipStream_t)stream, sa);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            set_error("lstm_bwd_split_kernel launch failed: %s", hipGetErrorString(e));
+            return TTSC_EHIP;
+        }
+        return TTSC_OK;
+    }
     const int threads = (int)round_up(H, 64);
     hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)B, (unsigned)ndir), dim3(threads), (size_t)4 * H * sizeof(float), (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
@@ -299,6 +512,30 @@ static int lstm_forward_impl(const float* xg_dev, const float* whh_packed_dev, f
     TTSC_REQUIRE(B > 0 && T > 0 && ndir >= 1 && ndir <= 2 && H >= 4 && H <= 512 && H % 4 == 0, "ttsc_lstm_seq_forward: bad shape B=%d T=%d H=%d ndir=%d", B, T, H, ndir);
     TTSC_REQUIRE(ldy >= (int64_t)yoff + (int64_t)ndir * H, "ttsc_lstm_seq_forward: ldy too small");
     LstmArgs a{xg_dev, whh_packed_dev, y_dev, lengths_dev, hn_dev, cn_dev, h0_dev, c0_dev, B, T, H, ndir, (int)ldy, yoff, gates_dev, c_dev};
+    // Inference keeps the single-workgroup kernel by default: its results must not depend on how many utterances share a
+    // launch (a padded batch reproduces every utterance run alone bit for bit, tests/test_lstm_gpu.py), and the split changes
+    // the summation order with G.  Training forwards (gates_dev != NULL) take the split; TTSC_LSTM_SPLIT_INFER=1 opts inference in.
+    static const bool split_infer = getenv("TTSC_LSTM_SPLIT_INFER") && atoi(getenv("TTSC_LSTM_SPLIT_INFER")) != 0;
+    const int G = (gates_dev || split_infer) ? lstm_split_members(B, ndir, H) : 1;
+    if (G > 1) {
+        unsigned* words = lstm_sync_words(B * ndir, (hipStream_t)stream);
+        TTSC_REQUIRE(words, "ttsc_lstm_seq_forward: cannot allocate the hand-off counters");
+        LstmSplitArgs sa{};
+        sa.f = a;
+        sa.cnt = words;
+        sa.abort_word = words + 8192;
+        sa.G = G;
+        sa.HU = H / G;
+        sa.KS = 512 / sa.HU;
+        const size_t lds = ((size_t)H + (size_t)sa.KS * 4 * sa.HU) * sizeof(float);
+        hipLaunchKernelGGL(lstm_seq_split_kernel, dim3((unsigned)G, (unsigned)B, (unsigned)ndir), dim3(512), lds, (hipStream_t)stream, sa);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            set_error("lstm_seq_split_kernel launch failed: %s", hipGetErrorString(e));
+            return TTSC_EHIP;
+        }
+        return TTSC_OK;
+    }
     const int threads = (int)round_up(H, 64);
     const int bt = B * ndir > 512 ? 2 : 1;
     dim3 grid((unsigned)ceil_div(B, bt), (unsigned)ndir);

@@ -70,4 +70,35 @@ __device__ __forceinline__ void lstm_chain(float (&acc)[BT][NG], const float* __
     }
 }
 
+// ---- inter-workgroup hand-off used by the split recurrences (gru.hip, lstm.hip); protocol of wavernn_cluster.hip ----------
+// payload: agent-scope relaxed atomic stores / loads (write-through, L1-bypassing); arrival: every storing wave drains
+// vmcnt(0), one lane bumps a monotonic counter; consumers poll it from one lane with a bounded spin and a shared abort word.
+__device__ __forceinline__ void g_st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float g_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+constexpr unsigned GS_SPIN_LIMIT = 1u << 22;
+
+__device__ __forceinline__ bool g_wait(unsigned* cnt, unsigned want, unsigned* abort_word, int* ok_s) {
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        unsigned spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            if (++spins > GS_SPIN_LIMIT || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        *ok_s = ok;
+    }
+    __syncthreads();
+    return *ok_s != 0;
+}
+__device__ __forceinline__ void g_publish(unsigned* cnt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+
 }  // namespace ttsc
