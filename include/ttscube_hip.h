@@ -259,8 +259,8 @@ int ttsc_lstm_seq_forward(const float* xg_dev, const float* whh_packed_dev, floa
  *   ttsc_lstm_seq_backward      backward through time: dy [B,T,ldy] (columns yoff + d*H ...) -> gradient wrt the pre-activation
  *                               gates dgates [B,T,ndir*4H] (zero beyond lengths).  The caller finishes with plain GEMMs:
  *                               dx = dgates W_ih, dW_ih = dgates^T x, dW_hh = dgates^T h_prev, db = sum dgates. */
-/* With few sequences (G * B * ndir <= number of CUs; G <= 4, env TTSC_LSTM_SPLIT caps it, 1 = off) the train-forward and backward
- * recurrences (and, with env TTSC_LSTM_SPLIT_INFER=1, the inference forward) split every (utterance, direction) over G workgroups that exchange the state once per step (see
+/* With few sequences (G * B * ndir <= number of CUs; G <= 4, env TTSC_LSTM_SPLIT caps it, 1 = off) the forward, train-forward and
+ * backward recurrences split every (utterance, direction) over G workgroups (TTSC_LSTM_SPLIT_INFER=0 exempts inference) that exchange the state once per step (see
  * ttsc_gru_split_status); results then differ from the single-workgroup kernels in summation order only (<= 1e-6 relative).
  * ttsc_lstm_split_status: 0 = all hand-offs of the last split launch completed, 1 = a bounded spin timed out. */
 int32_t ttsc_lstm_split_status(void);
