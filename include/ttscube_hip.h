@@ -262,7 +262,8 @@ int ttsc_lstm_seq_forward(const float* xg_dev, const float* whh_packed_dev, floa
 /* With few sequences (G * B * ndir <= number of CUs; G <= 4, env TTSC_LSTM_SPLIT caps it, 1 = off) the forward, train-forward and
  * backward recurrences split every (utterance, direction) over G workgroups (TTSC_LSTM_SPLIT_INFER=0 exempts inference) that exchange the state once per step (see
  * ttsc_gru_split_status); results then differ from the single-workgroup kernels in summation order only (<= 1e-6 relative).
- * ttsc_lstm_split_status: 0 = all hand-offs of the last split launch completed, 1 = a bounded spin timed out. */
+ * ttsc_lstm_split_status: 0 = every hand-off since the last call completed, 1 = a bounded spin timed out (sticky until read:
+ * later split launches give up at once, so callers that care check it once per step / synthesis).  Synchronises the device. */
 int32_t ttsc_lstm_split_status(void);
 int ttsc_lstm_pack_whh_device(const float* whh_dev, int32_t ndir, int32_t H, int32_t transpose, float* out_dev, void* stream);
 int ttsc_lstm_seq_forward_train(const float* xg_dev, const float* whh_packed_dev, float* y_dev, const int32_t* lengths_dev,
@@ -279,7 +280,8 @@ int ttsc_lstm_seq_backward(const float* dy_dev, const float* gates_dev, const fl
  *                             the caller finishes with GEMMs: dx = dgi W_ih, dW_ih = dgi^T x, dW_hh = dgh^T h_prev, biases = sums */
 /* With few utterances (B * G <= number of CUs) both recurrences split every utterance over G workgroups (env TTSC_GRU_SPLIT caps
  * G, default 4, 1 = off) that exchange the state through y / dgh once per step; launches of one process must then be
- * stream-ordered (shared hand-off counters).  ttsc_gru_split_status: 0 = all hand-offs of the last launch completed. */
+ * stream-ordered (shared hand-off counters).  ttsc_gru_split_status: 0 = every hand-off since the last call completed, 1 = a spin timed out
+ * (sticky until read).  Synchronises the device. */
 int32_t ttsc_gru_split_status(void);
 int ttsc_gru_pack_whh_device(const float* whh_dev, int32_t H, int32_t transpose, float* out_dev, void* stream);
 int ttsc_gru_seq_forward(const float* xg_dev, const float* whh_packed_dev, const float* bhh_dev, float* y_dev, float* saved_dev,

@@ -166,3 +166,13 @@ def dev_ptr(t):
     import torch
     assert t.is_cuda and t.is_contiguous(), 'expected a contiguous device tensor'
     return C.c_void_p(t.data_ptr())
+
+
+def check_split_status(where):
+    """Raise if a multi-workgroup recurrence (split LSTM / GRU kernels) gave up on an inter-workgroup hand-off since the last
+    check — its outputs are then invalid.  Synchronises the device: call once per training step / synthesis, not per layer."""
+    L = lib()
+    bad = [n for n, f in (('LSTM', L.ttsc_lstm_split_status), ('GRU', L.ttsc_gru_split_status)) if f() != 0]
+    if bad:
+        raise TTSCError('%s: split %s recurrence aborted on a hand-off timeout (are other kernels occupying the CUs? '
+                        'TTSC_LSTM_SPLIT=1 / TTSC_GRU_SPLIT=1 select the single-workgroup kernels)' % (where, '/'.join(bad)))

@@ -349,8 +349,12 @@ static unsigned* g_gru_words = nullptr;   // [0..4095] per-utterance counters, [
 
 static unsigned* gru_sync_words(int B, hipStream_t s) {
     if (B > 4096) return nullptr;
-    if (!g_gru_words && hipMalloc((void**)&g_gru_words, 4097 * sizeof(unsigned)) != hipSuccess) return nullptr;
-    if (hipMemsetAsync(g_gru_words, 0, 4097 * sizeof(unsigned), s) != hipSuccess) return nullptr;
+    if (!g_gru_words) {
+        if (hipMalloc((void**)&g_gru_words, 4097 * sizeof(unsigned)) != hipSuccess) return nullptr;
+        if (hipMemset(g_gru_words, 0, 4097 * sizeof(unsigned)) != hipSuccess) return nullptr;
+    }
+    // counters restart at zero; the abort word [4096] is STICKY until ttsc_gru_split_status() has reported it
+    if (hipMemsetAsync(g_gru_words, 0, 4096 * sizeof(unsigned), s) != hipSuccess) return nullptr;
     return g_gru_words;
 }
 
@@ -360,7 +364,8 @@ extern "C" int32_t ttsc_gru_split_status(void) {
     if (!g_gru_words) return 0;
     unsigned v = 0;
     if (hipMemcpy(&v, g_gru_words + 4096, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return (int32_t)v;
+    if (v && hipMemset(g_gru_words + 4096, 0, sizeof(unsigned)) != hipSuccess) return -1;   // reported once, then re-armed
+    return (int32_t)(v != 0);
 }
 
 extern "C" int ttsc_gru_pack_whh_device(const float* whh_dev, int32_t H, int32_t transpose, float* out_dev, void* stream) {

@@ -422,8 +422,12 @@ static unsigned* g_lstm_words = nullptr;   // [0..8191] per-(utterance, directio
 
 static unsigned* lstm_sync_words(int n, hipStream_t s) {
     if (n > 8192) return nullptr;
-    if (!g_lstm_words && hipMalloc((void**)&g_lstm_words, 8193 * sizeof(unsigned)) != hipSuccess) return nullptr;
-    if (hipMemsetAsync(g_lstm_words, 0, 8193 * sizeof(unsigned), s) != hipSuccess) return nullptr;
+    if (!g_lstm_words) {
+        if (hipMalloc((void**)&g_lstm_words, 8193 * sizeof(unsigned)) != hipSuccess) return nullptr;
+        if (hipMemset(g_lstm_words, 0, 8193 * sizeof(unsigned)) != hipSuccess) return nullptr;
+    }
+    // counters restart at zero; the abort word [8192] is STICKY until ttsc_lstm_split_status() has reported it
+    if (hipMemsetAsync(g_lstm_words, 0, 8192 * sizeof(unsigned), s) != hipSuccess) return nullptr;
     return g_lstm_words;
 }
 
@@ -432,7 +436,8 @@ extern "C" int32_t ttsc_lstm_split_status(void) {
     if (!g_lstm_words) return 0;
     unsigned v = 0;
     if (hipMemcpy(&v, g_lstm_words + 8192, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return (int32_t)v;
+    if (v && hipMemset(g_lstm_words + 8192, 0, sizeof(unsigned)) != hipSuccess) return -1;   // reported once, then re-armed
+    return (int32_t)(v != 0);
 }
 
 static int lstm_forward_impl(const float* xg_dev, const float* whh_packed_dev, float* y_dev, const int32_t* lengths_dev,

@@ -7,6 +7,8 @@ import json
 import os
 
 import torch
+
+from .. import _lib
 import torch.nn as nn
 
 from ..hifigan.env import AttrDict
@@ -58,6 +60,7 @@ class Cubegan(nn.Module):
                 cond = torch.zeros((cond.shape[0], 1, cond.shape[2]), device=self.get_device())
                 flens = [1] * cond.shape[0]
             wav = self._generator(cond.permute(0, 2, 1).contiguous(), frames=flens if cond.shape[0] > 1 else None)
+        _lib.check_split_status('Cubegan.inference')   # the BiLSTM recurrences may run split over several workgroups
         if return_lengths:
             return wav, [self._generator.out_len(f) if f > 0 else 0 for f in flens]
         return wav

@@ -79,7 +79,9 @@ class CubenetTextcoder(nn.Module):
                 return torch.zeros((1, 0, 80), device=dev)
             h = self._lstm('_rnn_overlay')(h)
             mel = self._ar_decode(h, dropout_masks)
-            return self._postnet(mel, add_residual=True)
+            out = self._postnet(mel, add_residual=True)
+            _lib.check_split_status('CubenetTextcoder.inference')
+            return out
 
     def _melar_handle(self):
         """(re)build the persistent AR-decoder handle when a parameter changed"""

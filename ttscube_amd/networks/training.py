@@ -4,6 +4,7 @@
 they serve validation and the forced-alignment synthesis (`Cubegan.forward`, cubegan.py:65-72)."""
 import torch
 
+from .. import _lib
 from ..hip_layers import linear_hip
 from .modules import _expand_rows
 
@@ -238,6 +239,7 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
         reducers[2].reduce()
     opt_t.step()
     opt_b.step()
+    _lib.check_split_status('cubegan_training_step')
     model._global_step += 1
     model._current_lr = model._compute_lr(model._learning_rate, 1e-5, model._global_step)
     for o in (opt_d, opt_g, opt_t):
@@ -297,6 +299,7 @@ def vocoder_training_step(voc, batch, optimizers, reducers=None):
     torch.nn.utils.clip_grad_norm_(voc._wavernn_hr.parameters(), 5)
     opt_lr.step()
     opt_hr.step()
+    _lib.check_split_status('vocoder_training_step')
     voc._global_step += 1
     alpha = voc._compute_lr(voc._learning_rate, 5e-5, voc._global_step)
     opt_lr.param_groups[0]['lr'] = alpha
