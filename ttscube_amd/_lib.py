@@ -102,6 +102,7 @@ SIGNATURES = {
     'ttsc_linear_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                       C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     'ttsc_lstm_split_status': (C.c_int32, []),
+    'ttsc_melar_split_status': (C.c_int32, []),
     'ttsc_lstm_pack_whh_device': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     'ttsc_lstm_seq_forward_train': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                               C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -172,7 +173,7 @@ def check_split_status(where):
     """Raise if a multi-workgroup recurrence (split LSTM / GRU kernels) gave up on an inter-workgroup hand-off since the last
     check — its outputs are then invalid.  Synchronises the device: call once per training step / synthesis, not per layer."""
     L = lib()
-    bad = [n for n, f in (('LSTM', L.ttsc_lstm_split_status), ('GRU', L.ttsc_gru_split_status)) if f() != 0]
+    bad = [n for n, f in (('LSTM', L.ttsc_lstm_split_status), ('GRU', L.ttsc_gru_split_status), ('mel-AR', L.ttsc_melar_split_status)) if f() != 0]
     if bad:
         raise TTSCError('%s: split %s recurrence aborted on a hand-off timeout (are other kernels occupying the CUs? '
                         'TTSC_LSTM_SPLIT=1 / TTSC_GRU_SPLIT=1 select the single-workgroup kernels)' % (where, '/'.join(bad)))

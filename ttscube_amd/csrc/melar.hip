@@ -12,6 +12,7 @@
 // Dropout masks: injected ({0,1} floats, parity tests) or drawn in-kernel from Philox-4x32-10 counters (step, layer, unit).
 #include "common.hpp"
 #include "../../include/ttscube_math.h"
+#include "rnn_chain.hpp"
 
 namespace ttsc {
 
@@ -151,6 +152,133 @@ __global__ __launch_bounds__(512) void melar_kernel(MelArArgs a) {
         for (int i = tid; i < O; i += blockDim.x) a.y[((size_t)b * a.S + t) * O + i] = 0.f;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Split variant: the reference API decodes ONE utterance (B = 1), i.e. one workgroup streaming 15.5 MB of weights per AR
+// step from L2 through one CU's load path (209 us/step).  Here G workgroups share the utterance: member m owns H/G hidden
+// units of BOTH LSTM layers (their gate rows only: (2.1 + 3 x 4.2) MB / G per step), its 512 threads are (unit, k-slice)
+// pairs reduced through LDS, and the members exchange h1_t and h2_t (two hand-offs per step, protocol of rnn_chain.hpp).
+// The PreNet (0.34 MB) and the output Linear (0.5 MB) are evaluated redundantly by every member, so the fed-back frame
+// never has to be exchanged; member 0 writes y.  Results differ from melar_kernel in summation order only.
+struct MelArSplitArgs {
+    MelArArgs a;
+    float* xh;            // [B][2 (layer)][2 (step parity)][H] exchanged hidden states
+    unsigned* cnt;        // [B] monotonic counters
+    unsigned* abort_word;
+    int G, HU, KS;
+};
+
+__global__ __launch_bounds__(512) void melar_split_kernel(MelArSplitArgs s) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ int ok_s;
+    const MelArArgs& a = s.a;
+    const int H = a.H, P = a.P, M = a.M, O = a.O, H4 = 4 * H, HU = s.HU, KS = s.KS;
+    float* h1 = sm;               // [H] full h1_{t-1} / h1_t
+    float* h2 = h1 + H;           // [H]
+    float* p1 = h2 + H;           // [P]
+    float* p2 = p1 + P;           // [P]
+    float* lm = p2 + P;           // [M] last mel frame
+    float* part = lm + M;         // [KS][4][HU]
+    const int tid = threadIdx.x, u = tid % HU, ks = tid / HU;
+    const int m = blockIdx.x, b = blockIdx.y;
+    const int j = m * HU + u;
+    const bool owner = ks == 0;
+    const int KP = P / KS, KH = H / KS;
+    const int nsteps = a.steps ? a.steps[b] : a.S;
+    unsigned* cnt = s.cnt + b;
+    float* xh1 = s.xh + (size_t)b * 4 * H;
+    float* xh2 = xh1 + 2 * H;
+    for (int i = tid; i < 2 * H; i += 512) sm[i] = 0.f;
+    for (int i = tid; i < M; i += 512) lm[i] = a.init_mel;
+    float c1 = 0.f, c2 = 0.f;
+    __syncthreads();
+    for (int t = 0; t < nsteps; ++t) {
+        const int par = t & 1;
+        auto mask = [&](int layer, int unit) -> float {
+            if (a.masks) return a.masks[(((size_t)b * a.S + t) * 2 + layer) * P + unit];
+            uint32_t r4[4];
+            ttsc_philox4x32((uint32_t)(unit >> 2), (uint32_t)t, (uint32_t)b, (uint32_t)layer, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r4);
+            return (r4[unit & 3] & 1u) ? 1.f : 0.f;
+        };
+        float xv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (owner) {
+            const float* xr = a.xg1 + ((size_t)b * a.S + t) * H4 + j;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xv[g] = xr[g * H];
+        }
+        // ---- PreNet (every member, identical arithmetic to melar_kernel) ----
+        if (tid < P) {
+            float acc[1] = {a.b_pn1[tid]};
+            ar_chain<1, 5>(acc, a.w_pn1, P, 0, tid, lm, M);
+            p1[tid] = fmaxf(acc[0], 0.f) * (mask(0, tid) * 2.f);
+        }
+        __syncthreads();
+        if (tid < P) {
+            float acc[1] = {a.b_pn2[tid]};
+            ar_chain<1, 8>(acc, a.w_pn2, P, 0, tid, p1, P);
+            p2[tid] = fmaxf(acc[0], 0.f) * (mask(1, tid) * 2.f);
+        }
+        __syncthreads();
+        // ---- LSTM layer 1, this member's units: partial sums over the k-slices of p2 and h1_{t-1} ----
+        {
+            float acc[1][4] = {{0.f, 0.f, 0.f, 0.f}};
+            lstm_chain<1, 4, 2>(acc, a.w_p2l + (size_t)(ks * KP / 4) * H4 * 4, H4, H, j, p2 + ks * KP, P, KP);
+            lstm_chain<1, 4, 2>(acc, a.w_hh1 + (size_t)(ks * KH / 4) * H4 * 4, H4, H, j, h1 + ks * KH, H, KH);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) part[(ks * 4 + g) * HU + u] = acc[0][g];
+        }
+        __syncthreads();
+        if (owner) {
+            float gs[4] = {xv[0], xv[1], xv[2], xv[3]};
+            for (int q = 0; q < KS; ++q)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gs[g] += part[(q * 4 + g) * HU + u];
+            const float ig = ttsc_sigmoidf(gs[0]), fg = ttsc_sigmoidf(gs[1]), gg = ttsc_tanhf(gs[2]), og = ttsc_sigmoidf(gs[3]);
+            c1 = fmaf(fg, c1, ig * gg);
+            g_st(xh1 + par * H + j, og * ttsc_tanhf(c1));
+        }
+        g_publish(cnt);
+        if (!g_wait(cnt, (unsigned)(2 * t + 1) * (unsigned)s.G, s.abort_word, &ok_s)) return;
+        for (int i = tid; i < H; i += 512) h1[i] = g_ld(xh1 + par * H + i);
+        __syncthreads();
+        // ---- LSTM layer 2 ----
+        {
+            float acc[1][4] = {{0.f, 0.f, 0.f, 0.f}};
+            lstm_chain<1, 4, 2>(acc, a.w_ih2 + (size_t)(ks * KH / 4) * H4 * 4, H4, H, j, h1 + ks * KH, H, KH);
+            lstm_chain<1, 4, 2>(acc, a.w_hh2 + (size_t)(ks * KH / 4) * H4 * 4, H4, H, j, h2 + ks * KH, H, KH);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) part[(ks * 4 + g) * HU + u] = acc[0][g];
+        }
+        __syncthreads();
+        if (owner) {
+            float gs[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gs[g] = a.b2[g * H + j];
+            for (int q = 0; q < KS; ++q)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gs[g] += part[(q * 4 + g) * HU + u];
+            const float ig = ttsc_sigmoidf(gs[0]), fg = ttsc_sigmoidf(gs[1]), gg = ttsc_tanhf(gs[2]), og = ttsc_sigmoidf(gs[3]);
+            c2 = fmaf(fg, c2, ig * gg);
+            g_st(xh2 + par * H + j, og * ttsc_tanhf(c2));
+        }
+        g_publish(cnt);
+        if (!g_wait(cnt, (unsigned)(2 * t + 2) * (unsigned)s.G, s.abort_word, &ok_s)) return;
+        for (int i = tid; i < H; i += 512) h2[i] = g_ld(xh2 + par * H + i);
+        __syncthreads();
+        // ---- output Linear H -> O (every member; member 0 stores); the last M values are fed back ----
+        if (tid < O) {
+            float acc[1] = {a.b_out[tid]};
+            ar_chain<1, 8>(acc, a.w_out, O, 0, tid, h2, H);
+            if (m == 0) a.y[((size_t)b * a.S + t) * O + tid] = acc[0];
+            if (tid >= O - M) lm[tid - (O - M)] = acc[0];
+        }
+        __syncthreads();
+    }
+    if (m == 0)
+        for (int t = nsteps; t < a.S; ++t)
+            for (int i = tid; i < O; i += 512) a.y[((size_t)b * a.S + t) * O + i] = 0.f;
+}
+
 }  // namespace ttsc
 
 using namespace ttsc;
@@ -221,6 +349,38 @@ extern "C" int ttsc_melar_set_weights(ttsc_melar* m, const float* w_ih1, int64_t
     return up(&m->b_pn2, pn_b2, P);
 }
 
+
+// split factor for the AR decoder: G <= 4 (hand-offs stay ~1 us), >= 32 units per member, all workgroups co-resident
+static int melar_split_members(int B, int H, int P) {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    }
+    int gmax = 4;
+    if (const char* ev = getenv("TTSC_MELAR_SPLIT")) gmax = atoi(ev);
+    int G = 1;
+    while (G * 2 <= gmax && (long)G * 2 * B <= cus && H % (G * 2) == 0 && H / (G * 2) >= 32 && 512 % (H / (G * 2)) == 0) {
+        const int HU = H / (G * 2), KS = 512 / HU;
+        if (H % KS != 0 || (H / KS) % 8 != 0 || P % KS != 0 || (P / KS) % 8 != 0) break;
+        G *= 2;
+    }
+    return G;
+}
+
+static float* g_melar_x = nullptr;       // exchange area [cap][4][H_max = 512] + counters
+static unsigned* g_melar_words = nullptr;  // [0..1023] counters, [1024] sticky abort word
+static int g_melar_cap = 0;
+
+// 0 = every hand-off since the last call completed, 1 = a bounded spin timed out (sticky until read).  Synchronises the device.
+extern "C" int32_t ttsc_melar_split_status(void) {
+    if (!g_melar_words) return 0;
+    unsigned v = 0;
+    if (hipMemcpy(&v, g_melar_words + 1024, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (v && hipMemset(g_melar_words + 1024, 0, sizeof(unsigned)) != hipSuccess) return -1;
+    return (int32_t)(v != 0);
+}
+
 extern "C" int ttsc_melar_decode(const ttsc_melar* m, const float* xg1_dev, int32_t B, int32_t S, const float* masks_dev,
                                  uint64_t seed, const int32_t* steps_dev, float* y_dev, void* stream) {
     TTSC_REQUIRE(m && xg1_dev && y_dev, "ttsc_melar_decode: null argument");
@@ -231,6 +391,41 @@ extern "C" int ttsc_melar_decode(const ttsc_melar* m, const float* xg1_dev, int3
     }
     MelArArgs a{xg1_dev, m->w_p2l, m->w_hh1, m->w_ih2, m->w_hh2, m->b2, m->w_out, m->b_out, m->w_pn1, m->b_pn1, m->w_pn2, m->b_pn2,
                 masks_dev, steps_dev, y_dev, B, S, m->H, m->P, m->M, m->O, -5.0f, seed};
+    const int G = B <= 1024 ? melar_split_members(B, m->H, m->P) : 1;
+    if (G > 1) {
+        hipStream_t st = (hipStream_t)stream;
+        if (!g_melar_words) {
+            TTSC_HIP_CHECK(hipMalloc((void**)&g_melar_words, 1025 * sizeof(unsigned)));
+            TTSC_HIP_CHECK(hipMemset(g_melar_words, 0, 1025 * sizeof(unsigned)));
+        }
+        if (B > g_melar_cap) {
+            if (g_melar_x) {
+                TTSC_HIP_CHECK(hipDeviceSynchronize());
+                (void)hipFree(g_melar_x);
+                g_melar_x = nullptr;
+            }
+            TTSC_HIP_CHECK(hipMalloc((void**)&g_melar_x, (size_t)B * 4 * 512 * sizeof(float)));
+            g_melar_cap = B;
+        }
+        TTSC_HIP_CHECK(hipMemsetAsync(g_melar_words, 0, 1024 * sizeof(unsigned), st));   // counters; the abort word stays sticky
+        MelArSplitArgs sa{};
+        sa.a = a;
+        sa.xh = g_melar_x;
+        sa.cnt = g_melar_words;
+        sa.abort_word = g_melar_words + 1024;
+        sa.G = G;
+        sa.HU = m->H / G;
+        sa.KS = 512 / sa.HU;
+        // the exchange area is indexed with H, not 512
+        const size_t ldsb = ((size_t)2 * m->H + 2 * m->P + m->M + (size_t)sa.KS * 4 * sa.HU + 16) * sizeof(float);
+        hipLaunchKernelGGL(melar_split_kernel, dim3((unsigned)G, (unsigned)B), dim3(512), ldsb, st, sa);
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) {
+            set_error("melar_split_kernel launch failed: %s", hipGetErrorString(e2));
+            return TTSC_EHIP;
+        }
+        return TTSC_OK;
+    }
     const size_t lds = ((size_t)4 * m->H + 2 * m->P + m->M + 16) * sizeof(float);
     hipLaunchKernelGGL(melar_kernel, dim3(B), dim3(512), lds, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
