@@ -8,13 +8,13 @@
 // (o + p) % s == r, its taps are k = r + j*s and it reads x[q - j]  (tap_step = -1).
 //
 // GEMM view per workgroup: M = output channels (MT rows), N = NT consecutive q positions, K = Cin*ntaps.
-// v_mfma_f32_32x32x2_f32 is an exact k-ordered fp32 fmaf chain at the fp32 vector rate (157 TF/chip);
-// one wave per SIMD with >=4 independent accumulators saturates the pipe, so the design goal is simply
-// "never starve it": the B operand (activations, with the dilation halo) is staged once per 16-channel
-// chunk through LDS with the leaky-relu prologue fused into the staging pass, and the A operand
-// (weights) is pre-packed on the host into MFMA fragment order so every fragment is ONE coalesced
-// 256-byte wave load that hits L2.  Epilogue fuses bias, residual add, scaling, tanh and the running
-// sum over residual blocks.
+// v_mfma_f32_32x32x2_f32 is an exact k-ordered fp32 fmaf chain at the fp32 vector rate (157 TF/chip).  The B operand
+// (activations, with the dilation halo) is staged per 16-channel chunk through double-buffered LDS with the leaky-relu
+// prologue fused into the staging pass, the A operand (weights) is pre-packed into MFMA fragment order (on the host for
+// inference, by pack_w_kernel from the live parameter for training) so every fragment is ONE coalesced 256-byte wave load
+// that hits L2; both streams are software-pipelined explicitly (see conv_mfma_kernel).  Epilogue fuses bias, residual
+// add, scaling, tanh, the running sum over residual blocks and — for data-gradient launches — the leaky-relu derivative.
+// The split-precision kernels further down (conv_f16x3_kernel, respair32_f16x3_kernel) are the default for the generator.
 #include <cmath>
 #include <cstdlib>
 
