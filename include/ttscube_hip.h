@@ -304,7 +304,7 @@ int ttsc_melar_create(int32_t H, int32_t P, int32_t M, int32_t O, ttsc_melar** o
 int ttsc_melar_set_weights(ttsc_melar* m, const float* w_ih1, int64_t ld1, const float* w_hh1, const float* w_ih2,
                            const float* w_hh2, const float* b_ih2, const float* b_hh2, const float* w_out, const float* b_out,
                            const float* pn_w1, const float* pn_b1, const float* pn_w2, const float* pn_b2);
-/* With few utterances (G * B <= number of CUs; G <= 4, env TTSC_MELAR_SPLIT caps it, 1 = off) the decode loop of one utterance is
+/* With few utterances (G * B <= number of CUs; G <= 8, env TTSC_MELAR_SPLIT caps it, 1 = off) the decode loop of one utterance is
  * split over G workgroups (each owns H/G units of both LSTM layers; h1 / h2 exchanged every step, protocol of
  * ttsc_lstm_split_status); results differ from the single-workgroup kernel in summation order only. */
 int32_t ttsc_melar_split_status(void);
