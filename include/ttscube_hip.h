@@ -113,6 +113,18 @@ int ttsc_conv1d_forward_split(const ttsc_conv1d* c, const float* x_dev, const vo
 int ttsc_respair_supported(const ttsc_conv1d* conv1, const ttsc_conv1d* conv2);
 int ttsc_respair_forward(const ttsc_conv1d* conv1, const ttsc_conv1d* conv2, const float* x_dev, int32_t B, int64_t L,
                          float* y_dev, int32_t accumulate, const int32_t* len_dev, void* stream);
+/* Fused ResBlock1 chain  x <- x + conv2_p(lrelu(conv1_p(lrelu(x), 0.1), 0.1)),  p = 0..npairs-1 (npairs <= 3), y (+)= x:
+ * hifigan.models.ResBlock1.forward [EXTERNAL; call sites cube/networks/cubegan.py:72,83 via Generator.forward] for the 32- and
+ * 64-channel stages, where every single convolution is HBM-bound.  The residual stream of a time tile stays in registers and
+ * the activations in LDS for the whole chain; HBM sees one read of x and one write (read-modify-write when `accumulate`) of y.
+ * All layers C -> C with C in {32, 64}, one odd kernel size K in {3, 7, 11}, conv1 dilation <= 5, conv2 undilated, "same"
+ * padding, TTSC_PREC_F16X3, host-set weights with bias.  `supported` returns 1 when the fused kernel applies.
+ * tile_shape: -1 = pick by halo, 0 = small tile (512 columns at C=32 / 256 at C=64; two workgroups per CU), 1 = large tile
+ * (1024 / 512 columns, one 8-wave workgroup per CU).  y must not alias x. */
+int ttsc_rbchain_supported(const ttsc_conv1d* const* convs1, const ttsc_conv1d* const* convs2, int32_t npairs);
+int ttsc_rbchain_forward(const ttsc_conv1d* const* convs1, const ttsc_conv1d* const* convs2, int32_t npairs, const float* x_dev,
+                         int32_t B, int64_t L, float* y_dev, int32_t accumulate, const int32_t* len_dev, int32_t tile_shape,
+                         void* stream);
 void ttsc_conv1d_destroy(ttsc_conv1d* c);
 
 /* Weight gradient of the generator's convolutions (training: `Cubegan.training_step`, cube/networks/cubegan.py:85-189,

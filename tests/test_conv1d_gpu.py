@@ -232,3 +232,85 @@ def test_split_activation_roundtrip(cin, cout, k, d, L, B):
                                                 None, C.byref(ep1), None, None, _lib.current_stream()), 'split-in')
         ref2 = F.conv1d(F.leaky_relu(ref / 3.0, 0.1), w2, None, padding=1)
         assert float((z.cpu() - ref2).abs().max()) < F16X3_TOL
+
+
+def _chain_layers(C, k, dils, seed=0):
+    from ttscube_amd.hip_layers import Conv1dHip
+    c1s, c2s, ws = [], [], []
+    for m, d in enumerate(dils):
+        c1 = Conv1dHip(C, C, k, padding=d * (k - 1) // 2, dilation=d).set_precision('f16x3')
+        c2 = Conv1dHip(C, C, k, padding=(k - 1) // 2).set_precision('f16x3')
+        w1, b1 = _mk((C, C, k), seed + 10 * m + 1, 1.0 / (C * k) ** 0.5), _mk((C,), seed + 10 * m + 2, 0.1)
+        w2, b2 = _mk((C, C, k), seed + 10 * m + 3, 1.0 / (C * k) ** 0.5), _mk((C,), seed + 10 * m + 4, 0.1)
+        c1.set_weight(w1, b1)
+        c2.set_weight(w2, b2)
+        c1s.append(c1)
+        c2s.append(c2)
+        ws.append((w1, b1, w2, b2, d))
+    return c1s, c2s, ws
+
+
+def _chain_ref(x, ws, k):
+    for w1, b1, w2, b2, d in ws:
+        xt = F.conv1d(F.leaky_relu(x, 0.1), w1, b1, padding=d * (k - 1) // 2, dilation=d)
+        x = x + F.conv1d(F.leaky_relu(xt, 0.1), w2, b2, padding=(k - 1) // 2)
+    return x
+
+
+def _chain_call(c1s, c2s, xd, y, accumulate, lens, shape):
+    import ctypes as C
+    from ttscube_amd import _lib
+    n = len(c1s)
+    a1 = (C.c_void_p * n)(*[c._h for c in c1s])
+    a2 = (C.c_void_p * n)(*[c._h for c in c2s])
+    L_ = _lib.lib()
+    assert L_.ttsc_rbchain_supported(a1, a2, n) == 1
+    B, _, L = xd.shape
+    _lib.check(L_.ttsc_rbchain_forward(a1, a2, n, _lib.dev_ptr(xd), B, L, _lib.dev_ptr(y), accumulate,
+                                       _lib.dev_ptr(lens) if lens is not None else None, shape, _lib.current_stream()),
+               'ttsc_rbchain_forward')
+
+
+@pytest.mark.parametrize('C,k,dils,L,B,shape', [
+    (32, 3, (1, 3, 5), 1500, 2, 0), (32, 3, (1, 3, 5), 2311, 1, 1), (32, 7, (1, 3, 5), 1111, 2, 0), (32, 7, (1, 3, 5), 2048, 1, 1),
+    (32, 11, (1, 3, 5), 1999, 2, 0), (32, 11, (1, 3, 5), 3000, 1, 1), (32, 11, (5,), 7, 2, -1), (32, 3, (1, 3), 392, 1, -1),
+    (64, 3, (1, 3, 5), 900, 2, 0), (64, 7, (1, 3, 5), 777, 1, 0), (64, 7, (1, 3, 5), 1300, 2, 1), (64, 11, (1, 3, 5), 1100, 1, 1),
+    (64, 11, (3,), 600, 2, 0), (64, 3, (5,), 257, 1, 1),
+])
+def test_fused_resblock_chain_matches_torch(C, k, dils, L, B, shape):
+    """rbchain_f16x3_kernel (resblock.hip) through ttsc_rbchain_forward: the whole ResBlock1
+    x <- x + conv2(lrelu(conv1_d(lrelu(x)))) for every dilation, residual stream in registers, activations in LDS."""
+    c1s, c2s, ws = _chain_layers(C, k, dils, seed=100 * k + C)
+    x = _mk((B, C, L), 5)
+    s0 = _mk((B, C, L), 6)
+    ref = _chain_ref(x, ws, k)
+    xd = x.cuda()
+    for accumulate in (0, 1):
+        y = s0.clone().cuda()
+        _chain_call(c1s, c2s, xd, y, accumulate, None, shape)
+        want = ref + s0 if accumulate else ref
+        err = float((y.cpu() - want).abs().max())
+        assert err < 3e-5, (accumulate, err)
+    if B > 1 and L > 600:
+        # ragged: utterance 0 is shorter; its valid part equals the utterance run alone, the tail is left untouched
+        n = L - 333
+        lens = torch.tensor([n] + [L] * (B - 1), dtype=torch.int32).cuda()
+        y = torch.full_like(xd, 7.0)
+        _chain_call(c1s, c2s, xd, y, 0, lens, shape)
+        solo = _chain_ref(x[:1, :, :n], ws, k)
+        assert float((y[:1, :, :n].cpu() - solo).abs().max()) < 3e-5
+        assert float((y[1:].cpu() - ref[1:]).abs().max()) < 3e-5
+
+
+def test_fused_resblock_chain_not_eligible():
+    import ctypes as C
+    from ttscube_amd import _lib
+    c1s, c2s, _ = _chain_layers(32, 7, (1, 3))
+    c1s[1].set_precision('fp32')
+    a1 = (C.c_void_p * 2)(*[c._h for c in c1s])
+    a2 = (C.c_void_p * 2)(*[c._h for c in c2s])
+    assert _lib.lib().ttsc_rbchain_supported(a1, a2, 2) == 0
+    c1s, c2s, _ = _chain_layers(128, 3, (1,))
+    a1 = (C.c_void_p * 1)(c1s[0]._h)
+    a2 = (C.c_void_p * 1)(c2s[0]._h)
+    assert _lib.lib().ttsc_rbchain_supported(a1, a2, 1) == 0

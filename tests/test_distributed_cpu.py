@@ -2,6 +2,7 @@
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -15,7 +16,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, use_rs):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -30,19 +31,29 @@ def _worker(rank, world, port, q):
     xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]   # rank-distinct shard of the global batch
     loss = ((net(xs) - ys) ** 2).mean()
     loss.backward()
-    red = FlatBucketReducer(list(net.parameters()) + list(frozen.parameters()), bucket_mb=0.0001)  # forces several buckets
+    partial = torch.nn.Linear(3, 1)                     # a parameter with a gradient on rank 0 only
+    if rank == 0:
+        partial(torch.ones(1, 3)).sum().backward()
+    red = FlatBucketReducer(list(net.parameters()) + list(frozen.parameters()) + list(partial.parameters()), bucket_mb=0.0001,
+                            use_reduce_scatter=use_rs)   # tiny buckets: several of them, none a multiple of the world size
     red.reduce()
+    assert all(p.grad is None for p in frozen.parameters())        # no gradient anywhere -> stays None (as single-process)
+    assert torch.allclose(partial.weight.grad, torch.full((1, 3), 0.5))   # mean of (ones, zeros)
+    assert red.bytes_exchanged > 0
     q.put((rank, [p.grad.clone() for p in net.parameters()], [p.detach().clone() for p in net.parameters()]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_flat_bucket_allreduce_matches_single_process_gradient():
+@pytest.mark.parametrize('use_rs', [True, False])
+def test_flat_bucket_allreduce_matches_single_process_gradient(use_rs):
+    """use_rs=True is the production exchange (reduce_scatter_tensor into a shard buffer + all_gather_into_tensor), the same
+    calls RCCL runs on the GPUs; False is the plain all_reduce."""
     world = 2
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, use_rs)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}

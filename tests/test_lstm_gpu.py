@@ -62,3 +62,18 @@ def test_lstm_initial_state_chaining():
     y1, st1 = h(x[:, :4], return_state=True)
     y2, st2 = h(x[:, 4:], hx=st1, return_state=True)
     assert torch.equal(torch.cat([y1, y2], 1), y) and torch.equal(st2[0], st[0]) and torch.equal(st2[1], st[1])
+
+
+def test_lstm_two_utterances_per_workgroup():
+    """lstm_seq_kernel<2> (B * ndir > 512 sequences: two utterances share one W_hh stream), ragged, vs torch.nn.LSTM."""
+    from ttscube_amd.hip_layers import LSTMHip
+    torch.manual_seed(9)
+    m = nn.LSTM(input_size=24, hidden_size=64, num_layers=1, bidirectional=True, batch_first=True)
+    B, T = 301, 6
+    x = torch.randn(B, T, 24)
+    lens = [(b % T) + 1 for b in range(B)]
+    with torch.no_grad():
+        packed = nn.utils.rnn.pack_padded_sequence(x, lens, batch_first=True, enforce_sorted=False)
+        ref, _ = nn.utils.rnn.pad_packed_sequence(m(packed)[0], batch_first=True, total_length=T)
+    y = LSTMHip(m.cuda())(x.cuda(), lengths=lens).cpu()
+    assert float((y - ref).abs().max()) < 2e-5

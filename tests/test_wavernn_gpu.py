@@ -82,8 +82,39 @@ def test_matches_oracle_bit_exact(H, N, lowres, B, T, mode, wr_kernel):
     assert np.array_equal(logits.cpu().numpy(), rlog)  # logits themselves are bit-exact
 
 
+@pytest.mark.parametrize('bt,B,H,N,mode', [(2, 5, 64, 1, 'noise'), (4, 7, 64, 2, 'philox'), (8, 13, 128, 1, 'noise'), (2, 3, 512, 1, 'philox'),
+                                           (4, 6, 512, 2, 'argmax'), (8, 9, 512, 1, 'noise'), (0, 300, 64, 1, 'philox'), (0, 600, 64, 1, 'argmax')])
+def test_utterance_tiles_bit_exact(bt, B, H, N, mode, monkeypatch, wr_kernel):
+    """wr_decode_kernel<2/4/8> (several utterances per workgroup sharing one weight stream): forced through TTSC_WR_BT with a
+    batch that is NOT a multiple of the tile, and selected by the dispatcher itself at B=300 (BT=2) / B=600 (BT=4)."""
+    if wr_kernel == 'quad':
+        pytest.skip('the utterance-tile template belongs to the streaming kernel')
+    if bt:
+        monkeypatch.setenv('TTSC_WR_BT', str(bt))
+    else:
+        monkeypatch.delenv('TTSC_WR_BT', raising=False)
+    sd = O.synthetic_state_dict(H=H, num_layers=N, use_lowres=True, seed=500 + H + N + bt)
+    net = _net(H, N, True, sd)
+    T = 1
+    mel, x_low = O.synthetic_inputs(B, T, seed=13 + B)
+    X = {'mel': torch.from_numpy(mel), 'x_low': torch.from_numpy(x_low)}
+    L = T * 240
+    noise = None
+    if mode == 'noise':
+        u = np.random.RandomState(8).uniform(1e-6, 1 - 1e-6, size=(B, L, 256))
+        noise = (-np.log(-np.log(u))).astype(np.float32)
+    omode = {'noise': O.MODE_NOISE, 'philox': O.MODE_PHILOX, 'argmax': O.MODE_ARGMAX}[mode]
+    ridx, rwav, rlog = O.decode(sd, mel, x_low, num_layers=N, H=H, mode=omode, noise=noise, seed=0xBEEF, want_logits=True)
+    idx, wav, logits = net.decode(X, mode=mode, noise=noise, seed=0xBEEF, want_logits=True)
+    assert net.last_kernel == 'stream'
+    assert np.array_equal(idx.cpu().numpy(), ridx), 'first index mismatch at %s' % (np.argwhere(idx.cpu().numpy() != ridx)[:3],)
+    assert np.array_equal(wav.cpu().numpy(), rwav)
+    assert np.array_equal(logits.cpu().numpy(), rlog)
+
+
 def test_ragged_tile_and_batch_independence():
-    """B not a multiple of the utterance tile; utterance b alone == utterance b inside the batch."""
+    """A batch of 7 (one utterance per workgroup at this size; the multi-utterance tiles are covered by
+    test_utterance_tiles_bit_exact): utterance b alone == utterance b inside the batch."""
     H, N = 64, 1
     sd = O.synthetic_state_dict(H=H, num_layers=N, use_lowres=True, seed=9)
     net = _net(H, N, True, sd)

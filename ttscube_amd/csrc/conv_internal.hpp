@@ -1,0 +1,29 @@
+// Internal layout of a conv layer handle, shared by conv1d.hip (single-layer launches) and resblock.hip (fused chains).
+#pragma once
+#include "common.hpp"
+
+struct ConvPhase {
+    float* wp_dev = nullptr;
+    void* wph_dev = nullptr;  // f16x3 fragments
+    int ntaps = 0, tap_base = 0, tap_step = 0;
+    int out_stride = 1, out_off = 0;
+    int r = 0;  // phase index (transposed)
+    std::vector<int> taps;  // kernel taps (or tap indices when vfused) of this phase, in GEMM order
+};
+
+struct ttsc_conv1d {
+    ttsc_conv1d_cfg cfg;
+    int MT = 32, NT = 512, CinP = 0, CoutP = 0;
+    std::vector<ConvPhase> phases;
+    float* bias_dev = nullptr;
+    bool has_weight = false;
+    int precision = TTSC_PREC_FP32;
+    bool vfused = false;   // ConvTranspose1d with Cout % 32 == 0: all `stride` phases as extra GEMM rows of ONE launch
+    int CoutV = 0;         // stride * Cout when vfused
+    float w_unscale = 1.f;
+    std::vector<float> w_host, b_host;  // kept so that the precision can be switched (repack) at any time
+    bool has_bias = false;
+    bool dev_weights = false;  // weights were last written by ttsc_conv1d_set_weight_device (host copy is stale)
+    const float* bias_ext = nullptr;  // device-weight mode: the caller's bias tensor
+};
+

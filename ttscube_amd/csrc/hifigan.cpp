@@ -41,6 +41,8 @@ struct ttsc_hifigan {
     std::map<std::string, std::unique_ptr<Layer>> layers;
     std::vector<int> stage_ch;  // channels after upsample i
     bool use_fused = true;      // env TTSC_HIFIGAN_FUSED=0 disables the fused residual-pair kernel (A/B measurements)
+    bool use_chain = true;      // env TTSC_HIFIGAN_CHAIN=0 disables the whole-ResBlock fused chain kernel (resblock.hip)
+    int chain_shape = -1;       // env TTSC_HIFIGAN_CHAIN_SHAPE: tile shape of the chain kernel (-1 = by halo)
     bool use_split = false;     // env TTSC_HIFIGAN_SPLIT=1 enables the producer-side split-activation flow (measured: no gain —
                                 // the consumer-side conversion hides behind the MFMA loop, the extra tensors cost HBM traffic)
     int precision = TTSC_PREC_FP32;
@@ -88,6 +90,8 @@ extern "C" int ttsc_hifigan_create(const ttsc_hifigan_cfg* cfg, ttsc_hifigan** o
     g->cfg = *cfg;
     if (const char* ev = getenv("TTSC_HIFIGAN_FUSED")) g->use_fused = atoi(ev) != 0;
     if (const char* ev = getenv("TTSC_HIFIGAN_SPLIT")) g->use_split = atoi(ev) != 0;
+    if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN")) g->use_chain = atoi(ev) != 0;
+    if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN_SHAPE")) g->chain_shape = atoi(ev);
     int rc = add_layer(g.get(), "conv_pre", cfg->num_mels, cfg->upsample_initial_channel, 7, 1, 3, 1, 0);
     if (rc) return rc;
     int ch = cfg->upsample_initial_channel;
@@ -304,7 +308,20 @@ extern "C" int ttsc_hifigan_forward_ragged(ttsc_hifigan* g, const float* mel, in
                 const std::string rb = "resblocks." + std::to_string(i * c.num_kernels + j);
                 fused_stage = ttsc_respair_supported(layer(rb + ".convs1." + std::to_string(m)), layer(rb + ".convs2." + std::to_string(m))) != 0;
             }
-        const bool stage_split = split_ok && !fused_stage && ch % 16 == 0;
+        // ... or, better, does every ResBlock1 of the stage run as ONE fused chain launch (32 / 64 channels)?
+        bool chain_stage = (c.resblock == 1) && g->use_chain;
+        for (int j = 0; chain_stage && j < c.num_kernels; ++j) {
+            const std::string rb = "resblocks." + std::to_string(i * c.num_kernels + j);
+            const ttsc_conv1d *c1[TTSC_HIFIGAN_MAX_DIL], *c2[TTSC_HIFIGAN_MAX_DIL];
+            const int nd = c.num_dilations[j];
+            for (int m = 0; m < nd; ++m) {
+                c1[m] = layer(rb + ".convs1." + std::to_string(m));
+                c2[m] = layer(rb + ".convs2." + std::to_string(m));
+            }
+            chain_stage = nd <= 3 && ttsc_rbchain_supported(c1, c2, nd) != 0;
+        }
+        if (chain_stage) fused_stage = false;
+        const bool stage_split = split_ok && !fused_stage && !chain_stage && ch % 16 == 0;
         // x = ups[i](lrelu(x / nk_prev, 0.1)); the stage input is needed in fp32 (residual of the first pair) and, in the
         // split flow, as split(lrelu(x, 0.1)) for the three first convs
         ttsc_conv1d_epilogue eu{sum_scale, 0.1f, 1.f, TTSC_ACT_NONE, 0};
@@ -320,6 +337,17 @@ extern "C" int ttsc_hifigan_forward_ragged(ttsc_hifigan* g, const float* mel, in
         for (int j = 0; j < c.num_kernels; ++j) {
             const std::string rb = "resblocks." + std::to_string(i * c.num_kernels + j);
             const int nd = c.num_dilations[j];
+            if (chain_stage) {
+                // the whole ResBlock1 in one launch: X -> S (+= for the second and third block)
+                const ttsc_conv1d *c1[TTSC_HIFIGAN_MAX_DIL], *c2[TTSC_HIFIGAN_MAX_DIL];
+                for (int m = 0; m < nd; ++m) {
+                    c1[m] = layer(rb + ".convs1." + std::to_string(m));
+                    c2[m] = layer(rb + ".convs2." + std::to_string(m));
+                }
+                rc = ttsc_rbchain_forward(c1, c2, nd, X, B, L, S, j > 0 ? 1 : 0, ln, g->chain_shape, stream);
+                if (rc) return rc;
+                continue;
+            }
             if (fused_stage) {
                 // ONE fused launch per pair (inner activation stays in LDS); the residual stream ping-pongs between R and
                 // XT because a fused tile reads its neighbours' halo of the input.

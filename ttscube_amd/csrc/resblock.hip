@@ -1,0 +1,376 @@
+// Fused HiFi-GAN ResBlock1 chain for the narrow stages (32 / 64 channels), split-precision (f16x3) MFMA, gfx950.
+//
+//     for p in 0..npairs-1:   x = x + conv2_p( lrelu( conv1_p( lrelu(x) ) ) )           [ y (+)= x at the end ]
+//
+// (hifigan.models.ResBlock1.forward [EXTERNAL]; reference call sites cube/networks/cubegan.py:72,83 through
+// Generator.forward.)  At 32 / 64 channels every convolution of the block is HBM-bound when it runs as its own
+// launch (24..140 FLOP per byte moved against a ridge of ~130), so the whole chain is evaluated per time tile:
+//
+//   * the fp32 residual stream of the tile lives in REGISTERS, in the MFMA C/D layout (the wave that owns a group of
+//     columns owns them for every convolution of the chain), so the residual add never touches memory;
+//   * ONE activation image in LDS, as fp16 (hi, lo) planes [8-channel group][hi|lo][column] of 16-byte items — the B
+//     fragment of any tap is a single conflict-free ds_read_b128.  conv1 reads lrelu(x) from it, its epilogue
+//     overwrites it in place with lrelu(conv1 + b1) (one extra barrier instead of a second image), conv2 reads that;
+//   * weight fragments (pre-packed in A-fragment order, see conv1d.hip::pack_phase_f16) stream from L2/L1 straight into
+//     registers two (tap, chunk) steps ahead of the MFMAs that use them — all waves of a workgroup read the same
+//     fragments at about the same time, so they hit in the CU's L1;
+//   * the tile carries `halo` extra columns per side (sum over the chain of every convolution's half receptive field);
+//     columns whose receptive field leaves the tile go stale and are never stored.
+//
+// HBM traffic per chain: read x once (+ halo), write y once (read-modify-write when accumulating the block sum) —
+// 2-3 tensor passes instead of 15 for three unfused pairs.
+#include "conv_internal.hpp"
+
+namespace ttsc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+constexpr int RB_MAXP = 3;
+
+struct ChainArgs {
+    const float* x;       // [B, C, L] chain input
+    float* y;             // [B, C, L] chain output (must not alias x: neighbouring tiles read x's halo)
+    const half8* w1[RB_MAXP];   // f16x3 fragments [tap][C/16][C/32][hi|lo][64 lanes][8 half]
+    const half8* w2[RB_MAXP];
+    const float* b1[RB_MAXP];
+    const float* b2[RB_MAXP];
+    float us1[RB_MAXP], us2[RB_MAXP];   // 2^-s weight un-scale factors
+    int d1[RB_MAXP];      // dilation of conv1 (conv2 is undilated)
+    const int* len;       // [B] valid length or null
+    int L, npairs, accumulate;
+    int halo, nto;        // columns of halo per side, output columns per tile (NCOL - 2*halo)
+};
+
+// MI = C/32 row tiles, K taps, CT 32-column tiles per wave, NW waves per workgroup, WPS = waves per SIMD the register
+// allocation has to leave room for (2: two workgroups of 4 waves or one of 8 per CU; 1: a single 4-wave workgroup).
+template <int MI, int K, int CT, int NW, int WPS>
+__global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int C = 32 * MI, NCH = 2 * MI, NG = 4 * MI;
+    constexpr int NCOL = NW * CT * 32;
+    constexpr int MARG = (K == 3) ? 8 : (K == 7 ? 16 : 26);   // >= the largest tap offset (dilation 5: 5*(K-1)/2)
+    constexpr int PW = NCOL + 2 * MARG;
+    constexpr int NTHR = 64 * NW;
+    half8* P = reinterpret_cast<half8*>(smem_raw);   // plane (group g, pl) at P + (g*2 + pl) * PW, tile column c at + MARG + c
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y;
+    const int q0 = blockIdx.x * a.nto;
+    const int lin = a.len ? a.len[b] : a.L;
+    if (q0 >= lin) return;
+    const int colw = wv * (CT * 32);                 // first tile column of this wave
+    const int pos_w = q0 - a.halo + colw + l31;      // sequence position of this lane's column in column tile 0
+    const float* xb = a.x + (size_t)b * C * a.L;
+
+    // the margins only feed columns that are never stored, but they must hold finite numbers
+    for (int i = tid; i < NG * 2 * 2 * MARG; i += NTHR) {
+        const int pl = i / (2 * MARG), m = i - pl * (2 * MARG);
+        half8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.f;
+        P[(size_t)pl * PW + (m < MARG ? m : NCOL + m)] = z;
+    }
+
+    // residual stream of the tile: C/D layout, channel = 32*mi + (r & 3) + 8*(r >> 2) + 4*half, column = lane & 31
+    f32x16 xres[MI][CT];
+    bool pok[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int pos = pos_w + ct * 32;
+        pok[ct] = pos >= 0 && pos < lin;
+        int pc = pos < lin - 1 ? pos : lin - 1;
+        pc = pc < 0 ? 0 : pc;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half;
+                xres[mi][ct][r] = xb[(size_t)ch * a.L + pc];
+            }
+    }
+
+    // four channels (one lane's share of 8-channel group 4*mi + gi) of one column -> (hi, lo) halves in the image
+    auto store_split = [&](int mi, int ct, int gi, float v0, float v1, float v2, float v3) __attribute__((always_inline)) {
+        half4 vh, vl;
+        const float v[4] = {v0, v1, v2, v3};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const _Float16 hh = (_Float16)v[e];
+            vh[e] = hh;
+            vl[e] = (_Float16)(v[e] - (float)hh);
+        }
+        _Float16* ph = reinterpret_cast<_Float16*>(P + (size_t)((mi * 4 + gi) * 2) * PW + MARG + colw + ct * 32 + l31) + 4 * half;
+        *reinterpret_cast<half4*>(ph) = vh;
+        *reinterpret_cast<half4*>(ph + (size_t)PW * 8) = vl;
+    };
+    // image <- split(lrelu(x)), zero outside the sequence (the convolutions pad with zeros)
+    auto xres_to_image = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int gi = 0; gi < 4; ++gi) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = xres[mi][ct][4 * gi + e];
+                        t = fmaxf(t, t * 0.1f);
+                        v[e] = pok[ct] ? t : 0.f;
+                    }
+                    store_split(mi, ct, gi, v[0], v[1], v[2], v[3]);
+                }
+    };
+    auto loadA = [&](half8 (&A)[MI][2], const half8* w, int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            A[mi][0] = w[((size_t)(s * MI + mi) * 2 + 0) * 64 + lane];
+            A[mi][1] = w[((size_t)(s * MI + mi) * 2 + 1) * 64 + lane];
+        }
+    };
+    // acc = sum over taps j and 16-channel chunks c of  W[j][c] x image[c][column + (j - (K-1)/2) * d]   (three split products)
+    auto conv = [&](const half8* w, int d, f32x16 (&acc)[MI][CT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ct][r] = 0.f;
+        constexpr int NS = K * NCH;   // pipeline steps: (tap, chunk), in the order the fragments are stored
+        const half8* base = P + (size_t)(half * 2) * PW + MARG + colw + l31 - d * ((K - 1) / 2);
+        // Software pipeline, written out because hipcc will not build it: weight fragments travel two steps ahead
+        // (global -> registers), activation fragments one step ahead (LDS -> registers); a scheduling barrier per step
+        // keeps that order.  Left alone the compiler sinks every load to just before its first use (s_waitcnt
+        // vmcnt(0) / lgkmcnt(0) in front of every fourth MFMA).
+        half8 A[3][MI][2];
+        half8 Bf[2][2][CT];
+        auto readB = [&](half8 (&Bq)[2][CT], int s) __attribute__((always_inline)) {
+            const int j = s / NCH, c = s % NCH;
+            const half8* bp = base + (size_t)(c * 4) * PW + j * d;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                Bq[0][ct] = bp[ct * 32];
+                Bq[1][ct] = bp[PW + ct * 32];
+            }
+        };
+        loadA(A[0], w, 0);
+        loadA(A[1], w, 1);
+        readB(Bf[0], 0);
+        constexpr int NM = 3 * MI * CT;   // MFMAs per step
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (s + 2 < NS) loadA(A[(s + 2) % 3], w, s + 2);
+            const int jn = (s + 1) / NCH, cn = (s + 1) % NCH;
+            const half8* bpn = base + (size_t)(cn * 4) * PW + jn * d;
+            __builtin_amdgcn_sched_barrier(0);
+            // issue order of a step, pinned: (MFMA, one LDS read of the next step's fragments) pairs, then the rest of
+            // the MFMAs.  Term order lo_w*hi_x, hi_w*lo_x, hi_w*hi_x; consecutive MFMAs go to different accumulators.
+#pragma unroll
+            for (int q = 0; q < NM; ++q) {
+                const int term = q / (MI * CT), mi = (q / CT) % MI, ct = q % CT;
+                acc[mi][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s % 3][mi][term == 0 ? 1 : 0], Bf[s & 1][term == 1 ? 1 : 0][ct],
+                                                                   acc[mi][ct], 0, 0, 0);
+                if (q < 2 * CT && s + 1 < NS) Bf[(s + 1) & 1][q / CT][q % CT] = bpn[(q / CT) * PW + (q % CT) * 32];
+                if (q < 2 * CT) __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    xres_to_image();
+    __syncthreads();
+    for (int p = 0; p < a.npairs; ++p) {
+        f32x16 acc[MI][CT];
+        conv(a.w1[p], a.d1[p], acc);
+        __syncthreads();   // every wave has finished reading lrelu(x): the image is overwritten in place
+        {
+            const float us = a.us1[p];
+            const float* bias = a.b1[p];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int gi = 0; gi < 4; ++gi) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 32 * mi + 8 * gi + 4 * half);
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float t = acc[mi][ct][4 * gi + e] * us + bv[e];
+                            t = fmaxf(t, t * 0.1f);
+                            v[e] = pok[ct] ? t : 0.f;
+                        }
+                        store_split(mi, ct, gi, v[0], v[1], v[2], v[3]);
+                    }
+                }
+        }
+        __syncthreads();
+        conv(a.w2[p], 1, acc);
+        {
+            const float us = a.us2[p];
+            const float* bias = a.b2[p];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int gi = 0; gi < 4; ++gi) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 32 * mi + 8 * gi + 4 * half);
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) xres[mi][ct][4 * gi + e] += acc[mi][ct][4 * gi + e] * us + bv[e];
+                }
+        }
+        if (p + 1 < a.npairs) {
+            __syncthreads();   // every wave has finished reading conv1's activation
+            xres_to_image();
+            __syncthreads();
+        }
+    }
+
+    // store the nto central columns (all loads of a 32x32 tile before its stores)
+    float* yb = a.y + (size_t)b * C * a.L;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int col = colw + ct * 32 + l31;
+        const int pos = q0 - a.halo + col;
+        const bool ok = col >= a.halo && col < a.halo + a.nto && pos < lin;
+        const int pc = ok ? pos : 0;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            float yv[16];
+            if (a.accumulate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    yv[r] = yb[(size_t)ch * a.L + pc];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yv[r] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (ok) yb[(size_t)ch * a.L + pc] = xres[mi][ct][r] + yv[r];
+            }
+        }
+    }
+}
+
+#ifdef TTSC_RB_PROBE   // development: compile ONE instantiation (tools/isa_stats.py -DTTSC_RB_PROBE=1,11,4,4,2)
+template __global__ void rbchain_f16x3_kernel<TTSC_RB_PROBE>(ChainArgs);
+}  // namespace ttsc
+#else
+template <int MI, int K, int CT, int NW, int WPS>
+static int launch_chain(ChainArgs& a, int B, hipStream_t s) {
+    constexpr int NCOL = NW * CT * 32;
+    constexpr int MARG = (K == 3) ? 8 : (K == 7 ? 16 : 26);
+    constexpr size_t lds = (size_t)(4 * MI) * 2 * (NCOL + 2 * MARG) * 16;
+    static_assert(lds <= 160 * 1024, "activation image exceeds the LDS");
+    a.nto = NCOL - 2 * a.halo;
+    TTSC_REQUIRE(a.nto >= 64, "rbchain: halo %d leaves no output columns in a %d-column tile", a.halo, NCOL);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)rbchain_f16x3_kernel<MI, K, CT, NW, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    dim3 grid((unsigned)ceil_div(a.L, a.nto), (unsigned)B);
+    hipLaunchKernelGGL((rbchain_f16x3_kernel<MI, K, CT, NW, WPS>), grid, dim3(64 * NW), lds, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("rbchain_f16x3_kernel launch failed: %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    return TTSC_OK;
+}
+
+// tile shapes: 0 = 4 waves x 128 columns (two workgroups per CU at 32 channels), 1 = 8 waves x 128 columns (32 channels) /
+// 8 waves x 64 columns (64 channels), one workgroup per CU
+template <int MI, int K>
+static int launch_chain_k(ChainArgs& a, int B, int shape, hipStream_t s) {
+    if (MI == 1) {
+        if (shape == 1) return launch_chain<1, K, 4, 8, 2>(a, B, s);
+        return launch_chain<1, K, 4, 4, 2>(a, B, s);
+    }
+    if (shape == 1) return launch_chain<2, K, 2, 8, 2>(a, B, s);
+    return launch_chain<2, K, 2, 4, 2>(a, B, s);
+}
+
+}  // namespace ttsc
+
+using namespace ttsc;
+
+static int chain_pair_ok(const ttsc_conv1d* c1, const ttsc_conv1d* c2, int C, int k) {
+    if (!c1 || !c2) return 0;
+    const auto &g1 = c1->cfg, &g2 = c2->cfg;
+    if (g1.transposed || g2.transposed) return 0;
+    if (g1.in_channels != C || g1.out_channels != C || g2.in_channels != C || g2.out_channels != C) return 0;
+    if (g1.kernel_size != k || g2.kernel_size != k) return 0;
+    if (g2.dilation != 1 || g2.padding != (k - 1) / 2 || g1.padding != g1.dilation * (k - 1) / 2) return 0;
+    if (g1.dilation < 1 || g1.dilation > 5) return 0;
+    if (c1->precision != TTSC_PREC_F16X3 || c2->precision != TTSC_PREC_F16X3) return 0;
+    if (!c1->has_weight || !c2->has_weight || !c1->bias_dev || !c2->bias_dev || c1->dev_weights || c2->dev_weights) return 0;
+    if (c1->phases.size() != 1 || c2->phases.size() != 1 || !c1->phases[0].wph_dev || !c2->phases[0].wph_dev) return 0;
+    return 1;
+}
+
+extern "C" int ttsc_rbchain_supported(const ttsc_conv1d* const* convs1, const ttsc_conv1d* const* convs2, int32_t npairs) {
+    if (!convs1 || !convs2 || npairs < 1 || npairs > RB_MAXP || !convs1[0]) return 0;
+    const int C = convs1[0]->cfg.in_channels, k = convs1[0]->cfg.kernel_size;
+    if (!(C == 32 || C == 64) || !(k == 3 || k == 7 || k == 11)) return 0;
+    int halo = 0;
+    for (int p = 0; p < npairs; ++p) {
+        if (!chain_pair_ok(convs1[p], convs2[p], C, k)) return 0;
+        halo += (convs1[p]->cfg.dilation + 1) * (k - 1) / 2;
+    }
+    // the smallest tile (256 columns at 64 channels, 512 at 32) must keep a useful share of output columns
+    const int ncol = C == 32 ? 512 : 256;
+    return ncol - 2 * halo >= ncol / 2 ? 1 : 0;
+}
+
+extern "C" int ttsc_rbchain_forward(const ttsc_conv1d* const* convs1, const ttsc_conv1d* const* convs2, int32_t npairs, const float* x,
+                                    int32_t B, int64_t L, float* y, int32_t accumulate, const int32_t* len_dev, int32_t shape,
+                                    void* stream) {
+    TTSC_REQUIRE(convs1 && convs2 && x && y, "ttsc_rbchain_forward: null argument");
+    TTSC_REQUIRE(ttsc_rbchain_supported(convs1, convs2, npairs), "ttsc_rbchain_forward: these layers are not eligible for the fused chain");
+    TTSC_REQUIRE(x != y, "ttsc_rbchain_forward: y must not alias x");
+    TTSC_REQUIRE(B > 0 && L > 0 && L < (1ll << 30), "ttsc_rbchain_forward: bad B/L");
+    ChainArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x;
+    a.y = y;
+    a.len = len_dev;
+    a.L = (int)L;
+    a.npairs = npairs;
+    a.accumulate = accumulate;
+    const int C = convs1[0]->cfg.in_channels, k = convs1[0]->cfg.kernel_size;
+    for (int p = 0; p < npairs; ++p) {
+        a.w1[p] = reinterpret_cast<const half8*>(convs1[p]->phases[0].wph_dev);
+        a.w2[p] = reinterpret_cast<const half8*>(convs2[p]->phases[0].wph_dev);
+        a.b1[p] = convs1[p]->bias_dev;
+        a.b2[p] = convs2[p]->bias_dev;
+        a.us1[p] = convs1[p]->w_unscale;
+        a.us2[p] = convs2[p]->w_unscale;
+        a.d1[p] = convs1[p]->cfg.dilation;
+        a.halo += (a.d1[p] + 1) * (k - 1) / 2;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (shape < 0) {
+        // default: the big tile once the halo would eat more than ~1/6 of the small one
+        const int small = C == 32 ? 512 : 256;
+        shape = (2 * a.halo * 6 > small) ? 1 : 0;
+    }
+    if (C == 32) {
+        if (k == 3) return launch_chain_k<1, 3>(a, B, shape, s);
+        if (k == 7) return launch_chain_k<1, 7>(a, B, shape, s);
+        return launch_chain_k<1, 11>(a, B, shape, s);
+    }
+    if (k == 3) return launch_chain_k<2, 3>(a, B, shape, s);
+    if (k == 7) return launch_chain_k<2, 7>(a, B, shape, s);
+    return launch_chain_k<2, 11>(a, B, shape, s);
+}
+#endif  // TTSC_RB_PROBE

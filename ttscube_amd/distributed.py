@@ -16,19 +16,36 @@ def is_dist():
 
 class FlatBucketReducer:
     """Average the .grad of `params` across ranks.  bucket_mb: bucket size in MiB (large buckets: xGMI links are
-    bandwidth- not latency-friendly; 64 MiB keeps ~6 buckets in flight for the 98 M-parameter Cubegan)."""
+    bandwidth- not latency-friendly; 64 MiB keeps ~6 buckets in flight for the 98 M-parameter Cubegan).
 
-    def __init__(self, params, bucket_mb=64, group=None, use_reduce_scatter=True):
+    use_reduce_scatter=True: reduce_scatter_tensor into a separate shard buffer + all_gather_into_tensor back (every GPU
+    drives all of its xGMI links); False: one all_reduce per bucket.  Both run on nccl (RCCL) and gloo.
+    A parameter that has no gradient on ANY rank keeps `.grad is None` (decided once, collectively, at the first reduce), so
+    the optimizer treats it exactly as in a single-process run; one that has a gradient on some ranks gets the average
+    with zeros for the others.  `force=True` runs the exchange even with a world of one process (tests)."""
+
+    def __init__(self, params, bucket_mb=64, group=None, use_reduce_scatter=True, force=False):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.use_rs = use_reduce_scatter
+        self.force = force
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
         self._buckets = None
+        self.bytes_exchanged = 0   # payload bytes handed to the collectives by the last reduce() (per rank)
+
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and (self.force or dist.get_world_size(self.group) > 1)
 
     def _build(self):
-        world = dist.get_world_size(self.group) if is_dist() else 1
+        world = dist.get_world_size(self.group)
+        # which parameters take part: those with a gradient on at least one rank (one small collective, once)
+        dev = self.params[0].device if self.params else torch.device('cpu')
+        has = torch.tensor([1.0 if p.grad is not None else 0.0 for p in self.params], dtype=torch.float32, device=dev)
+        if has.numel():
+            dist.all_reduce(has, op=dist.ReduceOp.MAX, group=self.group)
+        live = [p for p, h in zip(self.params, has.tolist()) if h > 0]
         buckets, cur, n = [], [], 0
-        for p in self.params:
+        for p in live:
             if n + p.numel() > self.bucket_elems and cur:
                 buckets.append(cur)
                 cur, n = [], 0
@@ -41,19 +58,20 @@ class FlatBucketReducer:
             total = sum(p.numel() for p in ps)
             padded = (total + world - 1) // world * world
             flat = torch.zeros(padded, dtype=torch.float32, device=ps[0].device)
-            self._buckets.append((ps, flat, total))
+            shard = torch.empty(padded // world, dtype=torch.float32, device=ps[0].device)
+            self._buckets.append((ps, flat, shard, total))
 
     @torch.no_grad()
     def reduce(self):
-        """all-reduce (mean) of every parameter's .grad; parameters without a grad contribute zeros."""
-        if not is_dist():
+        """all-reduce (mean) of every participating parameter's .grad."""
+        if not self._active():
             return
         if self._buckets is None:
             self._build()
         world = dist.get_world_size(self.group)
-        rank = dist.get_rank(self.group)
         works = []
-        for ps, flat, total in self._buckets:
+        self.bytes_exchanged = 0
+        for ps, flat, shard, total in self._buckets:
             off = 0
             for p in ps:
                 n = p.numel()
@@ -63,25 +81,17 @@ class FlatBucketReducer:
                     flat[off:off + n].zero_()
                 off += n
             flat.div_(world)
-            rs_ok = self.use_rs and flat.is_cuda
-            if rs_ok:
-                shard = flat.numel() // world
-                out = flat[rank * shard:(rank + 1) * shard]
-                w1 = dist.reduce_scatter_tensor(out, flat, group=self.group, async_op=True)
-                works.append((w1, ps, flat, total, True))
+            if self.use_rs:
+                w1 = dist.reduce_scatter_tensor(shard, flat, group=self.group, async_op=True)
             else:
                 w1 = dist.all_reduce(flat, group=self.group, async_op=True)
-                works.append((w1, ps, flat, total, False))
+            works.append(w1)
+            self.bytes_exchanged += flat.numel() * 4 * (2 if self.use_rs else 1)
         gathers = []
-        for w1, ps, flat, total, rs in works:
+        for w1, (ps, flat, shard, total) in zip(works, self._buckets):
             w1.wait()
-            if rs:
-                shard = flat.numel() // world
-                gathers.append((dist.all_gather_into_tensor(flat, flat[rank * shard:(rank + 1) * shard].clone(),
-                                                            group=self.group, async_op=True), ps, flat))
-            else:
-                gathers.append((None, ps, flat))
-        for w2, ps, flat in gathers:
+            gathers.append(dist.all_gather_into_tensor(flat, shard, group=self.group, async_op=True) if self.use_rs else None)
+        for w2, (ps, flat, shard, total) in zip(gathers, self._buckets):
             if w2 is not None:
                 w2.wait()
             off = 0
