@@ -314,3 +314,46 @@ def test_fused_resblock_chain_not_eligible():
     a1 = (C.c_void_p * 1)(c1s[0]._h)
     a2 = (C.c_void_p * 1)(c2s[0]._h)
     assert _lib.lib().ttsc_rbchain_supported(a1, a2, 1) == 0
+
+
+@pytest.mark.parametrize('C,k,d,L,B', [(256, 3, 1, 300, 2), (256, 3, 5, 129, 1), (256, 7, 3, 257, 2), (256, 7, 5, 128, 1), (256, 11, 1, 400, 1),
+                                       (256, 11, 5, 131, 2), (128, 3, 3, 700, 2), (128, 3, 5, 256, 1), (128, 7, 1, 513, 1), (128, 7, 5, 300, 2),
+                                       (128, 11, 3, 255, 2), (128, 11, 5, 1000, 1), (128, 7, 3, 5, 2)])
+def test_conv1d_f16x3_wide_tile_kernel(C, k, d, L, B, monkeypatch):
+    """conv_f16x3_wide_kernel (square 128/256-channel layers; chosen by machine fill in production, forced here):
+    prologue leaky-relu, residual, running sum, ragged lengths — against torch, and bit-identical batch independence."""
+    from ttscube_amd.hip_layers import Conv1dHip
+    monkeypatch.setenv('TTSC_CONV_WIDE', '2')
+    pad = d * (k - 1) // 2
+    w = _mk((C, C, k), 1, 1.0 / (C * k) ** 0.5)
+    b = _mk((C,), 2, 0.1)
+    x = _mk((B, C, L), 3)
+    r = _mk((B, C, L), 4)
+    s0 = _mk((B, C, L), 5)
+    conv = Conv1dHip(C, C, k, padding=pad, dilation=d).set_precision('f16x3')
+    conv.set_weight(w, b)
+    out = s0.clone().cuda()
+    conv(x.cuda(), resid=r.cuda(), out=out, in_scale=1.0 / 3.0, in_slope=0.1, accumulate=True)
+    ref = s0 + F.conv1d(F.leaky_relu(x / 3.0, 0.1), w, b, padding=pad, dilation=d) + r
+    assert float((out.cpu() - ref).abs().max()) < F16X3_TOL
+    y = conv(x.cuda(), in_slope=0.1)
+    ref = F.conv1d(F.leaky_relu(x, 0.1), w, b, padding=pad, dilation=d)
+    assert float((y.cpu() - ref).abs().max()) < F16X3_TOL
+    # the old 64-row kernel computes the same chains in another order: results agree to rounding
+    monkeypatch.setenv('TTSC_CONV_WIDE', '0')
+    y0 = conv(x.cuda(), in_slope=0.1)
+    assert float((y0 - y).abs().max()) < 1e-5
+    monkeypatch.setenv('TTSC_CONV_WIDE', '2')
+    if B > 1 and L > 100:
+        import ctypes as C_
+        from ttscube_amd import _lib
+        n = L - 77
+        lens = torch.tensor([n] + [L] * (B - 1), dtype=torch.int32).cuda()
+        yr = torch.zeros(B, C, L, device='cuda')
+        ep = _lib.Conv1dEpilogue(1.0, 0.1, 1.0, _lib.ACT_NONE, 0, None, 1.0)
+        xd = x.cuda()
+        _lib.check(_lib.lib().ttsc_conv1d_forward_ragged(conv._h, _lib.dev_ptr(xd), B, L, _lib.dev_ptr(yr), None, C_.byref(ep),
+                                                         _lib.dev_ptr(lens), _lib.dev_ptr(lens), _lib.current_stream()), 'ragged')
+        solo = conv(x[:1, :, :n].contiguous().cuda(), in_slope=0.1)
+        assert torch.equal(yr[:1, :, :n], solo)           # ragged == the utterance run alone, bit for bit
+        assert torch.equal(yr[1:], y[1:])

@@ -39,6 +39,7 @@ def main():
     ap.add_argument('--B', type=int, default=64)
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--ks', default='3,7,11')
+    ap.add_argument('--only-chain', action='store_true')
     a = ap.parse_args()
     L_ = _lib.lib()
     for st in [int(v) for v in a.stages.split(',')]:
@@ -79,7 +80,15 @@ def main():
                 _lib.check(L_.ttsc_rbchain_forward(a1, a2, 3, _lib.dev_ptr(x), a.B, L, _lib.dev_ptr(y), 0, None, shape,
                                                    _lib.current_stream()), 'rbchain')
 
-            res = [('pairs', timed(pairs, a.iters))]
+            if Cc >= 128:
+                os.environ['TTSC_CONV_WIDE'] = '0'
+                res = [('old', timed(pairs, a.iters))]
+                os.environ['TTSC_CONV_WIDE'] = '1'
+                res.append(('wide', timed(pairs, a.iters)))
+            else:
+                res = [('pairs', timed(pairs, a.iters))]
+            if a.only_chain:
+                res = []
             if L_.ttsc_rbchain_supported(a1, a2, 3):
                 res.append(('chain0', timed(lambda: chain(0), a.iters)))
                 res.append(('chain1', timed(lambda: chain(1), a.iters)))

@@ -17,6 +17,7 @@
 // The split-precision kernels further down (conv_f16x3_kernel, respair32_f16x3_kernel) are the default for the generator.
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -564,6 +565,173 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Wide-tile variant for the square layers of the wide stages (Cin = Cout in {128, 256}, K in {3, 7, 11}).
+// What bounds conv_f16x3_kernel there (PMC, round 1: MFMA pipe 47 % busy, 4.8 VALU per MFMA, a third of the wave cycles
+// parked at barriers) is structural: a workgroup owns 64 output channels, so the same activation window is loaded,
+// leaky-relu'ed and split by Cout/64 workgroups, and every channel chunk costs two barriers with nothing in flight.
+// Here
+//   * a wave owns 64 x 128 outputs (MI = 2, NJ = 4: 24 MFMAs per tap for 8 activation-fragment reads), the four waves are
+//     stacked along M first (256 x 128 workgroup tile at Cout = 256, 128 x 256 at Cout = 128): the activation window is
+//     staged ONCE for all output channels;
+//   * weight fragments are private to a wave (its own 64 rows), so they go global/L2 -> registers directly, one tap ahead,
+//     with the issue order pinned by scheduling barriers (hipcc sinks such loads to their first use otherwise);
+//   * the activation tile is double-buffered in LDS: chunk c+1 is converted and written while chunk c is multiplied
+//     (the conversion's VALU work sits between MFMAs of the same wave), ONE barrier per chunk;
+//   * the global loads of chunk c+2 are issued right after chunk c+1 left the staging registers: a whole chunk of MFMAs
+//     (K x 24 per wave) covers their latency.
+// K is a template parameter (the tap loop is unrolled, register rings are statically indexed); CinP/16 must be even.
+template <int C, int K, int D>
+__global__ __launch_bounds__(256, 2) void conv_f16x3_wide_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int WM = C == 256 ? 4 : 2, WN = 4 / WM;
+    constexpr int MI = 2, NJ = 4, NT = WN * NJ * 32;
+    constexpr int SPAN = NT + (K - 1) * D;          // staged positions per channel ("same" padding: halo (K-1)*D)
+    constexpr int SPANP = (SPAN + 63) & ~63;
+    constexpr int BUFSZ = 4 * SPAN + 2;             // items per buffer: 4 planes (h, hi|lo) + a dump slot pair
+    constexpr int NCHUNK = C / 16, COTN = C / 32;
+    half8* Xp = reinterpret_cast<half8*>(smem_raw);   // [buffer][plane (h, pl)][SPAN] 16-byte items
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z;
+    const int q0 = blockIdx.x * NT;
+    const int lin = a.in_len ? a.in_len[b] : a.Lin;
+    if (a.out_len && q0 >= a.out_len[b]) return;
+    const int cot0 = wm * MI;
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const float* xb = a.x + (size_t)b * C * a.Lin;
+    const int lo = q0 - D * ((K - 1) / 2);
+    const half8* wsrc = reinterpret_cast<const half8*>(a.wph) + (size_t)cot0 * 128 + lane;
+
+    // ---- activation staging: work item = (channel half h, position p) = 8 fp32 channels -> one (hi, lo) pair of items
+    constexpr int XIT = (2 * SPANP + 255) / 256;
+    float xr[XIT][8];
+    unsigned xoff[XIT];
+    int xslot[XIT];
+    bool xok[XIT];
+#pragma unroll
+    for (int e = 0; e < XIT; ++e) {
+        const int i = tid + e * 256;
+        const int h = i >= SPANP ? 1 : 0;
+        const int p = i - h * SPANP;
+        const int pos = lo + p;
+        xok[e] = pos >= 0 && pos < lin;
+        int pc = pos > lin - 1 ? lin - 1 : pos;
+        pc = pc < 0 ? 0 : pc;
+        xoff[e] = (unsigned)(h * 8 * a.Lin + pc);   // channel half folded into the offset
+        // lanes beyond the window write to a dump slot behind the planes (no divergent branch around the LDS stores)
+        xslot[e] = (p < SPAN && i < 2 * SPANP) ? (h * 2) * SPAN + p : 4 * SPAN;
+    }
+    auto x_issue_item = [&](int e, int c) __attribute__((always_inline)) {
+        const float* rc = xb + (size_t)(c * 16) * a.Lin;
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) xr[e][ch] = rc[(size_t)ch * a.Lin + xoff[e]];
+    };
+    auto x_commit_item = [&](int e, half8* buf) __attribute__((always_inline)) {
+        half8 vh, vl;
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+            float v = xok[e] ? xr[e][ch] * a.in_scale : 0.f;
+            v = fmaxf(v, v * a.in_slope);
+            const _Float16 hh = (_Float16)v;
+            vh[ch] = hh;
+            vl[ch] = (_Float16)(v - (float)hh);
+        }
+        buf[xslot[e]] = vh;
+        buf[xslot[e] + (xslot[e] < 4 * SPAN ? SPAN : 1)] = vl;   // (the dump slot's partner is the item right behind it)
+    };
+    // weight fragments of (tap j, chunk c) for this wave's MI row tiles: [j][c][cot][hi|lo][64 lanes]
+    auto loadA = [&](half8 (&A)[MI][2], int c, int j) __attribute__((always_inline)) {
+        const half8* wj = wsrc + (size_t)(j * NCHUNK + c) * (COTN * 128);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            A[i][0] = wj[i * 128];
+            A[i][1] = wj[i * 128 + 64];
+        }
+    };
+
+    half8 A[2][MI][2];
+    // all LDS reads of a wave hang off ONE base register: buffer, plane and tap offsets are immediates (D, K, NT are
+    // template parameters) — per-tap address registers were what pushed the first version of this kernel into scratch
+    const half8* xbase = Xp + (unsigned)((half * 2) * SPAN + wn * (NJ * 32) + l31);
+    // one channel chunk: K taps on buffer BUF; meanwhile chunk c+1 is converted into the other buffer and the loads of
+    // chunk c+2 are issued (item e at tap K-1-e, so that a tap carries at most one item's conversion).  PAR = parity of
+    // the weight ring at the chunk's first tap (K is odd, the parity flips from chunk to chunk).
+    auto chunk = [&](int c, auto buf_tag, auto par_tag) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        constexpr int PAR = decltype(par_tag)::value;
+        half8* nxt = Xp + (1 - BUF) * BUFSZ;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            // the next step's weight fragments leave first ...
+            if (j + 1 < K)
+                loadA(A[(PAR + j + 1) & 1], c, j + 1);
+            else
+                loadA(A[(PAR + j + 1) & 1], c + 1 < NCHUNK ? c + 1 : c, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            half8 bh[NJ], bl[NJ];
+#pragma unroll
+            for (int n = 0; n < NJ; ++n) {
+                bh[n] = xbase[BUF * BUFSZ + j * D + n * 32];
+                bl[n] = xbase[BUF * BUFSZ + SPAN + j * D + n * 32];
+            }
+            // ... then (one tap per staging item, last taps of the chunk) convert + publish chunk c+1 and refill the
+            // staging registers with chunk c+2 (past the last chunk this handles clamped garbage nobody reads: no branches)
+            const int e = K - 1 - j;
+            if (e < XIT) {
+                x_commit_item(e, nxt);
+                x_issue_item(e, c + 2 < NCHUNK ? c + 2 : NCHUNK - 1);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(PAR + j) & 1][i][1], bh[n], acc[i][n], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(PAR + j) & 1][i][0], bl[n], acc[i][n], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(PAR + j) & 1][i][0], bh[n], acc[i][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();   // chunk c fully read, chunk c+1 fully written
+    };
+
+    // prologue: chunk 0 -> buffer 0, chunk 1 into the staging registers, first weight fragments
+    loadA(A[0], 0, 0);
+#pragma unroll
+    for (int e = 0; e < XIT; ++e) x_issue_item(e, 0);
+#pragma unroll
+    for (int e = 0; e < XIT; ++e) x_commit_item(e, Xp);
+#pragma unroll
+    for (int e = 0; e < XIT; ++e) x_issue_item(e, 1);
+    __syncthreads();
+    for (int c = 0; c < NCHUNK; c += 2) {
+        chunk(c, std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
+        chunk(c + 1, std::integral_constant<int, 1>(), std::integral_constant<int, (K & 1)>());
+    }
+
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int n = 0; n < NJ; ++n) {
+            const int q = q0 + wn * (NJ * 32) + n * 32 + l31;
+            epilogue_tile(acc[i][n], a, b, (cot0 + i) * 32, q, q < a.Lout, half, a.w_unscale);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Fused residual pair for 32-channel stages (HiFi-GAN ResBlock1, last upsample stage):
 //     y = x + conv2_{d=1}( lrelu( conv1_{d}( lrelu(x) ) ) )          [ + running sum ]
 // The 32-channel stage is HBM-bound when its two convolutions run as separate launches (24..88 FLOP per byte moved);
@@ -780,6 +948,40 @@ static int launch_f16_t(const ConvArgs& a, int B, hipStream_t s) {
         return TTSC_EHIP;
     }
     return TTSC_OK;
+}
+
+template <int C, int K, int D>
+static int launch_f16_wide(const ConvArgs& a, int B, hipStream_t s) {
+    constexpr int WM = C == 256 ? 4 : 2, WN = 4 / WM, NT = WN * 128;
+    constexpr int SPAN = NT + (K - 1) * D;
+    dim3 grid((unsigned)ceil_div(a.Lout, NT), 1, (unsigned)B);
+    constexpr size_t lds = (size_t)2 * (4 * SPAN + 2) * 16;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv_f16x3_wide_kernel<C, K, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((conv_f16x3_wide_kernel<C, K, D>), grid, dim3(256), lds, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("conv_f16x3_wide_kernel launch failed: %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    return TTSC_OK;
+}
+
+template <int C, int K>
+static int launch_f16_wide_d(const ConvArgs& a, int B, int d, hipStream_t s) {
+    if (d == 1) return launch_f16_wide<C, K, 1>(a, B, s);
+    if (d == 3) return launch_f16_wide<C, K, 3>(a, B, s);
+    return launch_f16_wide<C, K, 5>(a, B, s);
+}
+
+template <int C>
+static int launch_f16_wide_k(const ConvArgs& a, int B, int d, hipStream_t s) {
+    if (a.ntaps == 3) return launch_f16_wide_d<C, 3>(a, B, d, s);
+    if (a.ntaps == 7) return launch_f16_wide_d<C, 7>(a, B, d, s);
+    return launch_f16_wide_d<C, 11>(a, B, d, s);
 }
 
 template <int MI, int NJ, bool SPLIT_IN>
@@ -1281,8 +1483,22 @@ extern "C" int ttsc_conv1d_forward_split(const ttsc_conv1d* c, const float* x, c
                 a.span_pad = a.span;
             };
             static const bool big_only = getenv("TTSC_F16_TILE") && atoi(getenv("TTSC_F16_TILE")) == 0;
+            const char* wide_ev = getenv("TTSC_CONV_WIDE");
+            const int wide_env = wide_ev ? atoi(wide_ev) : 1;   // 0 = off, 2 = also for problems too small to fill the chip (tests)
             const long want16 = 512;
-            if (c->MT >= 64) {
+            // square "same"-padded layers of the wide stages (the generator's ResBlock convolutions at 128 / 256 channels):
+            // the wide-tile kernel (activation window staged once for all output channels)
+            const bool wide_shape = !g.transposed && !a.xs && !a.ys && !a.gate && g.in_channels == g.out_channels &&
+                                    (g.out_channels == 128 || g.out_channels == 256) &&
+                                    (g.kernel_size == 3 || g.kernel_size == 7 || g.kernel_size == 11) &&
+                                    (g.dilation == 1 || g.dilation == 3 || g.dilation == 5) &&
+                                    g.padding == g.dilation * (g.kernel_size - 1) / 2;
+            if (wide_env && wide_shape && (wide_env == 2 || (long)ceil_div(a.Lout, g.out_channels == 256 ? 128 : 256) * B >= want16)) {
+                if (g.out_channels == 256)
+                    rc = launch_f16_wide_k<256>(a, B, g.dilation, s);
+                else
+                    rc = launch_f16_wide_k<128>(a, B, g.dilation, s);
+            } else if (c->MT >= 64) {
                 if (a.xs || big_only || wgs16(64, 256) >= want16)
                     rc = launch_f16<2, 2>(a, B, s);   // 64 x 256 tile (MT=128 layers run as two M tiles)
                 else if (wgs16(64, 128) >= want16) {
