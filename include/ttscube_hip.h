@@ -324,6 +324,18 @@ int ttsc_melar_decode(const ttsc_melar* m, const float* xg1_dev, int32_t B, int3
                       const int32_t* steps_dev, float* y_dev, void* stream);
 void ttsc_melar_destroy(ttsc_melar* m);
 
+/* Device-side duration -> alignment (row f2 of SURVEY.md §8; replaces the host round trip of
+ * cube/networks/modules.py:946-953,1043-1053 and cube/networks/textcoder.py:160-166,291-302).
+ * ttsc_align_durations: logits [B,N,D] fp32 (duration head) -> durs [B,N] int32 = argmax over D (first maximum; 0 beyond
+ *   len_dev[b], len_dev NULL = N), f2p [B,Fcap] int32 frame -> phone map (phone p repeated durs[b,p] times, in order),
+ *   flen [B] int32 = number of frames (clamped to Fcap).
+ * ttsc_expand_rows: out [B,F,C] = rows of x [B,N,C] gathered through every stride-th entry of f2p; frames beyond an
+ *   utterance's own count repeat its last aligned row (stride 1) or row N-1 (stride > 1), as the reference's gathers pad. */
+int ttsc_align_durations(const float* logits_dev, const int32_t* len_dev, int32_t B, int32_t N, int32_t D, int32_t* durs_dev,
+                         int32_t* f2p_dev, int32_t* flen_dev, int32_t Fcap, void* stream);
+int ttsc_expand_rows(const float* x_dev, const int32_t* f2p_dev, const int32_t* flen_dev, int32_t B, int32_t N, int32_t C, int32_t Fcap,
+                     int32_t stride, int32_t F, float* out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,6 +75,13 @@ def test_batched_synthesis_equals_per_sentence_and_sharding(tmp_path):
     for t, got in zip(texts, batch):
         solo = tts(t, speaker='s0')
         assert got.shape == solo.shape and np.array_equal(got, solo)
+    # out-of-vocabulary phones are encoded as 0 — the padding id — also at the END of a sentence: lengths come from the
+    # collate (x_len), so the batched result still equals the single-sentence call (it used to be truncated)
+    texts_oov = ['a b ?? c d e ??', 'f g', 'h ?? i j k l m n ?? ??', '?? a']
+    batch = tts.synthesize_batch(texts_oov, speaker='s0', max_batch=4)
+    for t, got in zip(texts_oov, batch):
+        solo = tts(t, speaker='s0')
+        assert got.shape == solo.shape and np.array_equal(got, solo), t
     # utterance sharding over ranks: the union of the shards is the whole list, in order, no collectives involved
     shards = [TTSCube.shard(texts, r, 2) for r in range(2)]
     assert shards[0] + shards[1] == texts

@@ -95,3 +95,34 @@ def test_textcoder_matches_reference_golden(golden_dir):
     assert float((o_dur.cpu() - torch.from_numpy(z['tf_dur'])).abs().max()) < 1e-4
     assert float((o_mel.cpu() - torch.from_numpy(z['tf_mel'])).pow(2).mean().sqrt()) < 1e-4
     assert float((o_post.cpu() - torch.from_numpy(z['tf_post'])).pow(2).mean().sqrt()) < 1e-4
+
+
+@pytest.mark.parametrize('B,N,D,stride', [(1, 30, 102, 1), (5, 67, 102, 1), (3, 300, 17, 3), (2, 1, 5, 1), (4, 513, 9, 3)])
+def test_device_side_alignment_matches_host_loops(B, N, D, stride):
+    """csrc/align.hip (ttsc_align_durations + ttsc_expand_rows) against the reference's host procedure: argmax -> nested
+    loops -> index gather with the reference's padding rule (modules.py:946-953,1043-1053; textcoder.py:160-166,291-302)."""
+    from ttscube_amd.networks.modules import _expand_rows, align_durations
+    rng = np.random.RandomState(B * 1000 + N)
+    logits = rng.randn(B, N, D).astype(np.float32)
+    logits[:, ::7, :] = 0.25                      # ties: argmax must return the FIRST maximum (index 0)
+    logits[0, :min(3, N), 0] = 50.0               # leading zero-length phones
+    lens = [N] + [int(rng.randint(1, N + 1)) for _ in range(B - 1)]
+    al = align_durations(torch.from_numpy(logits).cuda(), lens if B > 1 else None)
+    durs = logits.argmax(-1)
+    want_f2p = []
+    for b in range(B):
+        a = []
+        for p in range(lens[b]):
+            a.extend([p] * int(durs[b, p]))
+        want_f2p.append(a)
+    assert al.tolist() == want_f2p and al == want_f2p
+    got_d = al.durations()
+    for b in range(B):
+        assert list(got_d[b, :lens[b]]) == list(durs[b, :lens[b]]) and not got_d[b, lens[b]:].any()
+    assert al.flens == [len(a) for a in want_f2p]
+    x = torch.from_numpy(rng.randn(B, N, 40).astype(np.float32)).cuda()
+    got, flens = _expand_rows(x, al, stride=stride)
+    want, wlens = _expand_rows(x, want_f2p, stride=stride)      # the host (list of lists) path = the reference's gather
+    assert flens == wlens and torch.equal(got, want)
+    x3 = torch.from_numpy(rng.randn(B, N, 7).astype(np.float32)).cuda()  # C not a multiple of 4: scalar copy path
+    assert torch.equal(_expand_rows(x3, al, stride=stride)[0], _expand_rows(x3, want_f2p, stride=stride)[0])

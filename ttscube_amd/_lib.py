@@ -121,6 +121,10 @@ SIGNATURES = {
     'ttsc_lstm_seq_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
+    'ttsc_align_durations': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                       C.c_void_p]),
+    'ttsc_expand_rows': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_void_p, C.c_void_p]),
     'ttsc_device_free': (None, [C.c_void_p]),
     'ttsc_melar_create': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     'ttsc_melar_set_weights': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 11),

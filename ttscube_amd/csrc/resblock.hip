@@ -30,6 +30,13 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 constexpr int RB_MAXP = 3;
 
+// ablation switches: measurement build only (-DTTSC_ABLATE, tools/ablate.cpp), constants in the product library
+#ifdef TTSC_ABLATE
+#define TTSC_DBG(args, bit) (((args).dbg & (bit)) != 0)
+#else
+#define TTSC_DBG(args, bit) false
+#endif
+
 struct ChainArgs {
     const float* x;       // [B, C, L] chain input
     float* y;             // [B, C, L] chain output (must not alias x: neighbouring tiles read x's halo)
@@ -42,6 +49,7 @@ struct ChainArgs {
     const int* len;       // [B] valid length or null
     int L, npairs, accumulate;
     int halo, nto;        // columns of halo per side, output columns per tile (NCOL - 2*halo)
+    int dbg;              // -DTTSC_ABLATE builds: 1 skip the epilogue -> image conversions, 2 skip barriers, 4 skip the final store, 8 skip the x load, 16 skip weight loads in the loop
 };
 
 // MI = C/32 row tiles, K taps, CT 32-column tiles per wave, NW waves per workgroup, WPS = waves per SIMD the register
@@ -89,12 +97,13 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ch = 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half;
-                xres[mi][ct][r] = xb[(size_t)ch * a.L + pc];
+                xres[mi][ct][r] = TTSC_DBG(a, 8) ? (float)(ch + pc) * 1e-3f : xb[(size_t)ch * a.L + pc];
             }
     }
 
     // four channels (one lane's share of 8-channel group 4*mi + gi) of one column -> (hi, lo) halves in the image
     auto store_split = [&](int mi, int ct, int gi, float v0, float v1, float v2, float v3) __attribute__((always_inline)) {
+        if (TTSC_DBG(a, 1)) return;
         half4 vh, vl;
         const float v[4] = {v0, v1, v2, v3};
 #pragma unroll
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
         constexpr int NM = 3 * MI * CT;   // MFMAs per step
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            if (s + 2 < NS) loadA(A[(s + 2) % 3], w, s + 2);
+            if (s + 2 < NS && !TTSC_DBG(a, 16)) loadA(A[(s + 2) % 3], w, s + 2);
             const int jn = (s + 1) / NCH, cn = (s + 1) % NCH;
             const half8* bpn = base + (size_t)(cn * 4) * PW + jn * d;
             __builtin_amdgcn_sched_barrier(0);
@@ -182,11 +191,11 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
     };
 
     xres_to_image();
-    __syncthreads();
+    if (!TTSC_DBG(a, 2)) __syncthreads();
     for (int p = 0; p < a.npairs; ++p) {
         f32x16 acc[MI][CT];
         conv(a.w1[p], a.d1[p], acc);
-        __syncthreads();   // every wave has finished reading lrelu(x): the image is overwritten in place
+        if (!TTSC_DBG(a, 2)) __syncthreads();   // every wave has finished reading lrelu(x): the image is overwritten in place
         {
             const float us = a.us1[p];
             const float* bias = a.b1[p];
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
                     }
                 }
         }
-        __syncthreads();
+        if (!TTSC_DBG(a, 2)) __syncthreads();
         conv(a.w2[p], 1, acc);
         {
             const float us = a.us2[p];
@@ -225,13 +234,22 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
                 }
         }
         if (p + 1 < a.npairs) {
-            __syncthreads();   // every wave has finished reading conv1's activation
+            if (!TTSC_DBG(a, 2)) __syncthreads();   // every wave has finished reading conv1's activation
             xres_to_image();
-            __syncthreads();
+            if (!TTSC_DBG(a, 2)) __syncthreads();
         }
     }
 
     // store the nto central columns (all loads of a 32x32 tile before its stores)
+    if (TTSC_DBG(a, 4)) {
+        float t = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) t += xres[mi][ct][0] + xres[mi][ct][9];
+        if (t == 12345.678f) a.y[0] = 1.f;
+        return;
+    }
     float* yb = a.y + (size_t)b * C * a.L;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
@@ -347,6 +365,9 @@ extern "C" int ttsc_rbchain_forward(const ttsc_conv1d* const* convs1, const ttsc
     a.L = (int)L;
     a.npairs = npairs;
     a.accumulate = accumulate;
+#ifdef TTSC_ABLATE
+    if (const char* ev = getenv("TTSC_CHAIN_DBG")) a.dbg = atoi(ev);
+#endif
     const int C = convs1[0]->cfg.in_channels, k = convs1[0]->cfg.kernel_size;
     for (int p = 0; p < npairs; ++p) {
         a.w1[p] = reinterpret_cast<const half8*>(convs1[p]->phases[0].wph_dev);

@@ -86,7 +86,10 @@ class CubeganCollate:
         for ii, example in enumerate(batch):
             m = len(example['meta']['phones'])
             y_dur[ii, :m] = np.clip(y_dur[ii, :m], 0, 100)
-        return {'x_char': torch.tensor(x_char, dtype=torch.long), 'x_words': None, 'x_tok_ids': None, 'x_word2tok': None,
+        # x_len is an addition to the reference's dict: the true phone count per example.  An out-of-vocabulary phone is encoded
+        # as 0 — the padding id — so lengths cannot be recovered from x_char alone (batched inference masks by length).
+        x_len = [len(e['meta']['phones']) for e in batch]
+        return {'x_char': torch.tensor(x_char, dtype=torch.long), 'x_len': torch.tensor(x_len, dtype=torch.long), 'x_words': None, 'x_tok_ids': None, 'x_word2tok': None,
                 'x_phon2word': torch.tensor(x_p2w), 'x_speaker': torch.tensor(x_speaker, dtype=torch.long),
                 'y_mgc': torch.tensor(y_mgc, dtype=torch.float), 'y_frame2phone': y_frame2phone,
                 'y_pitch': torch.tensor(y_pitch, dtype=torch.long), 'y_dur': torch.tensor(y_dur, dtype=torch.long),

@@ -307,9 +307,87 @@ def _cnn_forward(stack, emb, lengths):
     return h.permute(0, 2, 1).contiguous()
 
 
+class Alignment:
+    """Frame -> phone map built ON THE DEVICE from a duration head (csrc/align.hip): `f2p` int32 [B, Fcap] (phone index of
+    every frame, valid up to `flens[b]`), `durs` int32 [B, N].  Behaves like the reference's list of per-utterance lists
+    (`X['y_frame2phone']`, modules.py:946-953) when indexed / compared — the host copy is made only then."""
+
+    def __init__(self, f2p, flen_dev, flens, durs):
+        self.f2p, self.flen_dev, self.flens, self.durs = f2p, flen_dev, flens, durs
+        self._lists = None
+
+    def tolist(self):
+        if self._lists is None:
+            m = max(self.flens) if self.flens else 0
+            host = self.f2p[:, :m].cpu().tolist() if m else [[] for _ in self.flens]
+            self._lists = [row[:n] for row, n in zip(host, self.flens)]
+        return self._lists
+
+    def durations(self):
+        return self.durs.cpu().numpy()
+
+    def __len__(self):
+        return len(self.flens)
+
+    def __getitem__(self, i):
+        return self.tolist()[i]
+
+    def __iter__(self):
+        return iter(self.tolist())
+
+    def __eq__(self, other):
+        return self.tolist() == (other.tolist() if isinstance(other, Alignment) else other)
+
+
+def _char_lengths(X, x_char):
+    """Valid phones per utterance of a padded batch.  Preferred: the collate's own count X['x_len'] — id 0 is BOTH the padding
+    and an out-of-vocabulary phone (io_cubegan.py:196-199), so counting non-zeros would cut a sentence short at an OOV phone.
+    Batches made by the reference's collate carry no x_len: fall back to the position of the last non-zero id."""
+    B, N = x_char.shape
+    if X.get('x_len') is not None:
+        return [int(v) for v in torch.as_tensor(X['x_len']).reshape(-1).tolist()]
+    if B == 1:
+        return [N]
+    pos = torch.arange(1, N + 1, device=x_char.device)[None, :]
+    return ((x_char != 0).long() * pos).max(dim=1).values.tolist()
+
+
+def align_durations(out_dur, lengths):
+    """argmax over the duration head [B, N, D], exclusive scan and scatter of phone indices, all in one kernel; the host
+    reads back B frame counts (it needs them to size the expanded tensors) and nothing else."""
+    out_dur = out_dur.float().contiguous()
+    B, N, D = out_dur.shape
+    dev = out_dur.device
+    fcap = max(1, N * (D - 1))
+    durs = torch.empty((B, N), dtype=torch.int32, device=dev)
+    f2p = torch.empty((B, fcap), dtype=torch.int32, device=dev)
+    flen = torch.empty((B,), dtype=torch.int32, device=dev)
+    len_t = torch.as_tensor(lengths, dtype=torch.int32, device=dev) if lengths is not None else None
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().ttsc_align_durations(_lib.dev_ptr(out_dur), _lib.dev_ptr(len_t) if len_t is not None else None, B, N, D,
+                                                   _lib.dev_ptr(durs), _lib.dev_ptr(f2p), _lib.dev_ptr(flen), fcap, _lib.current_stream()),
+                   'ttsc_align_durations')
+    return Alignment(f2p, flen, flen.cpu().tolist(), durs)
+
+
 def _expand_rows(x, alignments, stride=1):
     """Gather rows of x [B, N, C] by per-utterance frame->phone alignments (every `stride`-th frame), padding short
-    utterances with their last aligned row (Languasito2._expand_i modules.py:1043-1053 / Textcoder._expand 291-302)."""
+    utterances with their last aligned row (Languasito2._expand_i modules.py:1043-1053 / Textcoder._expand 291-302).
+    `alignments`: an Alignment (device-side map: one gather kernel, no host data) or a list of lists (teacher forcing with the
+    alignments a collate supplies — host data to begin with)."""
+    if isinstance(alignments, Alignment):
+        al = alignments
+        flens = [n // stride for n in al.flens]
+        m = max(flens) if flens else 0
+        if m == 0:
+            return x[:, :0], [0] * len(flens)
+        x = x.float().contiguous()
+        B, N, C_ = x.shape
+        out = torch.empty((B, m, C_), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ttsc_expand_rows(_lib.dev_ptr(x), _lib.dev_ptr(al.f2p), _lib.dev_ptr(al.flen_dev), B, N, C_, al.f2p.shape[1],
+                                                   stride, m, _lib.dev_ptr(out), _lib.current_stream()), 'ttsc_expand_rows')
+        return out, flens
     sel = [[a[j * stride] for j in range(len(a) // stride)] for a in alignments]
     m = max(len(s) for s in sel) if sel else 0
     if m == 0:
@@ -411,25 +489,20 @@ class Languasito2(nn.Module):
         x_char = X['x_char'].to(dev)
         x_speaker = X['x_speaker'].to(dev)
         B, N = x_char.shape
-        lengths = (x_char != 0).sum(dim=1).tolist() if B > 1 else [N]
+        lengths = _char_lengths(X, x_char)
         with torch.no_grad():
             hcs = self._text_stack('t', x_char, x_speaker, lengths, X, hf_cond)
             hd = self._lstm('_dur_rnn')(hcs, lengths=lengths)
             out_dur = linear_hip(hd, self._dur_output.linear_layer.weight, self._dur_output.linear_layer.bias)
-            durs = torch.argmax(out_dur, dim=-1).cpu().numpy()           # device->host sync, as modules.py:946
-            f2p = []
-            for b in range(B):
-                a = []
-                for p in range(lengths[b]):
-                    a.extend([p] * int(durs[b, p]))
-                f2p.append(a)
+            # duration head -> frame->phone map on the device (the reference goes through the host here, modules.py:946-953)
+            f2p = align_durations(out_dur, lengths)
             X['y_frame2phone'] = f2p
             hexp, flens = _expand_rows(hcs, f2p)
             F_ = hexp.shape[1]
             if F_ == 0:
                 X['y_pitch'] = torch.zeros((B, 0), device=dev)
                 cond = torch.zeros((B, 0, 80), device=dev)
-                return (cond, durs, flens) if return_aux else cond
+                return (cond, f2p.durations(), flens) if return_aux else cond
             hp = self._lstm('_pitch_rnn')(hexp, lengths=flens)
             op = linear_hip(hp, self._pitch_output.linear_layer.weight, self._pitch_output.linear_layer.bias, act='sigmoid')
             vuv = torch.round(op[:, :, 1])
@@ -443,7 +516,7 @@ class Languasito2(nn.Module):
             if B > 1:
                 fmask = (torch.arange(F_, device=dev)[None, :] < torch.as_tensor(flens, device=dev)[:, None]).float()
                 cond = cond * fmask[:, :, None]
-        return (cond, durs, flens) if return_aux else cond
+        return (cond, f2p.durations(), flens) if return_aux else cond
 
     @torch.jit.ignore
     def save(self, path):

@@ -8,7 +8,7 @@ import torch.nn as nn
 
 from .. import _lib
 from ..hip_layers import LSTMHip, linear_hip
-from .modules import ConvNorm, LinearNorm, PostNet, PreNet, _ConvStack, _cnn_forward, _expand_rows
+from .modules import ConvNorm, LinearNorm, PostNet, PreNet, _ConvStack, _char_lengths, _cnn_forward, _expand_rows, align_durations
 
 
 class CubenetTextcoder(nn.Module):
@@ -72,9 +72,8 @@ class CubenetTextcoder(nn.Module):
         assert x_char.shape[0] == 1, 'CubenetTextcoder.inference follows the reference: one utterance per call'
         with torch.no_grad():
             h, out_dur = self._text_stack(x_char, x_speaker, None)
-            durs = torch.argmax(out_dur, dim=-1).cpu().numpy().reshape(-1)
-            f2p = [p for p, d in enumerate(durs) for _ in range(int(d))]
-            h, _ = _expand_rows(h, [f2p], stride=self._pframes)
+            # duration head -> alignment -> gathered overlay input, all on the device (textcoder.py:160-166,291-302 do it on the host)
+            h, _ = _expand_rows(h, align_durations(out_dur, None), stride=self._pframes)
             if h.shape[1] == 0:
                 return torch.zeros((1, 0, 80), device=dev)
             h = self._lstm('_rnn_overlay')(h)
@@ -149,7 +148,7 @@ class CubenetTextcoder(nn.Module):
         dev = self._get_device()
         x_char, x_speaker = X['x_char'].to(dev), X['x_speaker'].to(dev)
         B = x_char.shape[0]
-        lengths = (x_char != 0).sum(dim=1).tolist() if B > 1 else None
+        lengths = _char_lengths(X, x_char) if B > 1 else None
         with torch.no_grad():
             h, out_dur = self._text_stack(x_char, x_speaker, lengths)
             h, flens = _expand_rows(h, X['y_frame2phone'], stride=self._pframes)

@@ -6,7 +6,7 @@ import torch
 
 from .. import _lib
 from ..hip_layers import linear_hip
-from .modules import _expand_rows
+from .modules import _char_lengths, _expand_rows
 
 
 def languasito_forward(lang, X):
@@ -15,7 +15,7 @@ def languasito_forward(lang, X):
     dev = lang._get_device()
     x_char, x_speaker = X['x_char'].to(dev), X['x_speaker'].to(dev)
     B = x_char.shape[0]
-    lengths = (x_char != 0).sum(dim=1).tolist() if B > 1 else None
+    lengths = _char_lengths(X, x_char) if B > 1 else None
     f2p = X['y_frame2phone']
     with torch.no_grad():
         hcs = lang._text_stack('t', x_char, x_speaker, lengths, X, None)
