@@ -573,31 +573,32 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Wide-tile variant for the square layers of the wide stages (Cin = Cout in {128, 256}, K in {3, 7, 11}).
+// Wide-tile variant for the square layers of the wide stages (Cin = Cout in {128, 256}, K in {3, 7, 11}, dilation 1/3/5).
 // What bounds conv_f16x3_kernel there (PMC, round 1: MFMA pipe 47 % busy, 4.8 VALU per MFMA, a third of the wave cycles
 // parked at barriers) is structural: a workgroup owns 64 output channels, so the same activation window is loaded,
 // leaky-relu'ed and split by Cout/64 workgroups, and every channel chunk costs two barriers with nothing in flight.
 // Here
-//   * a wave owns 64 x 128 outputs (MI = 2, NJ = 4: 24 MFMAs per tap for 8 activation-fragment reads), the four waves are
-//     stacked along M first (256 x 128 workgroup tile at Cout = 256, 128 x 256 at Cout = 128): the activation window is
-//     staged ONCE for all output channels;
-//   * weight fragments are private to a wave (its own 64 rows), so they go global/L2 -> registers directly, one tap ahead,
-//     with the issue order pinned by scheduling barriers (hipcc sinks such loads to their first use otherwise);
+//   * a wave owns 64 x 128 outputs (MI = 2, NJ = 4: 24 MFMAs per tap for 8 activation- and 4 weight-fragment reads), four
+//     waves form a 128 x 256 workgroup tile: the activation window is staged once per 128 output channels;
+//   * weight fragments travel global -> LDS by LDS-DMA one tap ahead (no VGPRs, two 1-KB instructions per wave and tap) and
+//     are shared by the two waves of a row tile; the barrier that ends a tap publishes them.  (Round-2 ablation: per-wave
+//     global -> register fragment loads cost ~30 % of this kernel's time in the CU's vector-memory path.)
 //   * the activation tile is double-buffered in LDS: chunk c+1 is converted and written while chunk c is multiplied
-//     (the conversion's VALU work sits between MFMAs of the same wave), ONE barrier per chunk;
-//   * the global loads of chunk c+2 are issued right after chunk c+1 left the staging registers: a whole chunk of MFMAs
-//     (K x 24 per wave) covers their latency.
-// K is a template parameter (the tap loop is unrolled, register rings are statically indexed); CinP/16 must be even.
+//     (the conversion's VALU work sits between MFMAs of the same wave);
+//   * the global loads of chunk c+2 are issued right after chunk c+1 left the staging registers.
+// K and the dilation are template parameters: the tap loop is unrolled and every LDS address is base register + immediate.
 template <int C, int K, int D>
 __global__ __launch_bounds__(256, 2) void conv_f16x3_wide_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int WM = C == 256 ? 4 : 2, WN = 4 / WM;
+    constexpr int WM = 2, WN = 2;                   // 128 output channels x 256 positions per workgroup (grid.y = C / 128)
     constexpr int MI = 2, NJ = 4, NT = WN * NJ * 32;
     constexpr int SPAN = NT + (K - 1) * D;          // staged positions per channel ("same" padding: halo (K-1)*D)
     constexpr int SPANP = (SPAN + 63) & ~63;
-    constexpr int BUFSZ = 4 * SPAN + 2;             // items per buffer: 4 planes (h, hi|lo) + a dump slot pair
+    constexpr int BUFSZ = 4 * SPAN + 2;             // items per activation buffer: 4 planes (h, hi|lo) + a dump slot pair
     constexpr int NCHUNK = C / 16, COTN = C / 32;
-    half8* Xp = reinterpret_cast<half8*>(smem_raw);   // [buffer][plane (h, pl)][SPAN] 16-byte items
+    constexpr int AITEMS = WM * MI * 2 * 64;        // weight items of one (tap, chunk) for the workgroup's 128 rows (8 KB)
+    half8* Xp = reinterpret_cast<half8*>(smem_raw);   // [2 buffers][plane (h, pl)][SPAN] 16-byte items
+    half8* Aw = Xp + 2 * BUFSZ;                       // [2 slots][AITEMS] weight fragments
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, l31 = lane & 31;
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_wide_kernel(ConvArgs a) {
     const int q0 = blockIdx.x * NT;
     const int lin = a.in_len ? a.in_len[b] : a.Lin;
     if (a.out_len && q0 >= a.out_len[b]) return;
-    const int cot0 = wm * MI;
+    const int cotg = blockIdx.y * (WM * MI);        // first 32-row tile of the workgroup
 
     f32x16 acc[MI][NJ];
 #pragma unroll
@@ -617,10 +618,25 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_wide_kernel(ConvArgs a) {
 
     const float* xb = a.x + (size_t)b * C * a.Lin;
     const int lo = q0 - D * ((K - 1) / 2);
-    const half8* wsrc = reinterpret_cast<const half8*>(a.wph) + (size_t)cot0 * 128 + lane;
+    const half8* wsrc = reinterpret_cast<const half8*>(a.wph) + (size_t)cotg * 128 + lane;
+
+    // ---- weights: global -> LDS by LDS-DMA, one (tap, chunk) step ahead; the two waves that share a row tile (and, at
+    // 256 channels, nobody else) read them back as ds_read_b128.  Fetched per wave straight into registers (the first
+    // version of this kernel) the fragments cost ~30 % of the run time in the CU's vector-memory path.
+    auto stage_A = [&](int c, int j, int slot) __attribute__((always_inline)) {
+        if (TTSC_DBG(a, 8)) return;
+        const half8* wj = wsrc + (size_t)(j * NCHUNK + c) * (COTN * 128);
+#pragma unroll
+        for (int i = 0; i < AITEMS / 64 / 4; ++i) {
+            const int blk = wave + i * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wj + blk * 64),
+                                             (__attribute__((address_space(3))) void*)(Aw + slot * AITEMS + blk * 64), 16, 0, 0);
+        }
+    };
 
     // ---- activation staging: work item = (channel half h, position p) = 8 fp32 channels -> one (hi, lo) pair of items
     constexpr int XIT = (2 * SPANP + 255) / 256;
+    static_assert(XIT <= K, "one staging item per tap");
     float xr[XIT][8];
     unsigned xoff[XIT];
     int xslot[XIT];
@@ -656,45 +672,42 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_wide_kernel(ConvArgs a) {
         buf[xslot[e]] = vh;
         buf[xslot[e] + (xslot[e] < 4 * SPAN ? SPAN : 1)] = vl;   // (the dump slot's partner is the item right behind it)
     };
-    // weight fragments of (tap j, chunk c) for this wave's MI row tiles: [j][c][cot][hi|lo][64 lanes]
-    auto loadA = [&](half8 (&A)[MI][2], int c, int j) __attribute__((always_inline)) {
-        const half8* wj = wsrc + (size_t)(j * NCHUNK + c) * (COTN * 128);
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            A[i][0] = wj[i * 128];
-            A[i][1] = wj[i * 128 + 64];
-        }
-    };
 
-    half8 A[2][MI][2];
-    // all LDS reads of a wave hang off ONE base register: buffer, plane and tap offsets are immediates (D, K, NT are
+    // all LDS reads of a wave hang off two base registers: buffer, plane, slot and tap offsets are immediates (D, K, NT are
     // template parameters) — per-tap address registers were what pushed the first version of this kernel into scratch
     const half8* xbase = Xp + (unsigned)((half * 2) * SPAN + wn * (NJ * 32) + l31);
-    // one channel chunk: K taps on buffer BUF; meanwhile chunk c+1 is converted into the other buffer and the loads of
-    // chunk c+2 are issued (item e at tap K-1-e, so that a tap carries at most one item's conversion).  PAR = parity of
-    // the weight ring at the chunk's first tap (K is odd, the parity flips from chunk to chunk).
+    const half8* abase = Aw + (unsigned)(wm * (MI * 128) + lane);
+    // one channel chunk: K taps on activation buffer BUF; meanwhile chunk c+1 is converted into the other buffer and the
+    // loads of chunk c+2 are issued (item e at tap K-1-e, so that a tap carries at most one item's conversion).  PAR =
+    // weight slot of the chunk's first tap (K is odd: it flips from chunk to chunk).  One barrier per tap: it publishes the
+    // next tap's weights and, after the last tap, the next chunk's activations.
     auto chunk = [&](int c, auto buf_tag, auto par_tag) __attribute__((always_inline)) {
         constexpr int BUF = decltype(buf_tag)::value;
         constexpr int PAR = decltype(par_tag)::value;
         half8* nxt = Xp + (1 - BUF) * BUFSZ;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            // the next step's weight fragments leave first ...
-            if (!TTSC_DBG(a, 8)) {
-                if (j + 1 < K)
-                    loadA(A[(PAR + j + 1) & 1], c, j + 1);
-                else
-                    loadA(A[(PAR + j + 1) & 1], c + 1 < NCHUNK ? c + 1 : c, 0);
-            }
+            const int slot = (PAR + j) & 1;
+            // the next step's weights leave first, then (staging taps) the loads of chunk c+2 ...
+            if (j + 1 < K)
+                stage_A(c, j + 1, slot ^ 1);
+            else
+                stage_A(c + 1 < NCHUNK ? c + 1 : c, 0, slot ^ 1);
             __builtin_amdgcn_sched_barrier(0);
-            half8 bh[NJ], bl[NJ];
+            half8 ah[MI], al[MI], bh[NJ], bl[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                ah[i] = abase[slot * AITEMS + i * 128];
+                al[i] = abase[slot * AITEMS + i * 128 + 64];
+            }
 #pragma unroll
             for (int n = 0; n < NJ; ++n) {
                 bh[n] = xbase[BUF * BUFSZ + j * D + n * 32];
                 bl[n] = xbase[BUF * BUFSZ + SPAN + j * D + n * 32];
             }
-            // ... then (one tap per staging item, last taps of the chunk) convert + publish chunk c+1 and refill the
-            // staging registers with chunk c+2 (past the last chunk this handles clamped garbage nobody reads: no branches)
+            // ... then, on the staging taps (the last XIT taps of a chunk, one item each), chunk c+1 is converted and
+            // published and the staging registers are refilled with chunk c+2 — the compiler interleaves this VALU work
+            // with the tap's MFMAs (past the last chunk it handles clamped garbage nobody reads: no branches)
             const int e = K - 1 - j;
             if (e < XIT && !TTSC_DBG(a, 1)) {
                 x_commit_item(e, nxt);
@@ -703,22 +716,22 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_wide_kernel(ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(PAR + j) & 1][i][1], bh[n], acc[i][n], 0, 0, 0);
+                for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[n], acc[i][n], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(PAR + j) & 1][i][0], bl[n], acc[i][n], 0, 0, 0);
+                for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[n], acc[i][n], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(PAR + j) & 1][i][0], bh[n], acc[i][n], 0, 0, 0);
+                for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[n], acc[i][n], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (!TTSC_DBG(a, 2)) __syncthreads();
         }
-        if (!TTSC_DBG(a, 2)) __syncthreads();   // chunk c fully read, chunk c+1 fully written
     };
 
-    // prologue: chunk 0 -> buffer 0, chunk 1 into the staging registers, first weight fragments
-    loadA(A[0], 0, 0);
+    // prologue: chunk 0 -> buffer 0, chunk 1 into the staging registers, first weight step
+    stage_A(0, 0, 0);
 #pragma unroll
     for (int e = 0; e < XIT; ++e) x_issue_item(e, 0);
 #pragma unroll
@@ -745,7 +758,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_wide_kernel(ConvArgs a) {
 #pragma unroll
         for (int n = 0; n < NJ; ++n) {
             const int q = q0 + wn * (NJ * 32) + n * 32 + l31;
-            epilogue_tile(acc[i][n], a, b, (cot0 + i) * 32, q, q < a.Lout, half, a.w_unscale);
+            epilogue_tile(acc[i][n], a, b, (cotg + wm * MI + i) * 32, q, q < a.Lout, half, a.w_unscale);
         }
     }
 }
@@ -971,10 +984,10 @@ static int launch_f16_t(const ConvArgs& a, int B, hipStream_t s) {
 
 template <int C, int K, int D>
 static int launch_f16_wide(const ConvArgs& a, int B, hipStream_t s) {
-    constexpr int WM = C == 256 ? 4 : 2, WN = 4 / WM, NT = WN * 128;
+    constexpr int NT = 256;
     constexpr int SPAN = NT + (K - 1) * D;
-    dim3 grid((unsigned)ceil_div(a.Lout, NT), 1, (unsigned)B);
-    constexpr size_t lds = (size_t)2 * (4 * SPAN + 2) * 16;
+    dim3 grid((unsigned)ceil_div(a.Lout, NT), (unsigned)(C / 128), (unsigned)B);
+    constexpr size_t lds = (size_t)2 * (4 * SPAN + 2) * 16 + (size_t)2 * (2 * 2 * 2 * 64) * 16;   // activations + 2 weight slots
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)conv_f16x3_wide_kernel<C, K, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1514,7 +1527,7 @@ extern "C" int ttsc_conv1d_forward_split(const ttsc_conv1d* c, const float* x, c
                                     (g.kernel_size == 3 || g.kernel_size == 7 || g.kernel_size == 11) &&
                                     (g.dilation == 1 || g.dilation == 3 || g.dilation == 5) &&
                                     g.padding == g.dilation * (g.kernel_size - 1) / 2;
-            if (wide_env && wide_shape && (wide_env == 2 || (long)ceil_div(a.Lout, g.out_channels == 256 ? 128 : 256) * B >= want16)) {
+            if (wide_env && wide_shape && (wide_env == 2 || (long)ceil_div(a.Lout, 256) * (g.out_channels / 128) * B >= want16)) {
                 if (g.out_channels == 256)
                     rc = launch_f16_wide_k<256>(a, B, g.dilation, s);
                 else

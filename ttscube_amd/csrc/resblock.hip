@@ -11,9 +11,9 @@
 //   * ONE activation image in LDS, as fp16 (hi, lo) planes [8-channel group][hi|lo][column] of 16-byte items — the B
 //     fragment of any tap is a single conflict-free ds_read_b128.  conv1 reads lrelu(x) from it, its epilogue
 //     overwrites it in place with lrelu(conv1 + b1) (one extra barrier instead of a second image), conv2 reads that;
-//   * weight fragments (pre-packed in A-fragment order, see conv1d.hip::pack_phase_f16) stream from L2/L1 straight into
-//     registers two (tap, chunk) steps ahead of the MFMAs that use them — all waves of a workgroup read the same
-//     fragments at about the same time, so they hit in the CU's L1;
+//   * weight fragments (pre-packed in A-fragment order, see conv1d.hip::pack_phase_f16) are shared by all waves of the
+//     workgroup: they are copied global -> LDS by LDS-DMA (global_load_lds, no VGPRs) one group of two (tap, chunk)
+//     steps ahead of the MFMAs and read as ds_read_b128 like the activations; one barrier per group publishes them;
 //   * the tile carries `halo` extra columns per side (sum over the chain of every convolution's half receptive field);
 //     columns whose receptive field leaves the tile go stale and are never stored.
 //
@@ -52,8 +52,11 @@ struct ChainArgs {
     int dbg;              // -DTTSC_ABLATE builds: 1 skip the epilogue -> image conversions, 2 skip barriers, 4 skip the final store, 8 skip the x load, 16 skip weight loads in the loop
 };
 
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+
 // MI = C/32 row tiles, K taps, CT 32-column tiles per wave, NW waves per workgroup, WPS = waves per SIMD the register
-// allocation has to leave room for (2: two workgroups of 4 waves or one of 8 per CU; 1: a single 4-wave workgroup).
+// allocation has to leave room for (2: two workgroups of 4 waves or one of 8 per CU).
 template <int MI, int K, int CT, int NW, int WPS>
 __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -62,7 +65,13 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
     constexpr int MARG = (K == 3) ? 8 : (K == 7 ? 16 : 26);   // >= the largest tap offset (dilation 5: 5*(K-1)/2)
     constexpr int PW = NCOL + 2 * MARG;
     constexpr int NTHR = 64 * NW;
+    constexpr int STEP_ITEMS = MI * 2 * 64;       // 16-byte items of the weight fragments of one (tap, chunk) step
+    constexpr int GRP = 2;                        // steps per weight group = one LDS slot = one barrier interval
+    constexpr int GRP_ITEMS = GRP * STEP_ITEMS;
+    constexpr int NS = K * NCH, NGRP = NS / GRP;
+    static_assert(NS % GRP == 0, "weight groups");
     half8* P = reinterpret_cast<half8*>(smem_raw);   // plane (group g, pl) at P + (g*2 + pl) * PW, tile column c at + MARG + c
+    half8* Aw = P + (size_t)NG * 2 * PW;             // weight fragments: [2 slots][GRP_ITEMS]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -73,6 +82,23 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
     const int colw = wv * (CT * 32);                 // first tile column of this wave
     const int pos_w = q0 - a.halo + colw + l31;      // sequence position of this lane's column in column tile 0
     const float* xb = a.x + (size_t)b * C * a.L;
+
+    // Weight fragments reach the MFMAs through LDS: one group (GRP steps, 4*MI KB) is copied global -> LDS by the LDS-DMA
+    // path (no VGPRs, one 1-KB instruction per wave) while the previous group is multiplied; the barrier that ends a group
+    // publishes the next one.  Every wave of the workgroup needs the same fragments: fetched per wave straight into registers
+    // (the first version of this kernel) they cost a quarter to a third of the run time in the CU's vector-memory path.
+    auto stage_group = [&](const half8* w, int g, int slot) __attribute__((always_inline)) {
+        constexpr int NI = GRP_ITEMS / 64;   // 1-KB wave instructions per group
+        if (TTSC_DBG(a, 16)) return;
+#pragma unroll
+        for (int i = 0; i < (NI + NW - 1) / NW; ++i) {
+            const int blk = wv + i * NW;     // wave-uniform
+            if (blk < NI)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w + (size_t)g * GRP_ITEMS + blk * 64 + lane),
+                                                 (__attribute__((address_space(3))) void*)(Aw + slot * GRP_ITEMS + blk * 64), 16, 0, 0);
+        }
+    };
+    stage_group(a.w1[0], 0, 0);
 
     // the margins only feed columns that are never stored, but they must hold finite numbers
     for (int i = tid; i < NG * 2 * 2 * MARG; i += NTHR) {
@@ -101,17 +127,15 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
             }
     }
 
-    // four channels (one lane's share of 8-channel group 4*mi + gi) of one column -> (hi, lo) halves in the image
+    // four channels (one lane's share of 8-channel group 4*mi + gi) of one column -> (hi, lo) halves in the image.
+    // Written pairwise so that the conversions are packed: cvt_pk (hi), two cvt back, two subtractions, cvt_pk (lo).
     auto store_split = [&](int mi, int ct, int gi, float v0, float v1, float v2, float v3) __attribute__((always_inline)) {
         if (TTSC_DBG(a, 1)) return;
-        half4 vh, vl;
-        const float v[4] = {v0, v1, v2, v3};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const _Float16 hh = (_Float16)v[e];
-            vh[e] = hh;
-            vl[e] = (_Float16)(v[e] - (float)hh);
-        }
+        const float2v p0 = {v0, v1}, p1 = {v2, v3};
+        const half2v h0 = __builtin_convertvector(p0, half2v), h1 = __builtin_convertvector(p1, half2v);
+        const half2v l0 = __builtin_convertvector(p0 - __builtin_convertvector(h0, float2v), half2v);
+        const half2v l1 = __builtin_convertvector(p1 - __builtin_convertvector(h1, float2v), half2v);
+        const half4 vh = {h0[0], h0[1], h1[0], h1[1]}, vl = {l0[0], l0[1], l1[0], l1[1]};
         _Float16* ph = reinterpret_cast<_Float16*>(P + (size_t)((mi * 4 + gi) * 2) * PW + MARG + colw + ct * 32 + l31) + 4 * half;
         *reinterpret_cast<half4*>(ph) = vh;
         *reinterpret_cast<half4*>(ph + (size_t)PW * 8) = vl;
@@ -134,14 +158,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
                     store_split(mi, ct, gi, v[0], v[1], v[2], v[3]);
                 }
     };
-    auto loadA = [&](half8 (&A)[MI][2], const half8* w, int s) __attribute__((always_inline)) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            A[mi][0] = w[((size_t)(s * MI + mi) * 2 + 0) * 64 + lane];
-            A[mi][1] = w[((size_t)(s * MI + mi) * 2 + 1) * 64 + lane];
-        }
-    };
-    // acc = sum over taps j and 16-channel chunks c of  W[j][c] x image[c][column + (j - (K-1)/2) * d]   (three split products)
+    // acc = sum over taps j and 16-channel chunks c of  W[j][c] x image[c][column + (j - (K-1)/2) * d]   (three split products).
+    // Precondition: weight group 0 of `w` sits in slot 0, published by a barrier.  Ends with a barrier (every wave has
+    // finished reading the image and the weight slots).
     auto conv = [&](const half8* w, int d, f32x16 (&acc)[MI][CT]) __attribute__((always_inline)) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -149,44 +168,54 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ct][r] = 0.f;
-        constexpr int NS = K * NCH;   // pipeline steps: (tap, chunk), in the order the fragments are stored
         const half8* base = P + (size_t)(half * 2) * PW + MARG + colw + l31 - d * ((K - 1) / 2);
-        // Software pipeline, written out because hipcc will not build it: weight fragments travel two steps ahead
-        // (global -> registers), activation fragments one step ahead (LDS -> registers); a scheduling barrier per step
-        // keeps that order.  Left alone the compiler sinks every load to just before its first use (s_waitcnt
-        // vmcnt(0) / lgkmcnt(0) in front of every fourth MFMA).
-        half8 A[3][MI][2];
+        // Software pipeline, written out and pinned with scheduling barriers because hipcc will not build it (it sinks
+        // every LDS read to just before its first use): the activation fragments of step s+1 are read between the MFMAs
+        // of step s; the weight fragments of the group's second step are read during its first.
+        half8 Af[2][MI][2];
         half8 Bf[2][2][CT];
-        auto readB = [&](half8 (&Bq)[2][CT], int s) __attribute__((always_inline)) {
-            const int j = s / NCH, c = s % NCH;
-            const half8* bp = base + (size_t)(c * 4) * PW + j * d;
+        auto readA = [&](half8 (&Aq)[MI][2], int s) __attribute__((always_inline)) {
+            const half8* ap = Aw + ((s / GRP) & 1) * GRP_ITEMS + (s % GRP) * STEP_ITEMS + lane;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                Bq[0][ct] = bp[ct * 32];
-                Bq[1][ct] = bp[PW + ct * 32];
+            for (int mi = 0; mi < MI; ++mi) {
+                Aq[mi][0] = ap[(mi * 2 + 0) * 64];
+                Aq[mi][1] = ap[(mi * 2 + 1) * 64];
             }
         };
-        loadA(A[0], w, 0);
-        loadA(A[1], w, 1);
-        readB(Bf[0], 0);
+        {
+            const half8* bp = base;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                Bf[0][0][ct] = bp[ct * 32];
+                Bf[0][1][ct] = bp[PW + ct * 32];
+            }
+        }
         constexpr int NM = 3 * MI * CT;   // MFMAs per step
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            if (s + 2 < NS && !TTSC_DBG(a, 16)) loadA(A[(s + 2) % 3], w, s + 2);
+            if (s % GRP == 0) {
+                if (s / GRP + 1 < NGRP) stage_group(w, s / GRP + 1, (s / GRP + 1) & 1);   // next group: DMA behind this group's MFMAs
+                readA(Af[s & 1], s);
+            }
             const int jn = (s + 1) / NCH, cn = (s + 1) % NCH;
             const half8* bpn = base + (size_t)(cn * 4) * PW + jn * d;
             __builtin_amdgcn_sched_barrier(0);
-            // issue order of a step, pinned: (MFMA, one LDS read of the next step's fragments) pairs, then the rest of
-            // the MFMAs.  Term order lo_w*hi_x, hi_w*lo_x, hi_w*hi_x; consecutive MFMAs go to different accumulators.
+            // issue order of a step, pinned: (MFMA, one LDS read for the next step) pairs, then the rest of the MFMAs.
+            // Term order lo_w*hi_x, hi_w*lo_x, hi_w*hi_x; consecutive MFMAs go to different accumulators.
 #pragma unroll
             for (int q = 0; q < NM; ++q) {
                 const int term = q / (MI * CT), mi = (q / CT) % MI, ct = q % CT;
-                acc[mi][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s % 3][mi][term == 0 ? 1 : 0], Bf[s & 1][term == 1 ? 1 : 0][ct],
+                acc[mi][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[s & 1][mi][term == 0 ? 1 : 0], Bf[s & 1][term == 1 ? 1 : 0][ct],
                                                                    acc[mi][ct], 0, 0, 0);
                 if (q < 2 * CT && s + 1 < NS) Bf[(s + 1) & 1][q / CT][q % CT] = bpn[(q / CT) * PW + (q % CT) * 32];
-                if (q < 2 * CT) __builtin_amdgcn_sched_barrier(0);
+                if (q >= 2 * CT && q < 2 * CT + 2 * MI && (s + 1) % GRP != 0) {   // next step of the same group: its weights
+                    const int i = q - 2 * CT;
+                    Af[(s + 1) & 1][i >> 1][i & 1] = Aw[(((s + 1) / GRP) & 1) * GRP_ITEMS + ((s + 1) % GRP) * STEP_ITEMS + i * 64 + lane];
+                }
+                if (q < 2 * CT + 2 * MI) __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if ((s + 1) % GRP == 0 && !TTSC_DBG(a, 2)) __syncthreads();   // publishes the next weight group, retires this one
         }
     };
 
@@ -194,8 +223,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
     if (!TTSC_DBG(a, 2)) __syncthreads();
     for (int p = 0; p < a.npairs; ++p) {
         f32x16 acc[MI][CT];
-        conv(a.w1[p], a.d1[p], acc);
-        if (!TTSC_DBG(a, 2)) __syncthreads();   // every wave has finished reading lrelu(x): the image is overwritten in place
+        conv(a.w1[p], a.d1[p], acc);           // (ends with a barrier: the image may be overwritten in place)
+        stage_group(a.w2[p], 0, 0);            // conv2's first weight group travels while the epilogue runs
         {
             const float us = a.us1[p];
             const float* bias = a.b1[p];
@@ -209,7 +238,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
                         float v[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float t = acc[mi][ct][4 * gi + e] * us + bv[e];
+                            float t = __builtin_fmaf(acc[mi][ct][4 * gi + e], us, bv[e]);
                             t = fmaxf(t, t * 0.1f);
                             v[e] = pok[ct] ? t : 0.f;
                         }
@@ -219,6 +248,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
         }
         if (!TTSC_DBG(a, 2)) __syncthreads();
         conv(a.w2[p], 1, acc);
+        if (p + 1 < a.npairs) stage_group(a.w1[p + 1], 0, 0);
         {
             const float us = a.us2[p];
             const float* bias = a.b2[p];
@@ -230,11 +260,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) xres[mi][ct][4 * gi + e] += acc[mi][ct][4 * gi + e] * us + bv[e];
+                        for (int e = 0; e < 4; ++e) xres[mi][ct][4 * gi + e] += __builtin_fmaf(acc[mi][ct][4 * gi + e], us, bv[e]);
                 }
         }
         if (p + 1 < a.npairs) {
-            if (!TTSC_DBG(a, 2)) __syncthreads();   // every wave has finished reading conv1's activation
             xres_to_image();
             if (!TTSC_DBG(a, 2)) __syncthreads();
         }
@@ -287,7 +316,7 @@ template <int MI, int K, int CT, int NW, int WPS>
 static int launch_chain(ChainArgs& a, int B, hipStream_t s) {
     constexpr int NCOL = NW * CT * 32;
     constexpr int MARG = (K == 3) ? 8 : (K == 7 ? 16 : 26);
-    constexpr size_t lds = (size_t)(4 * MI) * 2 * (NCOL + 2 * MARG) * 16;
+    constexpr size_t lds = (size_t)(4 * MI) * 2 * (NCOL + 2 * MARG) * 16 + (size_t)2 * 2 * (MI * 2 * 64) * 16;   // image + 2 weight slots
     static_assert(lds <= 160 * 1024, "activation image exceeds the LDS");
     a.nto = NCOL - 2 * a.halo;
     TTSC_REQUIRE(a.nto >= 64, "rbchain: halo %d leaves no output columns in a %d-column tile", a.halo, NCOL);
