@@ -196,7 +196,10 @@ void ttsc_hifigan_destroy(ttsc_hifigan* g);
 /* ------------------------------------------------------------------------------------------------
  * WaveRNN autoregressive vocoder network.  Replaces `cube.networks.modules.WaveRNN._inference`
  * (cube/networks/modules.py:453-503; constructed vocoder.py:45-57) — the per-sample python loop of
- * nn.GRU(seq=1) -> tanh(Linear) -> Linear -> Categorical.sample -> µ-law decode — with one persistent kernel.
+ * nn.GRU(seq=1) -> tanh(Linear) -> Linear -> output_functions.sample — with one persistent kernel.  Every output distribution
+ * of cube/networks/loss.py is sampled in the kernel: MULAWOutput / RAWOutput (Categorical.sample as Gumbel-max, loss.py:218-307),
+ * MOLOutput (the reference default; Gumbel-max over 10 mixtures + logistic inverse CDF, loss.py:163-201), GaussianOutput
+ * (loss.py:50-52) and BetaOutput (two Marsaglia-Tsang gamma variates, loss.py:83-92).
  * Weight names are the reference state_dict keys: "_rnns.<l>.weight_ih_l0", "_rnns.<l>.weight_hh_l0",
  * "_rnns.<l>.bias_ih_l0", "_rnns.<l>.bias_hh_l0", "_lowres_conv.<i>.conv.weight|bias",
  * "_preoutput.linear_layer.weight|bias", "_output.linear_layer.weight|bias"; "_skip.*" is accepted and ignored
@@ -204,8 +207,11 @@ void ttsc_hifigan_destroy(ttsc_hifigan* g);
  * ------------------------------------------------------------------------------------------------ */
 typedef struct ttsc_wavernn ttsc_wavernn;
 
-enum { TTSC_WR_OUT_MULAW = 0, TTSC_WR_OUT_RAW = 1 };
-/* sampler: argmax(logits) | argmax(logits + injected Gumbel noise[B,L,S]) | argmax(logits + Philox Gumbel noise) */
+enum { TTSC_WR_OUT_MULAW = 0, TTSC_WR_OUT_RAW = 1, TTSC_WR_OUT_MOL = 2, TTSC_WR_OUT_GM = 3, TTSC_WR_OUT_BETA = 4 };
+/* sampler noise: none (arg-max / distribution mode) | injected [B,L,W] | in-kernel Philox-4x32-10 counters.
+ * W (floats per step) = 256 for mulaw/raw (Gumbel terms), 11 for MOL (10 Gumbel terms -log(-log u) + 1 logistic term
+ * log u - log(1-u)), 1 for Gaussian (0.8 * N(0,1)), 18 for Beta (per gamma variate: boost uniform + 4 (normal, uniform) rounds);
+ * defined next to the samplers in include/ttscube_math.h. */
 enum { TTSC_WR_MODE_ARGMAX = 0, TTSC_WR_MODE_NOISE = 1, TTSC_WR_MODE_PHILOX = 2 };
 
 typedef struct {
@@ -214,7 +220,7 @@ typedef struct {
     int32_t use_lowres;   /* 1: high-res net conditioned on x_low (in_dim 102); 0: low-res net (in_dim 81) */
     int32_t upsample;     /* mel repeat factor: 240 (hr) / 24 (lr) */
     int32_t upsample_low; /* 10 */
-    int32_t S;            /* output_functions.sample_size: 256 for mulaw/raw */
+    int32_t S;            /* output_functions.sample_size: 256 mulaw/raw, 30 mol, 2 gm/beta */
     int32_t n_mel;        /* 80 */
     int32_t out_kind;     /* TTSC_WR_OUT_* */
 } ttsc_wavernn_cfg;
@@ -224,9 +230,9 @@ int ttsc_wavernn_set_weight(ttsc_wavernn* w, const char* name, const float* host
 /* samples emitted for T mel frames / Tl low-res samples: min(T*upsample, Tl*upsample_low) (modules.py:467) */
 int64_t ttsc_wavernn_out_len(const ttsc_wavernn* w, int64_t T, int64_t Tl);
 size_t ttsc_wavernn_workspace_bytes(const ttsc_wavernn* w, int32_t B, int64_t T, int64_t Tl);
-/* mel_dev [B,T,n_mel]; xlow_dev [B,Tl] (hr net) or NULL; noise_dev [B,L,S] (mode NOISE) or NULL;
+/* mel_dev [B,T,n_mel]; xlow_dev [B,Tl] (hr net) or NULL; noise_dev [B,L,W] (mode NOISE) or NULL;
  * forced_x_dev [B,L] or NULL (teacher forcing: feedback = forced_x[t], logits then equal _train_forward);
- * outputs idx_dev uint8 [B,L], wav_dev fp32 [B,L] (decoded samples, what _inference returns), logits_dev
+ * outputs idx_dev uint8 [B,L] (class index; mixture index for MOL; 0 for gm/beta), wav_dev fp32 [B,L] (what _inference returns), logits_dev
  * fp32 [B,L,S] or NULL. */
 int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel_dev, const float* xlow_dev, int32_t B, int64_t T, int64_t Tl,
                         int32_t mode, const float* noise_dev, uint64_t seed, const float* forced_x_dev,

@@ -7,6 +7,8 @@
  *   ConvNorm low-res convs    cube/networks/modules.py:416-420, 459-461
  *   nn.GRU cell (r,z,n)       torch semantics used at modules.py:427,485
  *   MULAWOutput.sample/decode cube/networks/loss.py:227-230,257-269;  RAWOutput loss.py:288-299
+ *   MOLOutput.sample          cube/networks/loss.py:163-201  (the default of WaveRNN, modules.py:398)
+ *   GaussianOutput.sample     cube/networks/loss.py:50-52;   BetaOutput.sample loss.py:83-92
  *
  * Arithmetic contract (shared with the HIP kernel so that µ-law indices are bit-exact): every dot product
  * is ONE k-ordered fp32 fmaf chain seeded with the bias; sigmoid/tanh/log come from include/ttscube_math.h;
@@ -29,6 +31,9 @@
 
 #define OUT_MULAW 0
 #define OUT_RAW 1
+#define OUT_MOL 2    /* S = 30: 10 mixture logits | 10 means | 10 log-scales; noise [B, L, 11] = 10 Gumbel terms + 1 logistic term */
+#define OUT_GM 3     /* S = 2: mean, log-std; noise [B, L, 1] = 0.8 * N(0,1) */
+#define OUT_BETA 4   /* S = 2: log alpha, log beta; noise [B, L, 18] = per gamma variate: boost uniform + 4 (normal, uniform) rounds */
 
 typedef struct {
     int32_t H;            /* GRU size */
@@ -38,7 +43,7 @@ typedef struct {
     int32_t upsample_low; /* 10 */
     int32_t S;            /* logits per sample (256) */
     int32_t n_mel;        /* 80 */
-    int32_t out_kind;     /* OUT_MULAW / OUT_RAW */
+    int32_t out_kind;     /* OUT_* */
 } wr_cfg;
 
 typedef struct {
@@ -102,8 +107,17 @@ int64_t wr_out_len(const wr_cfg* c, int T, int Tl) {
     return L;
 }
 
+int wr_noise_width(const wr_cfg* c) {
+    switch (c->out_kind) {
+        case OUT_MOL: return TTSC_MOL_NOISE;
+        case OUT_GM: return TTSC_GM_NOISE;
+        case OUT_BETA: return TTSC_BETA_NOISE;
+        default: return c->S;
+    }
+}
+
 /*
- * mel [B,T,n_mel]; x_low [B,Tl] (hr only); noise [B,L,S] (MODE_NOISE); forced_x [B,L] or NULL: when given,
+ * mel [B,T,n_mel]; x_low [B,Tl] (hr only); noise [B,L,wr_noise_width] (MODE_NOISE); forced_x [B,L] or NULL: when given,
  * the fed-back sample at step t is forced_x[b][t] (teacher forcing: logits then equal WaveRNN._train_forward).
  * Outputs: out_idx [B,L] uint8, out_wav [B,L] float, out_logits [B,L,S] or NULL.
  */
@@ -172,28 +186,50 @@ int wr_decode(const wr_cfg* c, const wr_weights* w, const float* mel, const floa
             for (int s = 0; s < S; ++s) logits[s] = dot_chain(w->w_out + (size_t)s * 256, pre, 256, w->b_out[s]);
             if (out_logits) memcpy(out_logits + ((size_t)b * L + t) * S, logits, sizeof(float) * S);
             int best = 0;
-            float bs = 0.f;
-            for (int s = 0; s < S; ++s) {
-                float g = 0.f;
-                if (mode == MODE_NOISE) {
-                    g = noise[((size_t)b * L + t) * S + s];
-                } else if (mode == MODE_PHILOX) {
-                    uint32_t r4[4];
-                    ttsc_philox4x32((uint32_t)(s >> 2), (uint32_t)t, (uint32_t)b, 0u,
-                                    (uint32_t)seed, (uint32_t)(seed >> 32), r4);
-                    g = ttsc_gumbel(r4[s & 3]);
-                }
-                const float sc = logits[s] + g;
-                if (s == 0 || sc > bs) {
-                    bs = sc;
-                    best = s;
-                }
-            }
             float wav;
-            if (c->out_kind == OUT_MULAW)
-                wav = w->lut[best];
-            else
-                wav = (((float)best / 255.0f) - 0.5f) * 2.0f; /* loss.py:297-299 */
+            if (c->out_kind == OUT_MULAW || c->out_kind == OUT_RAW) {
+                float bs = 0.f;
+                for (int s = 0; s < S; ++s) {
+                    float g = 0.f;
+                    if (mode == MODE_NOISE) {
+                        g = noise[((size_t)b * L + t) * S + s];
+                    } else if (mode == MODE_PHILOX) {
+                        uint32_t r4[4];
+                        ttsc_philox4x32((uint32_t)(s >> 2), (uint32_t)t, (uint32_t)b, 0u,
+                                        (uint32_t)seed, (uint32_t)(seed >> 32), r4);
+                        g = ttsc_gumbel(r4[s & 3]);
+                    }
+                    const float sc = logits[s] + g;
+                    if (s == 0 || sc > bs) {
+                        bs = sc;
+                        best = s;
+                    }
+                }
+                if (c->out_kind == OUT_MULAW)
+                    wav = w->lut[best];
+                else
+                    wav = (((float)best / 255.0f) - 0.5f) * 2.0f; /* loss.py:297-299 */
+            } else {
+                /* continuous outputs: MODE_ARGMAX = zero noise (the mode of the selected component / the mean) */
+                float nz[TTSC_BETA_NOISE];
+                const int nw = wr_noise_width(c);
+                for (int i = 0; i < nw; ++i) nz[i] = 0.f;
+                if (mode == MODE_NOISE) {
+                    memcpy(nz, noise + ((size_t)b * L + t) * nw, sizeof(float) * nw);
+                } else if (mode == MODE_PHILOX) {
+                    if (c->out_kind == OUT_MOL) ttsc_noise_mol((uint32_t)t, (uint32_t)b, seed, nz);
+                    else if (c->out_kind == OUT_GM) ttsc_noise_gm((uint32_t)t, (uint32_t)b, seed, nz);
+                    else ttsc_noise_beta((uint32_t)t, (uint32_t)b, seed, nz);
+                } else if (c->out_kind == OUT_BETA) {
+                    for (int v = 0; v < 2; ++v) nz[v * (1 + 2 * TTSC_BETA_TRIES)] = 0.5f, nz[v * (1 + 2 * TTSC_BETA_TRIES) + 2] = 0.5f;
+                }
+                if (c->out_kind == OUT_MOL)
+                    wav = ttsc_sample_mol(logits, nz, nz[TTSC_MOL_NMIX], &best);
+                else if (c->out_kind == OUT_GM)
+                    wav = ttsc_sample_gm(logits, nz[0]);
+                else
+                    wav = ttsc_sample_beta(logits, nz);
+            }
             out_idx[(size_t)b * L + t] = (uint8_t)best;
             out_wav[(size_t)b * L + t] = wav;
             last_x = forced_x ? forced_x[(size_t)b * L + t] : wav;
@@ -216,6 +252,10 @@ float wr_logf(float x) { return ttsc_logf(x); }
 float wr_tanhf(float x) { return ttsc_tanhf(x); }
 float wr_sigmoidf(float x) { return ttsc_sigmoidf(x); }
 float wr_gumbel(uint32_t r) { return ttsc_gumbel(r); }
+float wr_normal_icdf(float p) { return ttsc_normal_icdf(p); }
+float wr_sample_beta(const float* y, const float* nz) { return ttsc_sample_beta(y, nz); }
+float wr_sample_mol(const float* y, const float* nz, int* k) { return ttsc_sample_mol(y, nz, nz[TTSC_MOL_NMIX], k); }
+void wr_noise_beta(uint32_t t, uint32_t b, uint64_t seed, float* nz) { ttsc_noise_beta(t, b, seed, nz); }
 void wr_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
     ttsc_philox4x32(c0, c1, c2, c3, k0, k1, out);
 }

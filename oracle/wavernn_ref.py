@@ -10,7 +10,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, '_build', 'libwavernn_ref.so')
 MODE_ARGMAX, MODE_NOISE, MODE_PHILOX = 0, 1, 2
-OUT_MULAW, OUT_RAW = 0, 1
+OUT_MULAW, OUT_RAW, OUT_MOL, OUT_GM, OUT_BETA = 0, 1, 2, 3, 4
+OUT_KIND = {'mulaw': OUT_MULAW, 'raw': OUT_RAW, 'mol': OUT_MOL, 'gm': OUT_GM, 'beta': OUT_BETA}
+SAMPLE_SIZE = {'mulaw': 256, 'raw': 256, 'mol': 30, 'gm': 2, 'beta': 2}      # loss.py sample_size
+NOISE_WIDTH = {'mulaw': 256, 'raw': 256, 'mol': 11, 'gm': 1, 'beta': 18}     # injected noise scalars per step (wavernn_ref.c)
 
 
 class Cfg(C.Structure):
@@ -40,6 +43,14 @@ def lib():
             getattr(_lib, f).argtypes = [C.c_float]
         _lib.wr_gumbel.restype = C.c_float
         _lib.wr_gumbel.argtypes = [C.c_uint32]
+        _lib.wr_normal_icdf.restype = C.c_float
+        _lib.wr_normal_icdf.argtypes = [C.c_float]
+        _lib.wr_sample_beta.restype = C.c_float
+        _lib.wr_sample_beta.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.wr_sample_mol.restype = C.c_float
+        _lib.wr_sample_mol.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.wr_noise_beta.restype = None
+        _lib.wr_noise_beta.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p]
     return _lib
 
 
@@ -73,8 +84,9 @@ def decode(sd, mel, x_low=None, num_layers=1, H=512, use_lowres=True, upsample=2
     L_ = lib()
     mel = _f32(mel)
     B, T, NM = mel.shape
-    S = 256
-    cfg = Cfg(H, num_layers, int(use_lowres), upsample, upsample_low, S, NM, OUT_MULAW if output == 'mulaw' else OUT_RAW)
+    S = SAMPLE_SIZE[output]
+    NW = NOISE_WIDTH[output]
+    cfg = Cfg(H, num_layers, int(use_lowres), upsample, upsample_low, S, NM, OUT_KIND[output])
     keep = []
 
     def P(name):
@@ -107,7 +119,7 @@ def decode(sd, mel, x_low=None, num_layers=1, H=512, use_lowres=True, upsample=2
     nz = _f32(noise) if noise is not None else None
     fx = _f32(forced_x) if forced_x is not None else None
     if nz is not None:
-        assert nz.shape == (B, L, S), (nz.shape, (B, L, S))
+        assert nz.shape == (B, L, NW), (nz.shape, (B, L, NW))
     if fx is not None:
         assert fx.shape[0] == B and fx.shape[1] >= L
         fx = _f32(fx[:, :L])

@@ -86,3 +86,62 @@ def test_vocoder_fold_matches_reference(golden_dir):
     f = O.inference_batch(z['mel'], z['x_low'], num_batches=20)
     assert np.array_equal(f['mel'], z['fold_mel']) and np.array_equal(f['x_low'], z['fold_x_low'])
     assert np.array_equal(O.compose_batched_inference(z['hr']), z['composed'])
+
+
+# ---- continuous outputs (MOL is the reference's default, cube/networks/modules.py:398) -----------------------------------
+CONT = ['wavernn_hr_h64_mol', 'wavernn_hr_h512_mol', 'wavernn_lr_h64_gm', 'wavernn_hr_h64_beta']
+
+
+def _case_cont(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + '.npz'))
+    out = str(z['output'])
+    kw = dict(num_layers=int(z['N']), H=int(z['H']), use_lowres=bool(z['use_lowres']),
+              upsample=240 if bool(z['use_lowres']) else 24, output=out)
+    sd = O.synthetic_state_dict(H=kw['H'], num_layers=kw['num_layers'], use_lowres=kw['use_lowres'], seed=int(z['seed']),
+                                S=O.SAMPLE_SIZE[out])
+    sd['_output.linear_layer.weight'], sd['_output.linear_layer.bias'] = z['out_w'], z['out_b']   # (rescaled by the generator)
+    return z, sd, kw
+
+
+@pytest.mark.parametrize('name', CONT[:3])
+def test_continuous_samples_match_reference(golden_dir, name):
+    """MOLOutput.sample / GaussianOutput.sample (loss.py:163-201,50-52) with the reference's own random terms replayed:
+    the mixture index of every step is identical and the samples agree to 1e-5 over the whole autoregressive run (the only
+    arithmetic difference is one exp() per sample: shared fp32 definition here, libm in torch)."""
+    z, sd, kw = _case_cont(golden_dir, name)
+    idx, wav, _ = O.decode(sd, z['mel'], z['x_low'] if kw['use_lowres'] else None, mode=O.MODE_NOISE, noise=z['noise'], **kw)
+    assert wav.shape == z['wav'].shape
+    if kw['output'] == 'mol':
+        assert np.array_equal(idx, z['idx']), 'first mixture-index mismatch at %s' % (np.argwhere(idx != z['idx'])[:3],)
+    assert float(np.abs(wav - z['wav']).max()) < 1e-5
+
+
+@pytest.mark.parametrize('name', CONT)
+def test_continuous_teacher_forced_outputs_match_reference(golden_dir, name):
+    z, sd, kw = _case_cont(golden_dir, name)
+    _, _, logits = O.decode(sd, z['mel'], z['x_low'] if kw['use_lowres'] else None, mode=O.MODE_ARGMAX, forced_x=z['audio'],
+                            want_logits=True, **kw)
+    assert logits.shape == z['logits_tf'].shape
+    assert float(np.abs(logits - z['logits_tf']).max()) < 1e-4
+
+
+def test_normal_quantile_and_beta_sampler_distribution():
+    """The Beta sampler cannot replay torch's rejection sampler draw for draw; it is pinned distributionally: Marsaglia-Tsang
+    gammas from the counter RNG -> Kolmogorov-Smirnov against scipy's Beta for shapes on both sides of 1 (loss.py:83-92)."""
+    import ctypes as C
+    from scipy import stats
+    L = O.lib()
+    ps = np.concatenate([np.linspace(1e-6, 1 - 1e-6, 2001), [1e-7, 0.02425, 0.97575]]).astype(np.float32)
+    got = np.array([L.wr_normal_icdf(float(p)) for p in ps])
+    assert np.max(np.abs(got - stats.norm.ppf(ps.astype(np.float64)))) < 5e-4   # fp32 evaluation of the rational approximation
+    nz = (C.c_float * 18)()
+    for a_, b_ in ((0.4, 0.7), (1.0, 1.0), (2.5, 0.8), (5.0, 9.0), (30.0, 30.0)):
+        y = (C.c_float * 2)(float(np.log(a_)), float(np.log(b_)))
+        xs = []
+        for t in range(6000):
+            L.wr_noise_beta(t, 3, C.c_uint64(12345), nz)
+            xs.append(L.wr_sample_beta(y, nz))
+        xs = (np.asarray(xs, dtype=np.float64) + 1.0) / 2.0          # back to (0, 1)
+        assert 0.0 <= xs.min() and xs.max() <= 1.0
+        ks = stats.kstest(xs, stats.beta(a_, b_).cdf)
+        assert ks.pvalue > 1e-3, (a_, b_, ks)

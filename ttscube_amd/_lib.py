@@ -42,7 +42,7 @@ class WavernnCfg(C.Structure):
                 ('upsample_low', C.c_int32), ('S', C.c_int32), ('n_mel', C.c_int32), ('out_kind', C.c_int32)]
 
 
-WR_OUT_MULAW, WR_OUT_RAW = 0, 1
+WR_OUT_MULAW, WR_OUT_RAW, WR_OUT_MOL, WR_OUT_GM, WR_OUT_BETA = 0, 1, 2, 3, 4
 WR_MODE_ARGMAX, WR_MODE_NOISE, WR_MODE_PHILOX = 0, 1, 2
 
 _lib = None

@@ -334,7 +334,9 @@ __global__ __launch_bounds__(WR_THREADS) void wr_decode_kernel(WrArgs a) {
                     const size_t o = ((size_t)BIDX(u) * a.L + t) * S + row;
                     if (a.out_logits && BOK(u)) a.out_logits[o] = acc;
                     float g = 0.f;
-                    if (a.mode == 1) {
+                    if (a.out_kind >= 2) {
+                        // continuous outputs: the noise enters in the sampler stage below
+                    } else if (a.mode == 1) {
                         g = a.noise[o];
                     } else if (a.mode == 2) {
                         uint32_t r4[4];
@@ -347,8 +349,90 @@ __global__ __launch_bounds__(WR_THREADS) void wr_decode_kernel(WrArgs a) {
             }
         }
         __syncthreads();
+        // ---- continuous output distributions (MOL is the reference default): a few lanes of wave u sample utterance u ----
+        // Same arithmetic as oracle/wavernn_ref.c through include/ttscube_math.h; the per-scalar noise terms are computed
+        // one per lane (Philox rounds + logs would otherwise sit serially on the per-step critical path).
+        if (a.out_kind >= 2) {
+            for (int u = wave; u < BT; u += WR_THREADS / 64) {
+                const float* y = score + u * S;
+                const size_t o = (size_t)BIDX(u) * a.L + t;
+                float wv = 0.f;
+                int bi = 0;
+                if (a.out_kind == TTSC_WR_OUT_MOL) {
+                    float gi = 0.f;
+                    if (lane <= TTSC_MOL_NMIX) {
+                        if (a.mode == 1) {
+                            gi = a.noise[o * TTSC_MOL_NOISE + lane];
+                        } else if (a.mode == 2) {
+                            const float uu = ttsc_u01_clip(ttsc_philox_word((uint32_t)lane, (uint32_t)t, (uint32_t)BIDX(u), a.seed));
+                            gi = lane < TTSC_MOL_NMIX ? -ttsc_logf(-ttsc_logf(uu)) : ttsc_logistic(uu);
+                        }
+                    }
+                    float v = lane < TTSC_MOL_NMIX ? y[lane] + gi : -INFINITY;
+                    int k = lane;
+#pragma unroll
+                    for (int off = 8; off >= 1; off >>= 1) {
+                        const float ov = __shfl_xor(v, off);
+                        const int ok = __shfl_xor(k, off);
+                        if (ov > v || (ov == v && ok < k)) {   // first maximum wins, like the oracle's sequential scan
+                            v = ov;
+                            k = ok;
+                        }
+                    }
+                    const float lg = __shfl(gi, TTSC_MOL_NMIX);
+                    k = __shfl(k, 0);
+                    const float mean = y[TTSC_MOL_NMIX + k];
+                    float ls = y[2 * TTSC_MOL_NMIX + k];
+                    ls = ls < TTSC_LOG_SCALE_MIN ? TTSC_LOG_SCALE_MIN : ls;
+                    wv = mean + ttsc_expf(ls) * lg;
+                    wv = wv < -1.0f ? -1.0f : wv;
+                    wv = wv > 1.0f ? 1.0f : wv;
+                    bi = k;
+                } else if (a.out_kind == TTSC_WR_OUT_GM) {
+                    float z = 0.f;
+                    if (a.mode == 1)
+                        z = a.noise[o];
+                    else if (a.mode == 2)
+                        z = 0.8f * ttsc_normal_icdf(ttsc_u01(ttsc_philox_word(0u, (uint32_t)t, (uint32_t)BIDX(u), a.seed)));
+                    wv = y[0] + z * ttsc_expf(y[1]);
+                } else {   // beta: lanes 0 / 1 draw the two gamma variates
+                    constexpr int NV = 1 + 2 * TTSC_BETA_TRIES;
+                    const int v = lane & 1;
+                    float nz[NV];
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) nz[i] = 0.f;
+                    if (a.mode == 1) {
+#pragma unroll
+                        for (int i = 0; i < NV; ++i) nz[i] = a.noise[o * TTSC_BETA_NOISE + v * NV + i];
+                    } else if (a.mode == 2) {
+                        nz[0] = ttsc_u01(ttsc_philox_word((uint32_t)(v * 16), (uint32_t)t, (uint32_t)BIDX(u), a.seed));
+#pragma unroll
+                        for (int i = 0; i < TTSC_BETA_TRIES; ++i) {
+                            nz[1 + 2 * i] = ttsc_normal_icdf(ttsc_u01(ttsc_philox_word((uint32_t)(v * 16 + 1 + 2 * i), (uint32_t)t, (uint32_t)BIDX(u), a.seed)));
+                            nz[2 + 2 * i] = ttsc_u01(ttsc_philox_word((uint32_t)(v * 16 + 2 + 2 * i), (uint32_t)t, (uint32_t)BIDX(u), a.seed));
+                        }
+                    } else {
+                        nz[0] = 0.5f;
+                        nz[2] = 0.5f;
+                    }
+                    const float gv = ttsc_gamma_mt(ttsc_expf(y[v]), nz);
+                    const float ga = __shfl(gv, 0), gb = __shfl(gv, 1);
+                    float sx = ga / (ga + gb);
+                    sx = sx < 1.17549435e-38f ? 1.17549435e-38f : sx;
+                    sx = sx > 0.99999994f ? 0.99999994f : sx;
+                    wv = (sx - 0.5f) * 2.0f;
+                }
+                if (lane == 0) {
+                    if (BOK(u)) {
+                        a.out_idx[o] = (uint8_t)bi;
+                        a.out_wav[o] = wv;
+                    }
+                    lastx[u] = a.forced_x ? a.forced_x[o] : wv;
+                }
+            }
+        }
         // ---- Gumbel-max: first maximum wins; wave u reduces utterance u ------------------------------------
-        for (int u = wave; u < BT; u += WR_THREADS / 64) {
+        for (int u = wave; a.out_kind < 2 && u < BT; u += WR_THREADS / 64) {
             float bs = score[u * S + lane];
             int bi = lane;
             for (int s = lane + 64; s < S; s += 64) {
@@ -455,7 +539,11 @@ extern "C" int ttsc_wavernn_create(const ttsc_wavernn_cfg* cfg, ttsc_wavernn** o
     TTSC_REQUIRE(cfg->S >= 1 && cfg->S <= 256, "ttsc_wavernn_create: sample_size must be in [1,256] (mulaw/raw = 256)");
     TTSC_REQUIRE(cfg->n_mel >= 1 && cfg->n_mel <= 100, "ttsc_wavernn_create: n_mel must be in [1,100]");
     TTSC_REQUIRE(cfg->upsample >= 1 && cfg->upsample_low >= 1, "ttsc_wavernn_create: bad upsample factors");
-    TTSC_REQUIRE(cfg->out_kind == TTSC_WR_OUT_MULAW || cfg->out_kind == TTSC_WR_OUT_RAW, "ttsc_wavernn_create: output must be mulaw or raw");
+    TTSC_REQUIRE(cfg->out_kind >= TTSC_WR_OUT_MULAW && cfg->out_kind <= TTSC_WR_OUT_BETA, "ttsc_wavernn_create: unknown output kind %d", cfg->out_kind);
+    {
+        const int want = cfg->out_kind == TTSC_WR_OUT_MOL ? 3 * TTSC_MOL_NMIX : (cfg->out_kind >= TTSC_WR_OUT_GM ? 2 : 256);
+        TTSC_REQUIRE(cfg->S == want, "ttsc_wavernn_create: output kind %d has sample_size %d (cube/networks/loss.py), got %d", cfg->out_kind, want, cfg->S);
+    }
     ttsc_wavernn* w = new ttsc_wavernn();
     w->cfg = *cfg;
     w->in0 = cfg->n_mel + 1 + (cfg->use_lowres ? 21 : 0);

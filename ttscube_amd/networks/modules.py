@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
-from .loss import MULAWOutput, RAWOutput
+from .loss import BetaOutput, GaussianOutput, MOLOutput, MULAWOutput, RAWOutput
 
 
 class LinearNorm(nn.Module):
@@ -68,13 +68,10 @@ class WaveRNN(nn.Module):
             ic = layer_size
         self._rnns = nn.ModuleList(rnn_list)
         self._preoutput = LinearNorm(layer_size, 256)
-        if output == 'mulaw':
-            self._output_functions = MULAWOutput()
-        elif output == 'raw':
-            self._output_functions = RAWOutput()
-        else:
-            raise NotImplementedError("output='%s': the HIP sampler implements the discrete outputs 'mulaw' and 'raw' "
-                                      "(cube/networks/loss.py:218-307)" % output)
+        outs = {'mol': MOLOutput, 'gm': GaussianOutput, 'beta': BetaOutput, 'mulaw': MULAWOutput, 'raw': RAWOutput}
+        if output not in outs:
+            raise ValueError("output must be one of %s (cube/networks/modules.py:429-438), got %r" % (sorted(outs), output))
+        self._output_functions = outs[output]()
         self._output_name = output
         self._output = LinearNorm(256, self._output_functions.sample_size, w_init_gain='linear')
         self._val_loss = 9999
@@ -91,8 +88,7 @@ class WaveRNN(nn.Module):
         if self._handle is None:
             _lib.require_gpu()
             cfg = _lib.WavernnCfg(self._layer_size, self._num_layers, int(self._use_lowres), self._upsample,
-                                  self._upsample_low, self._output_functions.sample_size, 80,
-                                  _lib.WR_OUT_MULAW if self._output_name == 'mulaw' else _lib.WR_OUT_RAW)
+                                  self._upsample_low, self._output_functions.sample_size, 80, self._output_functions.kind)
             hnd = C.c_void_p()
             _lib.check(L.ttsc_wavernn_create(C.byref(cfg), C.byref(hnd)), 'ttsc_wavernn_create')
             self._handle = hnd
@@ -113,8 +109,10 @@ class WaveRNN(nn.Module):
     def decode(self, X, mode='philox', noise=None, seed=None, forced_x=None, want_logits=False):
         """Device-side decode.  Returns (idx uint8 [B,L], wav fp32 [B,L], logits fp32 [B,L,S] | None) as device tensors.
 
-        mode: 'philox' (in-kernel counter RNG, seeded from torch's generator unless `seed` is given), 'noise'
-        (injected Gumbel noise [B,L,S], used by the parity tests) or 'argmax'."""
+        mode: 'philox' (in-kernel counter RNG, seeded from torch's generator unless `seed` is given), 'noise' (injected noise
+        [B, L, output_functions.noise_width]: Gumbel terms for mulaw/raw, the sampler's random terms for mol/gm/beta — used by the
+        parity tests) or 'argmax' (no noise: the arg-max class / the mode of the selected component).  idx holds the class index
+        (mulaw/raw), the mixture index (mol) or zeros."""
         L = _lib.lib()
         self._sync()
         dev = self._get_device()
@@ -133,9 +131,10 @@ class WaveRNN(nn.Module):
         nz = None
         if mode == 'noise':
             if noise is None:
-                raise _lib.TTSCError("WaveRNN.decode: mode='noise' needs a noise tensor [B, L, S]")
+                raise _lib.TTSCError("WaveRNN.decode: mode='noise' needs a noise tensor [B, L, %d]" % self._output_functions.noise_width)
             nz = torch.as_tensor(noise).to(dev).float().contiguous()
-            assert tuple(nz.shape) == (B, Lout, S), (tuple(nz.shape), (B, Lout, S))
+            W = self._output_functions.noise_width
+            assert tuple(nz.shape) == (B, Lout, W), (tuple(nz.shape), (B, Lout, W))
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if mode == 'philox' else 0
         fx = None
