@@ -357,3 +357,50 @@ def test_conv1d_f16x3_wide_tile_kernel(C, k, d, L, B, monkeypatch):
         solo = conv(x[:1, :, :n].contiguous().cuda(), in_slope=0.1)
         assert torch.equal(yr[:1, :, :n], solo)           # ragged == the utterance run alone, bit for bit
         assert torch.equal(yr[1:], y[1:])
+
+
+@pytest.mark.parametrize('cin,k,L,B,prec', [(32, 7, 5003, 2, 'f16x3'), (32, 7, 1024, 1, 'fp32'), (64, 11, 2050, 1, 'f16x3'), (20, 3, 7, 2, 'fp32')])
+def test_single_output_channel_conv(cin, k, L, B, prec):
+    """conv_cout1_kernel (HiFi-GAN conv_post, 32 -> 1, tanh): prologue scale + leaky-relu, residual, running sum, ragged."""
+    import ctypes as C_
+    from ttscube_amd import _lib
+    from ttscube_amd.hip_layers import Conv1dHip
+    pad = (k - 1) // 2
+    w, b = _mk((1, cin, k), 1, 1.0 / (cin * k) ** 0.5), _mk((1,), 2, 0.1)
+    x, r, s0 = _mk((B, cin, L), 3), _mk((B, 1, L), 4), _mk((B, 1, L), 5)
+    conv = Conv1dHip(cin, 1, k, padding=pad).set_precision(prec)
+    conv.set_weight(w, b)
+    out = s0.clone().cuda()
+    conv(x.cuda(), resid=r.cuda(), out=out, in_scale=1.0 / 3.0, in_slope=0.01, out_scale=0.5, act='tanh', accumulate=True)
+    ref = s0 + torch.tanh((F.conv1d(F.leaky_relu(x / 3.0, 0.01), w, b, padding=pad) + r) * 0.5)
+    assert float((out.cpu() - ref).abs().max()) < TOL
+    if B > 1:
+        n = L - 3
+        lens = torch.tensor([n] + [L] * (B - 1), dtype=torch.int32).cuda()
+        yr = torch.zeros(B, 1, L, device='cuda')
+        ep = _lib.Conv1dEpilogue(1.0, 0.1, 1.0, _lib.ACT_NONE, 0, None, 1.0)
+        xd = x.cuda()
+        _lib.check(_lib.lib().ttsc_conv1d_forward_ragged(conv._h, _lib.dev_ptr(xd), B, L, _lib.dev_ptr(yr), None, C_.byref(ep),
+                                                         _lib.dev_ptr(lens), _lib.dev_ptr(lens), _lib.current_stream()), 'ragged')
+        solo = conv(x[:1, :, :n].contiguous().cuda(), in_slope=0.1)
+        assert torch.equal(yr[:1, :, :n], solo)
+
+
+@pytest.mark.parametrize('cin,cout,L,B', [(64, 32, 8192, 8), (128, 64, 300, 2), (16, 8, 33, 1)])
+def test_conv_transpose_k4s4_interleaved_rows(cin, cout, L, B):
+    """ConvTranspose1d(kernel_size = stride = 4) in f16x3: GEMM rows interleaved (channel, phase) so that a lane stores four
+    consecutive samples (epilogue_tile_v4) — with residual, running sum and activation, at a size that takes the big tile."""
+    from ttscube_amd.hip_layers import Conv1dHip
+    w, b = _mk((cin, cout, 4), 1, 1.0 / cin ** 0.5), _mk((cout,), 2, 0.1)
+    x = _mk((B, cin, L), 3)
+    conv = Conv1dHip(cin, cout, 4, stride=4, padding=0, transposed=True).set_precision('f16x3')
+    conv.set_weight(w, b)
+    ref = F.conv_transpose1d(F.leaky_relu(x / 3.0, 0.1), w, b, stride=4)
+    xd = x.cuda()
+    y = conv(xd, in_scale=1.0 / 3.0, in_slope=0.1)
+    assert y.shape == ref.shape and float((y.cpu() - ref).abs().max()) < F16X3_TOL
+    if L <= 300:
+        r, s0 = _mk(tuple(ref.shape), 4), _mk(tuple(ref.shape), 5)
+        out = s0.clone().cuda()
+        conv(xd, resid=r.cuda(), out=out, in_scale=1.0 / 3.0, in_slope=0.1, out_scale=0.5, act='tanh', accumulate=True)
+        assert float((out.cpu() - (s0 + torch.tanh((ref + r) * 0.5))).abs().max()) < F16X3_TOL

@@ -60,7 +60,8 @@ struct ConvArgs {
     void* ys;         // split output or null
     float ys_scale, ys_slope;
     int write_f32;    // 0: only the split output is written
-    int vphase;       // fused ConvTranspose1d phases: GEMM row v = r * vphase + co (vphase = real Cout), output o += r; 0 = off
+    int vphase;       // fused ConvTranspose1d phases: GEMM row v = r * vphase + co (vphase = real Cout), output o += r; 0 = off;
+                      // -4 = rows interleaved v = co * 4 + r (kernel_size == stride == 4): see epilogue_tile_v4
     int dbg;          // ablation switches, ONLY in -DTTSC_ABLATE builds (tools/ablate.cpp; never in libttscube_hip.so): see TTSC_DBG
     const float* gate;  // data-gradient launches: [B,Cout,Lout] pre-activation saved by the forward; the conv result is
     float gate_slope;   // multiplied by d lrelu/dx = (gate > 0 ? 1 : gate_slope) BEFORE the residual is added; null = off
@@ -158,6 +159,34 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& acc, const ConvArgs&
             *reinterpret_cast<half4*>(ph) = vh;
             *reinterpret_cast<half4*>(ph + (size_t)a.Lout * 8) = vl;
         }
+    }
+}
+
+// Epilogue of a 32x32 tile of a ConvTranspose1d with kernel_size == stride == 4 whose GEMM rows are interleaved as
+// v = co * 4 + r (phase r of output channel co): the four consecutive accumulator registers of a lane are the four phases of
+// ONE output channel at ONE input position q, i.e. four CONSECUTIVE output samples o = 4q .. 4q+3 — one 16-byte store per
+// lane, 512 contiguous bytes per half-wave.  (With rows ordered r * Cout + co every lane writes single floats at a 16-byte
+// stride and the four phases arrive in four separate store instructions: 1.2 ms instead of ~0.4 ms for the last upsampler.)
+__device__ __forceinline__ void epilogue_tile_v4(const f32x16& acc, const ConvArgs& a, int b, int row_base, int q, bool qok, int half,
+                                                 float acc_scale) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int co = (row_base >> 2) + 2 * g + half;
+        const bool ok = qok && co < a.Cout;
+        const int co_c = co < a.Cout ? co : a.Cout - 1;
+        const size_t idx = ((size_t)b * a.Cout + co_c) * a.Lout + (size_t)(ok ? q : 0) * 4;
+        const float bv = a.bias ? a.bias[co_c] : 0.f;
+        f32x4 rv = {0.f, 0.f, 0.f, 0.f}, yv = {0.f, 0.f, 0.f, 0.f};
+        if (a.resid) rv = *reinterpret_cast<const f32x4*>(a.resid + idx);
+        if (a.accumulate) yv = *reinterpret_cast<const f32x4*>(a.y + idx);
+        f32x4 res;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = (acc[4 * g + e] * acc_scale + bv + rv[e]) * a.out_scale;
+            res[e] = (a.out_act == TTSC_ACT_NONE ? t : apply_act(t, a.out_act)) + yv[e];
+        }
+        if (ok) *reinterpret_cast<f32x4*>(a.y + idx) = res;
     }
 }
 
@@ -561,6 +590,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
             int cb = (cot0 + i) * 32;
             long oo = o;
             bool ok = qok;
+            if (a.vphase == -4) {   // interleaved rows (phase, channel): four consecutive samples per lane
+                epilogue_tile_v4(acc[i][n], a, b, cb, q, (q < q_hi) && (q >= 0) && ((long)q * 4 + 3 < a.Lout), half, a.w_unscale);
+                continue;
+            }
             if (a.vphase) {   // virtual row tile -> (phase r, real channel tile); tiles never straddle phases (Cout % 32 == 0)
                 const int r = cb / a.vphase;
                 cb -= r * a.vphase;
@@ -962,6 +995,80 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 2)) void respair32_f16x3_ke
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Single-output-channel Conv1d (HiFi-GAN conv_post: 32 -> 1, K = 7, tanh): an M = 1 problem wastes 31/32 of an MFMA
+// tile and its time goes into staging, so it runs on the vector ALU as an fp32 fmaf chain (ci-major, tap-minor) and is
+// bound by the one HBM read of its input.  1024 outputs per workgroup; 8-channel chunks of the activated input window
+// go through LDS (coalesced dword loads in, conflict-free ds_read_b128 out); a thread owns 4 consecutive outputs.
+__global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs a) {
+    constexpr int NT = 1024, CH = 8, HALO = 16;          // HALO >= (K - 1) * dilation, K <= 16, dilation 1
+    __shared__ __attribute__((aligned(16))) float xs[CH][NT + 2 * HALO];
+    __shared__ float ws[64 * 16];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int q0 = blockIdx.x * NT;
+    const int lin = a.in_len ? a.in_len[b] : a.Lin;
+    if (a.out_len && q0 >= a.out_len[b]) return;
+    const int K = a.ntaps;
+    for (int i = tid; i < a.Cin * K; i += 256) ws[i] = a.wp[i];     // plain [Cin][K] fp32 weights (see conv_repack)
+    const float* xb = a.x + (size_t)b * a.Cin * a.Lin;
+    const int lo = q0 + a.tap_base;                                  // x position of LDS column 0
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < a.Cin; c0 += CH) {
+        __syncthreads();
+        for (int i = tid; i < CH * (NT + 2 * HALO); i += 256) {
+            const int c = i / (NT + 2 * HALO), p = i - c * (NT + 2 * HALO);
+            const int pos = lo + p;
+            float v = 0.f;
+            if (c0 + c < a.Cin && pos >= 0 && pos < lin) {
+                v = xb[(size_t)(c0 + c) * a.Lin + pos] * a.in_scale;
+                v = fmaxf(v, v * a.in_slope);
+            }
+            xs[c][p] = v;
+        }
+        __syncthreads();
+        const int nc = a.Cin - c0 < CH ? a.Cin - c0 : CH;
+        for (int c = 0; c < nc; ++c) {
+            // outputs 4*tid .. 4*tid+3 read window columns 4*tid .. 4*tid + 3 + K - 1  (<= 4*tid + 18)
+            float w[20];
+#pragma unroll
+            for (int v4 = 0; v4 < 5; ++v4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(&xs[c][4 * tid + 4 * v4]);
+                w[4 * v4] = t[0]; w[4 * v4 + 1] = t[1]; w[4 * v4 + 2] = t[2]; w[4 * v4 + 3] = t[3];
+            }
+            const float* wk = ws + (c0 + c) * K;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (j < K) {
+                    const float wj = wk[j];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = fmaf(wj, w[e + j], acc[e]);
+                }
+            }
+        }
+    }
+    const float bv = a.bias ? a.bias[0] : 0.f;
+    float* yb = a.y + (size_t)b * a.Lout;
+    const float* rb = a.resid ? a.resid + (size_t)b * a.Lout : nullptr;
+    const int q = q0 + 4 * tid;
+    float res[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bool ok = q + e < a.Lout;
+        float t = (acc[e] + bv + (rb && ok ? rb[q + e] : 0.f)) * a.out_scale;
+        t = apply_act(t, a.out_act);
+        res[e] = t + (a.accumulate && ok ? yb[q + e] : 0.f);
+    }
+    if (q + 3 < a.Lout && (((uintptr_t)(yb + q)) & 15) == 0) {
+        const f32x4 o = {res[0], res[1], res[2], res[3]};
+        *reinterpret_cast<f32x4*>(yb + q) = o;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (q + e < a.Lout) yb[q + e] = res[e];
+    }
+}
+
 template <int MI, int NJ, int TMAX, bool SPLIT_IN>
 static int launch_f16_t(const ConvArgs& a, int B, hipStream_t s) {
     constexpr int NT = 4 * NJ * 32;
@@ -1106,6 +1213,7 @@ extern "C" void ttsc_conv1d_destroy(ttsc_conv1d* c) {
     if (!c) return;
     free_phases(c);
     if (c->bias_dev) (void)hipFree(c->bias_dev);
+    if (c->w_plain_dev) (void)hipFree(c->w_plain_dev);
     delete c;
 }
 
@@ -1162,7 +1270,12 @@ static void pack_phase_f16(const ttsc_conv1d* c, const float* w, const std::vect
                         const int ci = ch * 16 + 8 * (lane >> 5) + e;
                         int kk = k;
                         bool ok = co < c->CoutV && ci < Cin;
-                        if (c->vfused) {
+                        if (c->vfused && c->vrow4) {   // rows interleaved co * 4 + r (see epilogue_tile_v4)
+                            const int r = co & 3;
+                            co >>= 2;
+                            kk = r + k * g.stride;
+                            ok = ok && kk < K;
+                        } else if (c->vfused) {
                             const int r = co / Cout;
                             co -= r * Cout;
                             kk = r + k * g.stride;
@@ -1293,6 +1406,7 @@ static int set_weight_device_impl(ttsc_conv1d* c, const float* w_dev, const floa
         hipLaunchKernelGGL(pack_w_kernel, dim3(blocks), dim3(256), 0, s, p);
     }
     c->bias_ext = bias_dev;   // read straight from the caller's tensor by the launches that follow (no copy)
+    c->w_plain_ext = flipT ? nullptr : w_dev;   // torch layout, used as is by the single-output-channel kernel
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("pack_w_kernel launch failed: %s", hipGetErrorString(e));
@@ -1325,6 +1439,9 @@ static int conv_repack(ttsc_conv1d* c) {
         wscale = ldexpf(1.f, e);
         c->w_unscale = ldexpf(1.f, -e);
     }
+    // kernel_size == stride == 4 (the last two upsamplers of HiFi-GAN V1): interleave the virtual rows so that a lane's
+    // accumulator registers are four consecutive output samples (epilogue_tile_v4)
+    c->vrow4 = c->vfused && c->precision == TTSC_PREC_F16X3 && g.stride == 4 && g.kernel_size == 4 && g.padding == 0;
     std::vector<int> cur_taps;
     auto upload = [&](ConvPhase& ph) -> int {
         if (c->precision == TTSC_PREC_F16X3) {
@@ -1399,6 +1516,15 @@ static int conv_repack(ttsc_conv1d* c) {
         TTSC_HIP_CHECK(hipMalloc((void**)&c->bias_dev, g.out_channels * sizeof(float)));
         TTSC_HIP_CHECK(hipMemcpy(c->bias_dev, bias, g.out_channels * sizeof(float), hipMemcpyHostToDevice));
     }
+    if (c->w_plain_dev) {
+        (void)hipFree(c->w_plain_dev);
+        c->w_plain_dev = nullptr;
+    }
+    if (!g.transposed && g.out_channels == 1) {   // conv_cout1_kernel reads the weights in torch layout [1][Cin][K]
+        TTSC_HIP_CHECK(hipMalloc((void**)&c->w_plain_dev, c->w_host.size() * sizeof(float)));
+        TTSC_HIP_CHECK(hipMemcpy(c->w_plain_dev, c->w_host.data(), c->w_host.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    c->w_plain_ext = nullptr;
     c->has_weight = true;
     return TTSC_OK;
 }
@@ -1461,7 +1587,11 @@ extern "C" int ttsc_conv1d_forward_split(const ttsc_conv1d* c, const float* x, c
 #ifdef TTSC_ABLATE
         if (const char* ev = getenv("TTSC_CONV_DBG")) a.dbg = atoi(ev);
 #endif
-        a.vphase = c->vfused ? g.out_channels : 0;
+        a.vphase = c->vfused ? ((c->vrow4 && c->precision == TTSC_PREC_F16X3) ? -4 : g.out_channels) : 0;
+        if (a.vphase == -4) {
+            TTSC_REQUIRE(!a.ys && !(ep && ep->gate_dev), "ttsc_conv1d_forward: split output / gate are not available on this transposed layer");
+            TTSC_REQUIRE(((uintptr_t)y % 16 == 0) && (!resid || (uintptr_t)resid % 16 == 0), "ttsc_conv1d_forward: y / resid must be 16-byte aligned for ConvTranspose1d(k=4, s=4)");
+        }
         a.Cin = g.in_channels;
         a.CinP = c->CinP;
         a.Cout = g.out_channels;
@@ -1503,7 +1633,20 @@ extern "C" int ttsc_conv1d_forward_split(const ttsc_conv1d* c, const float* x, c
         a.gate = ep ? ep->gate_dev : nullptr;
         a.gate_slope = ep ? ep->gate_slope : 1.f;
         int rc;
-        if (c->precision == TTSC_PREC_F16X3) {
+        const float* w_plain = c->dev_weights ? c->w_plain_ext : c->w_plain_dev;
+        if (!g.transposed && g.out_channels == 1 && g.in_channels <= 64 && g.kernel_size <= 16 && g.dilation == 1 && w_plain && !a.xs &&
+            !a.ys && !a.gate) {
+            // one output channel (conv_post): vector-ALU kernel, bound by the single read of its input
+            a.wp = w_plain;
+            dim3 grid((unsigned)ceil_div(Lout, 1024), (unsigned)B);
+            hipLaunchKernelGGL(conv_cout1_kernel, grid, dim3(256), 0, s, a);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) {
+                set_error("conv_cout1_kernel launch failed: %s", hipGetErrorString(e));
+                return TTSC_EHIP;
+            }
+            rc = TTSC_OK;
+        } else if (c->precision == TTSC_PREC_F16X3) {
             // the split kernel's N tile is fixed by its 4-waves-along-N shape
             const int nt = c->MT >= 64 ? 256 : 512;
             a.span = nt + (last < 0 ? -last : last);

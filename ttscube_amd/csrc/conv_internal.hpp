@@ -20,10 +20,13 @@ struct ttsc_conv1d {
     int precision = TTSC_PREC_FP32;
     bool vfused = false;   // ConvTranspose1d with Cout % 32 == 0: all `stride` phases as extra GEMM rows of ONE launch
     int CoutV = 0;         // stride * Cout when vfused
+    bool vrow4 = false;    // vfused, f16x3 fragments packed with rows interleaved v = co * 4 + r (kernel_size == stride == 4, padding 0)
     float w_unscale = 1.f;
     std::vector<float> w_host, b_host;  // kept so that the precision can be switched (repack) at any time
     bool has_bias = false;
     bool dev_weights = false;  // weights were last written by ttsc_conv1d_set_weight_device (host copy is stale)
     const float* bias_ext = nullptr;  // device-weight mode: the caller's bias tensor
+    float* w_plain_dev = nullptr;     // out_channels == 1: weights in torch layout [1][Cin][K] for conv_cout1_kernel
+    const float* w_plain_ext = nullptr;   // device-weight mode: the caller's weight tensor (same layout)
 };
 
