@@ -23,32 +23,111 @@ if ROOT not in sys.path:
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (no sparsity)
 PEAK_HBM_GBS = 8000.0
+TRAFFIC_CSV = os.path.join(ROOT, 'profiles', 'r02_bench_hbm_pmc.csv')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this workload
 
 
-def cpu_baseline(h, sd, budget_s=12.0):
-    """Oracle (torch fp32 CPU restatement of the reference generator) on the host cores, bounded sample."""
+def measured_traffic(precision, B, T):
+    """HBM bytes of ONE forward from the committed PMC summary (profiles/r02_bench_hbm_pmc.csv: separate FETCH_SIZE and
+    WRITE_SIZE passes over `bench.py --steps 1`, summed over all kernels of a forward, gfx950 corrections of
+    MI355X_MICROARCH.md applied in the file's `bytes_per_forward` row).  None when the file does not describe this
+    configuration — the number is never a literal in this script."""
+    try:
+        rows = [l.strip() for l in open(TRAFFIC_CSV) if l.strip() and not l.startswith('#')]
+        kv = dict(l.split(',', 1) for l in rows if l.count(',') == 1)
+        if kv.get('precision') == precision and int(kv.get('batch', -1)) == B and int(kv.get('frames', -1)) == T:
+            return float(kv['bytes_per_forward'])
+    except Exception:
+        pass
+    return None
+
+
+def self_check(g, mel, out, h, sd, tol=1e-4):
+    """Refuse to report a time for wrong results: the head of utterance 0 (30 frames = 7 200 samples, beyond the ~4.9 k-sample
+    receptive field) must equal the oracle run on a 60-frame prefix within the parity gate (1e-4 RMS)."""
+    import torch
+    from oracle import hifigan_ref as R
+    T = min(60, mel.shape[2])
+    ref = R.generator_forward(R.fold_state_dict(sd), h, mel[:1, :, :T].cpu())
+    n = min(240 * 30, ref.shape[2]) if mel.shape[2] > T else ref.shape[2]
+    d = out[0, 0, :n].detach().cpu() - ref[0, 0, :n]
+    rms = float(d.pow(2).mean().sqrt())
+    assert rms < tol, 'bench self-check failed: rms %.3e vs the oracle on utterance 0' % rms
+    return rms
+
+
+def time_forward(g, mel, steps, warmup):
+    """(device ms per forward, last output) of `steps` forwards after `warmup`, HIP events on the launch stream."""
+    import torch
+    with torch.no_grad():
+        for _ in range(warmup):
+            out = g(mel)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            out = g(mel)
+        e1.record()
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps, out
+
+
+def extra_legs(g, h, sd, rank_dev, R):
+    """Secondary measurements the driver times with the same command: exact-fp32 arithmetic on the same
+    workload, the reference API's own B=1 x 3 s case (BASELINE configs[0] shape on the GPU), and WaveRNN decode (configs[2])."""
+    import numpy as np
+    import torch
+    legs = {}
+    try:
+        mel1 = R.synthetic_mel(1, 300, seed=77).to(rank_dev)
+        ms, o1 = time_forward(g, mel1, 20, 3)
+        legs['single_utterance_3s'] = {'ms': ms, 'samples_per_s': o1.shape[2] / (ms * 1e-3), 'rms_vs_oracle': self_check(g, mel1, o1, h, sd)}
+    except Exception as e:   # a secondary leg must never take the headline number down
+        legs['single_utterance_3s'] = {'error': str(e)[:200]}
+    try:
+        from oracle import wavernn_ref as WO
+        from ttscube_amd.networks.modules import WaveRNN
+        wsd = WO.synthetic_state_dict(H=512, num_layers=1, use_lowres=True, seed=5)
+        net = WaveRNN(num_layers=1, layer_size=512, upsample=240, upsample_low=10, use_lowres=True, output='mulaw')
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in wsd.items()}, strict=True)
+        net = net.to(rank_dev).eval()
+        Bw, Tw = 256, 10
+        wm, wx = WO.synthetic_inputs(Bw, Tw, seed=6)
+        X = {'mel': torch.from_numpy(wm), 'x_low': torch.from_numpy(wx)}
+        net.decode(X, mode='philox', seed=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        idx, _, _ = net.decode(X, mode='philox', seed=2)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ridx, _, _ = WO.decode(wsd, wm[:2, :1], wx[:2, :24], num_layers=1, H=512, mode=WO.MODE_PHILOX, seed=2)
+        assert np.array_equal(idx[:2, :240].cpu().numpy(), ridx), 'WaveRNN indices differ from the oracle'
+        legs['wavernn_decode_b256'] = {'us_per_step': dt / (Tw * 240) * 1e6, 'samples_per_s': Bw * Tw * 240 / dt, 'H': 512, 'layers': 1,
+                                       'output': 'mulaw', 'indices_bit_exact_vs_oracle': True, 'kernel': net.last_kernel}
+    except Exception as e:
+        legs['wavernn_decode_b256'] = {'error': str(e)[:200]}
+    return legs
+
+
+def cpu_baseline(h, sd, mel_dev, budget_s=10.0):
+    """Oracle (torch fp32 CPU restatement of the reference generator) on the host cores, on a bounded sample of the BENCHED
+    inputs (the first 2 utterances, first 300 frames).  Fixed protocol: min(32, cpu_count) threads — torch's
+    conv kernels stop scaling there, 256 logical CPUs oversubscribe them — plus a 1-thread figure on one 1-second utterance."""
     import torch
     from oracle import hifigan_ref as R
     ncpu = os.cpu_count() or 1
+    cores = min(32, ncpu)
     w = R.fold_state_dict(sd)
-    # pick the thread count that is actually fastest on this host (256 logical CPUs oversubscribe small convs)
-    probe = R.synthetic_mel(1, 40, seed=1)
-    best, cores = None, 1
+    mel = mel_dev[:2, :, :300].detach().cpu().contiguous()
+    B, T = mel.shape[0], mel.shape[2]
     with torch.no_grad():
-        for th in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu}):
-            torch.set_num_threads(th)
-            R.generator_forward(w, h, probe)
-            t0 = time.perf_counter()
-            R.generator_forward(w, h, probe)
-            dt = time.perf_counter() - t0
-            if best is None or dt < best:
-                best, cores = dt, th
-            if dt > 3.0:
-                break
-    torch.set_num_threads(cores)
-    B, T = 2, 300  # 2 utterances x 3 s (BASELINE configs[0] shape, doubled)
-    mel = R.synthetic_mel(B, T, seed=1234)
-    with torch.no_grad():
+        torch.set_num_threads(1)
+        one = mel[:1, :, :100].contiguous()
+        R.generator_forward(w, h, one[:, :, :20])
+        t0 = time.perf_counter()
+        o1 = R.generator_forward(w, h, one)
+        t1 = time.perf_counter() - t0
+        torch.set_num_threads(cores)
+        R.generator_forward(w, h, mel[:, :, :40])   # warm-up
         n, t0 = 0, time.perf_counter()
         while True:
             out = R.generator_forward(w, h, mel)
@@ -58,8 +137,10 @@ def cpu_baseline(h, sd, budget_s=12.0):
                 break
     samples = n * out.shape[0] * out.shape[2]
     return {'value': samples / el, 'unit': 'audio samples/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d x oracle generator_forward(B=%d, T=%d frames = 3 s) in %.1f s, torch CPU fp32, %d threads'
-                      % (n, B, T, el, cores)}
+            'value_1_thread': o1.shape[2] / t1,
+            'sample': '%d x oracle generator_forward on the first %d utterances x %d frames of the benched batch in %.1f s, torch CPU '
+                      'fp32, %d threads (host has %d logical CPUs); 1-thread figure: one 100-frame utterance in %.1f s'
+                      % (n, B, T, el, cores, ncpu, t1)}
 
 
 def main():
@@ -70,6 +151,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='utterances per GPU')
     ap.add_argument('--frames', type=int, default=800, help='mel frames per utterance (800 = 8 s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the secondary legs (fp32, B=1, WaveRNN)')
     args = ap.parse_args()
 
     import torch
@@ -123,6 +205,7 @@ def main():
         elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels run on (torch current stream)
     assert bool(torch.isfinite(out).all())
+    check_rms = self_check(g, mel, out, h, sd) if rank == 0 else None   # never report a time for wrong results
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -139,16 +222,12 @@ def main():
         if precision == 'f16x3':
             # split precision: every algorithmic product is three fp16 MFMA products (hi*hi + hi*lo + lo*hi, fp32 accumulate),
             # so the MFMA ceiling for fp32-accurate results is the dense f16 peak / 3
-            peak, kname = PEAK_F16_MFMA_TFLOPS / 3.0, 'conv_f16x3_kernel + respair32_f16x3_kernel (v_mfma_f32_32x32x16_f16 x3 split-precision implicit-GEMM conv; all launches of one forward)'
+            peak, kname = PEAK_F16_MFMA_TFLOPS / 3.0, 'conv_f16x3_wide_kernel + rbchain_f16x3_kernel + conv_f16x3_kernel (v_mfma_f32_32x32x16_f16 x3 split-precision implicit-GEMM conv; all launches of one forward)'
             executed = 3.0 * achieved
         else:
             peak, kname = PEAK_FP32_MFMA_TFLOPS, 'conv_mfma_kernel (v_mfma_f32_32x32x2_f32 implicit-GEMM conv; all launches of one forward)'
             executed = achieved
-        # HBM traffic of ONE forward of this exact workload, from the rocprofv3 PMC passes committed in
-        # profiles/r01_bench_f16x3_hbm_pmc.csv (FETCH_SIZE 64.5 GB + WRITE_SIZE 62.1 GB, separate passes, KiB units; the
-        # kernels stage with 4 B/lane loads, for which the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md — x2 for
-        # 16 B/lane streams — does not apply).  Only reported for the configuration it was measured on.
-        traffic = 126.6e9 if (precision == 'f16x3' and B == 64 and T == 800) else None
+        traffic = measured_traffic(precision, B, T)
         res = {
             'metric': 'audio samples/sec (HiFi-GAN vocoder inference)', 'value': value, 'unit': 'samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
@@ -162,7 +241,7 @@ def main():
             'rtf_24k': value / world / 24000.0, 'rtf_22k05': value / world / 22050.0,
             'per_gpu_samples_s': value / world,
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak, 'traffic': traffic, 'traffic_unit': 'bytes per step (PMC, profiles/r01_bench_f16x3_hbm_pmc.csv)',
+                         'frac': achieved / peak, 'traffic': traffic, 'traffic_unit': 'HBM bytes per step (rocprofv3 PMC, profiles/r02_bench_hbm_pmc.csv)',
                          'kernel': kname,
                          'flops_per_step': flops_step, 'device_ms_per_step': dev_ms / args.steps,
                          'mfma_executed_tflops': executed, 'mfma_dense_peak_tflops': PEAK_F16_MFMA_TFLOPS if precision == 'f16x3' else PEAK_FP32_MFMA_TFLOPS,
@@ -170,8 +249,22 @@ def main():
                          'hbm_compulsory_GBs': alg_bytes * args.steps / (dev_ms * 1e-3) / 1e9,
                          'hbm_frac_compulsory': alg_bytes * args.steps / (dev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
         }
+        res['self_check_rms_vs_oracle'] = check_rms
+        if world == 1 and not args.no_extra:
+            res['extra'] = extra_legs(g, h, sd, dev, R)
+            if precision == 'f16x3':   # the same workload on the exact fp32 MFMA (k-ordered fmaf chain), for the record
+                try:
+                    g.set_precision('fp32')
+                    ms32, o32 = time_forward(g, mel, max(2, args.steps // 4), 1)
+                    res['extra']['exact_fp32_same_workload'] = {'ms_per_step': ms32, 'samples_per_s': B * Lout / (ms32 * 1e-3),
+                                                                'algorithmic_tflops': flops_step / (ms32 * 1e-3) / 1e12,
+                                                                'frac_of_fp32_mfma_peak': flops_step / (ms32 * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                                                'rms_vs_oracle': self_check(g, mel, o32, h, sd)}
+                    g.set_precision('f16x3')
+                except Exception as e:
+                    res['extra']['exact_fp32_same_workload'] = {'error': str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:   # reported baseline: rank 0 at N=1 only
-            res['cpu_baseline'] = cpu_baseline(h, sd)
+            res['cpu_baseline'] = cpu_baseline(h, sd, mel)
         else:
             res['cpu_baseline'] = None
         print(json.dumps(res))

@@ -88,6 +88,13 @@ int ttsc_conv1d_set_weight_device_dgrad(ttsc_conv1d* c, const float* fwd_weight_
 int ttsc_conv1d_set_precision(ttsc_conv1d* c, int32_t precision);
 int64_t ttsc_conv1d_out_len(const ttsc_conv1d* c, int64_t Lin);
 int32_t ttsc_conv1d_in_channels(const ttsc_conv1d* c);
+/* TTSC_PREC_F16X3 carries activations as fp16 (hi, lo) pairs: below |x| ~ 2^-3 the low half goes subnormal (accuracy decays
+ * towards fp16's), above 65504 the high half overflows.  `scale` (a power of two) multiplies this layer's INPUT while it is
+ * staged and is divided out of the accumulator in the epilogue — both exact; 1 = off.  Ignored by TTSC_PREC_FP32. */
+int ttsc_conv1d_set_activation_scale(ttsc_conv1d* c, float scale);
+float ttsc_conv1d_get_activation_scale(const ttsc_conv1d* c);
+/* out_dev[0] = max(out_dev[0], max_i |x_i|) over n device floats (out_dev zeroed by the caller); feeds the calibration below */
+int ttsc_absmax(const float* x_dev, int64_t n, float* out_dev, void* stream);
 /* x_dev [B,Cin,Lin] -> y_dev [B,Cout,Lout]; resid_dev NULL or [B,Cout,Lout]; ep NULL = plain conv */
 int ttsc_conv1d_forward(const ttsc_conv1d* c, const float* x_dev, int32_t B, int64_t Lin, float* y_dev,
                         const float* resid_dev, const ttsc_conv1d_epilogue* ep, void* stream);
@@ -190,6 +197,14 @@ int ttsc_hifigan_forward(ttsc_hifigan* g, const float* mel_dev, int32_t B, int64
 int ttsc_hifigan_forward_ragged(ttsc_hifigan* g, const float* mel_dev, int32_t B, int64_t T, const int32_t* frames_host,
                                 float* wav_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 /* algorithmic FLOPs (2 x MAC) of one forward at (B, T): the roofline numerator used by bench.py */
+/* Activation pre-scales of the split-precision path: one layer-by-layer forward on `mel` with an abs-max reduction in front of
+ * every convolution; every layer's input scale becomes the power of two that puts that maximum in [2^9, 2^10) (six binades of
+ * head-room below fp16's 65504, full 22-bit accuracy for values down to 2^-13 of the maximum).  ttsc_hifigan_forward runs it by
+ * itself on the first call after the weights or the precision changed (env TTSC_HIFIGAN_CALIBRATE=0: all scales stay 1); call it
+ * explicitly to re-calibrate on other data.  wav_dev / workspace as for the forward (wav_dev receives that forward's output). */
+int ttsc_hifigan_calibrate(ttsc_hifigan* g, const float* mel_dev, int32_t B, int64_t T, float* wav_dev, void* workspace_dev,
+                           size_t workspace_bytes, void* stream);
+int ttsc_hifigan_get_activation_scale(const ttsc_hifigan* g, const char* layer_name, float* scale_out);
 int ttsc_hifigan_algorithmic_flops(const ttsc_hifigan* g, int32_t B, int64_t T, double* flops_out);
 void ttsc_hifigan_destroy(ttsc_hifigan* g);
 

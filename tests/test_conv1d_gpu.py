@@ -404,3 +404,24 @@ def test_conv_transpose_k4s4_interleaved_rows(cin, cout, L, B):
         out = s0.clone().cuda()
         conv(xd, resid=r.cuda(), out=out, in_scale=1.0 / 3.0, in_slope=0.1, out_scale=0.5, act='tanh', accumulate=True)
         assert float((out.cpu() - (s0 + torch.tanh((ref + r) * 0.5))).abs().max()) < F16X3_TOL
+
+
+@pytest.mark.parametrize('xscale,act_scale', [(1e-4, 2.0 ** 22), (1e-7, 2.0 ** 32), (3e4, 2.0 ** -6), (1.0, 2.0 ** 9)])
+def test_conv1d_f16x3_activation_prescale(xscale, act_scale):
+    """activations far outside fp16's comfortable range keep ~fp32 accuracy once the layer's power-of-two input pre-scale is
+    set (ttsc_conv1d_set_activation_scale): 1e-4 and 1e-7 (hi/lo halves subnormal without it), 3e4 (a 64-channel sum
+    overflows fp16 without it)."""
+    from ttscube_amd.hip_layers import Conv1dHip
+    cin = cout = 64
+    w = _mk((cout, cin, 7), 1, 1.0 / (cin * 7) ** 0.5)
+    b = _mk((cout,), 2, 0.1 * xscale)
+    x = _mk((2, cin, 300), 3, xscale)
+    conv = Conv1dHip(cin, cout, 7, padding=3).set_precision('f16x3')
+    conv.set_weight(w, b)
+    ref = F.conv1d(F.leaky_relu(x, 0.1), w, b, padding=3)
+    conv.set_activation_scale(act_scale)
+    y = conv(x.cuda(), in_slope=0.1).cpu()
+    rel = float((y - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    assert rel < 2e-6, (xscale, rel)
+    with pytest.raises(Exception):
+        conv.set_activation_scale(3.0)       # not a power of two

@@ -1016,15 +1016,31 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs a) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c0 = 0; c0 < a.Cin; c0 += CH) {
         __syncthreads();
-        for (int i = tid; i < CH * (NT + 2 * HALO); i += 256) {
-            const int c = i / (NT + 2 * HALO), p = i - c * (NT + 2 * HALO);
-            const int pos = lo + p;
-            float v = 0.f;
-            if (c0 + c < a.Cin && pos >= 0 && pos < lin) {
-                v = xb[(size_t)(c0 + c) * a.Lin + pos] * a.in_scale;
-                v = fmaxf(v, v * a.in_slope);
+        // stage 8 channel rows: every thread issues 8 x 5 independent, clamped, unconditional loads (no integer division, no
+        // branch around a load — the first version of this loop ran one dependent load at a time), then activates and stores
+        {
+            constexpr int PER = (NT + 2 * HALO + 255) / 256;   // 5 columns per thread and row
+            float v[CH][PER];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int ci = c0 + c < a.Cin ? c0 + c : a.Cin - 1;
+                const float* row = xb + (size_t)ci * a.Lin;
+#pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    int pos = lo + tid + k * 256;
+                    pos = pos < 0 ? 0 : (pos > a.Lin - 1 ? a.Lin - 1 : pos);
+                    v[c][k] = row[pos];
+                }
             }
-            xs[c][p] = v;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    const int p = tid + k * 256, pos = lo + p;
+                    float t = v[c][k] * a.in_scale;
+                    t = fmaxf(t, t * a.in_slope);
+                    if (p < NT + 2 * HALO) xs[c][p] = (c0 + c < a.Cin && pos >= 0 && pos < lin) ? t : 0.f;
+                }
         }
         __syncthreads();
         const int nc = a.Cin - c0 < CH ? a.Cin - c0 : CH;
@@ -1542,6 +1558,43 @@ extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, 
 
 extern "C" int32_t ttsc_conv1d_in_channels(const ttsc_conv1d* c) { return c ? c->cfg.in_channels : 0; }
 
+// Split precision carries an fp32 value as two fp16 halves, so an activation tensor must sit inside fp16's range: with |x|
+// below ~2^-3 the low half goes subnormal (the accuracy degrades towards fp16's), above 65504 the high half overflows.  The
+// layer's input is therefore multiplied by a power of two while it is staged (exact) and the accumulated result by its
+// inverse in the epilogue (exact; leaky-relu is positively homogeneous).  scale = 1 restores the plain behaviour.
+extern "C" int ttsc_conv1d_set_activation_scale(ttsc_conv1d* c, float scale) {
+    TTSC_REQUIRE(c, "ttsc_conv1d_set_activation_scale: null argument");
+    int e = 0;
+    TTSC_REQUIRE(scale > 0.f && std::isfinite(scale) && frexpf(scale, &e) == 0.5f, "ttsc_conv1d_set_activation_scale: scale must be a power of two, got %g", scale);
+    c->act_scale = scale;
+    return TTSC_OK;
+}
+extern "C" float ttsc_conv1d_get_activation_scale(const ttsc_conv1d* c) { return c ? c->act_scale : 0.f; }
+
+namespace ttsc {
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));   // non-negative floats order like their bit patterns
+}
+}  // namespace ttsc
+
+// out_dev (one float, device) = max(out_dev, max_i |x_i|); the caller zeroes it first.  Non-finite inputs end up as a NaN/inf
+// bit pattern, which compares above every finite value: the caller sees it.
+extern "C" int ttsc_absmax(const float* x_dev, int64_t n, float* out_dev, void* stream) {
+    TTSC_REQUIRE(x_dev && out_dev && n > 0, "ttsc_absmax: bad argument");
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x_dev, (long)n, reinterpret_cast<unsigned*>(out_dev));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("absmax_kernel launch failed: %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    return TTSC_OK;
+}
+
 extern "C" size_t ttsc_split_bytes(int32_t B, int32_t C, int64_t L) { return (size_t)B * (size_t)((C + 7) / 8) * 2 * (size_t)L * 16; }
 
 extern "C" int ttsc_conv1d_forward_split(const ttsc_conv1d* c, const float* x, const void* x_split, int32_t B, int64_t Lin, float* y,
@@ -1626,6 +1679,13 @@ extern "C" int ttsc_conv1d_forward_split(const ttsc_conv1d* c, const float* x, c
         a.span = c->NT + (last < 0 ? -last : last);
         a.span_pad = a.span + 1;
         a.in_scale = ep ? ep->in_scale : 1.f;
+        const float* w_plain = c->dev_weights ? c->w_plain_ext : c->w_plain_dev;
+        const bool use_cout1 = !g.transposed && g.out_channels == 1 && g.in_channels <= 64 && g.kernel_size <= 16 && g.dilation == 1 &&
+                               w_plain && !x_split && !y_split && !(ep && ep->gate_dev);
+        if (c->precision == TTSC_PREC_F16X3 && !a.xs && !use_cout1) {   // activation pre-scale (exact powers of two, see ttsc_conv1d_set_activation_scale)
+            a.in_scale *= c->act_scale;
+            a.w_unscale = c->w_unscale / c->act_scale;
+        }
         a.in_slope = ep ? ep->in_slope : 1.f;
         a.out_scale = ep ? ep->out_scale : 1.f;
         a.out_act = ep ? ep->out_act : TTSC_ACT_NONE;
@@ -1633,9 +1693,7 @@ extern "C" int ttsc_conv1d_forward_split(const ttsc_conv1d* c, const float* x, c
         a.gate = ep ? ep->gate_dev : nullptr;
         a.gate_slope = ep ? ep->gate_slope : 1.f;
         int rc;
-        const float* w_plain = c->dev_weights ? c->w_plain_ext : c->w_plain_dev;
-        if (!g.transposed && g.out_channels == 1 && g.in_channels <= 64 && g.kernel_size <= 16 && g.dilation == 1 && w_plain && !a.xs &&
-            !a.ys && !a.gate) {
+        if (use_cout1) {
             // one output channel (conv_post): vector-ALU kernel, bound by the single read of its input
             a.wp = w_plain;
             dim3 grid((unsigned)ceil_div(Lout, 1024), (unsigned)B);

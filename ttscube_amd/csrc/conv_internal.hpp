@@ -22,6 +22,7 @@ struct ttsc_conv1d {
     int CoutV = 0;         // stride * Cout when vfused
     bool vrow4 = false;    // vfused, f16x3 fragments packed with rows interleaved v = co * 4 + r (kernel_size == stride == 4, padding 0)
     float w_unscale = 1.f;
+    float act_scale = 1.f;   // f16x3: power-of-two pre-scale of this layer's INPUT (see ttsc_conv1d_set_activation_scale)
     std::vector<float> w_host, b_host;  // kept so that the precision can be switched (repack) at any time
     bool has_bias = false;
     bool dev_weights = false;  // weights were last written by ttsc_conv1d_set_weight_device (host copy is stale)

@@ -46,6 +46,12 @@ struct ttsc_hifigan {
     bool use_split = false;     // env TTSC_HIFIGAN_SPLIT=1 enables the producer-side split-activation flow (measured: no gain —
                                 // the consumer-side conversion hides behind the MFMA loop, the extra tensors cost HBM traffic)
     int precision = TTSC_PREC_FP32;
+    // Split precision keeps activations as fp16 (hi, lo) pairs, so every layer's input gets a power-of-two pre-scale that
+    // centres it in fp16's range (ttsc_conv1d_set_activation_scale).  The scales come from ONE calibration forward — the
+    // first forward after the weights changed, on that call's own input, run layer by layer with an abs-max reduction in
+    // front of every convolution — and stay fixed afterwards (env TTSC_HIFIGAN_CALIBRATE=0: all scales 1).
+    bool auto_calibrate = true;
+    bool calibrated = false;
     // pack + upload every layer whose host copy changed; returns the name of the first incomplete layer (or "")
     int flush_weights(std::string* missing) {
         for (auto& kv : layers) {
@@ -59,6 +65,7 @@ struct ttsc_hifigan {
                 if (rc) return rc;
                 L->dirty = false;
                 L->uploaded = true;
+                calibrated = false;   // new weights, new activation statistics
             }
         }
         return TTSC_OK;
@@ -92,6 +99,7 @@ extern "C" int ttsc_hifigan_create(const ttsc_hifigan_cfg* cfg, ttsc_hifigan** o
     if (const char* ev = getenv("TTSC_HIFIGAN_SPLIT")) g->use_split = atoi(ev) != 0;
     if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN")) g->use_chain = atoi(ev) != 0;
     if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN_SHAPE")) g->chain_shape = atoi(ev);
+    if (const char* ev = getenv("TTSC_HIFIGAN_CALIBRATE")) g->auto_calibrate = atoi(ev) != 0;
     int rc = add_layer(g.get(), "conv_pre", cfg->num_mels, cfg->upsample_initial_channel, 7, 1, 3, 1, 0);
     if (rc) return rc;
     int ch = cfg->upsample_initial_channel;
@@ -137,6 +145,7 @@ extern "C" int ttsc_hifigan_set_precision(ttsc_hifigan* g, int32_t precision) {
         if (rc) return rc;
     }
     g->precision = precision;
+    g->calibrated = false;
     return TTSC_OK;
 }
 
@@ -228,8 +237,70 @@ extern "C" int ttsc_hifigan_forward(ttsc_hifigan* g, const float* mel, int32_t B
     return ttsc_hifigan_forward_ragged(g, mel, B, T, nullptr, wav, ws, ws_bytes, stream);
 }
 
+namespace {
+struct CalibSite {
+    ttsc_conv1d* layer;
+    float in_scale;
+};
+}  // namespace
+
+static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, const int32_t* frames, float* wav, void* ws, size_t ws_bytes,
+                       void* stream, float* calib_stats, std::vector<CalibSite>* calib_sites);
+
+extern "C" int ttsc_hifigan_calibrate(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, float* wav, void* ws, size_t ws_bytes,
+                                      void* stream) {
+    TTSC_REQUIRE(g && mel && wav && ws, "ttsc_hifigan_calibrate: null argument");
+    for (auto& kv : g->layers) {
+        int rc = ttsc_conv1d_set_activation_scale(kv.second->c, 1.f);
+        if (rc) return rc;
+    }
+    g->calibrated = true;   // (also keeps hifigan_run from recursing)
+    if (g->precision != TTSC_PREC_F16X3) return TTSC_OK;
+    std::vector<CalibSite> sites;
+    float* stats = nullptr;
+    const size_t nstat = g->layers.size() + 8;
+    TTSC_HIP_CHECK(hipMalloc((void**)&stats, nstat * sizeof(float)));
+    hipError_t me = hipMemsetAsync(stats, 0, nstat * sizeof(float), (hipStream_t)stream);
+    int rc = me == hipSuccess ? hifigan_run(g, mel, B, T, nullptr, wav, ws, ws_bytes, stream, stats, &sites) : TTSC_EHIP;
+    std::vector<float> host(nstat, 0.f);
+    if (!rc && (hipStreamSynchronize((hipStream_t)stream) != hipSuccess ||
+                hipMemcpy(host.data(), stats, nstat * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)) {
+        set_error("ttsc_hifigan_calibrate: reading the activation statistics failed");
+        rc = TTSC_EHIP;
+    }
+    (void)hipFree(stats);
+    if (rc) return rc;
+    for (size_t i = 0; i < sites.size(); ++i) {
+        const float m = host[i] * fabsf(sites[i].in_scale);
+        float sc = 1.f;
+        if (m > 0.f && std::isfinite(m)) {
+            int e = 0;
+            (void)frexpf(m, &e);           // m = f * 2^e, f in [0.5, 1)  ->  m * 2^(10 - e) in [2^9, 2^10)
+            e = 10 - e;
+            e = e > 40 ? 40 : (e < -20 ? -20 : e);
+            sc = ldexpf(1.f, e);
+        }
+        rc = ttsc_conv1d_set_activation_scale(sites[i].layer, sc);
+        if (rc) return rc;
+    }
+    return TTSC_OK;
+}
+
+extern "C" int ttsc_hifigan_get_activation_scale(const ttsc_hifigan* g, const char* layer, float* out) {
+    TTSC_REQUIRE(g && layer && out, "ttsc_hifigan_get_activation_scale: null argument");
+    auto it = g->layers.find(layer);
+    TTSC_REQUIRE(it != g->layers.end(), "ttsc_hifigan_get_activation_scale: unknown layer '%s'", layer);
+    *out = ttsc_conv1d_get_activation_scale(it->second->c);
+    return TTSC_OK;
+}
+
 extern "C" int ttsc_hifigan_forward_ragged(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, const int32_t* frames,
                                            float* wav, void* ws, size_t ws_bytes, void* stream) {
+    return hifigan_run(g, mel, B, T, frames, wav, ws, ws_bytes, stream, nullptr, nullptr);
+}
+
+static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, const int32_t* frames, float* wav, void* ws, size_t ws_bytes,
+                       void* stream, float* calib_stats, std::vector<CalibSite>* calib_sites) {
     TTSC_REQUIRE(g && mel && wav && ws, "ttsc_hifigan_forward: null argument");
     TTSC_REQUIRE(B > 0 && T > 0, "ttsc_hifigan_forward: bad B/T (%d, %lld)", B, (long long)T);
     {
@@ -245,6 +316,11 @@ extern "C" int ttsc_hifigan_forward_ragged(ttsc_hifigan* g, const float* mel, in
     if (ws_bytes < need) {
         set_error("ttsc_hifigan_forward: workspace %zu < required %zu bytes", ws_bytes, need);
         return TTSC_ENOMEM;
+    }
+    const bool calib = calib_stats != nullptr;
+    if (!calib && !g->calibrated && g->auto_calibrate && g->precision == TTSC_PREC_F16X3) {
+        int crc = ttsc_hifigan_calibrate(g, mel, B, T, wav, ws, ws_bytes, stream);   // first forward after new weights
+        if (crc) return crc;
     }
     const auto& c = g->cfg;
     const size_t be = buf_elems(g, B, T);
@@ -271,7 +347,7 @@ extern "C" int ttsc_hifigan_forward_ragged(ttsc_hifigan* g, const float* mel, in
         TTSC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));  // `tab` is pageable host memory going out of scope
         for (int i = 0; i <= c.num_upsamples; ++i) lens[i] = dtab + (size_t)i * B;
     }
-    auto layer = [&](const std::string& n) -> const ttsc_conv1d* { return g->layers.at(n)->c; };
+    auto layer = [&](const std::string& n) -> ttsc_conv1d* { return g->layers.at(n)->c; };
     int rc;
 
     // ---- split-activation flow (TTSC_PREC_F16X3, ResBlock1) ------------------------------------------------------
@@ -281,10 +357,15 @@ extern "C" int ttsc_hifigan_forward_ragged(ttsc_hifigan* g, const float* mel, in
     float* Xs = S + be;   // (the length table of ragged batches lives behind the 7th buffer)
     float* Rs = Xs + be;
     float* Ss = Rs + be;
-    const bool split_ok = g->use_split && c.resblock == 1 && g->precision == TTSC_PREC_F16X3;
+    const bool split_ok = !calib && g->use_split && c.resblock == 1 && g->precision == TTSC_PREC_F16X3;
     auto in16 = [&](const ttsc_conv1d* l) { return ttsc_conv1d_in_channels(l) % 16 == 0; };
-    auto conv = [&](const ttsc_conv1d* l, const float* x, const void* xs, int64_t Lin, float* y, void* ys, float ys_scale,
+    auto conv = [&](ttsc_conv1d* l, const float* x, const void* xs, int64_t Lin, float* y, void* ys, float ys_scale,
                     float ys_slope, const float* resid, const ttsc_conv1d_epilogue& e, const int32_t* il, const int32_t* ol) {
+        if (calib && x && !xs) {   // calibration forward: abs-max of this layer's input
+            int arc = ttsc_absmax(x, (int64_t)B * ttsc_conv1d_in_channels(l) * Lin, calib_stats + calib_sites->size(), stream);
+            if (arc) return arc;
+            calib_sites->push_back(CalibSite{l, e.in_scale});
+        }
         return ttsc_conv1d_forward_split(l, xs ? nullptr : x, xs, B, Lin, y, ys, ys_scale, ys_slope, resid, &e, il, ol, stream);
     };
     const float inv_nk = 1.f / (float)c.num_kernels;
@@ -293,23 +374,23 @@ extern "C" int ttsc_hifigan_forward_ragged(ttsc_hifigan* g, const float* mel, in
     float sum_scale = 1.f;   // pending division by nk of the previous stage's block sum (fp32 consumers)
     bool s_split = false;    // Ss holds split(lrelu(S * scale, 0.1)) for the next upsampler
     {
-        const ttsc_conv1d* up0 = layer("ups.0");
+        ttsc_conv1d* up0 = layer("ups.0");
         s_split = split_ok && in16(up0) && c.upsample_initial_channel % 8 == 0;
         rc = conv(layer("conv_pre"), mel, nullptr, T, s_split ? nullptr : S, s_split ? (void*)Ss : nullptr, 1.f, 0.1f, nullptr, ep, lens[0], lens[0]);
         if (rc) return rc;
     }
     for (int i = 0; i < c.num_upsamples; ++i) {
         const int ch = g->stage_ch[i];
-        const ttsc_conv1d* up = layer("ups." + std::to_string(i));
+        ttsc_conv1d* up = layer("ups." + std::to_string(i));
         // is this stage's ResBlock1 chain run by the fused 32-channel pair kernel?
-        bool fused_stage = (c.resblock == 1) && g->use_fused;
+        bool fused_stage = !calib && (c.resblock == 1) && g->use_fused;
         for (int j = 0; fused_stage && j < c.num_kernels; ++j)
             for (int m = 0; fused_stage && m < c.num_dilations[j]; ++m) {
                 const std::string rb = "resblocks." + std::to_string(i * c.num_kernels + j);
                 fused_stage = ttsc_respair_supported(layer(rb + ".convs1." + std::to_string(m)), layer(rb + ".convs2." + std::to_string(m))) != 0;
             }
         // ... or, better, does every ResBlock1 of the stage run as ONE fused chain launch (32 / 64 channels)?
-        bool chain_stage = (c.resblock == 1) && g->use_chain;
+        bool chain_stage = !calib && (c.resblock == 1) && g->use_chain;
         for (int j = 0; chain_stage && j < c.num_kernels; ++j) {
             const std::string rb = "resblocks." + std::to_string(i * c.num_kernels + j);
             const ttsc_conv1d *c1[TTSC_HIFIGAN_MAX_DIL], *c2[TTSC_HIFIGAN_MAX_DIL];
@@ -393,7 +474,7 @@ extern "C" int ttsc_hifigan_forward_ragged(ttsc_hifigan* g, const float* mel, in
                     // where an in-place update would race with neighbouring tiles' halo reads -> ping-pong via XT.
                     float* d2 = dst;
                     if (dst == src) d2 = XT;
-                    rc = ttsc_conv1d_forward_ragged(layer(rb + ".convs." + std::to_string(m)), src, B, L, d2, src, &e2, ln, ln, stream);
+                    rc = conv(layer(rb + ".convs." + std::to_string(m)), src, nullptr, L, d2, nullptr, 1.f, 1.f, src, e2, ln, ln);
                     if (rc) return rc;
                     if (d2 != dst) std::swap(R, XT);
                 }

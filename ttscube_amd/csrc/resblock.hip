@@ -44,7 +44,8 @@ struct ChainArgs {
     const half8* w2[RB_MAXP];
     const float* b1[RB_MAXP];
     const float* b2[RB_MAXP];
-    float us1[RB_MAXP], us2[RB_MAXP];   // 2^-s weight un-scale factors
+    float us1[RB_MAXP], us2[RB_MAXP];   // epilogue factors: conv1 -> image  t' = fma(acc, us1, b1 * bs1);  conv2 -> residual  x += fma(acc, us2, b2)
+    float xs[RB_MAXP], bs1[RB_MAXP];    // activation pre-scales (powers of two): image <- xs * lrelu(x);  bs1 = pre-scale of conv2's input
     int d1[RB_MAXP];      // dilation of conv1 (conv2 is undilated)
     const int* len;       // [B] valid length or null
     int L, npairs, accumulate;
@@ -140,8 +141,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
         *reinterpret_cast<half4*>(ph) = vh;
         *reinterpret_cast<half4*>(ph + (size_t)PW * 8) = vl;
     };
-    // image <- split(lrelu(x)), zero outside the sequence (the convolutions pad with zeros)
-    auto xres_to_image = [&]() __attribute__((always_inline)) {
+    // image <- split(s * lrelu(x)), zero outside the sequence (the convolutions pad with zeros); s = power-of-two pre-scale
+    auto xres_to_image = [&](float s) __attribute__((always_inline)) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float t = xres[mi][ct][4 * gi + e];
+                        float t = xres[mi][ct][4 * gi + e] * s;
                         t = fmaxf(t, t * 0.1f);
                         v[e] = pok[ct] ? t : 0.f;
                     }
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
         }
     };
 
-    xres_to_image();
+    xres_to_image(a.xs[0]);
     if (!TTSC_DBG(a, 2)) __syncthreads();
     for (int p = 0; p < a.npairs; ++p) {
         f32x16 acc[MI][CT];
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int gi = 0; gi < 4; ++gi) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 32 * mi + 8 * gi + 4 * half);
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 32 * mi + 8 * gi + 4 * half) * a.bs1[p];
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {
                         float v[4];
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
                 }
         }
         if (p + 1 < a.npairs) {
-            xres_to_image();
+            xres_to_image(a.xs[p + 1]);
             if (!TTSC_DBG(a, 2)) __syncthreads();
         }
     }
@@ -403,8 +404,13 @@ extern "C" int ttsc_rbchain_forward(const ttsc_conv1d* const* convs1, const ttsc
         a.w2[p] = reinterpret_cast<const half8*>(convs2[p]->phases[0].wph_dev);
         a.b1[p] = convs1[p]->bias_dev;
         a.b2[p] = convs2[p]->bias_dev;
-        a.us1[p] = convs1[p]->w_unscale;
-        a.us2[p] = convs2[p]->w_unscale;
+        // activation pre-scales of the two layers (ttsc_conv1d_set_activation_scale): s1 multiplies lrelu(x) on its way into the
+        // image, conv1's accumulator comes out s1 too large, conv2's input is written s2 * lrelu(t), conv2's accumulator s2 too large
+        const float s1 = convs1[p]->act_scale, s2 = convs2[p]->act_scale;
+        a.xs[p] = s1;
+        a.us1[p] = convs1[p]->w_unscale * (s2 / s1);
+        a.bs1[p] = s2;
+        a.us2[p] = convs2[p]->w_unscale / s2;
         a.d1[p] = convs1[p]->cfg.dilation;
         a.halo += (a.d1[p] + 1) * (k - 1) / 2;
     }

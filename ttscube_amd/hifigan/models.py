@@ -232,6 +232,30 @@ class Generator(nn.Module):
                        'ttsc_hifigan_forward')
         return y
 
+    def calibrate(self, x):
+        """(Re)derive the split-precision path's per-layer activation pre-scales from `x` [B, num_mels, T] (ttsc_hifigan_calibrate:
+        one layer-by-layer forward with an abs-max reduction per layer).  The first forward after loading weights does this
+        by itself on its own input; call it to re-calibrate on more representative data.  Returns that forward's output."""
+        L = _lib.lib()
+        self._sync()
+        x = x.detach().float().contiguous()
+        B, _, T = x.shape
+        need = L.ttsc_hifigan_workspace_bytes(self._handle, B, T)
+        if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != x.device:
+            self._ws = None
+            self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+        y = torch.empty((B, 1, self.out_len(T)), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.ttsc_hifigan_calibrate(self._handle, _lib.dev_ptr(x), B, T, _lib.dev_ptr(y), _lib.dev_ptr(self._ws),
+                                                self._ws.numel() * 4, _lib.current_stream()), 'ttsc_hifigan_calibrate')
+        return y
+
+    def activation_scale(self, layer_name):
+        """power-of-two pre-scale currently applied to the input of `layer_name` (e.g. 'resblocks.3.convs1.0')"""
+        out = C.c_float()
+        _lib.check(_lib.lib().ttsc_hifigan_get_activation_scale(self._handle, layer_name.encode(), C.byref(out)), 'get_activation_scale')
+        return out.value
+
     def remove_weight_norm(self):
         self.conv_pre.remove_weight_norm()
         for l in self.ups:

@@ -27,6 +27,11 @@ class Conv1dHip:
         _lib.check(_lib.lib().ttsc_conv1d_set_precision(self._h, mode), 'ttsc_conv1d_set_precision')
         return self
 
+    def set_activation_scale(self, scale):
+        """power-of-two pre-scale of this layer's input on the split-precision path (ttsc_conv1d_set_activation_scale)"""
+        _lib.check(_lib.lib().ttsc_conv1d_set_activation_scale(self._h, float(scale)), 'ttsc_conv1d_set_activation_scale')
+        return self
+
     def set_weight(self, weight, bias=None):
         w = weight.detach().float().cpu().contiguous()
         exp = ((self.cfg.in_channels, self.cfg.out_channels) if self.cfg.transposed else
