@@ -99,8 +99,10 @@ def extra_legs(g, h, sd, rank_dev, R):
         idx, _, _ = net.decode(X, mode='philox', seed=2)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        ridx, _, _ = WO.decode(wsd, wm[:2, :1], wx[:2, :24], num_layers=1, H=512, mode=WO.MODE_PHILOX, seed=2)
-        assert np.array_equal(idx[:2, :240].cpu().numpy(), ridx), 'WaveRNN indices differ from the oracle'
+        # oracle on 2 utterances x 2 frames; the first frame (240 samples) is outside the reach of the truncation (the low-res
+        # conv stack looks 9 low-res samples = 90 samples ahead)
+        ridx, _, _ = WO.decode(wsd, wm[:2, :2], wx[:2, :48], num_layers=1, H=512, mode=WO.MODE_PHILOX, seed=2)
+        assert np.array_equal(idx[:2, :240].cpu().numpy(), ridx[:, :240]), 'WaveRNN indices differ from the oracle'
         legs['wavernn_decode_b256'] = {'us_per_step': dt / (Tw * 240) * 1e6, 'samples_per_s': Bw * Tw * 240 / dt, 'H': 512, 'layers': 1,
                                        'output': 'mulaw', 'indices_bit_exact_vs_oracle': True, 'kernel': net.last_kernel}
     except Exception as e:

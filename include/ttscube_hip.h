@@ -254,10 +254,9 @@ int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel_dev, const float* xlow
                         uint8_t* idx_dev, float* wav_dev, float* logits_dev, void* workspace_dev, size_t workspace_bytes,
                         void* stream);
 /* Which kernel ran the last decode and whether its hand-offs completed.  Synchronises `stream`, then: -1 = single-workgroup
- * streaming kernel; 2 = quad kernel (4 workgroups step 4 utterances, each streaming a quarter of the weight rows; opt-in
- * with env TTSC_WR_QUAD=1 when ceil(B/4)*4 <= number of CUs, 1 layer, H <= 512); 0 = 32-member weight-stationary
- * cluster kernel (env TTSC_WR_CLUSTER=1); 1 = a multi-workgroup kernel gave up on an inter-workgroup hand-off (bounded spin
- * timed out; outputs invalid). */
+ * streaming kernel; 2 = quad kernel (4 workgroups step 4 utterances, each streaming a quarter of the weight rows; chosen for
+ * one-layer networks at B >= 192 when ceil(B/4)*4 <= number of CUs, H <= 512; env TTSC_WR_QUAD=1 / 0 forces it on / off);
+ * 1 = the quad kernel gave up on an inter-workgroup hand-off (bounded spin timed out; outputs invalid). */
 int ttsc_wavernn_last_status(ttsc_wavernn* w, void* stream);
 void ttsc_wavernn_destroy(ttsc_wavernn* w);
 

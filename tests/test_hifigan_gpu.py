@@ -188,7 +188,8 @@ def test_split_precision_range_safety(regime, monkeypatch):
         out0 = g0(mel.cuda()).cpu()
     rel0 = _rel_rms(out0, ref) if bool(torch.isfinite(out0).all()) else float('inf')
     print(regime, 'without pre-scales: rel', rel0)
-    assert rel0 > rel
+    if regime == 'huge':
+        assert rel0 > 100 * rel     # overflow of the fp16 halves: inf / NaN or garbage
 
 
 def test_calibration_is_sticky_and_explicit():

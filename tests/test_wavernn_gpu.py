@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(params=['quad', 'stream'], autouse=True)
 def wr_kernel(request, monkeypatch):
-    """Every test runs twice: with the multi-workgroup quad kernel (opt-in, one-layer nets) and with the default
-    single-workgroup streaming kernel — both must be bit-exact."""
+    """Every test runs twice: with the multi-workgroup quad kernel forced on (one-layer nets; the default at B >= 192) and
+    with the single-workgroup streaming kernel — both must be bit-exact."""
     monkeypatch.setenv('TTSC_WR_QUAD', '1' if request.param == 'quad' else '0')
     return request.param
 
@@ -168,39 +168,6 @@ def test_cubenet_vocoder_fold_and_decode(golden_dir):
     assert np.array_equal(x_hr, O.compose_batched_inference(r_hr))
 
 
-def test_cluster_kernel_bit_exact(monkeypatch):
-    """Weight-stationary 32-workgroup cluster kernel (csrc/wavernn_cluster.hip, env TTSC_WR_CLUSTER=1): LDS-resident weight
-    slices, four L2 hand-offs per step with bounded spins — same fmaf chains, so indices/logits stay bit-exact."""
-    monkeypatch.setenv('TTSC_WR_CLUSTER', '1')
-    for H, lowres, B, T, mode in [(512, True, 40, 1, 'noise'), (64, True, 5, 2, 'philox'), (128, False, 33, 4, 'argmax')]:
-        sd = O.synthetic_state_dict(H=H, num_layers=1, use_lowres=lowres, seed=300 + H)
-        net = _net(H, 1, lowres, sd)
-        up = 240 if lowres else 24
-        mel, x_low = O.synthetic_inputs(B, T, seed=11 + T, upsample=up)
-        X = {'mel': torch.from_numpy(mel)}
-        if lowres:
-            X['x_low'] = torch.from_numpy(x_low)
-        L = T * up
-        noise = None
-        if mode == 'noise':
-            uu = np.random.RandomState(6).uniform(1e-6, 1 - 1e-6, size=(B, L, 256))
-            noise = (-np.log(-np.log(uu))).astype(np.float32)
-        omode = {'noise': O.MODE_NOISE, 'philox': O.MODE_PHILOX, 'argmax': O.MODE_ARGMAX}[mode]
-        ridx, rwav, rlog = O.decode(sd, mel, x_low if lowres else None, num_layers=1, H=H, use_lowres=lowres, upsample=up,
-                                    mode=omode, noise=noise, seed=77, want_logits=True)
-        idx, wav, logits = net.decode(X, mode=mode, noise=noise, seed=77, want_logits=True)
-        assert net.last_kernel == 'cluster'
-        assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(wav.cpu().numpy(), rwav)
-        assert np.array_equal(logits.cpu().numpy(), rlog)
-    monkeypatch.setenv('TTSC_WR_CLUSTER', '0')
-    monkeypatch.setenv('TTSC_WR_QUAD', '1')
-    net.decode(X, mode='argmax')
-    assert net.last_kernel == 'quad'
-    monkeypatch.setenv('TTSC_WR_QUAD', '0')
-    net.decode(X, mode='argmax')
-    assert net.last_kernel == 'stream'
-
-
 # ---- continuous output distributions (MOL = the reference's default, modules.py:398) ---------------------------------------
 CONT = ['wavernn_hr_h64_mol', 'wavernn_hr_h512_mol', 'wavernn_lr_h64_gm', 'wavernn_hr_h64_beta']
 
@@ -264,3 +231,16 @@ def test_reference_default_constructor_decodes():
     voc = CubenetVocoder(num_layers_lr=1, layer_size_lr=64, num_layers_hr=1, layer_size_hr=64, upsample=240, upsample_low=10).cuda().eval()
     x_lr, x_hr = voc({'mel': torch.randn(1, 40, 80)})
     assert x_lr.shape == (1, 960, 1) and x_hr.shape == (1, 6800) and np.isfinite(x_hr).all()
+
+
+def test_default_kernel_choice_by_batch(monkeypatch):
+    """no env override: the quad kernel takes one-layer networks at B >= 192 (every member resident), the streaming kernel the rest"""
+    monkeypatch.delenv('TTSC_WR_QUAD', raising=False)
+    sd = O.synthetic_state_dict(H=64, num_layers=1, use_lowres=True, seed=77)
+    net = _net(64, 1, True, sd)
+    for B, want in ((8, 'stream'), (200, 'quad')):
+        mel, x_low = O.synthetic_inputs(B, 1, seed=B)
+        idx, _, _ = net.decode({'mel': torch.from_numpy(mel), 'x_low': torch.from_numpy(x_low)}, mode='philox', seed=9)
+        assert net.last_kernel == want
+        ridx, _, _ = O.decode(sd, mel, x_low, num_layers=1, H=64, mode=O.MODE_PHILOX, seed=9)
+        assert np.array_equal(idx.cpu().numpy(), ridx)

@@ -237,15 +237,18 @@ extern "C" int ttsc_hifigan_forward(ttsc_hifigan* g, const float* mel, int32_t B
     return ttsc_hifigan_forward_ragged(g, mel, B, T, nullptr, wav, ws, ws_bytes, stream);
 }
 
-namespace {
-struct CalibSite {
-    ttsc_conv1d* layer;
-    float in_scale;
-};
-}  // namespace
-
 static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, const int32_t* frames, float* wav, void* ws, size_t ws_bytes,
-                       void* stream, float* calib_stats, std::vector<CalibSite>* calib_sites);
+                       void* stream, float* calib_stat);
+
+// scale that puts a layer's largest input magnitude m into [2^9, 2^10)
+static float calib_scale(float m) {
+    if (!(m > 0.f) || !std::isfinite(m)) return 1.f;
+    int e = 0;
+    (void)frexpf(m, &e);   // m = f * 2^e, f in [0.5, 1)
+    e = 10 - e;
+    e = e > 40 ? 40 : (e < -20 ? -20 : e);
+    return ldexpf(1.f, e);
+}
 
 extern "C" int ttsc_hifigan_calibrate(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, float* wav, void* ws, size_t ws_bytes,
                                       void* stream) {
@@ -256,34 +259,13 @@ extern "C" int ttsc_hifigan_calibrate(ttsc_hifigan* g, const float* mel, int32_t
     }
     g->calibrated = true;   // (also keeps hifigan_run from recursing)
     if (g->precision != TTSC_PREC_F16X3) return TTSC_OK;
-    std::vector<CalibSite> sites;
-    float* stats = nullptr;
-    const size_t nstat = g->layers.size() + 8;
-    TTSC_HIP_CHECK(hipMalloc((void**)&stats, nstat * sizeof(float)));
-    hipError_t me = hipMemsetAsync(stats, 0, nstat * sizeof(float), (hipStream_t)stream);
-    int rc = me == hipSuccess ? hifigan_run(g, mel, B, T, nullptr, wav, ws, ws_bytes, stream, stats, &sites) : TTSC_EHIP;
-    std::vector<float> host(nstat, 0.f);
-    if (!rc && (hipStreamSynchronize((hipStream_t)stream) != hipSuccess ||
-                hipMemcpy(host.data(), stats, nstat * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)) {
-        set_error("ttsc_hifigan_calibrate: reading the activation statistics failed");
-        rc = TTSC_EHIP;
-    }
-    (void)hipFree(stats);
-    if (rc) return rc;
-    for (size_t i = 0; i < sites.size(); ++i) {
-        const float m = host[i] * fabsf(sites[i].in_scale);
-        float sc = 1.f;
-        if (m > 0.f && std::isfinite(m)) {
-            int e = 0;
-            (void)frexpf(m, &e);           // m = f * 2^e, f in [0.5, 1)  ->  m * 2^(10 - e) in [2^9, 2^10)
-            e = 10 - e;
-            e = e > 40 ? 40 : (e < -20 ? -20 : e);
-            sc = ldexpf(1.f, e);
-        }
-        rc = ttsc_conv1d_set_activation_scale(sites[i].layer, sc);
-        if (rc) return rc;
-    }
-    return TTSC_OK;
+    // layer by layer: abs-max of the layer's input -> its scale -> the layer itself (so that every layer already runs inside
+    // fp16's range and hands finite, accurate data to the next measurement); one host read per layer, calibration only
+    float* stat = nullptr;
+    TTSC_HIP_CHECK(hipMalloc((void**)&stat, sizeof(float)));
+    int rc = hifigan_run(g, mel, B, T, nullptr, wav, ws, ws_bytes, stream, stat);
+    (void)hipFree(stat);
+    return rc;
 }
 
 extern "C" int ttsc_hifigan_get_activation_scale(const ttsc_hifigan* g, const char* layer, float* out) {
@@ -296,11 +278,11 @@ extern "C" int ttsc_hifigan_get_activation_scale(const ttsc_hifigan* g, const ch
 
 extern "C" int ttsc_hifigan_forward_ragged(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, const int32_t* frames,
                                            float* wav, void* ws, size_t ws_bytes, void* stream) {
-    return hifigan_run(g, mel, B, T, frames, wav, ws, ws_bytes, stream, nullptr, nullptr);
+    return hifigan_run(g, mel, B, T, frames, wav, ws, ws_bytes, stream, nullptr);
 }
 
 static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, const int32_t* frames, float* wav, void* ws, size_t ws_bytes,
-                       void* stream, float* calib_stats, std::vector<CalibSite>* calib_sites) {
+                       void* stream, float* calib_stat) {
     TTSC_REQUIRE(g && mel && wav && ws, "ttsc_hifigan_forward: null argument");
     TTSC_REQUIRE(B > 0 && T > 0, "ttsc_hifigan_forward: bad B/T (%d, %lld)", B, (long long)T);
     {
@@ -317,7 +299,7 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
         set_error("ttsc_hifigan_forward: workspace %zu < required %zu bytes", ws_bytes, need);
         return TTSC_ENOMEM;
     }
-    const bool calib = calib_stats != nullptr;
+    const bool calib = calib_stat != nullptr;
     if (!calib && !g->calibrated && g->auto_calibrate && g->precision == TTSC_PREC_F16X3) {
         int crc = ttsc_hifigan_calibrate(g, mel, B, T, wav, ws, ws_bytes, stream);   // first forward after new weights
         if (crc) return crc;
@@ -361,10 +343,18 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
     auto in16 = [&](const ttsc_conv1d* l) { return ttsc_conv1d_in_channels(l) % 16 == 0; };
     auto conv = [&](ttsc_conv1d* l, const float* x, const void* xs, int64_t Lin, float* y, void* ys, float ys_scale,
                     float ys_slope, const float* resid, const ttsc_conv1d_epilogue& e, const int32_t* il, const int32_t* ol) {
-        if (calib && x && !xs) {   // calibration forward: abs-max of this layer's input
-            int arc = ttsc_absmax(x, (int64_t)B * ttsc_conv1d_in_channels(l) * Lin, calib_stats + calib_sites->size(), stream);
+        if (calib && x && !xs) {   // calibration forward: abs-max of this layer's input -> its pre-scale, then the layer
+            float m = 0.f;
+            if (hipMemsetAsync(calib_stat, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return (int)TTSC_EHIP;
+            int arc = ttsc_absmax(x, (int64_t)B * ttsc_conv1d_in_channels(l) * Lin, calib_stat, stream);
             if (arc) return arc;
-            calib_sites->push_back(CalibSite{l, e.in_scale});
+            if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess ||
+                hipMemcpy(&m, calib_stat, sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+                set_error("ttsc_hifigan_calibrate: reading the activation statistics failed");
+                return (int)TTSC_EHIP;
+            }
+            arc = ttsc_conv1d_set_activation_scale(l, calib_scale(m * fabsf(e.in_scale)));
+            if (arc) return arc;
         }
         return ttsc_conv1d_forward_split(l, xs ? nullptr : x, xs, B, Lin, y, ys, ys_scale, ys_slope, resid, &e, il, ol, stream);
     };

@@ -25,7 +25,6 @@
 #include "common.hpp"
 #include "../../include/ttscube_math.h"
 #include "../../include/ttscube_mulaw_lut.h"
-#include "wavernn_cluster.hip"
 #include "wavernn_quad.hip"
 
 namespace ttsc {
@@ -489,16 +488,15 @@ struct ttsc_wavernn {
     float *wt_pre = nullptr, *b_pre = nullptr, *wt_out = nullptr, *b_out = nullptr, *lut = nullptr;
     float* lc_w[3] = {nullptr, nullptr, nullptr};
     float* lc_b[3] = {nullptr, nullptr, nullptr};
-    // host copies (torch layout) kept for the cluster kernel's per-member packing
+    // host copies (torch layout) kept for the quad kernel's per-member packing
     std::vector<float> h_wih0, h_whh0, h_bih0, h_bhh0, h_wpre, h_bpre, h_wout, h_bout;
     float *c_whh = nullptr, *c_wih = nullptr, *c_bih = nullptr, *c_bhh = nullptr, *c_wpre = nullptr, *c_bpre = nullptr, *c_wout = nullptr,
           *c_bout = nullptr;
-    bool cluster_dirty = true;
     float *q_whh = nullptr, *q_wih = nullptr, *q_bih = nullptr, *q_bhh = nullptr, *q_wpre = nullptr, *q_bpre = nullptr, *q_wout = nullptr,
           *q_bout = nullptr;   // quad kernel (wavernn_quad.hip): 4 row slices of every matrix
     bool quad_dirty = true;
-    int last_kind = 0;         // 0 streaming kernel, 1 cluster kernel, 2 quad kernel
-    unsigned* last_abort_word = nullptr;   // device word set by the cluster kernel when a hand-off timed out
+    int last_kind = 0;         // 0 streaming kernel, 2 quad kernel
+    unsigned* last_abort_word = nullptr;   // device word set by the quad kernel when a hand-off timed out
     std::vector<std::string> have;
     bool has(const std::string& n) const {
         for (auto& s : have)
@@ -639,81 +637,18 @@ extern "C" int ttsc_wavernn_set_weight(ttsc_wavernn* w, const char* name, const 
         TTSC_REQUIRE(false, "ttsc_wavernn_set_weight: unknown key '%s'", name);
     }
     if (rc == TTSC_OK && !w->has(n)) w->have.push_back(n);
-    w->cluster_dirty = true;
     w->quad_dirty = true;
     return rc;
 }
 
-// ---- cluster (weight-stationary) path ---------------------------------------------------------------------------
-static bool cluster_supported(const ttsc_wavernn* w, int B) {
-    const auto& c = w->cfg;
-    // OFF by default: measured on MI355X (H=512, B=1..256) the four all-to-all hand-offs per step cost as much as the
-    // weight stream they remove (48 us/step vs 45 us/step for the single-workgroup kernel); kept, bit-exact and tested,
-    // as the starting point for a cheaper exchange (env TTSC_WR_CLUSTER=1 enables it).
-    const char* ev = getenv("TTSC_WR_CLUSTER");
-    if (!ev || atoi(ev) == 0) return false;
-    if (c.num_layers != 1 || c.H % WC_NC != 0 || c.H > 512 || c.S % WC_NC != 0 || c.S > 256) return false;
-    const int G = (int)ceil_div(B, WC_BU);
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-    return G * WC_NC <= cus;   // every member must be resident (one workgroup per CU): otherwise the exchange deadlocks
-}
-
-static size_t cluster_exchange_bytes(const ttsc_wavernn* w, int B) {
-    const int G = (int)ceil_div(B, WC_BU);
-    const auto& c = w->cfg;
-    const size_t per = ((size_t)2 * c.H * WC_BU + (size_t)2 * 256 * WC_BU + (size_t)2 * WC_BU * c.S + 2 * WC_BU) * sizeof(float);
-    return (size_t)G * per + ((size_t)G * 4 + 64) * sizeof(unsigned) + 256;
-}
-
-// member m owns hidden units [m*UPW, (m+1)*UPW), pre rows [8m, 8m+8), output rows [m*SR, (m+1)*SR); packed [K/4][rows][4]
-static int cluster_pack(ttsc_wavernn* w) {
-    const auto& c = w->cfg;
-    const int H = c.H, UPW = H / WC_NC, R3 = 3 * UPW, I0 = w->in0, I0P = (int)round_up(I0, 4), S = c.S, SR = S / WC_NC;
-    std::vector<float> whh((size_t)WC_NC * H * R3, 0.f), wih((size_t)WC_NC * I0P * R3, 0.f), bih((size_t)WC_NC * R3), bhh((size_t)WC_NC * R3);
-    std::vector<float> wpre((size_t)WC_NC * H * 8), bpre((size_t)WC_NC * 8), wout((size_t)WC_NC * 256 * SR), bout((size_t)WC_NC * SR);
-    for (int m = 0; m < WC_NC; ++m) {
-        for (int q = 0; q < 3; ++q)
-            for (int j = 0; j < UPW; ++j) {
-                const int row = q * H + m * UPW + j, lr = q * UPW + j;
-                for (int k = 0; k < H; ++k) whh[(size_t)m * H * R3 + ((size_t)(k >> 2) * R3 + lr) * 4 + (k & 3)] = w->h_whh0[(size_t)row * H + k];
-                for (int k = 0; k < I0; ++k) wih[(size_t)m * I0P * R3 + ((size_t)(k >> 2) * R3 + lr) * 4 + (k & 3)] = w->h_wih0[(size_t)row * I0 + k];
-                bih[(size_t)m * R3 + lr] = w->h_bih0[row];
-                bhh[(size_t)m * R3 + lr] = w->h_bhh0[row];
-            }
-        for (int r = 0; r < 8; ++r) {
-            const int row = m * 8 + r;
-            for (int k = 0; k < H; ++k) wpre[(size_t)m * H * 8 + ((size_t)(k >> 2) * 8 + r) * 4 + (k & 3)] = w->h_wpre[(size_t)row * H + k];
-            bpre[(size_t)m * 8 + r] = w->h_bpre[row];
-        }
-        for (int r = 0; r < SR; ++r) {
-            const int row = m * SR + r;
-            for (int k = 0; k < 256; ++k) wout[(size_t)m * 256 * SR + ((size_t)(k >> 2) * SR + r) * 4 + (k & 3)] = w->h_wout[(size_t)row * 256 + k];
-            bout[(size_t)m * SR + r] = w->h_bout[row];
-        }
-    }
-    int rc;
-    if ((rc = upload(&w->c_whh, whh.data(), whh.size()))) return rc;
-    if ((rc = upload(&w->c_wih, wih.data(), wih.size()))) return rc;
-    if ((rc = upload(&w->c_bih, bih.data(), bih.size()))) return rc;
-    if ((rc = upload(&w->c_bhh, bhh.data(), bhh.size()))) return rc;
-    if ((rc = upload(&w->c_wpre, wpre.data(), wpre.size()))) return rc;
-    if ((rc = upload(&w->c_bpre, bpre.data(), bpre.size()))) return rc;
-    if ((rc = upload(&w->c_wout, wout.data(), wout.size()))) return rc;
-    if ((rc = upload(&w->c_bout, bout.data(), bout.size()))) return rc;
-    w->cluster_dirty = false;
-    return TTSC_OK;
-}
-
-
 // ---- quad path (wavernn_quad.hip): 4 workgroups step 4 utterances, each streaming a quarter of the rows -------------
 static bool quad_supported(const ttsc_wavernn* w, int B) {
     const auto& c = w->cfg;
-    // OFF by default (env TTSC_WR_QUAD=1): bit-exact and tested, but measured 41 us/step at any batch size against 36..45 us
-    // for the streaming kernel — the four hand-offs + three LDS stagings per step cost what the shorter weight stream saves,
-    // and lanes that share a weight address do not shorten the CU's address path.
+    // Measured on MI355X (H = 512, 1 layer): 41 us/step at any batch, against 36 us (small batches) .. 45 us (B = 256) for the
+    // streaming kernel, whose workgroups all pull the same 3.8 MB through L2 every step.  So: default for large batches
+    // (B >= 192) of one-layer networks; env TTSC_WR_QUAD=1 / 0 forces it on (whenever eligible) / off.  Bit-exact either way.
     const char* evq = getenv("TTSC_WR_QUAD");
-    if (!evq || atoi(evq) == 0) return false;
+    if (evq ? atoi(evq) == 0 : B < 192) return false;
     if (c.num_layers != 1 || c.H % (4 * WQ_NC) != 0 || c.H > 512 || c.S % WQ_NC != 0 || c.S > 256) return false;
     const int G = (int)ceil_div(B, WQ_BU);
     int dev = 0, cus = 0;
@@ -783,7 +718,7 @@ static size_t cond_bytes(const ttsc_wavernn* w, int32_t B, int64_t Tl) {
 
 extern "C" size_t ttsc_wavernn_workspace_bytes(const ttsc_wavernn* w, int32_t B, int64_t T, int64_t Tl) {
     if (!w) return 0;
-    return cond_bytes(w, B, Tl) + std::max(cluster_exchange_bytes(w, B), quad_exchange_bytes(w, B));
+    return cond_bytes(w, B, Tl) + quad_exchange_bytes(w, B);
 }
 
 extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const float* x_low, int32_t B, int64_t T, int64_t Tl,
@@ -862,49 +797,7 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
     }
     a.seed = seed;
     TTSC_REQUIRE(a.L > 0, "ttsc_wavernn_decode: nothing to decode (L=%d)", a.L);
-    if (cluster_supported(w, B)) {
-        if (w->cluster_dirty) {
-            int prc = cluster_pack(w);
-            if (prc) return prc;
-        }
-        const size_t need_all = ttsc_wavernn_workspace_bytes(w, B, T, Tl);
-        if (!ws || ws_bytes < need_all) {
-            set_error("ttsc_wavernn_decode: workspace %zu < required %zu bytes", ws_bytes, need_all);
-            return TTSC_ENOMEM;
-        }
-        const int G = (int)ceil_div(B, WC_BU);
-        char* xbase = (char*)ws + cond_bytes(w, B, Tl);
-        WcArgs ca;
-        memset(&ca, 0, sizeof(ca));
-        ca.mel = mel; ca.interp = a.interp; ca.feats = a.feats;
-        ca.whh = w->c_whh; ca.wih = w->c_wih; ca.bih = w->c_bih; ca.bhh = w->c_bhh;
-        ca.wpre = w->c_wpre; ca.bpre = w->c_bpre; ca.wout = w->c_wout; ca.bout = w->c_bout;
-        ca.lut = w->lut; ca.noise = noise; ca.forced_x = forced_x; ca.out_idx = idx; ca.out_wav = wav; ca.out_logits = logits;
-        float* f = (float*)xbase;
-        ca.xh = f; f += (size_t)G * 2 * c.H * WC_BU;
-        ca.xpre = f; f += (size_t)G * 2 * 256 * WC_BU;
-        ca.xlog = f; f += (size_t)G * 2 * WC_BU * c.S;
-        ca.xlx = f; f += (size_t)G * 2 * WC_BU;
-        ca.cnt = (unsigned*)f;
-        ca.B = B; ca.T = (int)T; ca.Tl = (int)Tl; ca.H = c.H; ca.UPW = c.H / WC_NC; ca.I0 = w->in0; ca.I0P = (int)round_up(w->in0, 4);
-        ca.use_lowres = c.use_lowres; ca.up = c.upsample; ca.up_low = c.upsample_low; ca.S = c.S; ca.SR = c.S / WC_NC; ca.n_mel = c.n_mel;
-        ca.out_kind = c.out_kind; ca.mode = mode; ca.L = a.L; ca.G = G; ca.seed = seed;
-        TTSC_HIP_CHECK(hipMemsetAsync(ca.cnt, 0, ((size_t)G * 4 + 64) * sizeof(unsigned), s));
-        const size_t lds = ((size_t)c.H * 3 * ca.UPW + (size_t)ca.I0P * 3 * ca.UPW + (size_t)c.H * 8 + (size_t)256 * ca.SR + c.S + 4096 + 64) * sizeof(float);
-        // (the kernel also has a few bytes of static LDS, so ask for exactly what is needed rather than the 160 KiB maximum)
-        TTSC_HIP_CHECK(hipFuncSetAttribute((const void*)wr_cluster_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(wr_cluster_kernel, dim3(G * WC_NC), dim3(WC_THREADS), lds, s, ca);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) {
-            set_error("wr_cluster_kernel launch failed: %s", hipGetErrorString(e));
-            return TTSC_EHIP;
-        }
-        // the abort word is checked by the caller-visible helper below (no host sync here)
-        w->last_abort_word = ca.cnt + (size_t)G * 4;
-        w->last_kind = 1;
-        return TTSC_OK;
-    }
-    if (!cluster_supported(w, B) && quad_supported(w, B)) {
+    if (quad_supported(w, B)) {
         if (w->quad_dirty) {
             int prc = quad_pack(w);
             if (prc) return prc;
@@ -971,7 +864,7 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
 }
 
 
-// After the stream has executed the last decode: -1 = streaming kernel (nothing to check), 0 = cluster kernel ok, 2 = quad
+// After the stream has executed the last decode: -1 = streaming kernel (nothing to check), 2 = quad
 // kernel ok, 1 = a multi-workgroup kernel aborted on a hand-off timeout (results invalid).  Synchronises the stream.
 extern "C" int ttsc_wavernn_last_status(ttsc_wavernn* w, void* stream) {
     if (!w) return TTSC_EINVAL;

@@ -5,9 +5,10 @@
 // utterances together; member m owns a quarter of the rows of every matrix (H/4 hidden units x 3 gates, 64 rows of the
 // pre-output layer, S/4 rows of the output layer) and streams ONLY those rows — each 16-byte weight word is used for
 // four utterances, so a member moves a quarter of the bytes per step while B = 256 still fills all 256 CUs (64 quads).
-// Per step the members exchange four small vectors (h_t, pre, logits, last_x) with the hand-off protocol of
-// wavernn_cluster.hip (write-through payload, monotonic counters, bounded spins + abort word); with 4 members a hand-off
-// costs ~1 us (measured on the GRU training kernels, gru.hip), against ~8 us for the 32-member cluster.
+// Per step the members exchange four small vectors (h_t, pre, logits, last_x): write-through (agent-scope) payload stores,
+// one monotonic arrival counter per edge, bounded spins + abort word; with 4 members a hand-off costs ~1 us (measured on the
+// GRU training kernels, gru.hip).  (A 32-member weight-stationary cluster variant was built in round 1 and measured slower
+// than both this kernel and the streaming one — ~8 us per all-to-all hand-off — and was removed.)
 //
 // Arithmetic is IDENTICAL to wavernn.hip / oracle/wavernn_ref.c: rows are split across members, never the reduction —
 // every (row, utterance) is one k-ordered fmaf chain seeded with the bias — so indices and logits stay bit-exact.
@@ -18,6 +19,49 @@ namespace ttsc {
 constexpr int WQ_NC = 4;        // members per quad
 constexpr int WQ_BU = 4;        // utterances per quad
 constexpr int WQ_THREADS = 512;
+
+constexpr unsigned WC_SPIN_LIMIT = 1u << 22;   // bounded spins: a member that is not resident must not hang the GPU
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ void st_f32(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float2 ld_f32x2(const float* p) {
+    const u64 x = __hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float2 r;
+    r.x = __uint_as_float((unsigned)x);
+    r.y = __uint_as_float((unsigned)(x >> 32));
+    return r;
+}
+__device__ __forceinline__ float ld_f32(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// one lane polls a monotonic counter; bounded; returns false after a timeout / when another member aborted
+__device__ __forceinline__ bool wait_count(unsigned* cnt, unsigned want, unsigned* abort_word) {
+    __shared__ int ok_s;
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        unsigned spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            if (++spins > WC_SPIN_LIMIT || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        ok_s = ok;
+    }
+    __syncthreads();
+    const bool r = ok_s != 0;
+    __syncthreads();
+    return r;
+}
+
+// every storing wave drains its write-through stores, then ONE lane bumps the arrival counter
+__device__ __forceinline__ void publish(unsigned* cnt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 struct WqArgs {
     const float* mel;      // [B, T, n_mel]
