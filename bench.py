@@ -107,6 +107,32 @@ def extra_legs(g, h, sd, rank_dev, R):
                                        'output': 'mulaw', 'indices_bit_exact_vs_oracle': True, 'kernel': net.last_kernel}
     except Exception as e:
         legs['wavernn_decode_b256'] = {'error': str(e)[:200]}
+    try:   # BASELINE configs[3] per-GPU share: one full Cubegan training step (no exchange at N = 1; `--mode train` runs it under RCCL)
+        import random
+        from ttscube_amd.io_utils.io_cubegan import CubeganCollate
+        from ttscube_amd.io_utils.synthetic import synthetic_encodings, synthetic_examples
+        from ttscube_amd.networks import training as T
+        from ttscube_amd.networks.cubegan import Cubegan
+        enc = synthetic_encodings()
+        torch.manual_seed(1234)
+        model = Cubegan(enc, conditioning=None, train=True).to(rank_dev)
+        model.train()
+        opts = T.cubegan_configure_optimizers(model)
+        batch = CubeganCollate(enc).collate_fn(list(synthetic_examples(16, 777, min_ph=30, max_ph=50)))
+        crop = random.Random(99)
+        for _ in range(2):
+            out = T.cubegan_training_step(model, batch, opts, rng=crop)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            out = T.cubegan_training_step(model, batch, opts, rng=crop)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        legs['cubegan_training_step_b16'] = {'ms_per_step': dt * 1e3, 'samples_per_s': 16 * 12000 / dt,
+                                             'losses': {k: round(float(v), 5) for k, v in out.items()}}
+        del model, opts
+    except Exception as e:
+        legs['cubegan_training_step_b16'] = {'error': str(e)[:200]}
     return legs
 
 
@@ -145,8 +171,98 @@ def cpu_baseline(h, sd, mel_dev, budget_s=10.0):
                       % (n, B, T, el, cores, ncpu, t1)}
 
 
+def bench_train(args):
+    """`--mode train`: BASELINE configs[3] per-GPU share — the full Cubegan adversarial training step (discriminator step,
+    generator step, text step; cube/networks/cubegan.py:85-189) on synthetic examples, b utterances x 12 000-sample crops per
+    GPU, data parallel: replicated parameters, rank-distinct data, three flat-bucket RCCL exchanges per step
+    (reduce_scatter + all_gather over xGMI, ttscube_amd/distributed.py).  The exchange runs at N = 1 too (a world of one), so the
+    single-GPU line times the same code path.  Weak scaling: the per-GPU batch is fixed."""
+    import random
+    import torch
+    import torch.distributed as dist
+    from ttscube_amd.distributed import FlatBucketReducer, broadcast_parameters
+    from ttscube_amd.io_utils.io_cubegan import CubeganCollate
+    from ttscube_amd.io_utils.synthetic import synthetic_encodings, synthetic_examples
+    from ttscube_amd.networks import training as T
+    from ttscube_amd.networks.cubegan import Cubegan
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29517')
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    b = args.train_batch
+    enc = synthetic_encodings()
+    torch.manual_seed(1234 + rank)                       # ranks start different on purpose: broadcast must make them equal
+    model = Cubegan(enc, conditioning=None, train=True).to(dev)
+    model.train()
+    broadcast_parameters(model)
+    opts = T.cubegan_configure_optimizers(model)
+    g, d, t = T.cubegan_param_groups(model)
+    reducers = tuple(FlatBucketReducer(ps, force=True) for ps in (g, d, t))
+    batch = CubeganCollate(enc).collate_fn(list(synthetic_examples(b, 777 + rank, min_ph=30, max_ph=50)))   # rank-distinct data
+    crop = random.Random(99 + rank)
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        out = T.cubegan_training_step(model, batch, opts, reducers, rng=crop)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = T.cubegan_training_step(model, batch, opts, reducers, rng=crop)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    # replicas must still be identical after the timed steps
+    chk = torch.stack([p.detach().double().abs().sum() for p in model.parameters()]).sum().reshape(1)
+    allchk = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(allchk, chk)
+    same = all(bool(torch.equal(c, allchk[0])) for c in allchk)
+    assert same, 'replicas diverged: parameter checksums %s' % [float(c) for c in allchk]
+    # the exchange alone, timed on its own (bytes / time = algorithm bandwidth of reduce_scatter + all_gather)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        for r in reducers:
+            r.reduce()
+    barrier()
+    ex_ms = (time.perf_counter() - t1) / 5 * 1e3
+    ex_bytes = sum(r.bytes_exchanged for r in reducers)
+    if rank == 0:
+        samples = world * b * 12000
+        nparam = sum(p.numel() for p in model.parameters())
+        res = {'metric': 'audio samples/sec (HiFi-GAN adversarial training step, Cubegan)', 'value': samples * args.steps / elapsed,
+               'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': max(1, args.warmup),
+               'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': 'Cubegan.training_step (D + G + text steps, 4 optimizers), %d utterances x 12000-sample crops per GPU, '
+                                      'generator + Languasito2 + MPD + MSD = %.1f M parameters' % (b, nparam / 1e6),
+                          'global_batch': world * b, 'parallelism': 'dp%d: replicated parameters, 3 flat-bucket RCCL exchanges per step '
+                                                                    '(reduce_scatter + all_gather)' % world},
+               'exchange': {'bytes_per_step_per_rank': ex_bytes, 'ms_per_step_alone': ex_ms,
+                            'algorithm_GBs': ex_bytes / (ex_ms * 1e-3) / 1e9 if ex_ms > 0 else None, 'replicas_identical': same},
+               'losses': {k: round(float(v), 5) for k, v in out.items()},
+               'roofline': None, 'cpu_baseline': None}
+        print(json.dumps(res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--mode', choices=('infer', 'train'), default='infer', help="'train': the Cubegan adversarial training step (BASELINE configs[3])")
+    ap.add_argument('--train-batch', type=int, default=16, help='utterances per GPU in --mode train')
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
@@ -155,6 +271,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the secondary legs (fp32, B=1, WaveRNN)')
     args = ap.parse_args()
+    if args.mode == 'train':
+        return bench_train(args)
 
     import torch
     import torch.distributed as dist

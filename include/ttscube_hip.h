@@ -356,6 +356,20 @@ int ttsc_align_durations(const float* logits_dev, const int32_t* len_dev, int32_
 int ttsc_expand_rows(const float* x_dev, const int32_t* f2p_dev, const int32_t* flen_dev, int32_t B, int32_t N, int32_t C, int32_t Fcap,
                      int32_t stride, int32_t F, float* out_dev, void* stream);
 
+/* STFT-magnitude / mel-spectrogram helpers around ttsc_linear_forward (the DFT and the mel projection are GEMMs):
+ * hifigan.meldataset.mel_spectrogram [EXTERNAL; cube/networks/cubegan.py:137-138,247-248 — the 45 x mel-L1 loss of the GAN step,
+ * forward and backward] and MelVocoder.melspectrogram (cube/io_utils/vocoder.py:54-98, feature extraction, row f4).
+ *   ttsc_stft_mag            reim [M, 2*NB] (re | im) -> mag [M, ldm] = sqrt(re^2 + im^2 + eps)  (columns >= NB zeroed)
+ *   ttsc_stft_mag_backward   d(re|im) = dmag * (re|im) / mag
+ *   ttsc_log_clamp           y = scale * ln(max(x, minv))  (scale 1: natural log; 1/ln 10: log10);  _backward: dx = dy*scale/x above minv
+ *   ttsc_overlap_add         backward of the framing: y [B, Lp] += frames [B, F, n_fft] at hop (fixed summation order) */
+int ttsc_stft_mag(const float* reim_dev, int64_t M, int32_t NB, int32_t ldm, float eps, float* mag_dev, void* stream);
+int ttsc_stft_mag_backward(const float* dmag_dev, const float* reim_dev, const float* mag_dev, int64_t M, int32_t NB, int32_t ldm,
+                           float* dreim_dev, void* stream);
+int ttsc_log_clamp(const float* x_dev, int64_t n, float minv, float scale, float* y_dev, void* stream);
+int ttsc_log_clamp_backward(const float* dy_dev, const float* x_dev, int64_t n, float minv, float scale, float* dx_dev, void* stream);
+int ttsc_overlap_add(const float* frames_dev, int32_t B, int32_t F, int32_t n_fft, int32_t hop, int64_t Lp, float* y_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

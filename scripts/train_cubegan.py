@@ -6,7 +6,13 @@ backward passes of the GAN step (cube/networks/cubegan.py:153,170,174).
 Files (train_cubegan.py:38-91 of the reference): <base>.yaml {sample_rate, hop_size, conditioning}, <base>.encodings,
 <base>.best / <base>.last (Cubegan state_dict), <base>.opt.last {'0'..'3': optimizer state, 'global_step'}; --resume
 restores model AND optimizers (the reference's resume silently drops the optimizer state: attribute-name mismatch at
-train_cubegan.py:135 vs cubegan.py:304).  Data: `--synthetic N` (seeded synthetic examples, per-rank distinct)."""
+train_cubegan.py:135 vs cubegan.py:304).
+
+Data: `--train-folder` / `--dev-folder` hold the reference's processed corpus (<id>.json / .mgc / .pitch / .wav, read by
+io_utils.io_cubegan.CubeganDataset); every rank trains on its own slice `examples[rank::world]`.  `.best` is selected on the
+DEV-set mel-L1 (Cubegan.validation_step / validation_epoch_end, cubegan.py:191-273), as the reference does.  With
+`--synthetic N` the folders are ignored and N seeded synthetic examples per rank (+ N/4 for the dev set) are used instead —
+that must be asked for explicitly: a missing or empty folder is an error, never a silent fall-back."""
 import os
 import random
 import sys
@@ -20,21 +26,9 @@ import yaml
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ttscube_amd.distributed import FlatBucketReducer, broadcast_parameters  # noqa: E402
 from ttscube_amd.io_utils.io_cubegan import CubeganCollate, CubeganEncodings  # noqa: E402
+from ttscube_amd.io_utils.synthetic import synthetic_examples  # noqa: E402
 from ttscube_amd.networks import training as T  # noqa: E402
 from ttscube_amd.networks.cubegan import Cubegan  # noqa: E402
-
-
-def synthetic_examples(n, seed, nphones=40):
-    rng = np.random.RandomState(seed)
-    for _ in range(n):
-        nph = rng.randint(20, 60)
-        durs = rng.randint(2, 12, size=nph)
-        f2p = [p for p, d in enumerate(durs) for _ in range(d)]
-        F_ = len(f2p)
-        yield {'meta': {'phones': ['p%d' % v for v in rng.randint(0, nphones, size=nph)], 'speaker': 's%d' % rng.randint(0, 2),
-                        'frame2phon': f2p, 'phon2word': [0] * nph},
-               'mgc': np.clip(rng.randn(F_, 80) - 2, -5, 1), 'pitch': rng.randint(60, 300, size=F_).astype(np.float64),
-               'audio': (0.3 * np.sin(np.cumsum(rng.uniform(0.01, 0.3, size=F_ * 240)))).astype(np.float32)}
 
 
 def _train(params):
@@ -46,17 +40,31 @@ def _train(params):
     if world > 1:
         dist.init_process_group('nccl', device_id=dev)
     conditioning = params.lm if params.lm not in (None, 'none') else None
-    examples = list(synthetic_examples(params.synthetic or 32, 1234 + rank))   # rank-distinct data and crops
+    if params.synthetic:
+        examples = list(synthetic_examples(params.synthetic, 1234 + rank))          # rank-distinct data and crops
+        dev_examples = list(synthetic_examples(max(2, params.synthetic // 4), 4321))
+        enc_source = list(synthetic_examples(params.synthetic, 1234)) if world > 1 else examples
+    else:
+        from ttscube_amd.io_utils.io_cubegan import CubeganDataset
+        for folder in (params.train_folder, params.dev_folder):
+            if not os.path.isdir(folder):
+                raise SystemExit('%s does not exist (pass --synthetic N to train on synthetic examples)' % folder)
+        trainset, devset = CubeganDataset(params.train_folder), CubeganDataset(params.dev_folder)
+        if len(trainset) == 0 or len(devset) == 0:
+            raise SystemExit('no <id>.json/.mgc/.pitch/.wav items under %s / %s' % (params.train_folder, params.dev_folder))
+        examples = [trainset[i] for i in range(rank, len(trainset), world)]             # this rank's slice of the corpus
+        dev_examples = [devset[i] for i in range(len(devset))]
+        enc_source = [trainset[i] for i in range(len(trainset))] if not params.resume else []
     enc = CubeganEncodings()
     if params.resume:
         enc.load('{0}.encodings'.format(params.output_base))
     else:
-        enc.compute(list(synthetic_examples(params.synthetic or 32, 1234)) if world > 1 else examples)
+        enc.compute(enc_source)
     if rank == 0:
         yaml.dump({'sample_rate': params.sample_rate, 'hop_size': params.hop_size, 'conditioning': conditioning},
                   open('{0}.yaml'.format(params.output_base), 'w'))
         enc.save('{0}.encodings'.format(params.output_base))
-    model = Cubegan(enc, conditioning=conditioning, train=True)
+    model = Cubegan(enc, lr=params.lr, conditioning=conditioning, train=True)
     if params.resume:
         model.load('{0}.last'.format(params.output_base))
         st = torch.load('{0}.opt.last'.format(params.output_base), map_location='cpu')
@@ -70,22 +78,38 @@ def _train(params):
     collate = CubeganCollate(enc)
     crop_rng = random.Random(99 + rank)
     best = 9999.0
+    val_rng = random.Random(7)
     for epoch in range(params.epochs):
         mel_loss, nb = 0.0, 0
+        random.Random(1000 * epoch + rank).shuffle(examples)
         for s in range(0, len(examples), params.batch_size):
             out = T.cubegan_training_step(model, collate.collate_fn(examples[s:s + params.batch_size]), opts, reducers, rng=crop_rng)
             mel_loss += out['loss_mel']
             nb += 1
         if rank == 0:
-            v = mel_loss / max(nb, 1)
-            if v < best:
-                best = v
+            # validation (train_cubegan.py:38-76 + cubegan.py:191-273): mean dev-set mel-L1 -> _val_loss -> .best
+            model.eval()
+            vals = [T.cubegan_validation_step(model, collate.collate_fn(dev_examples[s:s + params.batch_size]), rng=val_rng)['loss_mel']
+                    for s in range(0, len(dev_examples), params.batch_size)]
+            model.train()
+            model._val_loss = sum(vals) / max(len(vals), 1)
+            if model._val_loss < best:
+                best = model._val_loss
                 model.save('{0}.best'.format(params.output_base))
             model.save('{0}.last'.format(params.output_base))
             od = {str(i): o.state_dict() for i, o in enumerate(opts)}
             od['global_step'] = model._global_step
             torch.save(od, '{0}.opt.last'.format(params.output_base))
-            sys.stdout.write('epoch %d  mel-L1 %.4f  step %d  lr %.3e\n' % (epoch, v, model._global_step, model._current_lr))
+            sys.stdout.write('epoch %d  train mel-L1 %.4f  val mel-L1 %.4f  step %d  lr %.3e\n' %
+                             (epoch, mel_loss / max(nb, 1), model._val_loss, model._global_step, model._current_lr))
+            if params.generate_epoch and epoch % params.generate_epoch == 0 and not params.synthetic:
+                from ttscube_amd.io_utils.runtime import cubegan_synthesize_dataset
+                model.eval()
+                cubegan_synthesize_dataset(model, output_path='generated_files/free/', devset_path=params.dev_folder, limit=-1,
+                                           conditioning=conditioning)
+                model.train()
+        if world > 1:
+            dist.barrier()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -106,5 +130,6 @@ if __name__ == '__main__':
     p.add_argument('--lm', dest='lm', default=None, help='external conditioning (none | fasttext:<lang> | hf:<model>); only none is built')
     p.add_argument('--resume', dest='resume', action='store_true')
     p.add_argument('--epochs', type=int, default=1)
-    p.add_argument('--synthetic', type=int, default=0, help='train on N synthetic examples per rank')
+    p.add_argument('--synthetic', type=int, default=0, help='ignore the folders and train on N seeded synthetic examples per rank')
+    p.add_argument('--generate-epoch', dest='generate_epoch', type=int, default=0, help='synthesise the dev set every N epochs (0 = never)')
     _train(p.parse_args())

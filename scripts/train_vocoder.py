@@ -7,10 +7,13 @@ Files written (train_vocoder.py:36-75 of the reference): <base>.yaml (num_layers
 layer_size_hr, upsample, sample_rate, output, sample_rate_low, hop_size), <base>.lr.best / <base>.hr.best (bare WaveRNN
 state_dicts), <base>.last (CubenetVocoder state_dict, prefixes _wavernn_hr. / _wavernn_lr.); --resume reloads <base>.last.
 
-Data: `--synthetic N` trains on N seeded synthetic items (no dataset/librosa in this image); otherwise `--train-folder`
-must contain the reference's cache files `<id>.mgc.npy / .audio.npy / .audio_low.npy` (cube/io_utils/io_vocoder.py:46-63)."""
-import glob
+Data: `--train-folder` / `--dev-folder` hold .wav files; io_utils.io_vocoder.VocoderDataset reads them exactly as the reference's
+(normalise to 0.98 peak, low-rate copy, log10-mel — computed on the GPU here —, `data/cache` files, random hop-aligned crops
+of `--maximum-segment-size` samples).  Every rank trains on its own slice `files[rank::world]`; `.lr.best` / `.hr.best` are
+selected on the dev-set losses (train_vocoder.py:36-59 of the reference).  `--synthetic N` ignores the folders and uses N seeded
+synthetic items per rank; it must be asked for explicitly — a missing or empty folder is an error."""
 import os
+import random
 import sys
 from argparse import ArgumentParser
 
@@ -22,37 +25,47 @@ import yaml
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ttscube_amd.distributed import FlatBucketReducer, broadcast_parameters  # noqa: E402
 from ttscube_amd.networks import training as T  # noqa: E402
+from ttscube_amd.io_utils.io_vocoder import VocoderCollate  # noqa: E402
 from ttscube_amd.networks.vocoder import CubenetVocoder  # noqa: E402
 
 
-def _items(params, rank):
+def _synthetic_items(params, n, seed):
+    rng = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        m = params.maximum_segment_size
+        x = (0.5 * np.sin(np.cumsum(rng.uniform(0.01, 0.2, size=m))) * rng.uniform(0.3, 1.0)).astype(np.float32)
+        out.append((x, x[::params.sample_rate // params.sample_rate_low].copy(),
+                    np.clip(rng.randn(m // params.hop_size + 1, 80) - 2, -5, 1).astype(np.float32)))
+    return out
+
+
+class _RankSlice:
+    """items rank, rank + world, ... of a dataset (data-parallel sharding of the file list)"""
+
+    def __init__(self, ds, rank, world):
+        self.ds, self.idx = ds, list(range(rank, len(ds), world))
+
+    def __len__(self):
+        return len(self.idx)
+
+    def __getitem__(self, i):
+        return self.ds[self.idx[i]]
+
+
+def _datasets(params, rank, world):
     if params.synthetic:
-        rng = np.random.RandomState(1234 + rank)
-        for _ in range(params.synthetic):
-            n = params.maximum_segment_size
-            x = (0.5 * np.sin(np.cumsum(rng.uniform(0.01, 0.2, size=n))) * rng.uniform(0.3, 1.0)).astype(np.float32)
-            yield {'x': x, 'x_low': x[::params.sample_rate // params.sample_rate_low].copy(),
-                   'mel': np.clip(rng.randn(n // params.hop_size + 1, 80) - 2, -5, 1).astype(np.float32)}
-        return
-    for f in sorted(glob.glob(os.path.join(params.train_folder, '*.mgc.npy'))):
-        base = f[:-len('.mgc.npy')]
-        yield {'x': np.load(base + '.audio.npy').astype(np.float32), 'x_low': np.load(base + '.audio_low.npy').astype(np.float32),
-               'mel': np.load(f).astype(np.float32)}
-
-
-def _collate(items):
-    """VocoderCollate (io_vocoder.py:85-112): zero-pad audio, pad mel with -5."""
-    L = max(i['x'].shape[0] for i in items)
-    Ll = max(i['x_low'].shape[0] for i in items)
-    F_ = max(i['mel'].shape[0] for i in items)
-    x = np.zeros((len(items), L), dtype=np.float32)
-    xl = np.zeros((len(items), Ll), dtype=np.float32)
-    mel = np.ones((len(items), F_, 80), dtype=np.float32) * -5
-    for k, i in enumerate(items):
-        x[k, :i['x'].shape[0]] = i['x']
-        xl[k, :i['x_low'].shape[0]] = i['x_low']
-        mel[k, :i['mel'].shape[0]] = i['mel']
-    return {'x': torch.from_numpy(x), 'x_low': torch.from_numpy(xl), 'mel': torch.from_numpy(mel)}
+        return _synthetic_items(params, params.synthetic, 1234 + rank), _synthetic_items(params, max(2, params.synthetic // 4), 4321)
+    from ttscube_amd.io_utils.io_vocoder import VocoderDataset
+    for folder in (params.train_folder, params.dev_folder):
+        if not os.path.isdir(folder):
+            raise SystemExit('%s does not exist (pass --synthetic N to train on synthetic items)' % folder)
+    kw = dict(target_sample_rate=params.sample_rate, lowres_sample_rate=params.sample_rate_low, hop_size=params.hop_size)
+    train = VocoderDataset(params.train_folder, max_segment_size=params.maximum_segment_size, random_start=True, **kw)
+    dev = VocoderDataset(params.dev_folder, max_segment_size=params.maximum_segment_size, random_start=False, **kw)
+    if len(train) == 0 or len(dev) == 0:
+        raise SystemExit('no usable .wav files under %s / %s' % (params.train_folder, params.dev_folder))
+    return _RankSlice(train, rank, world), dev
 
 
 def _train(params):
@@ -77,24 +90,41 @@ def _train(params):
     broadcast_parameters(model)
     opts = (torch.optim.Adam(model._wavernn_lr.parameters(), lr=params.lr), torch.optim.Adam(model._wavernn_hr.parameters(), lr=params.lr))
     reducers = (FlatBucketReducer(model._wavernn_lr.parameters()), FlatBucketReducer(model._wavernn_hr.parameters())) if world > 1 else None
-    items = list(_items(params, rank))
+    train, dev_items = _datasets(params, rank, world)
+    collate = VocoderCollate().collate_fn
     best = {'lr': 9999.0, 'hr': 9999.0}
     for epoch in range(params.epochs):
         tot = {'lr': 0.0, 'hr': 0.0}
         nb = 0
-        for s in range(0, len(items), params.batch_size):
-            out = T.vocoder_training_step(model, _collate(items[s:s + params.batch_size]), opts, reducers)
+        order = list(range(len(train)))
+        random.Random(1000 * epoch + rank).shuffle(order)
+        for s in range(0, len(order), params.batch_size):
+            out = T.vocoder_training_step(model, collate([train[i] for i in order[s:s + params.batch_size]]), opts, reducers)
             tot['lr'] += out['lr']
             tot['hr'] += out['hr']
             nb += 1
         if rank == 0:
+            # validation (WaveRNN.validation_step, modules.py:541-551): teacher-forced loss on the dev set, no gradient
+            val = {'lr': 0.0, 'hr': 0.0}
+            nv = 0
+            model.eval()
+            with torch.no_grad():
+                for s in range(0, len(dev_items), params.batch_size):
+                    b = {k: v.to(dev) for k, v in collate([dev_items[i] for i in range(s, min(s + params.batch_size, len(dev_items)))]).items()}
+                    val['hr'] += float(T.wavernn_loss(model._wavernn_hr, {'x': b['x'], 'x_low': b['x_low'], 'mel': b['mel']}))
+                    val['lr'] += float(T.wavernn_loss(model._wavernn_lr, {'x': b['x_low'], 'mel': b['mel']}))
+                    nv += 1
+            model.train()
             for k, net in (('lr', model._wavernn_lr), ('hr', model._wavernn_hr)):
-                v = tot[k] / max(nb, 1)
+                v = val[k] / max(nv, 1)
                 if v < best[k]:
                     best[k] = v
                     net.save('{0}.{1}.best'.format(params.output_base, k))
             model.save('{0}.last'.format(params.output_base))
-            sys.stdout.write('epoch %d  loss_lr %.4f  loss_hr %.4f\n' % (epoch, tot['lr'] / max(nb, 1), tot['hr'] / max(nb, 1)))
+            sys.stdout.write('epoch %d  train lr %.4f hr %.4f   val lr %.4f hr %.4f\n' % (epoch, tot['lr'] / max(nb, 1), tot['hr'] / max(nb, 1),
+                                                                                          val['lr'] / max(nv, 1), val['hr'] / max(nv, 1)))
+        if world > 1:
+            dist.barrier()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -108,8 +138,8 @@ if __name__ == '__main__':
     p.add_argument('--maximum-segment-size', dest='maximum_segment_size', type=int, default=24000)
     p.add_argument('--accelerator', dest='accelerator', default='gpu')
     p.add_argument('--devices', dest='devices', default=1, type=int)
-    p.add_argument('--train-folder', dest='train_folder', default='data/cache/train')
-    p.add_argument('--dev-folder', dest='dev_folder', default='data/cache/dev')
+    p.add_argument('--train-folder', dest='train_folder', default='data/processed/train')
+    p.add_argument('--dev-folder', dest='dev_folder', default='data/processed/dev')
     p.add_argument('--sample-rate', dest='sample_rate', type=int, default=24000)
     p.add_argument('--sample-rate-low', dest='sample_rate_low', type=int, default=2400)
     p.add_argument('--layer-size-hr', dest='layer_size_hr', default=512, type=int)
@@ -119,8 +149,8 @@ if __name__ == '__main__':
     p.add_argument('--hop-size', dest='hop_size', type=int, default=240)
     p.add_argument('--upsample', dest='upsample', default=240, type=int)
     p.add_argument('--lr', dest='lr', default=1e-4, type=float)
-    p.add_argument('--output', dest='output', default='mulaw', help='mulaw|raw (the HIP sampler implements the discrete outputs)')
+    p.add_argument('--output', dest='output', default='mol', help='mol|gm|beta|mulaw|raw (cube/networks/loss.py)')
     p.add_argument('--resume', dest='resume', action='store_true')
     p.add_argument('--epochs', type=int, default=1)
-    p.add_argument('--synthetic', type=int, default=0, help='train on N synthetic items per rank')
+    p.add_argument('--synthetic', type=int, default=0, help='ignore the folders and train on N seeded synthetic items per rank')
     _train(p.parse_args())

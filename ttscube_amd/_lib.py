@@ -130,6 +130,11 @@ SIGNATURES = {
                                        C.c_void_p]),
     'ttsc_expand_rows': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_void_p, C.c_void_p]),
+    'ttsc_stft_mag': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    'ttsc_stft_mag_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    'ttsc_log_clamp': (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    'ttsc_log_clamp_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    'ttsc_overlap_add': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     'ttsc_device_free': (None, [C.c_void_p]),
     'ttsc_melar_create': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     'ttsc_melar_set_weights': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 11),

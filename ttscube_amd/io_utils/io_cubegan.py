@@ -1,11 +1,64 @@
-"""Mirror of cube/io_utils/io_cubegan.py:112-231: ``CubeganEncodings`` (same JSON file format) and
-``CubeganCollate.collate_fn`` (same batch-dict keys, dtypes and padding values — SURVEY.md §8b).  Dataset reading
-(librosa) is outside the hot path; external text conditioning (fastText / HF encoders) needs downloads and is not
+"""Mirror of cube/io_utils/io_cubegan.py: ``CubeganDataset`` (:20-110, the processed-corpus reader: <id>.json / .mgc / .pitch /
+.wav), ``CubeganEncodings`` (:112-160, same JSON file format) and ``CubeganCollate.collate_fn`` (:162-231, same batch-dict keys,
+dtypes and padding values — SURVEY.md §8b).  External text conditioning (fastText / HF encoders) needs downloads and is not
 available here — pass pre-computed ``x_words`` instead."""
 import json
+import os
 
 import numpy as np
 import torch
+
+from .audio import load_wav
+
+
+class CubeganDataset:
+    """cube/io_utils/io_cubegan.py:20-110.  `base_path` holds, per utterance id, `<id>.json` (phones, frame2phon, speaker,
+    left/right context ...), `<id>.mgc` and `<id>.pitch` (bare np.save streams) and `<id>.wav`.  Utterances with a phone longer
+    than 400 frames are dropped (:41-45); `__getitem__` silences the frames aligned to the first / last phone (:80-90)."""
+
+    def __init__(self, base_path, hf_model=None):
+        if hf_model is not None:
+            raise NotImplementedError('hf:<model> conditioning needs a downloaded tokenizer; this build supports conditioning=None')
+        self._base_path = base_path
+        self._examples = []
+        for f in sorted(os.listdir(base_path)):
+            if not f.endswith('.mgc'):
+                continue
+            bpath = os.path.join(base_path, f[:-4])
+            if not (os.path.exists(bpath + '.json') and os.path.exists(bpath + '.pitch')):
+                continue
+            example = json.load(open(bpath + '.json'))
+            durs = np.zeros((len(example['phones'])))
+            for index in example['frame2phon']:
+                durs[index] += 1
+            if durs.size == 0 or max(durs) > 400:
+                continue
+            example.setdefault('id', f[:-4])
+            example['words_left'] = str(example.get('left_context', '')).split()     # (the reference's SimpleTokenizer is a front-end
+            example['words_right'] = str(example.get('right_context', '')).split()   #  component; unused with conditioning=None)
+            self._examples.append(example)
+
+    def __len__(self):
+        return len(self._examples)
+
+    @staticmethod
+    def _make_absolute_silence(audio, pitch, meta):
+        max_phone = max(meta['frame2phon'])
+        for i_frame, ph in enumerate(meta['frame2phon']):
+            if ph == 0 or ph == max_phone:
+                audio[i_frame * 240:i_frame * 240 + 240] = 0
+                if i_frame < len(pitch):
+                    pitch[i_frame] = 0
+        return audio, pitch
+
+    def __getitem__(self, item):
+        description = self._examples[item]
+        base_fn = os.path.join(self._base_path, description['id'])
+        mgc = np.load(open(base_fn + '.mgc', 'rb'))
+        pitch = np.array(np.load(open(base_fn + '.pitch', 'rb')), dtype=np.float64)
+        audio, _ = load_wav(base_fn + '.wav', 24000)
+        audio, pitch = self._make_absolute_silence(np.array(audio), pitch, description)
+        return {'meta': description, 'mgc': mgc, 'pitch': pitch, 'audio': audio}
 
 
 class CubeganEncodings:

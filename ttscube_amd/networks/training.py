@@ -169,7 +169,8 @@ def cubegan_configure_optimizers(model):
 def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
     """Cubegan.training_step (cubegan.py:85-189): discriminator step, generator step (adv + feature + 45 x mel-L1),
     text step (duration CE + pitch/vuv L1); one gradient exchange per backward pass (reducers = (g, d, t))."""
-    from ..hifigan.discriminators import discriminator_loss, feature_loss, generator_loss, mel_spectrogram
+    from ..hifigan.discriminators import discriminator_loss, feature_loss, generator_loss
+    from ..io_utils.melspec import mel_spectrogram   # DFT / mel GEMMs + element-wise kernels on HIP, forward and backward
     opt_g, opt_d, opt_t, opt_b = optimizers
     rng = rng or random
     dev = model.get_device()
@@ -246,6 +247,47 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
         o.param_groups[0]['lr'] = model._current_lr
     return {'loss_g': float(loss_gen_all.detach()), 'loss_t': float(loss_text.detach()), 'loss_d': float(loss_disc_all.detach()),
             'loss_mel': float(loss_mel.detach()) / 45, 'lr': model._current_lr}
+
+
+def cubegan_validation_step(model, batch, rng=None):
+    """Cubegan.validation_step (cubegan.py:191-273) on the inference kernels (no autograd): teacher-forced Languasito2 with the
+    dev item's own alignments and pitch, a 200-frame / 48 000-sample crop per item, generator forward, mel-L1.  Returns
+    loss_mel — the quantity `validation_epoch_end` averages into `_val_loss`, i.e. what `.best` is selected on
+    (train_cubegan.py:38-76) — plus the duration / pitch losses.  (The adversarial terms of the reference's validation dict are
+    logged, never selected on; they are not evaluated here.)"""
+    from ..io_utils.melspec import mel_spectrogram
+    rng = rng or random
+    dev = model.get_device()
+    lang = model._languasito
+    with torch.no_grad():
+        p_dur, p_pitch, p_vuv, conditioning = languasito_forward(lang, batch)
+        t_dur = batch['y_dur'].to(dev)
+        t_pitch = batch['y_pitch'].to(dev).float()
+        t_vuv = (t_pitch > 1).float()
+        m = min(t_dur.shape[1], p_dur.shape[1])
+        t_dur, p_dur = t_dur[:, :m], p_dur[:, :m, :]
+        m = min(t_pitch.shape[1], p_pitch.shape[1])
+        t_pitch, p_pitch, t_vuv, p_vuv = t_pitch[:, :m], p_pitch[:, :m], t_vuv[:, :m], p_vuv[:, :m]
+        ignore = int(max(model._encodings.max_pitch, model._encodings.max_duration) + 1)
+        loss_duration = F.cross_entropy(p_dur.reshape(-1, p_dur.shape[2]), t_dur.reshape(-1), ignore_index=ignore)
+        loss_pitch = (torch.abs(t_pitch / lang._max_pitch - p_pitch) * t_vuv).mean() + torch.abs(t_vuv - p_vuv).mean()
+        y = batch['y_audio'].to(dev)
+        if y.shape[1] > 48000 - 240:
+            ys, cs = [], []
+            for ii in range(y.shape[0]):
+                max_frame = len(batch['y_frame2phone'][ii])
+                r = rng.randint(0, max_frame - 200 - 1) if max_frame > 201 else 0
+                cs.append(conditioning[ii, r:r + 200, :].unsqueeze(0))
+                ys.append(y[ii, r * 240:r * 240 + 48000].unsqueeze(0))
+            m = min(c.shape[1] for c in cs)
+            conditioning = torch.cat([c[:, :m] for c in cs], dim=0)
+            y = torch.cat([v[:, :m * 240] for v in ys], dim=0)
+        y_g_hat = model._generator(conditioning.permute(0, 2, 1).contiguous())
+        m = min(y.shape[1], y_g_hat.shape[2])
+        y_mel = mel_spectrogram(y[:, :m], 1024, 80, 24000, 240, 1024, 0, 12000)
+        y_g_hat_mel = mel_spectrogram(y_g_hat[:, 0, :m], 1024, 80, 24000, 240, 1024, 0, 12000)
+        loss_mel = F.l1_loss(y_mel, y_g_hat_mel)
+    return {'loss_mel': float(loss_mel), 'loss_t': float(loss_pitch + loss_duration)}
 
 
 def wavernn_logits_train(net, X):
