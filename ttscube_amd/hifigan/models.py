@@ -206,7 +206,9 @@ class Generator(nn.Module):
         y[b, 0, :out_len(frames[b])] equals that utterance run alone (ragged batching; not in the reference, B=1)."""
         if not x.is_cuda:
             raise _lib.TTSCError('Generator.forward: input must live on a HIP device (got %s); no CPU path' % x.device)
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        # differentiable path only when a gradient is actually wanted: the input carries one, or the module is in training mode.
+        # (An eval-mode call made without no_grad() must run the same kernels and precision as inference — ADVICE r1.)
+        if torch.is_grad_enabled() and (x.requires_grad or (self.training and any(p.requires_grad for p in self.parameters()))):
             from .autograd import generator_forward_with_grad
             return generator_forward_with_grad(self, x)
         return self._forward_hip(x, frames)

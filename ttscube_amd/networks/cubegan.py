@@ -55,7 +55,7 @@ class Cubegan(nn.Module):
         """cubegan.py:74-83: text -> conditioning (predicted durations/pitch) -> waveform [B,1,L] in (-1,1).
         With a padded batch (B>1, new capability) `return_lengths=True` also returns each utterance's sample count."""
         with torch.no_grad():
-            cond, _, flens = self._languasito.inference(X, return_aux=True)
+            cond, _, flens = self._languasito.inference(X, return_aux=True, check_status=False)
             if cond.shape[1] == 0:
                 cond = torch.zeros((cond.shape[0], 1, cond.shape[2]), device=self.get_device())
                 flens = [1] * cond.shape[0]

@@ -479,7 +479,7 @@ class Languasito2(nn.Module):
             h = torch.cat([h, sel], dim=-1)
         return h.contiguous()
 
-    def inference(self, X, hf_cond=None, return_aux=False):
+    def inference(self, X, hf_cond=None, return_aux=False, check_status=True):
         """modules.py:1001-1009.  X: 'x_char' long [B,N] (0 = pad), 'x_speaker' long [B,1].  Returns conditioning [B,F,80]
         (zero rows beyond each utterance's own frame count); X['y_frame2phone'] / X['y_pitch'] are (re)written like
         the reference does."""
@@ -515,6 +515,8 @@ class Languasito2(nn.Module):
             if B > 1:
                 fmask = (torch.arange(F_, device=dev)[None, :] < torch.as_tensor(flens, device=dev)[:, None]).float()
                 cond = cond * fmask[:, :, None]
+        if check_status:   # (Cubegan.inference polls once for the whole synthesis instead)
+            _lib.check_split_status('Languasito2.inference')
         return (cond, f2p.durations(), flens) if return_aux else cond
 
     @torch.jit.ignore

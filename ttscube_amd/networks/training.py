@@ -32,6 +32,7 @@ def languasito_forward(lang, X):
         g = torch.cat([g[:, :m], pitch[:, :m]], dim=-1).contiguous()
         g = lang._lstm('_cond_rnn')(g, lengths=[min(f, m) for f in flens] if B > 1 else None)
         cond = linear_hip(g, lang._cond_output.linear_layer.weight, lang._cond_output.linear_layer.bias)
+    _lib.check_split_status('languasito_forward')   # a timed-out split recurrence must not return garbage silently
     return out_dur, op[:, :, 0], op[:, :, 1], cond
 
 
@@ -43,6 +44,7 @@ def wavernn_loss(net, X):
     Xt['x'] = xin.to(net._get_device())
     logits = net._train_forward(Xt)
     L = logits.shape[1]
+    _lib.check_split_status('wavernn_loss')
     return net._output_functions.loss(logits, gs[:, :L].to(logits.device))
 
 
@@ -105,6 +107,9 @@ def generator_forward_train(gen, x):
 
 def languasito_forward_train(lang, X):
     """Differentiable Languasito2.forward (modules.py:996-999): (output_dur, output_pitch, output_vuv, conditioning)."""
+    if getattr(lang, '_use_cond', False):
+        raise NotImplementedError("training with external conditioning ('fasttext:..' / 'hf:..') is not built: the encoders cannot be "
+                                  "downloaded here and the conditioning branch (modules.py:963-990) is inference-only; use conditioning=None")
     dev = lang._get_device()
     x_char, x_speaker = X['x_char'].to(dev), X['x_speaker'].to(dev)
 
