@@ -264,7 +264,8 @@ void ttsc_wavernn_destroy(ttsc_wavernn* w);
  * Linear (fp32 MFMA NT GEMM): y[M, :N] = act(x[M, :K] . w[N,K]^T + bias) [+ y if accumulate].
  * Replaces torch.nn.Linear inside LinearNorm (cube/networks/modules.py:24-34) for _dur_output, _pitch_output,
  * _cond_output, _mel_output, PreNet, and carries the hoisted LSTM input projections.  All pointers are device
- * pointers (the weight is whatever torch holds: [out, in] row-major).
+ * pointers (the weight is whatever torch holds: [out, in] row-major).  ldx is a row stride only: 0 < ldx < K reads
+ * overlapping rows (STFT framing, io_utils/melspec.py); ldy >= N.
  * ------------------------------------------------------------------------------------------------ */
 int ttsc_linear_forward(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int64_t M, int32_t N,
                         int32_t K, int64_t ldx, int64_t ldy, int32_t act, int32_t accumulate, void* stream);

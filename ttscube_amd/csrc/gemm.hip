@@ -116,11 +116,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 
 using namespace ttsc;
 
-// x_dev [M, ldx] (first K columns used), w_dev [N, K], bias_dev [N] or NULL -> y_dev [M, ldy] (first N columns written)
+// x_dev [M, ldx] (first K columns used), w_dev [N, K], bias_dev [N] or NULL -> y_dev [M, ldy] (first N columns written).
+// ldx is only a row stride: 0 < ldx < K reads OVERLAPPING rows (row m = x_dev[m*ldx .. m*ldx+K)), which is how the
+// STFT frames a signal without materialising the frames (io_utils/melspec.py: ldx = hop, K = n_fft).
 extern "C" int ttsc_linear_forward(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int64_t M,
                                    int32_t N, int32_t K, int64_t ldx, int64_t ldy, int32_t act, int32_t accumulate, void* stream) {
     TTSC_REQUIRE(x_dev && w_dev && y_dev, "ttsc_linear_forward: null argument");
-    TTSC_REQUIRE(M > 0 && N > 0 && K > 0 && ldx >= K && ldy >= N, "ttsc_linear_forward: bad shape M=%lld N=%d K=%d ldx=%lld ldy=%lld",
+    TTSC_REQUIRE(M > 0 && N > 0 && K > 0 && ldx > 0 && ldy >= N, "ttsc_linear_forward: bad shape M=%lld N=%d K=%d ldx=%lld ldy=%lld",
                  (long long)M, N, K, (long long)ldx, (long long)ldy);
     TTSC_REQUIRE(M < (1ll << 31) && ldx < (1ll << 31) && ldy < (1ll << 31), "ttsc_linear_forward: dimension too large");
     GemmArgs a{x_dev, w_dev, bias_dev, y_dev, (int)M, N, K, (int)ldx, (int)ldy, act, accumulate};
