@@ -19,7 +19,11 @@ def main():
     ap.add_argument('--frames', type=int, default=10)
     ap.add_argument('--layers', type=int, default=1)
     ap.add_argument('--H', type=int, default=512)
+    ap.add_argument('--ablate', action='store_true', help='load the measurement build (make -C ttscube_amd/csrc ablate); with TTSC_WQ_PROF=1 the tile kernel prints its per-phase times')
     a = ap.parse_args()
+    if a.ablate:
+        from ttscube_amd import _lib
+        _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), 'libttscube_hip_ablate.so')
     for lowres in (True, False):
         up = 240 if lowres else 24
         sd = O.synthetic_state_dict(H=a.H, num_layers=a.layers, use_lowres=lowres, seed=1)

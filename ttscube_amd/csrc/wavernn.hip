@@ -495,6 +495,7 @@ struct ttsc_wavernn {
     float *q_whh = nullptr, *q_wih = nullptr, *q_bih = nullptr, *q_bhh = nullptr, *q_wpre = nullptr, *q_bpre = nullptr, *q_wout = nullptr,
           *q_bout = nullptr;   // quad kernel (wavernn_quad.hip): 4 row slices of every matrix
     bool quad_dirty = true;
+    int quad_nc_packed = 0;
     int last_kind = 0;         // 0 streaming kernel, 2 quad kernel
     unsigned* last_abort_word = nullptr;   // device word set by the quad kernel when a hand-off timed out
     std::vector<std::string> have;
@@ -641,31 +642,44 @@ extern "C" int ttsc_wavernn_set_weight(ttsc_wavernn* w, const char* name, const 
     return rc;
 }
 
-// ---- quad path (wavernn_quad.hip): 4 workgroups step 4 utterances, each streaming a quarter of the rows -------------
+// ---- tile path (wavernn_quad.hip): NC workgroups step NC utterances, each streaming 1/NC of the rows -------------
+static int quad_nc() {
+    // members (= utterances) per tile: 4 or 8.  env TTSC_WR_QUAD_NC overrides.
+    if (const char* ev = getenv("TTSC_WR_QUAD_NC")) {
+        const int v = atoi(ev);
+        if (v == 4 || v == 8) return v;
+    }
+    return 4;
+}
+
 static bool quad_supported(const ttsc_wavernn* w, int B) {
     const auto& c = w->cfg;
-    // Measured on MI355X (H = 512, 1 layer): 41 us/step at any batch, against 36 us (small batches) .. 45 us (B = 256) for the
-    // streaming kernel, whose workgroups all pull the same 3.8 MB through L2 every step.  So: default for large batches
+    // Measured on MI355X (H = 512, 1 layer, B = 256): see DESIGN.md; the streaming kernel, whose workgroups all pull the same
+    // 3.8 MB through L2 every step, takes 36 us (small batches) .. 45 us (B = 256).  So: default for large batches
     // (B >= 192) of one-layer networks; env TTSC_WR_QUAD=1 / 0 forces it on (whenever eligible) / off.  Bit-exact either way.
     const char* evq = getenv("TTSC_WR_QUAD");
     if (evq ? atoi(evq) == 0 : B < 192) return false;
-    if (c.num_layers != 1 || c.H % (4 * WQ_NC) != 0 || c.H > 512 || c.S % WQ_NC != 0 || c.S > 256) return false;
-    const int G = (int)ceil_div(B, WQ_BU);
+    const int NC = quad_nc();
+    if (c.out_kind != TTSC_WR_OUT_MULAW && c.out_kind != TTSC_WR_OUT_RAW) return false;   // discrete heads only
+    if (c.num_layers != 1 || c.H % (4 * NC) != 0 || c.H > 512 || c.S % NC != 0 || c.S > 256) return false;
+    if ((c.H / NC) * NC > WQ_THREADS) return false;
+    const int G = (int)ceil_div(B, NC);
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-    return G * WQ_NC <= cus;   // every member must be resident, otherwise the exchange cannot complete
+    return G * NC <= cus;   // every member must be resident, otherwise the exchange cannot complete
 }
 
 static size_t quad_exchange_bytes(const ttsc_wavernn* w, int B) {
-    const int G = (int)ceil_div(B, WQ_BU);
+    const int BU = 8;   // sized for the larger tile
+    const int G = (int)ceil_div(B, 4);
     const auto& c = w->cfg;
-    const size_t per = ((size_t)2 * WQ_BU * c.H + (size_t)2 * WQ_BU * 256 + (size_t)2 * WQ_BU * c.S + 2 * WQ_BU) * sizeof(float);
+    const size_t per = ((size_t)2 * BU * c.H + (size_t)2 * BU * 256 + (size_t)2 * BU * c.S + 2 * BU) * sizeof(float);
     return (size_t)G * per + ((size_t)G * 4 + 64) * sizeof(unsigned) + 256;
 }
 
 static int quad_pack(ttsc_wavernn* w) {
     const auto& c = w->cfg;
-    const int NC = WQ_NC, H = c.H, UPW = H / NC, R3 = 3 * UPW, I0 = w->in0, I0P = (int)round_up(I0, 4), S = c.S, SR = S / NC, PR = 256 / NC;
+    const int NC = quad_nc(), H = c.H, UPW = H / NC, R3 = 3 * UPW, I0 = w->in0, I0P = (int)round_up(I0, 4), S = c.S, SR = S / NC, PR = 256 / NC;
     std::vector<float> whh((size_t)NC * H * R3, 0.f), wih((size_t)NC * I0P * R3, 0.f), bih((size_t)NC * R3), bhh((size_t)NC * R3);
     std::vector<float> wpre((size_t)NC * H * PR), bpre((size_t)NC * PR), wout((size_t)NC * 256 * SR), bout((size_t)NC * SR);
     for (int m = 0; m < NC; ++m) {
@@ -698,6 +712,7 @@ static int quad_pack(ttsc_wavernn* w) {
     if ((rc = upload(&w->q_wout, wout.data(), wout.size()))) return rc;
     if ((rc = upload(&w->q_bout, bout.data(), bout.size()))) return rc;
     w->quad_dirty = false;
+    w->quad_nc_packed = NC;
     return TTSC_OK;
 }
 
@@ -798,7 +813,8 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
     a.seed = seed;
     TTSC_REQUIRE(a.L > 0, "ttsc_wavernn_decode: nothing to decode (L=%d)", a.L);
     if (quad_supported(w, B)) {
-        if (w->quad_dirty) {
+        const int NC = quad_nc(), BU = NC;
+        if (w->quad_dirty || w->quad_nc_packed != NC) {
             int prc = quad_pack(w);
             if (prc) return prc;
         }
@@ -807,7 +823,7 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
             set_error("ttsc_wavernn_decode: workspace %zu < required %zu bytes", ws_bytes, need_all);
             return TTSC_ENOMEM;
         }
-        const int G = (int)ceil_div(B, WQ_BU);
+        const int G = (int)ceil_div(B, BU);
         char* xbase = (char*)ws + cond_bytes(w, B, Tl);
         WqArgs qa;
         memset(&qa, 0, sizeof(qa));
@@ -816,22 +832,55 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
         qa.wpre = w->q_wpre; qa.bpre = w->q_bpre; qa.wout = w->q_wout; qa.bout = w->q_bout;
         qa.lut = w->lut; qa.noise = noise; qa.forced_x = forced_x; qa.out_idx = idx; qa.out_wav = wav; qa.out_logits = logits;
         float* f = (float*)xbase;
-        qa.xh = f; f += (size_t)G * 2 * WQ_BU * c.H;
-        qa.xpre = f; f += (size_t)G * 2 * WQ_BU * 256;
-        qa.xlog = f; f += (size_t)G * 2 * WQ_BU * c.S;
-        qa.xlx = f; f += (size_t)G * 2 * WQ_BU;
+        qa.xh = f; f += (size_t)G * 2 * BU * c.H;
+        qa.xpre = f; f += (size_t)G * 2 * BU * 256;
+        qa.xlog = f; f += (size_t)G * 2 * BU * c.S;
+        qa.xlx = f; f += (size_t)G * 2 * BU;
         qa.cnt = (unsigned*)f;
-        qa.B = B; qa.T = (int)T; qa.Tl = (int)Tl; qa.H = c.H; qa.UPW = c.H / WQ_NC; qa.I0 = w->in0; qa.I0P = (int)round_up(w->in0, 4);
-        qa.use_lowres = c.use_lowres; qa.up = c.upsample; qa.up_low = c.upsample_low; qa.S = c.S; qa.SR = c.S / WQ_NC; qa.PR = 256 / WQ_NC;
+        qa.B = B; qa.T = (int)T; qa.Tl = (int)Tl; qa.H = c.H; qa.UPW = c.H / NC; qa.I0 = w->in0; qa.I0P = (int)round_up(w->in0, 4);
+        qa.use_lowres = c.use_lowres; qa.up = c.upsample; qa.up_low = c.upsample_low; qa.S = c.S; qa.SR = c.S / NC; qa.PR = 256 / NC;
         qa.n_mel = c.n_mel; qa.out_kind = c.out_kind; qa.mode = mode; qa.L = a.L; qa.G = G; qa.seed = seed;
+        qa.GP = (int)round_up(G, WQ_XCDS);
         TTSC_HIP_CHECK(hipMemsetAsync(qa.cnt, 0, ((size_t)G * 4 + 64) * sizeof(unsigned), s));
-        const size_t lds = ((size_t)WQ_BU * (c.H > 256 ? c.H : 256) + c.S + 64) * sizeof(float);
-        hipLaunchKernelGGL(wr_quad_kernel, dim3(G * WQ_NC), dim3(WQ_THREADS), lds, s, qa);
+        const size_t lds = ((size_t)BU * (c.H + 4) + (size_t)BU * 260 + (size_t)3 * (c.H / NC) * BU + c.S + 64) * sizeof(float);
+#ifdef TTSC_ABLATE
+        unsigned long long* prof_dev = nullptr;
+        if (getenv("TTSC_WQ_PROF")) {
+            TTSC_HIP_CHECK(hipMalloc((void**)&prof_dev, (size_t)qa.GP * NC * 16 * sizeof(unsigned long long)));
+            TTSC_HIP_CHECK(hipMemsetAsync(prof_dev, 0, (size_t)qa.GP * NC * 16 * sizeof(unsigned long long), s));
+            qa.prof = prof_dev;
+        }
+#endif
+        if (NC == 4)
+            hipLaunchKernelGGL((wr_quad_kernel<4, 1>), dim3(qa.GP * NC), dim3(WQ_THREADS), lds, s, qa);
+        else
+            hipLaunchKernelGGL((wr_quad_kernel<8, 2>), dim3(qa.GP * NC), dim3(WQ_THREADS), lds, s, qa);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             set_error("wr_quad_kernel launch failed: %s", hipGetErrorString(e));
             return TTSC_EHIP;
         }
+#ifdef TTSC_ABLATE
+        if (prof_dev) {   // per-phase time of the tile kernel: mean over workgroups, microseconds per step
+            TTSC_HIP_CHECK(hipStreamSynchronize(s));
+            std::vector<unsigned long long> hp((size_t)qa.GP * NC * 16);
+            TTSC_HIP_CHECK(hipMemcpy(hp.data(), prof_dev, hp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            hipFree(prof_dev);
+            static const char* nm[12] = {"ih-prefix", "hh-chain", "wait-lastx", "gate+publish-h", "wait-h", "stage-h", "pre+publish", "wait-pre",
+                                         "stage-pre", "out+publish", "wait-logits", "sample+publish"};
+            double tot = 0;
+            for (int i = 0; i < 12; ++i) {
+                double sum = 0;
+                int n = 0;
+                for (size_t wg = 0; wg < (size_t)qa.GP * NC; ++wg)
+                    if (hp[wg * 16 + 1]) { sum += (double)hp[wg * 16 + i]; ++n; }
+                const double us = n ? sum / n / 100.0 / qa.L : 0.0;
+                tot += us;
+                fprintf(stderr, "wq-prof %-16s %7.2f us/step\n", nm[i], us);
+            }
+            fprintf(stderr, "wq-prof %-16s %7.2f us/step (NC=%d, B=%d, L=%d)\n", "total", tot, NC, B, qa.L);
+        }
+#endif
         w->last_abort_word = qa.cnt + (size_t)G * 4;
         w->last_kind = 2;
         return TTSC_OK;
