@@ -12,11 +12,14 @@ pytestmark = pytest.mark.gpu
 
 
 
-@pytest.fixture(params=['quad', 'stream'], autouse=True)
+@pytest.fixture(params=['tile', 'stream'], autouse=True)
 def wr_kernel(request, monkeypatch):
-    """Every test runs twice: with the multi-workgroup quad kernel forced on (one-layer nets; the default at B >= 192) and
-    with the single-workgroup streaming kernel — both must be bit-exact."""
-    monkeypatch.setenv('TTSC_WR_QUAD', '1' if request.param == 'quad' else '0')
+    """Every test runs twice: with the multi-workgroup tile kernel allowed (its default: one-layer nets with a discrete head,
+    B <= 256) and with the single-workgroup streaming kernel forced (TTSC_WR_TILE=0) — both must be bit-exact."""
+    if request.param == 'tile':
+        monkeypatch.delenv('TTSC_WR_TILE', raising=False)
+    else:
+        monkeypatch.setenv('TTSC_WR_TILE', '0')
     return request.param
 
 
@@ -76,7 +79,7 @@ def test_matches_oracle_bit_exact(H, N, lowres, B, T, mode, wr_kernel):
     ridx, rwav, rlog = O.decode(sd, mel, x_low if lowres else None, num_layers=N, H=H, use_lowres=lowres, upsample=up,
                                 mode=omode, noise=noise, seed=0xC0FFEE12345, want_logits=True)
     idx, wav, logits = net.decode(X, mode=mode, noise=noise, seed=0xC0FFEE12345, want_logits=True)
-    assert net.last_kernel == ('quad' if (wr_kernel == 'quad' and N == 1) else 'stream')
+    assert net.last_kernel == ('tile' if (wr_kernel == 'tile' and N == 1 and B <= 256) else 'stream')
     assert np.array_equal(idx.cpu().numpy(), ridx), 'first index mismatch at %s' % (np.argwhere(idx.cpu().numpy() != ridx)[:3],)
     assert np.array_equal(wav.cpu().numpy(), rwav)
     assert np.array_equal(logits.cpu().numpy(), rlog)  # logits themselves are bit-exact
@@ -87,7 +90,7 @@ def test_matches_oracle_bit_exact(H, N, lowres, B, T, mode, wr_kernel):
 def test_utterance_tiles_bit_exact(bt, B, H, N, mode, monkeypatch, wr_kernel):
     """wr_decode_kernel<2/4/8> (several utterances per workgroup sharing one weight stream): forced through TTSC_WR_BT with a
     batch that is NOT a multiple of the tile, and selected by the dispatcher itself at B=300 (BT=2) / B=600 (BT=4)."""
-    if wr_kernel == 'quad':
+    if wr_kernel == 'tile':
         pytest.skip('the utterance-tile template belongs to the streaming kernel')
     if bt:
         monkeypatch.setenv('TTSC_WR_BT', str(bt))
@@ -189,7 +192,7 @@ def test_continuous_outputs_match_reference_and_oracle(golden_dir, name, wr_kern
     """mol / gm / beta in the persistent kernel: with the reference's own random terms injected the samples follow the
     reference run to 1e-5 (mixture index identical at every step) and equal the C oracle BIT FOR BIT (one shared arithmetic
     definition) in noise, Philox and arg-max mode; teacher-forced outputs vs the reference's _train_forward <= 1e-4."""
-    if wr_kernel == 'quad':
+    if wr_kernel == 'tile':
         pytest.skip('continuous outputs run on the streaming kernel')
     z = np.load(os.path.join(golden_dir, name + '.npz'))
     net, sd, X, kw = _cont_net(z)
@@ -234,11 +237,12 @@ def test_reference_default_constructor_decodes():
 
 
 def test_default_kernel_choice_by_batch(monkeypatch):
-    """no env override: the quad kernel takes one-layer networks at B >= 192 (every member resident), the streaming kernel the rest"""
-    monkeypatch.delenv('TTSC_WR_QUAD', raising=False)
+    """no env override: the tile kernel takes one-layer networks with a discrete head while every member can be resident (B <= 256),
+    a partial last tile included; the streaming kernel takes the rest"""
+    monkeypatch.delenv('TTSC_WR_TILE', raising=False)
     sd = O.synthetic_state_dict(H=64, num_layers=1, use_lowres=True, seed=77)
     net = _net(64, 1, True, sd)
-    for B, want in ((8, 'stream'), (200, 'quad')):
+    for B, want in ((3, 'tile'), (200, 'tile'), (300, 'stream')):
         mel, x_low = O.synthetic_inputs(B, 1, seed=B)
         idx, _, _ = net.decode({'mel': torch.from_numpy(mel), 'x_low': torch.from_numpy(x_low)}, mode='philox', seed=9)
         assert net.last_kernel == want

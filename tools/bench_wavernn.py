@@ -19,7 +19,7 @@ def main():
     ap.add_argument('--frames', type=int, default=10)
     ap.add_argument('--layers', type=int, default=1)
     ap.add_argument('--H', type=int, default=512)
-    ap.add_argument('--ablate', action='store_true', help='load the measurement build (make -C ttscube_amd/csrc ablate); with TTSC_WQ_PROF=1 the tile kernel prints its per-phase times')
+    ap.add_argument('--ablate', action='store_true', help='load the measurement build (make -C ttscube_amd/csrc ablate); with TTSC_WT_PROF=1 the tile kernel prints its per-phase times')
     a = ap.parse_args()
     if a.ablate:
         from ttscube_amd import _lib

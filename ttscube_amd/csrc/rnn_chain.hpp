@@ -70,7 +70,7 @@ __device__ __forceinline__ void lstm_chain(float (&acc)[BT][NG], const float* __
     }
 }
 
-// ---- inter-workgroup hand-off used by the split recurrences (gru.hip, lstm.hip); protocol of wavernn_cluster.hip ----------
+// ---- inter-workgroup hand-off used by the split recurrences (gru.hip, lstm.hip); counter protocol ----------
 // payload: agent-scope relaxed atomic stores / loads (write-through, L1-bypassing); arrival: every storing wave drains
 // vmcnt(0), one lane bumps a monotonic counter; consumers poll it from one lane with a bounded spin and a shared abort word.
 __device__ __forceinline__ void g_st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -25,7 +25,7 @@
 #include "common.hpp"
 #include "../../include/ttscube_math.h"
 #include "../../include/ttscube_mulaw_lut.h"
-#include "wavernn_quad.hip"
+#include "wavernn_tile.hip"
 
 namespace ttsc {
 
@@ -488,16 +488,15 @@ struct ttsc_wavernn {
     float *wt_pre = nullptr, *b_pre = nullptr, *wt_out = nullptr, *b_out = nullptr, *lut = nullptr;
     float* lc_w[3] = {nullptr, nullptr, nullptr};
     float* lc_b[3] = {nullptr, nullptr, nullptr};
-    // host copies (torch layout) kept for the quad kernel's per-member packing
+    // host copies (torch layout) kept for the tile kernel's per-member packing
     std::vector<float> h_wih0, h_whh0, h_bih0, h_bhh0, h_wpre, h_bpre, h_wout, h_bout;
     float *c_whh = nullptr, *c_wih = nullptr, *c_bih = nullptr, *c_bhh = nullptr, *c_wpre = nullptr, *c_bpre = nullptr, *c_wout = nullptr,
           *c_bout = nullptr;
     float *q_whh = nullptr, *q_wih = nullptr, *q_bih = nullptr, *q_bhh = nullptr, *q_wpre = nullptr, *q_bpre = nullptr, *q_wout = nullptr,
-          *q_bout = nullptr;   // quad kernel (wavernn_quad.hip): 4 row slices of every matrix
-    bool quad_dirty = true;
-    int quad_nc_packed = 0;
-    int last_kind = 0;         // 0 streaming kernel, 2 quad kernel
-    unsigned* last_abort_word = nullptr;   // device word set by the quad kernel when a hand-off timed out
+          *q_bout = nullptr;   // tile kernel (wavernn_tile.hip): 8 row slices of every matrix
+    bool tile_dirty = true;
+    int last_kind = 0;         // 0 streaming kernel, 2 tile kernel
+    unsigned* last_abort_word = nullptr;   // device word set by the tile kernel when a hand-off timed out
     std::vector<std::string> have;
     bool has(const std::string& n) const {
         for (auto& s : have)
@@ -638,50 +637,46 @@ extern "C" int ttsc_wavernn_set_weight(ttsc_wavernn* w, const char* name, const 
         TTSC_REQUIRE(false, "ttsc_wavernn_set_weight: unknown key '%s'", name);
     }
     if (rc == TTSC_OK && !w->has(n)) w->have.push_back(n);
-    w->quad_dirty = true;
+    w->tile_dirty = true;
     return rc;
 }
 
-// ---- tile path (wavernn_quad.hip): NC workgroups step NC utterances, each streaming 1/NC of the rows -------------
-static int quad_nc() {
-    // members (= utterances) per tile: 4 or 8.  env TTSC_WR_QUAD_NC overrides.
-    if (const char* ev = getenv("TTSC_WR_QUAD_NC")) {
-        const int v = atoi(ev);
-        if (v == 4 || v == 8) return v;
-    }
-    return 4;
+// ---- tile path (wavernn_tile.hip): 8 workgroups step 8 utterances, each owning 1/8 of the rows -------------
+static size_t tile_lds_bytes(const ttsc_wavernn* w) {
+    const auto& c = w->cfg;
+    return ((size_t)c.H * 32 + (size_t)256 * 32 + (size_t)WT_NC * (c.H + 4) + (size_t)WT_NC * 260 + (size_t)3 * (c.H / WT_NC) * WT_NC + 64 + (size_t)3 * (c.H / WT_NC) + 16) * sizeof(float);
 }
 
-static bool quad_supported(const ttsc_wavernn* w, int B) {
+static bool tile_supported(const ttsc_wavernn* w, int B) {
     const auto& c = w->cfg;
-    // Measured on MI355X (H = 512, 1 layer, B = 256): see DESIGN.md; the streaming kernel, whose workgroups all pull the same
-    // 3.8 MB through L2 every step, takes 36 us (small batches) .. 45 us (B = 256).  So: default for large batches
-    // (B >= 192) of one-layer networks; env TTSC_WR_QUAD=1 / 0 forces it on (whenever eligible) / off.  Bit-exact either way.
-    const char* evq = getenv("TTSC_WR_QUAD");
-    if (evq ? atoi(evq) == 0 : B < 192) return false;
-    const int NC = quad_nc();
+    // Default for one-layer networks with a discrete head whenever every member can be resident (B <= 256 on MI355X);
+    // env TTSC_WR_TILE=0 forces the streaming kernel.  Bit-exact either way.  Measurements: DESIGN.md.
+    const char* ev = getenv("TTSC_WR_TILE");
+    if (ev && atoi(ev) == 0) return false;
     if (c.out_kind != TTSC_WR_OUT_MULAW && c.out_kind != TTSC_WR_OUT_RAW) return false;   // discrete heads only
-    if (c.num_layers != 1 || c.H % (4 * NC) != 0 || c.H > 512 || c.S % NC != 0 || c.S > 256) return false;
-    if ((c.H / NC) * NC > WQ_THREADS) return false;
-    const int G = (int)ceil_div(B, NC);
+    if (c.num_layers != 1 || c.H % (4 * WT_NC) != 0 || c.H > 512 || c.S % WT_NC != 0 || c.S > 256) return false;
+    if (tile_lds_bytes(w) > 160 * 1024) return false;
+    const int G = (int)ceil_div(B, WT_NC);
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-    return G * NC <= cus;   // every member must be resident, otherwise the exchange cannot complete
+    return G * WT_NC <= cus;   // every member must be resident, otherwise the exchange cannot complete
 }
 
-static size_t quad_exchange_bytes(const ttsc_wavernn* w, int B) {
-    const int BU = 8;   // sized for the larger tile
-    const int G = (int)ceil_div(B, 4);
+// granules (8 bytes) of the exchange area of G tiles + the abort word
+static size_t tile_exchange_granules(const ttsc_wavernn* w, int G) {
     const auto& c = w->cfg;
-    const size_t per = ((size_t)2 * BU * c.H + (size_t)2 * BU * 256 + (size_t)2 * BU * c.S + 2 * BU) * sizeof(float);
-    return (size_t)G * per + ((size_t)G * 4 + 64) * sizeof(unsigned) + 256;
+    return (size_t)G * 2 * ((size_t)WT_NC * c.H + (size_t)WT_NC * 256 + (size_t)WT_NC * c.S + WT_NC);
+}
+static size_t tile_exchange_bytes(const ttsc_wavernn* w, int B) {
+    return tile_exchange_granules(w, (int)ceil_div(B, WT_NC)) * 8 + 256;
 }
 
-static int quad_pack(ttsc_wavernn* w) {
+static int tile_pack(ttsc_wavernn* w) {
     const auto& c = w->cfg;
-    const int NC = quad_nc(), H = c.H, UPW = H / NC, R3 = 3 * UPW, I0 = w->in0, I0P = (int)round_up(I0, 4), S = c.S, SR = S / NC, PR = 256 / NC;
+    const int NC = WT_NC, H = c.H, UPW = H / NC, R3 = 3 * UPW, I0 = w->in0, I0P = (int)round_up(I0, 4), S = c.S, SR = S / NC, PR = 256 / NC;
     std::vector<float> whh((size_t)NC * H * R3, 0.f), wih((size_t)NC * I0P * R3, 0.f), bih((size_t)NC * R3), bhh((size_t)NC * R3);
-    std::vector<float> wpre((size_t)NC * H * PR), bpre((size_t)NC * PR), wout((size_t)NC * 256 * SR), bout((size_t)NC * SR);
+    // the output slice is padded to PR = 32 rows (zero rows beyond SR), so that both resident slices share one layout
+    std::vector<float> wpre((size_t)NC * H * PR), bpre((size_t)NC * PR), wout((size_t)NC * 256 * PR, 0.f), bout((size_t)NC * PR, 0.f);
     for (int m = 0; m < NC; ++m) {
         for (int q = 0; q < 3; ++q)
             for (int j = 0; j < UPW; ++j) {
@@ -698,8 +693,8 @@ static int quad_pack(ttsc_wavernn* w) {
         }
         for (int r = 0; r < SR; ++r) {
             const int row = m * SR + r;
-            for (int k = 0; k < 256; ++k) wout[(size_t)m * 256 * SR + ((size_t)(k >> 2) * SR + r) * 4 + (k & 3)] = w->h_wout[(size_t)row * 256 + k];
-            bout[(size_t)m * SR + r] = w->h_bout[row];
+            for (int k = 0; k < 256; ++k) wout[(size_t)m * 256 * PR + ((size_t)(k >> 2) * PR + r) * 4 + (k & 3)] = w->h_wout[(size_t)row * 256 + k];
+            bout[(size_t)m * PR + r] = w->h_bout[row];
         }
     }
     int rc;
@@ -711,8 +706,7 @@ static int quad_pack(ttsc_wavernn* w) {
     if ((rc = upload(&w->q_bpre, bpre.data(), bpre.size()))) return rc;
     if ((rc = upload(&w->q_wout, wout.data(), wout.size()))) return rc;
     if ((rc = upload(&w->q_bout, bout.data(), bout.size()))) return rc;
-    w->quad_dirty = false;
-    w->quad_nc_packed = NC;
+    w->tile_dirty = false;
     return TTSC_OK;
 }
 
@@ -733,7 +727,7 @@ static size_t cond_bytes(const ttsc_wavernn* w, int32_t B, int64_t Tl) {
 
 extern "C" size_t ttsc_wavernn_workspace_bytes(const ttsc_wavernn* w, int32_t B, int64_t T, int64_t Tl) {
     if (!w) return 0;
-    return cond_bytes(w, B, Tl) + quad_exchange_bytes(w, B);
+    return cond_bytes(w, B, Tl) + tile_exchange_bytes(w, B);
 }
 
 extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const float* x_low, int32_t B, int64_t T, int64_t Tl,
@@ -812,10 +806,10 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
     }
     a.seed = seed;
     TTSC_REQUIRE(a.L > 0, "ttsc_wavernn_decode: nothing to decode (L=%d)", a.L);
-    if (quad_supported(w, B)) {
-        const int NC = quad_nc(), BU = NC;
-        if (w->quad_dirty || w->quad_nc_packed != NC) {
-            int prc = quad_pack(w);
+    if (tile_supported(w, B)) {
+        const int NC = WT_NC, BU = WT_NC;
+        if (w->tile_dirty) {
+            int prc = tile_pack(w);
             if (prc) return prc;
         }
         const size_t need_all = ttsc_wavernn_workspace_bytes(w, B, T, Tl);
@@ -825,63 +819,73 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
         }
         const int G = (int)ceil_div(B, BU);
         char* xbase = (char*)ws + cond_bytes(w, B, Tl);
-        WqArgs qa;
+        WtArgs qa;
         memset(&qa, 0, sizeof(qa));
         qa.mel = mel; qa.interp = a.interp; qa.feats = a.feats;
         qa.whh = w->q_whh; qa.wih = w->q_wih; qa.bih = w->q_bih; qa.bhh = w->q_bhh;
         qa.wpre = w->q_wpre; qa.bpre = w->q_bpre; qa.wout = w->q_wout; qa.bout = w->q_bout;
         qa.lut = w->lut; qa.noise = noise; qa.forced_x = forced_x; qa.out_idx = idx; qa.out_wav = wav; qa.out_logits = logits;
-        float* f = (float*)xbase;
+        u64* f = (u64*)xbase;
         qa.xh = f; f += (size_t)G * 2 * BU * c.H;
         qa.xpre = f; f += (size_t)G * 2 * BU * 256;
         qa.xlog = f; f += (size_t)G * 2 * BU * c.S;
         qa.xlx = f; f += (size_t)G * 2 * BU;
-        qa.cnt = (unsigned*)f;
+        qa.abort_word = (unsigned*)f;
         qa.B = B; qa.T = (int)T; qa.Tl = (int)Tl; qa.H = c.H; qa.UPW = c.H / NC; qa.I0 = w->in0; qa.I0P = (int)round_up(w->in0, 4);
-        qa.use_lowres = c.use_lowres; qa.up = c.upsample; qa.up_low = c.upsample_low; qa.S = c.S; qa.SR = c.S / NC; qa.PR = 256 / NC;
+        qa.use_lowres = c.use_lowres; qa.up = c.upsample; qa.up_low = c.upsample_low; qa.S = c.S; qa.SR = c.S / NC;
         qa.n_mel = c.n_mel; qa.out_kind = c.out_kind; qa.mode = mode; qa.L = a.L; qa.G = G; qa.seed = seed;
-        qa.GP = (int)round_up(G, WQ_XCDS);
-        TTSC_HIP_CHECK(hipMemsetAsync(qa.cnt, 0, ((size_t)G * 4 + 64) * sizeof(unsigned), s));
-        const size_t lds = ((size_t)BU * (c.H + 4) + (size_t)BU * 260 + (size_t)3 * (c.H / NC) * BU + c.S + 64) * sizeof(float);
+        qa.GP = (int)round_up(G, WT_XCDS);
+        // all tags (and the abort word) start at zero; the first step carries tag 1
+        TTSC_HIP_CHECK(hipMemsetAsync(xbase, 0, tile_exchange_granules(w, G) * 8 + 64, s));
+        const size_t lds = tile_lds_bytes(w);
+        if (lds > 64 * 1024) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipError_t ae = hipFuncSetAttribute((const void*)wr_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (ae != hipSuccess) {
+                    (void)hipGetLastError();
+                    set_error("wr_tile_kernel: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(ae));
+                    return TTSC_EHIP;
+                }
+                attr_set = true;
+            }
+        }
 #ifdef TTSC_ABLATE
         unsigned long long* prof_dev = nullptr;
-        if (getenv("TTSC_WQ_PROF")) {
+        if (getenv("TTSC_WT_PROF")) {
             TTSC_HIP_CHECK(hipMalloc((void**)&prof_dev, (size_t)qa.GP * NC * 16 * sizeof(unsigned long long)));
             TTSC_HIP_CHECK(hipMemsetAsync(prof_dev, 0, (size_t)qa.GP * NC * 16 * sizeof(unsigned long long), s));
             qa.prof = prof_dev;
         }
 #endif
-        if (NC == 4)
-            hipLaunchKernelGGL((wr_quad_kernel<4, 1>), dim3(qa.GP * NC), dim3(WQ_THREADS), lds, s, qa);
-        else
-            hipLaunchKernelGGL((wr_quad_kernel<8, 2>), dim3(qa.GP * NC), dim3(WQ_THREADS), lds, s, qa);
+        hipLaunchKernelGGL(wr_tile_kernel, dim3(qa.GP * NC), dim3(WT_THREADS), lds, s, qa);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
-            set_error("wr_quad_kernel launch failed: %s", hipGetErrorString(e));
+            set_error("wr_tile_kernel launch failed: %s", hipGetErrorString(e));
             return TTSC_EHIP;
         }
 #ifdef TTSC_ABLATE
-        if (prof_dev) {   // per-phase time of the tile kernel: mean over workgroups, microseconds per step
+        if (prof_dev) {   // where a step of the tile kernel goes: thread 0 of every workgroup, mean, microseconds per step
             TTSC_HIP_CHECK(hipStreamSynchronize(s));
             std::vector<unsigned long long> hp((size_t)qa.GP * NC * 16);
             TTSC_HIP_CHECK(hipMemcpy(hp.data(), prof_dev, hp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             hipFree(prof_dev);
-            static const char* nm[12] = {"ih-prefix", "hh-chain", "wait-lastx", "gate+publish-h", "wait-h", "stage-h", "pre+publish", "wait-pre",
-                                         "stage-pre", "out+publish", "wait-logits", "sample+publish"};
+            static const char* nm[8] = {"loop", "ih-prefix+join", "lastx-handoff+gate", "h-handoff+stage", "tail:pre", "tail:pre-handoff",
+                                        "tail:out", "tail:logit-handoff+sample"};
             double tot = 0;
-            for (int i = 0; i < 12; ++i) {
+            for (int i = 0; i < 8; ++i) {
                 double sum = 0;
                 int n = 0;
                 for (size_t wg = 0; wg < (size_t)qa.GP * NC; ++wg)
-                    if (hp[wg * 16 + 1]) { sum += (double)hp[wg * 16 + i]; ++n; }
+                    if (hp[wg * 16 + 3]) { sum += (double)hp[wg * 16 + i]; ++n; }
                 const double us = n ? sum / n / 100.0 / qa.L : 0.0;
                 tot += us;
-                fprintf(stderr, "wq-prof %-16s %7.2f us/step\n", nm[i], us);
+                fprintf(stderr, "wt-prof %-28s %7.2f us/step\n", nm[i], us);
             }
-            fprintf(stderr, "wq-prof %-16s %7.2f us/step (NC=%d, B=%d, L=%d)\n", "total", tot, NC, B, qa.L);
+            fprintf(stderr, "wt-prof %-28s %7.2f us/step (B=%d, L=%d)\n", "total", tot, B, qa.L);
         }
 #endif
-        w->last_abort_word = qa.cnt + (size_t)G * 4;
+        w->last_abort_word = qa.abort_word;
         w->last_kind = 2;
         return TTSC_OK;
     }
@@ -913,7 +917,7 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
 }
 
 
-// After the stream has executed the last decode: -1 = streaming kernel (nothing to check), 2 = quad
+// After the stream has executed the last decode: -1 = streaming kernel (nothing to check), 2 = tile
 // kernel ok, 1 = a multi-workgroup kernel aborted on a hand-off timeout (results invalid).  Synchronises the stream.
 extern "C" int ttsc_wavernn_last_status(ttsc_wavernn* w, void* stream) {
     if (!w) return TTSC_EINVAL;

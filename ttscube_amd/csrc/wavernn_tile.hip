@@ -1,0 +1,577 @@
+// WaveRNN decode with every tile of 8 utterances spread over 8 workgroups ("members") — gfx950.
+//
+// The single-workgroup kernel (wavernn.hip) streams the whole fp32 weight set (3.8 MB for H=512) from L2 every step and is
+// bound by ONE CU's vector-memory path (64 B/clk): 45 us per step at B = 256.  Here 8 workgroups step 8 utterances
+// together; member m owns 1/8 of the rows of every matrix (H/8 hidden units x 3 gates, 32 rows of the pre-output layer,
+// S/8 rows of the output layer).  Its pre-output and output slices stay in LDS for the whole decode (98 KB at H = 512); only
+// the recurrent slice (393 KB) is streamed from L2 each step.  B = 256 still fills all 256 CUs (32 tiles).
+//
+// Arithmetic.  The row x utterance products run on the matrix pipe as v_mfma_f32_4x4x1_16B_f32: one instruction is 16
+// independent 4 (rows) x 4 (utterances) rank-1 updates  acc += w[row][k] * h[k][utt], one fused multiply-add per accumulator
+// and per k — bit for bit the k-ordered fmaf chain of wavernn.hip / oracle/wavernn_ref.c (tools/probes/mfma_f32_exact.hip
+// checks the instruction against fmaf, denormals included).  Lane l loads the 16-byte weight word of ITS row only and reads
+// the h words of ITS utterance, so no lane duplicates a neighbour's global load (round 1's version of this kernel did — 4
+// lanes per row — and was bound by exactly that).  Rows are split across members, never the reduction: every
+// (row, utterance) is one k-ordered chain seeded with the bias, so indices and logits stay bit-exact.
+//
+// Schedule.  A step is  h_t -> pre_t -> logits_t -> sample_t -> (gates of step t+1).  Only the last link needs the sample:
+// the recurrent product W_hh . h_t does not, and it is 80 % of the bytes.  So the workgroup forks after h_t is staged:
+//     wave 0      "tail" of step t:   pre slice -> hand-off -> output slice -> hand-off -> sample utterance m -> hand-off
+//     waves 1..3  recurrent product of step t+1 (three 64-row blocks, two 4-utterance accumulators each)
+// and joins for the gate math of step t+1 and the h_{t+1} hand-off.  The critical path of a step is the tail (two dependent
+// chains of 512 and 256 matrix instructions) plus four hand-offs; the weight stream hides behind it.
+//
+// Hand-offs.  Every exchanged value is an 8-byte granule {fp32 value, step tag} written with ONE agent-scope store; a
+// consumer lane polls the granules it needs until they carry the tag of the step (bounded spin, shared abort word).  No
+// separate flag or counter, no producer-side drain, no barrier on the consumer side beyond the one that publishes the staged
+// vector in LDS.  Buffers are double-buffered by step parity: a member overwrites the step-t granule only at step t+2, which
+// it cannot reach before every member has published step t+1, i.e. has consumed step t.  (tools/probes/handoff_probe.hip:
+// 0.75 us per hand-off with agent-scope accesses, same or different XCD; workgroup-scope accesses are NOT coherent across
+// CUs.)  Members of a tile are still placed on one XCD (blockIdx -> XCD is round-robin).
+#include "rnn_chain.hpp"
+
+namespace ttsc {
+
+constexpr int WT_NC = 8;          // members per tile = utterances per tile
+constexpr int WT_THREADS = 512;
+constexpr int WT_XCDS = 8;
+constexpr unsigned WT_SPIN_LIMIT = 1u << 20;   // bounded spins: a member that is not resident must not hang the GPU
+
+typedef unsigned long long u64;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void st_granule(u64* p, float v, unsigned tag) {
+    __hip_atomic_store(p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Poll N granules (p[i * stride]) until all carry `tag`; false after a timeout or when another member aborted.
+template <int N>
+__device__ __forceinline__ bool ld_granules(const u64* p, int stride, unsigned tag, float (&v)[N], unsigned* abort_word) {
+    u64 g[N];
+    unsigned spins = 0;
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) g[i] = __hip_atomic_load(p + (size_t)i * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool all = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) all = all && ((unsigned)(g[i] >> 32) == tag);
+        if (all) break;
+        if (++spins > WT_SPIN_LIMIT || ((spins & 63u) == 0u && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+            __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);   // (longer back-offs only add latency: measured 18.1 / 18.7 / 20.8 us per step for 0 / 1k / 4k clocks)
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = __uint_as_float((unsigned)g[i]);
+    return true;
+}
+
+// same, granules p[off[i]]
+template <int N>
+__device__ __forceinline__ bool ld_granules_at(const u64* p, const int (&off)[N], unsigned tag, float (&v)[N], unsigned* abort_word) {
+    u64 g[N];
+    unsigned spins = 0;
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) g[i] = __hip_atomic_load(p + off[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool all = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) all = all && ((unsigned)(g[i] >> 32) == tag);
+        if (all) break;
+        if (++spins > WT_SPIN_LIMIT || ((spins & 63u) == 0u && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+            __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);   // (longer back-offs only add latency: measured 18.1 / 18.7 / 20.8 us per step for 0 / 1k / 4k clocks)
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = __uint_as_float((unsigned)g[i]);
+    return true;
+}
+
+struct WtArgs {
+    const float* mel;      // [B, T, n_mel]
+    const float* interp;   // [B, Tl*up_low]
+    const float* feats;    // [B, 20, Tl]
+    // per-member row slices, packed [K/4][rows][4]; member m at offset m * (K * rows)
+    const float* whh;      // rows = 3*UPW (gate q, local unit j -> q*UPW + j), K = H
+    const float* wih;      // rows = 3*UPW, K = I0P (in_dim rounded up to 4, zero padded)
+    const float* bih;      // [NC][3*UPW]
+    const float* bhh;      // [NC][3*UPW]
+    const float* wpre;     // rows = 32 (= 256/NC), K = H
+    const float* bpre;     // [NC][32]
+    const float* wout;     // rows = 32 (first SR = S/NC real, rest zero), K = 256
+    const float* bout;     // [NC][32]
+    const float* lut;
+    const float* noise;    // [B, L, S] or null
+    const float* forced_x; // [B, L] or null
+    uint8_t* out_idx;
+    float* out_wav;
+    float* out_logits;
+    // exchange area (device memory, zeroed before the launch), per tile g, in granules
+    u64* xh;               // [G][2][H][8]
+    u64* xpre;             // [G][2][256][8]
+    u64* xlog;             // [G][2][8][S]
+    u64* xlx;              // [G][2][8]
+    unsigned* abort_word;
+    int B, T, Tl, H, UPW, I0, I0P, use_lowres, up, up_low, S, SR, n_mel, out_kind, mode, L, G, GP;
+    unsigned long long seed;
+    unsigned long long* prof;   // -DTTSC_ABLATE: [workgroup][16] accumulated 100 MHz ticks per segment (thread 0), or null
+};
+
+// A k-ordered chain block on the 4x4x1 fp32 matrix instruction, NB accumulators (4 utterances each) per lane:
+//   lane l streams the packed weight words w4[kb * wstride] of its own row and reads v[utt0 + 4*nb][4*kb .. 4*kb+3] from LDS;
+//   it ends up with rows (4 * (l >> 2) + i) of its 16 blocks in register i.  W_LDS: the weight words come from LDS.
+// Both operand streams are software-pipelined by hand (two register sets of UN k-blocks): the words of batch i+1 are issued
+// before the chain of batch i runs, so neither latency sits between two dependent matrix instructions.
+template <int NB, int UN>
+__device__ __forceinline__ void mfma_chain(f32x4_t (&acc)[NB], const float4* w4, int wstride, const float* hb, int vstride, int K) {
+    const int KB = K >> 2;
+    auto load = [&](float4 (&w)[UN], float4 (&hv)[UN][NB], int kb0) {
+#pragma unroll
+        for (int q = 0; q < UN; ++q) w[q] = w4[(size_t)(kb0 + q) * wstride];
+#pragma unroll
+        for (int q = 0; q < UN; ++q)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) hv[q][nb] = *reinterpret_cast<const float4*>(hb + 4 * nb * vstride + 4 * (kb0 + q));
+    };
+    auto fma_batch = [&](const float4 (&w)[UN], const float4 (&hv)[UN][NB]) {
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[q].x, hv[q][nb].x, acc[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[q].y, hv[q][nb].y, acc[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[q].z, hv[q][nb].z, acc[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[q].w, hv[q][nb].w, acc[nb], 0, 0, 0);
+        }
+    };
+    if (KB % UN == 0) {
+        float4 wa[UN], wb[UN], ha[UN][NB], hb2[UN][NB];
+        const int NBt = KB / UN;
+        load(wa, ha, 0);
+        int bi = 0;
+        // no conditional loads inside the loop: hipcc's wait-count insertion falls back to vmcnt(0) at a merge point, which
+        // would serialise the prefetch with the chain
+        for (; bi + 2 < NBt; bi += 2) {
+            load(wb, hb2, (bi + 1) * UN);
+            __builtin_amdgcn_sched_barrier(0);
+            fma_batch(wa, ha);
+            __builtin_amdgcn_sched_barrier(0);
+            load(wa, ha, (bi + 2) * UN);
+            __builtin_amdgcn_sched_barrier(0);
+            fma_batch(wb, hb2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (bi + 1 < NBt) {
+            load(wb, hb2, (bi + 1) * UN);
+            __builtin_amdgcn_sched_barrier(0);
+            fma_batch(wa, ha);
+            fma_batch(wb, hb2);
+        } else {
+            fma_batch(wa, ha);
+        }
+    } else {
+        for (int kb = 0; kb < KB; ++kb) {
+            const float4 w = w4[(size_t)kb * wstride];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const float4 hv = *reinterpret_cast<const float4*>(hb + 4 * nb * vstride + 4 * kb);
+                acc[nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.x, hv.x, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.y, hv.y, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.z, hv.z, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w, hv.w, acc[nb], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// The same chain with the weight words streamed from global memory: their prefetch distance is one batch of UN k-blocks
+// (L2 latency), while the h words (LDS latency) are read only two k-blocks ahead — which keeps the register count of the
+// two-accumulator recurrent blocks at ~100 instead of ~200.
+template <int NB, int UN>
+__device__ __forceinline__ void mfma_chain_g(f32x4_t (&acc)[NB], const float4* w4, int wstride, const float* hb, int vstride, int K) {
+    static_assert(UN % 4 == 0, "UN is consumed in pairs of pairs");
+    const int KB = K >> 2;
+    auto loadw = [&](float4 (&w)[UN], int kb0) {
+#pragma unroll
+        for (int q = 0; q < UN; ++q) w[q] = w4[(size_t)(kb0 + q) * wstride];
+    };
+    auto readh = [&](float4 (&hv)[2][NB], int kb) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) hv[q][nb] = *reinterpret_cast<const float4*>(hb + 4 * nb * vstride + 4 * (kb + q));
+    };
+    auto mf2 = [&](const float4& w0, const float4& w1, const float4 (&hv)[2][NB]) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(w0.x, hv[0][nb].x, acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(w0.y, hv[0][nb].y, acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(w0.z, hv[0][nb].z, acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(w0.w, hv[0][nb].w, acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(w1.x, hv[1][nb].x, acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(w1.y, hv[1][nb].y, acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(w1.z, hv[1][nb].z, acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(w1.w, hv[1][nb].w, acc[nb], 0, 0, 0);
+    };
+    auto fma_batch = [&](const float4 (&w)[UN], int kb0) {
+        float4 h0[2][NB], h1[2][NB];
+        readh(h0, kb0);
+#pragma unroll
+        for (int q = 0; q < UN; q += 4) {
+            readh(h1, kb0 + q + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mf2(w[q], w[q + 1], h0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 4 < UN) readh(h0, kb0 + q + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            mf2(w[q + 2], w[q + 3], h1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (KB % UN == 0) {
+        float4 wa[UN], wb[UN];
+        const int NBt = KB / UN;
+        loadw(wa, 0);
+        int bi = 0;
+        for (; bi + 2 < NBt; bi += 2) {   // no conditional loads inside the loop (see mfma_chain)
+            loadw(wb, (bi + 1) * UN);
+            __builtin_amdgcn_sched_barrier(0);
+            fma_batch(wa, bi * UN);
+            loadw(wa, (bi + 2) * UN);
+            __builtin_amdgcn_sched_barrier(0);
+            fma_batch(wb, (bi + 1) * UN);
+        }
+        if (bi + 1 < NBt) {
+            loadw(wb, (bi + 1) * UN);
+            __builtin_amdgcn_sched_barrier(0);
+            fma_batch(wa, bi * UN);
+            fma_batch(wb, (bi + 1) * UN);
+        } else {
+            fma_batch(wa, bi * UN);
+        }
+    } else {
+        mfma_chain<NB, 1>(acc, w4, wstride, hb, vstride, K);
+    }
+}
+
+#ifdef TTSC_ABLATE
+#define WT_TICK(i)                                                     \
+    do {                                                               \
+        if (a.prof && tid == 0) {                                      \
+            const unsigned long long now_ = wall_clock64();            \
+            pacc[i] += now_ - plast;                                   \
+            plast = now_;                                              \
+        }                                                              \
+    } while (0)
+#else
+#define WT_TICK(i) do {} while (0)
+#endif
+
+__global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
+    constexpr int NC = WT_NC, BU = WT_NC, PR = 256 / WT_NC;   // PR = 32 pre-output rows per member
+    // LDS: wpre[H/4][32][4] | wout[64][32][4] | hvec[BU][VH] | pvec[BU][VP] | gbuf[3*UPW][BU] | bias[32 + 32 + 3*UPW] | tail_fail, pre_ready
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int H = a.H, UPW = a.UPW, S = a.S, SR = a.SR, NM = a.n_mel, I0P = a.I0P;
+    const int R3 = 3 * UPW;
+    // tile placement: workgroups are dealt to the XCDs round-robin, so the members of a tile take blockIdx values that are
+    // congruent mod 8 (same XCD, same L2); GP = number of tiles rounded up to a multiple of 8, surplus workgroups leave at once
+    const int xcd = blockIdx.x % WT_XCDS, slot = blockIdx.x / WT_XCDS;
+    const int g = xcd * (a.GP / WT_XCDS) + slot / NC, m = slot % NC;
+    if (g >= a.G) return;
+    const int VH = H + 4, VP = 256 + 4;   // +4: the utterances a wave reads per LDS access land in different banks
+    float* wpreL = sm;
+    float* woutL = wpreL + (size_t)H * PR;
+    float* hvec = woutL + (size_t)256 * PR;
+    float* pvec = hvec + (size_t)BU * VH;
+    float* gbuf = pvec + (size_t)BU * VP;
+    float* biasL = gbuf + (size_t)R3 * BU;   // bpre[32] | bout[32] | bhh[R3]
+    int* tail_fail = reinterpret_cast<int*>(biasL + 64 + R3);
+    int* pre_ready = tail_fail + 1;   // helper waves that have staged the pre-output vector (monotonic)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int u = tid % BU;            // utterance slot (element-wise work)
+    const int j = tid / BU;            // local hidden unit
+    const int bu = g * BU + u;
+    const bool uok = bu < a.B;
+    const int bc = uok ? bu : a.B - 1;
+    const int nu = min(BU, a.B - g * BU);
+    const bool gru_thr = j < UPW;
+    const int jc = gru_thr ? j : 0;
+    const float* Whh = a.whh + (size_t)m * H * R3;
+    const float* Wih = a.wih + (size_t)m * I0P * R3;
+    float bih[3], w_int[3], w_lx[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        bih[q] = a.bih[(size_t)m * R3 + q * UPW + jc];
+        const int k1 = a.I0 - 1, k2 = a.I0 >= 2 ? a.I0 - 2 : 0;
+        w_lx[q] = Wih[((size_t)(k1 >> 2) * R3 + q * UPW + jc) * 4 + (k1 & 3)];
+        w_int[q] = Wih[((size_t)(k2 >> 2) * R3 + q * UPW + jc) * 4 + (k2 & 3)];
+    }
+    // matrix-pipe ownership
+    //   recurrent blocks (64 rows, two accumulators): lane l holds rows 4*(l >> 2) + i, utterances (l & 3) and (l & 3) + 4
+    //   pre / output blocks (32 rows, one accumulator): lanes 0..31 take utterances 0..3, lanes 32..63 the same rows for 4..7
+    const int mrow = 4 * (lane >> 2);
+    const int mutt = lane & 3;
+    const int trow = 4 * ((lane & 31) >> 2);
+    const int tutt = (lane & 3) + 4 * (lane >> 5);
+    const float* bpre_m = biasL;
+    const float* bout_m = biasL + 32;
+    const float* bhh_m = biasL + 64;
+    const int nblk = (R3 + 63) >> 6;
+    float pmel[3] = {0, 0, 0}, plow[3] = {0, 0, 0};
+    float hprev = 0.f;   // h_{t-1}[unit m*UPW + j][utterance u]: each (unit, utterance) has exactly one owner thread
+    u64* xh = a.xh + (size_t)g * 2 * BU * H;
+    u64* xpre = a.xpre + (size_t)g * 2 * BU * 256;
+    u64* xlog = a.xlog + (size_t)g * 2 * BU * S;
+    u64* xlx = a.xlx + (size_t)g * 2 * BU;
+
+    // resident slices of the pre-output and output layers, h_{-1} = 0 (fma(w, 0, acc) == acc)
+    {
+        const float4* sp = reinterpret_cast<const float4*>(a.wpre + (size_t)m * H * PR);
+        float4* dp = reinterpret_cast<float4*>(wpreL);
+        for (int i = tid; i < H * PR / 4; i += WT_THREADS) dp[i] = sp[i];
+        const float4* so = reinterpret_cast<const float4*>(a.wout + (size_t)m * 256 * PR);
+        float4* dq = reinterpret_cast<float4*>(woutL);
+        for (int i = tid; i < 256 * PR / 4; i += WT_THREADS) dq[i] = so[i];
+        for (int i = tid; i < BU * VH; i += WT_THREADS) hvec[i] = 0.f;
+        for (int i = tid; i < 64 + R3; i += WT_THREADS)
+            biasL[i] = i < 32 ? a.bpre[(size_t)m * PR + i] : (i < 64 ? a.bout[(size_t)m * PR + i - 32] : a.bhh[(size_t)m * R3 + i - 64]);
+        if (tid == 0) {
+            *tail_fail = 0;
+            *pre_ready = 0;
+        }
+    }
+    __syncthreads();
+#ifdef TTSC_ABLATE
+    unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, plast = wall_clock64();
+#endif
+
+    // Waves 4..7 stage the pre-output vector of step s (2048 granules, 8 per lane) into pvec while wave 0 computes its own slice.
+    auto stage_pre = [&](int s) {
+        const int hl = tid - 4 * 64;   // 0..255
+        const u64* src = xpre + (size_t)(s & 1) * 256 * BU + hl;
+        float v[8];
+        const bool okh = ld_granules<8>(src, 256, (unsigned)s + 1u, v, a.abort_word);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = r * 256 + hl;
+            pvec[(i & 7) * VP + (i >> 3)] = v[r];
+        }
+        if (!__all(okh) && lane == 0) *tail_fail = 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(pre_ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+
+    // The tail of step s on wave 0 (hvec holds h_s): pre slice, output slice, sample of utterance m.  Tag of step s = s + 1.
+    auto tail = [&](int s) -> bool {
+        const int par = s & 1;
+        const unsigned tag = (unsigned)s + 1u;
+        bool ok = true;
+        {   // pre-output: 32 rows x 8 utterances
+            f32x4_t acc[1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[0][i] = bpre_m[trow + i];
+            mfma_chain<1, 4>(acc, reinterpret_cast<const float4*>(wpreL) + (lane & 31), PR, hvec + tutt * VH, 0, H);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st_granule(xpre + ((size_t)par * 256 + m * PR + trow + i) * BU + tutt, ttsc_tanhf(acc[0][i]), tag);
+        }
+        WT_TICK(4);
+        {   // the full pre-output vector of the 8 utterances is staged by the helper waves (stage_pre): wait for the four of them
+            unsigned spins = 0;
+            while (__hip_atomic_load(pre_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (s + 1)) {
+                if (++spins > WT_SPIN_LIMIT) {
+                    ok = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        WT_TICK(5);
+        {   // output layer: SR (<= 32) rows x 8 utterances over the 256 pre-output values
+            f32x4_t acc[1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[0][i] = bout_m[trow + i];
+            mfma_chain<1, 4>(acc, reinterpret_cast<const float4*>(woutL) + (lane & 31), PR, pvec + tutt * VP, 0, 256);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int s_ = m * SR + trow + i;
+                if (trow + i < SR) {
+                    st_granule(xlog + ((size_t)par * BU + tutt) * S + s_, acc[0][i], tag);
+                    if (a.out_logits && g * BU + tutt < a.B) a.out_logits[((size_t)(g * BU + tutt) * a.L + s) * S + s_] = acc[0][i];
+                }
+            }
+        }
+        WT_TICK(6);
+        if (m < nu) {   // sample utterance m of the tile from its S logits
+            const int bs = g * BU + m;
+            float best = 0.f;
+            int bi = 0;
+            const u64* src = xlog + ((size_t)par * BU + m) * S;
+            int off[4];
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) off[r] = min(lane + 64 * r, S - 1);   // S is a multiple of 8 <= 256
+            ok = ld_granules_at<4>(src, off, tag, v, a.abort_word) && ok;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int s_ = lane + 64 * r;
+                if (s_ < S) {
+                    float g_ = 0.f;
+                    const size_t o = ((size_t)bs * a.L + s) * S + s_;
+                    if (a.mode == 1) {
+                        g_ = a.noise[o];
+                    } else if (a.mode == 2) {
+                        uint32_t r4[4];
+                        ttsc_philox4x32((uint32_t)(s_ >> 2), (uint32_t)s, (uint32_t)bs, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r4);
+                        g_ = ttsc_gumbel(r4[s_ & 3]);
+                    }
+                    const float sc = v[r] + g_;
+                    if (r == 0 || sc > best) {
+                        best = sc;
+                        bi = s_;
+                    }
+                }
+            }
+            if (lane >= S) {   // S < 64: idle lanes must lose every comparison
+                best = -INFINITY;
+                bi = 1 << 20;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float os = __shfl_xor(best, off);
+                const int oi = __shfl_xor(bi, off);
+                if (os > best || (os == best && oi < bi)) {
+                    best = os;
+                    bi = oi;
+                }
+            }
+            if (lane == 0) {
+                const float wv = a.out_kind == 0 ? a.lut[bi] : (((float)bi / 255.0f) - 0.5f) * 2.0f;
+                const size_t o = (size_t)bs * a.L + s;
+                a.out_idx[o] = (uint8_t)bi;
+                a.out_wav[o] = wv;
+                st_granule(xlx + par * BU + m, a.forced_x ? a.forced_x[o] : wv, tag);
+            }
+        }
+        WT_TICK(7);
+        return __all(ok);
+    };
+
+    int fr = 0, fr_phase = 0, lo = 0, lo_phase = 0;
+    for (int t = 0; t < a.L; ++t) {
+        const int par = t & 1;
+        WT_TICK(0);
+        // ---- fork: wave 0 finishes step t-1, waves 1..3 run the recurrent product of step t (both read hvec = h_{t-1}) ----
+        const float interp_t = (a.use_lowres && gru_thr) ? a.interp[(size_t)bc * ((size_t)a.Tl * a.up_low) + t] : 0.f;
+        if (wave == 0) {
+            if (t > 0 && !tail(t - 1)) *tail_fail = 1;
+        } else if (wave >= 4) {
+            if (t > 0) stage_pre(t - 1);
+        } else if (wave - 1 < nblk) {
+            const int r0 = (wave - 1) * 64;
+            f32x4_t acc[2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[nb][i] = bhh_m[min(r0 + mrow + i, R3 - 1)];
+            mfma_chain_g<2, 8>(acc, reinterpret_cast<const float4*>(Whh) + min(r0 + lane, R3 - 1), R3, hvec + mutt * VH, VH, H);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (r0 + mrow + i < R3) gbuf[(r0 + mrow + i) * BU + mutt + 4 * nb] = acc[nb][i];
+        }
+        // ---- cached prefixes of the layer-0 input chain (same order as wavernn.hip: mel | low-res feats | interp | last_x) ----
+        if (gru_thr) {
+            if (fr_phase == 0) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) pmel[q] = bih[q];
+                const float* mf = a.mel + ((size_t)bc * a.T + fr) * NM;
+                for (int k = 0; k < NM; ++k) {
+                    const float v = mf[k];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) pmel[q] = fmaf(Wih[((size_t)(k >> 2) * R3 + q * UPW + j) * 4 + (k & 3)], v, pmel[q]);
+                }
+            }
+            if (a.use_lowres && lo_phase == 0) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) plow[q] = pmel[q];
+#pragma unroll 4
+                for (int f = 0; f < 20; ++f) {
+                    const int k = NM + f;
+                    const float v = a.feats[((size_t)bc * 20 + f) * a.Tl + lo];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) plow[q] = fmaf(Wih[((size_t)(k >> 2) * R3 + q * UPW + j) * 4 + (k & 3)], v, plow[q]);
+                }
+            }
+        }
+        __syncthreads();   // join
+        WT_TICK(1);
+        // ---- gate math of step t: needs the sample of step t-1 of every utterance of the tile ----
+        bool ok = true;
+        if (gru_thr) {
+            float lx[1] = {0.f};
+            if (t > 0 && u < nu) ok = ld_granules<1>(xlx + (par ^ 1) * BU + u, 1, (unsigned)t, lx, a.abort_word);
+            float gi[3], gh[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                float acc = a.use_lowres ? plow[q] : pmel[q];
+                if (a.use_lowres) acc = fmaf(w_int[q], interp_t, acc);
+                gi[q] = fmaf(w_lx[q], lx[0], acc);
+                gh[q] = gbuf[(q * UPW + j) * BU + u];
+            }
+            const float r = ttsc_sigmoidf(gi[0] + gh[0]);
+            const float z = ttsc_sigmoidf(gi[1] + gh[1]);
+            const float rg = r * gh[2];
+            const float nn = ttsc_tanhf(gi[2] + rg);
+            const float d = hprev - nn;
+            hprev = fmaf(z, d, nn);
+            st_granule(xh + ((size_t)par * H + m * UPW + j) * BU + u, hprev, (unsigned)t + 1u);   // [k][u]: consecutive threads, consecutive granules
+        }
+        WT_TICK(2);
+        // ---- stage the full h_t of the 8 utterances: BU * H granules ----
+        {
+            const u64* src = xh + (size_t)par * H * BU;
+            for (int i0 = tid; i0 < BU * H; i0 += 8 * WT_THREADS) {
+                if (i0 + 7 * WT_THREADS < BU * H) {   // H = 512: one round trip for the whole vector
+                    float v[8];
+                    ok = ld_granules<8>(src + i0, WT_THREADS, (unsigned)t + 1u, v, a.abort_word) && ok;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const int i = i0 + r * WT_THREADS;
+                        hvec[(i & 7) * VH + (i >> 3)] = v[r];
+                    }
+                } else {
+                    for (int i = i0; i < BU * H; i += WT_THREADS) {
+                        float v[1];
+                        ok = ld_granules<1>(src + i, 1, (unsigned)t + 1u, v, a.abort_word) && ok;
+                        hvec[(i & 7) * VH + (i >> 3)] = v[0];
+                    }
+                }
+            }
+        }
+        if (__syncthreads_or((!ok) || *tail_fail)) return;   // also publishes hvec
+        WT_TICK(3);
+        if (++fr_phase == a.up) { fr_phase = 0; ++fr; }
+        if (++lo_phase == a.up_low) { lo_phase = 0; ++lo; }
+    }
+    if (wave >= 4) stage_pre(a.L - 1);
+    if (wave == 0) tail(a.L - 1);
+#ifdef TTSC_ABLATE
+    if (a.prof && tid == 0)
+        for (int i = 0; i < 16; ++i) a.prof[(size_t)blockIdx.x * 16 + i] = pacc[i];
+#endif
+}
+
+}  // namespace ttsc

@@ -156,7 +156,7 @@ class WaveRNN(nn.Module):
             st = L.ttsc_wavernn_last_status(self._handle, _lib.current_stream())
             if st == 1:
                 raise _lib.TTSCError('WaveRNN multi-workgroup kernel aborted on a hand-off timeout: ' + L.ttsc_last_error().decode())
-            self.last_kernel = {2: 'quad'}.get(st, 'stream')
+            self.last_kernel = {2: 'tile'}.get(st, 'stream')
         return idx, wav, logits
 
     def forward(self, X):
