@@ -104,15 +104,6 @@ int ttsc_conv1d_forward(const ttsc_conv1d* c, const float* x_dev, int32_t B, int
 int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x_dev, int32_t B, int64_t Lin, float* y_dev,
                                const float* resid_dev, const ttsc_conv1d_epilogue* ep, const int32_t* in_len_dev,
                                const int32_t* out_len_dev, void* stream);
-/* "Split activation" tensors (TTSC_PREC_F16X3 only): [B][C/8][hi|lo][L] items of 8 fp16 channels (16 bytes) holding
- * split(lrelu(scale * v, slope)) of an fp32 activation v as two fp16 halves.  A producer writes it once per element from
- * its epilogue (y_split_dev + ys_scale/ys_slope; y_dev may be NULL when only the split form is needed); a consumer given
- * x_split_dev stages pure 16-byte copies and ignores x_dev / ep->in_scale / ep->in_slope.  ttsc_split_bytes = buffer size. */
-size_t ttsc_split_bytes(int32_t B, int32_t C, int64_t L);
-int ttsc_conv1d_forward_split(const ttsc_conv1d* c, const float* x_dev, const void* x_split_dev, int32_t B, int64_t Lin,
-                              float* y_dev, void* y_split_dev, float ys_scale, float ys_slope, const float* resid_dev,
-                              const ttsc_conv1d_epilogue* ep, const int32_t* in_len_dev, const int32_t* out_len_dev,
-                              void* stream);
 /* Fused residual pair  y = x + conv2(lrelu(conv1(lrelu(x), 0.1), 0.1)) [+ y if accumulate]  of a HiFi-GAN ResBlock1
  * (both layers 32 -> 32 channels, odd kernel 3/7/11, conv2 undilated, both in TTSC_PREC_F16X3): the inner activation
  * stays in LDS, which removes two of the five HBM passes of the unfused pair.  `supported` returns 1 when the fused

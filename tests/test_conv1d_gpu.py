@@ -184,56 +184,6 @@ def test_fused_residual_pair_matches_torch(k, d, L, B):
     assert L_.ttsc_respair_supported(c1._h, c2._h) == 0
 
 
-def _split_ref(v):
-    """[B,C,L] fp32 -> reference split tensor [B, C/8, 2, L, 8] fp16 (hi, lo)"""
-    hi = v.half()
-    lo = (v - hi.float()).half()
-    B, C, L = v.shape
-    f = lambda t: t.reshape(B, C // 8, 8, L).permute(0, 1, 3, 2)      # [B, C/8, L, 8]
-    return torch.stack([f(hi), f(lo)], dim=2).contiguous()           # [B, C/8, 2, L, 8]
-
-
-@pytest.mark.parametrize('cin,cout,k,d,L,B', [(64, 64, 7, 3, 700, 2), (128, 256, 3, 1, 333, 1), (256, 128, 11, 5, 260, 1)])
-def test_split_activation_roundtrip(cin, cout, k, d, L, B):
-    """producer writes split(lrelu(scale*y, slope)) from its epilogue; consumer stages it with plain 16-byte copies"""
-    import ctypes as C
-    from ttscube_amd import _lib
-    from ttscube_amd.hip_layers import Conv1dHip
-    pad = d * (k - 1) // 2
-    w = _mk((cout, cin, k), 1, 1.0 / (cin * k) ** 0.5)
-    b = _mk((cout,), 2, 0.1)
-    x = _mk((B, cin, L), 3)
-    r = _mk((B, cout, L), 4)
-    conv = Conv1dHip(cin, cout, k, padding=pad, dilation=d).set_precision('f16x3')
-    conv.set_weight(w, b)
-    L_ = _lib.lib()
-    # (1) fp32 in -> fp32 + split out (with residual), scale 1/3 and slope 0.1 on the split copy
-    y = torch.empty(B, cout, L, device='cuda')
-    ys = torch.empty(B, cout // 8, 2, L, 8, dtype=torch.float16, device='cuda')
-    assert ys.numel() * 2 == L_.ttsc_split_bytes(B, cout, L)
-    ep = _lib.Conv1dEpilogue(1.0, 0.1, 1.0, _lib.ACT_NONE, 0)
-    xd, rd = x.cuda(), r.cuda()
-    _lib.check(L_.ttsc_conv1d_forward_split(conv._h, _lib.dev_ptr(xd), None, B, L, _lib.dev_ptr(y), C.c_void_p(ys.data_ptr()),
-                                            1.0 / 3.0, 0.1, _lib.dev_ptr(rd), C.byref(ep), None, None, _lib.current_stream()), 'split')
-    ref = F.conv1d(F.leaky_relu(x, 0.1), w, b, padding=pad, dilation=d) + r
-    assert float((y.cpu() - ref).abs().max()) < F16X3_TOL
-    want = _split_ref(F.leaky_relu(y.cpu() * (1.0 / 3.0), 0.1))
-    got = ys.cpu()
-    rec = got[:, :, 0].float() + got[:, :, 1].float()
-    assert float((rec - (want[:, :, 0].float() + want[:, :, 1].float())).abs().max()) < 1e-6
-    # (2) split in -> fp32 out: equals the fp32-input path on the already-activated tensor
-    if cout % 16 == 0:
-        conv2 = Conv1dHip(cout, cin, 3, padding=1).set_precision('f16x3')
-        w2 = _mk((cin, cout, 3), 5, 1.0 / (cout * 3) ** 0.5)
-        conv2.set_weight(w2, None)
-        z = torch.empty(B, cin, L, device='cuda')
-        ep1 = _lib.Conv1dEpilogue(1.0, 1.0, 1.0, _lib.ACT_NONE, 0)
-        _lib.check(L_.ttsc_conv1d_forward_split(conv2._h, None, C.c_void_p(ys.data_ptr()), B, L, _lib.dev_ptr(z), None, 1.0, 1.0,
-                                                None, C.byref(ep1), None, None, _lib.current_stream()), 'split-in')
-        ref2 = F.conv1d(F.leaky_relu(ref / 3.0, 0.1), w2, None, padding=1)
-        assert float((z.cpu() - ref2).abs().max()) < F16X3_TOL
-
-
 def _chain_layers(C, k, dils, seed=0):
     from ttscube_amd.hip_layers import Conv1dHip
     c1s, c2s, ws = [], [], []

@@ -129,23 +129,6 @@ def test_generator_errors():
         g(torch.zeros(1, 80, 4))  # CPU tensor
 
 
-def test_generator_split_activation_flow_matches_default(monkeypatch):
-    """TTSC_HIFIGAN_SPLIT=1 (producer-side lrelu + hi/lo split, consumers copy 16-byte items) == default flow to ~1e-6"""
-    h = dict(R.CONFIG_V1)
-    sd = R.synthetic_state_dict(h, seed=31)
-    mel = R.synthetic_mel(2, 33, seed=32)
-    w = R.fold_state_dict(sd)
-    ref = R.generator_forward(w, h, mel)
-    outs = {}
-    for flag in ('0', '1'):
-        monkeypatch.setenv('TTSC_HIFIGAN_SPLIT', flag)   # read at handle creation
-        g = _gen(h, sd, 'f16x3')
-        with torch.no_grad():
-            outs[flag] = g(mel.cuda()).cpu()
-        assert float((outs[flag] - ref).pow(2).mean().sqrt()) < 2e-5
-    assert float((outs['0'] - outs['1']).abs().max()) < 1e-5
-
-
 def _rel_rms(a, b):
     return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-30))
 

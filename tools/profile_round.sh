@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round profile passes on the GPU box (run through gpurun): kernel traces and PMC passes of the headline bench, the e2e path,
+# the training step and WaveRNN.  The rocpd databases are summarised here and deleted (gpurun returns <= 64 MiB).
+#   usage: bash tools/profile_round.sh r02
+R=${1:-r02}
+O=gpurun_out/$R
+mkdir -p $O; cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+B="python bench.py --no-extra --no-cpu-baseline"
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- $B --steps 5 --warmup 1 > $O/bench_trace.log 2>&1
+python tools/rocpd_stats.py $O/trace/t_results.db $O/bench_kernel_stats.csv 48 $O/bench_last_forward.csv >> $O/bench_trace.log 2>&1
+# PMC passes: calibration off so that every forward of the run is the same launch sequence (3 forwards each)
+for P in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" "grbm:GRBM_COUNT GRBM_GUI_ACTIVE"; do
+  N=${P%%:*}; C=${P#*:}
+  TTSC_HIFIGAN_CALIBRATE=0 timeout 300 rocprofv3 --pmc $C --kernel-trace -d $O/$N -o p -- $B --steps 1 --warmup 0 > $O/pmc_$N.log 2>&1
+done
+python tools/pmc_summary.py $O/bench_pmc.csv $O/fetch/p_results.db $O/write/p_results.db $O/sq/p_results.db $O/grbm/p_results.db --note "bench.py --steps 1 --warmup 0 (3 identical forwards, TTSC_HIFIGAN_CALIBRATE=0), one rocprofv3 --pmc pass per counter group; sums over all launches" > $O/pmc_summary.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/e2e -o e -- python tools/bench_e2e.py > $O/e2e.log 2>&1
+python tools/rocpd_stats.py $O/e2e/e_results.db $O/e2e_kernel_stats.csv >> $O/e2e.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/train -o r -- python bench.py --mode train --steps 3 --warmup 1 > $O/train.log 2>&1
+python tools/rocpd_stats.py $O/train/r_results.db $O/train_kernel_stats.csv >> $O/train.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/wr -o v -- python tools/bench_wavernn.py > $O/wavernn.log 2>&1
+python tools/rocpd_stats.py $O/wr/v_results.db $O/wavernn_kernel_stats.csv >> $O/wavernn.log 2>&1
+rm -rf $O/trace $O/fetch $O/write $O/sq $O/grbm $O/e2e $O/train $O/wr
+# the same workload on round 1's kernels only (no wide tiles, no fused chain), for the record
+(TTSC_CONV_WIDE=0 TTSC_HIFIGAN_CHAIN=0 timeout 200 $B --steps 5 --warmup 2) > $O/bench_r1_kernels.log 2>&1
+timeout 600 python bench.py > $O/bench_final.json 2> $O/bench_final.err
+du -sh $O; ls $O; tail -c 300 $O/bench_final.json

@@ -1,14 +1,17 @@
-"""Summarise a rocprofv3 rocpd sqlite database (kernel trace) into a per-kernel stats CSV
-(same columns as rocprofv3's kernel_stats.csv) plus a per-launch listing of the last N launches."""
+"""Summarise a rocprofv3 rocpd sqlite database (kernel trace) into a per-kernel stats CSV (same columns as rocprofv3's
+kernel_stats.csv) and, optionally, a per-launch listing of the last N launches (one forward / one step, in launch order).
+
+    python tools/rocpd_stats.py run_results.db stats.csv [N last.csv]"""
 import sqlite3
 import sys
 
 
-def main(db, out_csv):
+def main(db, out_csv, n_last=0, last_csv=None):
     c = sqlite3.connect(db)
-    rows = c.execute('select name, (end-start) from kernels').fetchall()
+    rows = c.execute('select name, start, end, grid_x, grid_y, grid_z, workgroup_x, lds_size, vgpr_count from kernels order by start').fetchall()
     agg = {}
-    for n, d in rows:
+    for r in rows:
+        n, d = r[0], r[2] - r[1]
         a = agg.setdefault(n, [0, 0, 1 << 62, 0])
         a[0] += 1
         a[1] += d
@@ -20,7 +23,14 @@ def main(db, out_csv):
         for n, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             f.write('"%s",%d,%d,%.1f,%.2f,%d,%d\n' % (n.replace('"', "'"), a[0], a[1], a[1] / a[0], 100.0 * a[1] / tot, a[2], a[3]))
     print('wrote', out_csv, 'kernels:', len(agg), 'total ms: %.3f' % (tot / 1e6))
+    if n_last and last_csv:
+        with open(last_csv, 'w') as f:
+            f.write('"Name","DurationNs","GridX","GridY","GridZ","WorkgroupX","LdsBytes","Vgprs"\n')
+            for r in rows[-n_last:]:
+                f.write('"%s",%d,%d,%d,%d,%d,%d,%d\n' % (r[0].replace('"', "'"), r[2] - r[1], r[3], r[4], r[5], r[6], r[7], r[8]))
+        print('wrote', last_csv, 'sum ms: %.3f' % (sum(r[2] - r[1] for r in rows[-n_last:]) / 1e6))
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2])
+    a = sys.argv
+    main(a[1], a[2], int(a[3]) if len(a) > 3 else 0, a[4] if len(a) > 4 else None)

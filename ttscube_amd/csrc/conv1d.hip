@@ -53,13 +53,6 @@ struct ConvArgs {
     int span, span_pad, min_shift;
     float in_scale, in_slope, out_scale;
     int out_act, accumulate;
-    // "split activation" tensors: [B][C/8][hi|lo][L] items of 8 fp16 channels (16 B) = the LDS plane layout of the
-    // f16x3 kernels.  A producer's epilogue writes  split(lrelu(ys_scale * y, ys_slope))  ONCE per element, so that the
-    // consumer stages pure 16-byte copies instead of converting fp32 -> (hi,lo) in every output-channel tile.
-    const void* xs;   // split input (then x / in_scale / in_slope are ignored) or null
-    void* ys;         // split output or null
-    float ys_scale, ys_slope;
-    int write_f32;    // 0: only the split output is written
     int vphase;       // fused ConvTranspose1d phases: GEMM row v = r * vphase + co (vphase = real Cout), output o += r; 0 = off;
                       // -4 = rows interleaved v = co * 4 + r (kernel_size == stride == 4): see epilogue_tile_v4
     int dbg;          // ablation switches, ONLY in -DTTSC_ABLATE builds (tools/ablate.cpp; never in libttscube_hip.so): see TTSC_DBG
@@ -85,9 +78,7 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& acc, const ConvArgs&
     // groups).  A per-element `ptr ? ptr[i] : 0` makes hipcc branch around every single load and wait for each one in turn.
     // The tile is processed as four groups of four rows (= the four 8-channel items a lane contributes to): all loads
     // of a group are issued before its stores, and only ~4 values per operand are live at a time (register pressure).
-    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
     const long o_c = qok ? o : 0;
-    const size_t c8n = (size_t)(a.Cout >> 3);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         float rv[4], yv[4], bv[4], res[4];
@@ -136,28 +127,10 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& acc, const ConvArgs&
 #pragma unroll
             for (int e = 0; e < 4; ++e) res[e] = apply_act((acc[4 * g + e] * acc_scale + bv[e] + rv[e]) * a.out_scale, a.out_act) + yv[e];
         }
-        if (a.write_f32) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int co = co_base + 8 * g + 4 * half + e;
-                if (qok && co < a.Cout) a.y[idx[e]] = res[e];
-            }
-        }
-        if (a.ys && qok && co_base + 8 * g + 4 * half < a.Cout) {
-            // split(lrelu(ys_scale * y, ys_slope)) of this lane's 4 channels of 8-channel item (co_base/8 + g)
-            half4 vh, vl;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = res[e] * a.ys_scale;
-                v = fmaxf(v, v * a.ys_slope);
-                const _Float16 hh = (_Float16)v;
-                vh[e] = hh;
-                vl[e] = (_Float16)(v - (float)hh);
-            }
-            const size_t item = (((size_t)b * c8n + (size_t)((co_base >> 3) + g)) * 2) * a.Lout + (size_t)o;
-            _Float16* ph = reinterpret_cast<_Float16*>(a.ys) + item * 8 + 4 * half;
-            *reinterpret_cast<half4*>(ph) = vh;
-            *reinterpret_cast<half4*>(ph + (size_t)a.Lout * 8) = vl;
+        for (int e = 0; e < 4; ++e) {
+            const int co = co_base + 8 * g + 4 * half + e;
+            if (qok && co < a.Cout) a.y[idx[e]] = res[e];
         }
     }
 }
@@ -388,7 +361,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_mfma_kernel(ConvArgs a) {
 // one position) is a single 16-byte ds_read; the fp32 -> (hi,lo) split and the leaky-relu prologue happen while staging.
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-template <int MI, int NJ, int TMAX, bool SPLIT_IN>
+template <int MI, int NJ, int TMAX>
 __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NT = 4 * NJ * 32;
@@ -444,18 +417,15 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
             if (idx < a_items) Ap[idx] = areg[e];
         }
     };
-    // ---- activation staging, two input formats --------------------------------------------------------------
-    //  fp32 [B,C,L]: work item = (position p, channel group h of 8): 8 dword loads, leaky-relu + hi/lo split in x_commit
-    //  split [B,C/8,2,L] items: work item = (plane, position): ONE 16-byte load, committed unchanged (the producer's
-    //  epilogue already applied the activation and the split)
-    constexpr int XIT = SPLIT_IN ? ((NT + 64) * 4 + 255) / 256 : ((NT + 64) * 2 + 255) / 256;
+    // ---- activation staging: fp32 [B,C,L]; work item = (position p, channel group h of 8): 8 dword loads, leaky-relu + hi/lo
+    // split in x_commit
+    constexpr int XIT = ((NT + 64) * 2 + 255) / 256;
     const int spanp = (a.span + 63) & ~63;
-    float xr[SPLIT_IN ? 1 : XIT][8];
-    half8 xq[SPLIT_IN ? XIT : 1];
+    float xr[XIT][8];
     unsigned xoff[XIT];
     int xslot[XIT];   // LDS item index, or -1
     bool xok[XIT];
-    int xh[XIT];      // fp32: channel half (0/1); split: plane index (h*2 + pl) in 0..3
+    int xh[XIT];      // channel half (0/1)
 #pragma unroll
     for (int e = 0; e < XIT; ++e) {
         const int i = tid + e * 256;
@@ -467,60 +437,35 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
         pc = pc < 0 ? 0 : pc;
         xoff[e] = (unsigned)pc;
         xh[e] = h;
-        if (SPLIT_IN)
-            xslot[e] = (p < a.span && h < 4) ? h * a.span_pad + p : -1;
-        else
-            xslot[e] = (p < a.span && h < 2) ? (h * 2) * a.span_pad + p : -1;
+        xslot[e] = (p < a.span && h < 2) ? (h * 2) * a.span_pad + p : -1;
     }
-    const half8* xsb = reinterpret_cast<const half8*>(a.xs) + (size_t)b * (a.Cin >> 3) * 2 * a.Lin;
     auto x_issue = [&](int c) {
-        if (SPLIT_IN) {
-            // plane (h, pl) of chunk c = 8-channel group (2c + h), plane pl: a wave-uniform row base + per-lane position
 #pragma unroll
-            for (int e = 0; e < XIT; ++e) {
-                const int hp = xh[e] < 4 ? xh[e] : 3;
-                int c8 = 2 * c + (hp >> 1);
-                c8 = c8 < (a.Cin >> 3) ? c8 : (a.Cin >> 3) - 1;
-                xq[SPLIT_IN ? e : 0] = xsb[((size_t)c8 * 2 + (hp & 1)) * a.Lin + xoff[e]];
-            }
-        } else {
+        for (int ch = 0; ch < 8; ++ch) {
+            // the two channel rows (h = 0 / 1) of this step are wave-uniform scalars: sgpr base + vgpr offset
+            const int c0 = c * 16 + ch, c1 = c * 16 + 8 + ch;
+            const float* r0 = xb + (size_t)(c0 < a.Cin ? c0 : a.Cin - 1) * a.Lin;
+            const float* r1 = xb + (size_t)(c1 < a.Cin ? c1 : a.Cin - 1) * a.Lin;
 #pragma unroll
-            for (int ch = 0; ch < 8; ++ch) {
-                // the two channel rows (h = 0 / 1) of this step are wave-uniform scalars: sgpr base + vgpr offset
-                const int c0 = c * 16 + ch, c1 = c * 16 + 8 + ch;
-                const float* r0 = xb + (size_t)(c0 < a.Cin ? c0 : a.Cin - 1) * a.Lin;
-                const float* r1 = xb + (size_t)(c1 < a.Cin ? c1 : a.Cin - 1) * a.Lin;
-#pragma unroll
-                for (int e = 0; e < XIT; ++e) xr[SPLIT_IN ? 0 : e][ch] = (xh[e] ? r1 : r0)[xoff[e]];
-            }
+            for (int e = 0; e < XIT; ++e) xr[e][ch] = (xh[e] ? r1 : r0)[xoff[e]];
         }
     };
     auto x_commit = [&](int c) {
 #pragma unroll
         for (int e = 0; e < XIT; ++e) {
             if (xslot[e] >= 0) {
-                if (SPLIT_IN) {
-                    const int c8 = 2 * c + (xh[e] >> 1);
-                    half8 v = xq[SPLIT_IN ? e : 0];
-                    if (!(xok[e] && c8 < (a.Cin >> 3))) {
+                const int cb = c * 16 + xh[e] * 8;
+                half8 vh, vl;
 #pragma unroll
-                        for (int ch = 0; ch < 8; ++ch) v[ch] = (_Float16)0.f;
-                    }
-                    Xp[xslot[e]] = v;
-                } else {
-                    const int cb = c * 16 + xh[e] * 8;
-                    half8 vh, vl;
-#pragma unroll
-                    for (int ch = 0; ch < 8; ++ch) {
-                        float v = (xok[e] && cb + ch < a.Cin) ? xr[SPLIT_IN ? 0 : e][ch] * a.in_scale : 0.f;
-                        v = fmaxf(v, v * a.in_slope);   // leaky-relu for slopes in [0,1] (1 = identity)
-                        const _Float16 hh = (_Float16)v;
-                        vh[ch] = hh;
-                        vl[ch] = (_Float16)(v - (float)hh);
-                    }
-                    Xp[xslot[e]] = vh;
-                    Xp[xslot[e] + a.span_pad] = vl;
+                for (int ch = 0; ch < 8; ++ch) {
+                    float v = (xok[e] && cb + ch < a.Cin) ? xr[e][ch] * a.in_scale : 0.f;
+                    v = fmaxf(v, v * a.in_slope);   // leaky-relu for slopes in [0,1] (1 = identity)
+                    const _Float16 hh = (_Float16)v;
+                    vh[ch] = hh;
+                    vl[ch] = (_Float16)(v - (float)hh);
                 }
+                Xp[xslot[e]] = vh;
+                Xp[xslot[e] + a.span_pad] = vl;
             }
         }
     };
@@ -977,11 +922,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 2)) void respair32_f16x3_ke
     ea.out_scale = 1.f;
     ea.out_act = TTSC_ACT_NONE;
     ea.accumulate = a.accumulate;
-    ea.xs = nullptr;
-    ea.ys = nullptr;
-    ea.ys_scale = 1.f;
-    ea.ys_slope = 1.f;
-    ea.write_f32 = 1;
     ea.dbg = 0;
     ea.gate = nullptr;
     ea.gate_slope = 1.f;
@@ -1085,7 +1025,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs a) {
     }
 }
 
-template <int MI, int NJ, int TMAX, bool SPLIT_IN>
+template <int MI, int NJ, int TMAX>
 static int launch_f16_t(const ConvArgs& a, int B, hipStream_t s) {
     constexpr int NT = 4 * NJ * 32;
     constexpr int MT = MI * 32;
@@ -1093,10 +1033,10 @@ static int launch_f16_t(const ConvArgs& a, int B, hipStream_t s) {
     const size_t lds = (size_t)a.span_pad * 4 * 16 + (size_t)a.ntaps * MI * 2 * 64 * 16;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv_f16x3_kernel<MI, NJ, TMAX, SPLIT_IN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_f16x3_kernel<MI, NJ, TMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL((conv_f16x3_kernel<MI, NJ, TMAX, SPLIT_IN>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_f16x3_kernel<MI, NJ, TMAX>), grid, dim3(256), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("conv_f16x3_kernel launch failed: %s", hipGetErrorString(e));
@@ -1139,17 +1079,12 @@ static int launch_f16_wide_k(const ConvArgs& a, int B, int d, hipStream_t s) {
     return launch_f16_wide_d<C, 11>(a, B, d, s);
 }
 
-template <int MI, int NJ, bool SPLIT_IN>
-static int launch_f16_s(const ConvArgs& a, int B, hipStream_t s) {
-    if (a.ntaps <= 3) return launch_f16_t<MI, NJ, 3, SPLIT_IN>(a, B, s);
-    if (a.ntaps <= 7) return launch_f16_t<MI, NJ, 7, SPLIT_IN>(a, B, s);
-    if (a.ntaps <= 11) return launch_f16_t<MI, NJ, 11, SPLIT_IN>(a, B, s);
-    return launch_f16_t<MI, NJ, 16, SPLIT_IN>(a, B, s);
-}
-
 template <int MI, int NJ>
 static int launch_f16(const ConvArgs& a, int B, hipStream_t s) {
-    return a.xs ? launch_f16_s<MI, NJ, true>(a, B, s) : launch_f16_s<MI, NJ, false>(a, B, s);
+    if (a.ntaps <= 3) return launch_f16_t<MI, NJ, 3>(a, B, s);
+    if (a.ntaps <= 7) return launch_f16_t<MI, NJ, 7>(a, B, s);
+    if (a.ntaps <= 11) return launch_f16_t<MI, NJ, 11>(a, B, s);
+    return launch_f16_t<MI, NJ, 16>(a, B, s);
 }
 
 template <int MI, int NJ, int WM, int WN>
@@ -1550,12 +1485,6 @@ extern "C" int ttsc_conv1d_forward(const ttsc_conv1d* c, const float* x, int32_t
     return ttsc_conv1d_forward_ragged(c, x, B, Lin, y, resid, ep, nullptr, nullptr, stream);
 }
 
-extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, int32_t B, int64_t Lin, float* y,
-                                          const float* resid, const ttsc_conv1d_epilogue* ep, const int32_t* in_len_dev,
-                                          const int32_t* out_len_dev, void* stream) {
-    return ttsc_conv1d_forward_split(c, x, nullptr, B, Lin, y, nullptr, 1.f, 1.f, resid, ep, in_len_dev, out_len_dev, stream);
-}
-
 extern "C" int32_t ttsc_conv1d_in_channels(const ttsc_conv1d* c) { return c ? c->cfg.in_channels : 0; }
 
 // Split precision carries an fp32 value as two fp16 halves, so an activation tensor must sit inside fp16's range: with |x|
@@ -1595,20 +1524,10 @@ extern "C" int ttsc_absmax(const float* x_dev, int64_t n, float* out_dev, void* 
     return TTSC_OK;
 }
 
-extern "C" size_t ttsc_split_bytes(int32_t B, int32_t C, int64_t L) { return (size_t)B * (size_t)((C + 7) / 8) * 2 * (size_t)L * 16; }
-
-extern "C" int ttsc_conv1d_forward_split(const ttsc_conv1d* c, const float* x, const void* x_split, int32_t B, int64_t Lin, float* y,
-                                         void* y_split, float ys_scale, float ys_slope, const float* resid,
-                                         const ttsc_conv1d_epilogue* ep, const int32_t* in_len_dev, const int32_t* out_len_dev,
-                                         void* stream) {
-    TTSC_REQUIRE(c && (x || x_split) && (y || y_split), "ttsc_conv1d_forward: null argument");
-    if (x_split || y_split) {
-        TTSC_REQUIRE(c->precision == TTSC_PREC_F16X3, "split activation tensors need TTSC_PREC_F16X3");
-        TTSC_REQUIRE(!x_split || c->cfg.in_channels % 16 == 0, "split input needs in_channels %% 16 == 0");
-        TTSC_REQUIRE(!y_split || c->cfg.out_channels % 8 == 0, "split output needs out_channels %% 8 == 0");
-        TTSC_REQUIRE(ys_slope >= 0.f && ys_slope <= 1.f, "ys_slope must be in [0,1]");
-        TTSC_REQUIRE(y || !(ep && ep->accumulate), "accumulate needs the fp32 output");
-    }
+extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, int32_t B, int64_t Lin, float* y,
+                                          const float* resid, const ttsc_conv1d_epilogue* ep, const int32_t* in_len_dev,
+                                          const int32_t* out_len_dev, void* stream) {
+    TTSC_REQUIRE(c && x && y, "ttsc_conv1d_forward: null argument");
     if (!c->has_weight) {
         set_error("ttsc_conv1d_forward: weights not set");
         return TTSC_ESTATE;
@@ -1631,18 +1550,13 @@ extern "C" int ttsc_conv1d_forward_split(const ttsc_conv1d* c, const float* x, c
         a.bias = (c->dev_weights && c->bias_ext) ? c->bias_ext : c->bias_dev;
         a.in_len = in_len_dev;
         a.out_len = out_len_dev;
-        a.xs = x_split;
-        a.ys = y_split;
-        a.ys_scale = ys_scale;
-        a.ys_slope = ys_slope;
-        a.write_f32 = y ? 1 : 0;
         a.dbg = 0;
 #ifdef TTSC_ABLATE
         if (const char* ev = getenv("TTSC_CONV_DBG")) a.dbg = atoi(ev);
 #endif
         a.vphase = c->vfused ? ((c->vrow4 && c->precision == TTSC_PREC_F16X3) ? -4 : g.out_channels) : 0;
         if (a.vphase == -4) {
-            TTSC_REQUIRE(!a.ys && !(ep && ep->gate_dev), "ttsc_conv1d_forward: split output / gate are not available on this transposed layer");
+            TTSC_REQUIRE(!(ep && ep->gate_dev), "ttsc_conv1d_forward: the gate epilogue is not available on this transposed layer");
             TTSC_REQUIRE(((uintptr_t)y % 16 == 0) && (!resid || (uintptr_t)resid % 16 == 0), "ttsc_conv1d_forward: y / resid must be 16-byte aligned for ConvTranspose1d(k=4, s=4)");
         }
         a.Cin = g.in_channels;
@@ -1681,8 +1595,8 @@ extern "C" int ttsc_conv1d_forward_split(const ttsc_conv1d* c, const float* x, c
         a.in_scale = ep ? ep->in_scale : 1.f;
         const float* w_plain = c->dev_weights ? c->w_plain_ext : c->w_plain_dev;
         const bool use_cout1 = !g.transposed && g.out_channels == 1 && g.in_channels <= 64 && g.kernel_size <= 16 && g.dilation == 1 &&
-                               w_plain && !x_split && !y_split && !(ep && ep->gate_dev);
-        if (c->precision == TTSC_PREC_F16X3 && !a.xs && !use_cout1) {   // activation pre-scale (exact powers of two, see ttsc_conv1d_set_activation_scale)
+                               w_plain && !(ep && ep->gate_dev);
+        if (c->precision == TTSC_PREC_F16X3 && !use_cout1) {   // activation pre-scale (exact powers of two, see ttsc_conv1d_set_activation_scale)
             a.in_scale *= c->act_scale;
             a.w_unscale = c->w_unscale / c->act_scale;
         }
@@ -1723,7 +1637,7 @@ extern "C" int ttsc_conv1d_forward_split(const ttsc_conv1d* c, const float* x, c
             const long want16 = 512;
             // square "same"-padded layers of the wide stages (the generator's ResBlock convolutions at 128 / 256 channels):
             // the wide-tile kernel (activation window staged once for all output channels)
-            const bool wide_shape = !g.transposed && !a.xs && !a.ys && !a.gate && g.in_channels == g.out_channels &&
+            const bool wide_shape = !g.transposed && !a.gate && g.in_channels == g.out_channels &&
                                     (g.out_channels == 128 || g.out_channels == 256) &&
                                     (g.kernel_size == 3 || g.kernel_size == 7 || g.kernel_size == 11) &&
                                     (g.dilation == 1 || g.dilation == 3 || g.dilation == 5) &&
@@ -1734,24 +1648,24 @@ extern "C" int ttsc_conv1d_forward_split(const ttsc_conv1d* c, const float* x, c
                 else
                     rc = launch_f16_wide_k<128>(a, B, g.dilation, s);
             } else if (c->MT >= 64) {
-                if (a.xs || big_only || wgs16(64, 256) >= want16)
+                if (big_only || wgs16(64, 256) >= want16)
                     rc = launch_f16<2, 2>(a, B, s);   // 64 x 256 tile (MT=128 layers run as two M tiles)
                 else if (wgs16(64, 128) >= want16) {
                     set_nt16(128);
-                    rc = launch_f16_s<2, 1, false>(a, B, s);
+                    rc = launch_f16<2, 1>(a, B, s);
                 } else {
                     set_nt16(128);
-                    rc = launch_f16_s<1, 1, false>(a, B, s);
+                    rc = launch_f16<1, 1>(a, B, s);
                 }
             } else {
-                if (a.xs || big_only || wgs16(32, 512) >= want16)
+                if (big_only || wgs16(32, 512) >= want16)
                     rc = launch_f16<1, 4>(a, B, s);   // 32 x 512 tile
                 else if (wgs16(32, 256) >= want16) {
                     set_nt16(256);
-                    rc = launch_f16_s<1, 2, false>(a, B, s);
+                    rc = launch_f16<1, 2>(a, B, s);
                 } else {
                     set_nt16(128);
-                    rc = launch_f16_s<1, 1, false>(a, B, s);
+                    rc = launch_f16<1, 1>(a, B, s);
                 }
             }
         } else {

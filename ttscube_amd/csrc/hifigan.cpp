@@ -43,8 +43,6 @@ struct ttsc_hifigan {
     bool use_fused = true;      // env TTSC_HIFIGAN_FUSED=0 disables the fused residual-pair kernel (A/B measurements)
     bool use_chain = true;      // env TTSC_HIFIGAN_CHAIN=0 disables the whole-ResBlock fused chain kernel (resblock.hip)
     int chain_shape = -1;       // env TTSC_HIFIGAN_CHAIN_SHAPE: tile shape of the chain kernel (-1 = by halo)
-    bool use_split = false;     // env TTSC_HIFIGAN_SPLIT=1 enables the producer-side split-activation flow (measured: no gain —
-                                // the consumer-side conversion hides behind the MFMA loop, the extra tensors cost HBM traffic)
     int precision = TTSC_PREC_FP32;
     // Split precision keeps activations as fp16 (hi, lo) pairs, so every layer's input gets a power-of-two pre-scale that
     // centres it in fp16's range (ttsc_conv1d_set_activation_scale).  The scales come from ONE calibration forward — the
@@ -96,7 +94,6 @@ extern "C" int ttsc_hifigan_create(const ttsc_hifigan_cfg* cfg, ttsc_hifigan** o
     std::unique_ptr<ttsc_hifigan> g(new ttsc_hifigan());
     g->cfg = *cfg;
     if (const char* ev = getenv("TTSC_HIFIGAN_FUSED")) g->use_fused = atoi(ev) != 0;
-    if (const char* ev = getenv("TTSC_HIFIGAN_SPLIT")) g->use_split = atoi(ev) != 0;
     if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN")) g->use_chain = atoi(ev) != 0;
     if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN_SHAPE")) g->chain_shape = atoi(ev);
     if (const char* ev = getenv("TTSC_HIFIGAN_CALIBRATE")) g->auto_calibrate = atoi(ev) != 0;
@@ -210,7 +207,7 @@ static size_t len_table_bytes(const ttsc_hifigan* g, int32_t B) {
 
 extern "C" size_t ttsc_hifigan_workspace_bytes(const ttsc_hifigan* g, int32_t B, int64_t T) {
     if (!g || B <= 0 || T <= 0) return 0;
-    return 7 * buf_elems(g, B, T) * sizeof(float) + len_table_bytes(g, B);
+    return 4 * buf_elems(g, B, T) * sizeof(float) + len_table_bytes(g, B);
 }
 
 extern "C" int ttsc_hifigan_algorithmic_flops(const ttsc_hifigan* g, int32_t B, int64_t T, double* out) {
@@ -324,7 +321,7 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
                 tab[(size_t)(i + 1) * B + b] = (int32_t)Lb;
             }
         }
-        int32_t* dtab = (int32_t*)(S + 4 * be);
+        int32_t* dtab = (int32_t*)(S + be);   // behind the fourth buffer
         TTSC_HIP_CHECK(hipMemcpyAsync(dtab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, (hipStream_t)stream));
         TTSC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));  // `tab` is pageable host memory going out of scope
         for (int i = 0; i <= c.num_upsamples; ++i) lens[i] = dtab + (size_t)i * B;
@@ -332,18 +329,9 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
     auto layer = [&](const std::string& n) -> ttsc_conv1d* { return g->layers.at(n)->c; };
     int rc;
 
-    // ---- split-activation flow (TTSC_PREC_F16X3, ResBlock1) ------------------------------------------------------
-    // Every conv input of the generator passes through a leaky-relu, so the producer writes split(lrelu(.)) of its output
-    // once (fp16 hi|lo planes, see conv1d.hip) and consumers stage plain 16-byte copies.  fp32 copies are kept only where
-    // a residual add or the running block sum needs them.  Xs/Rs/Ss are the split twins of X/R/S; XT only exists split.
-    float* Xs = S + be;   // (the length table of ragged batches lives behind the 7th buffer)
-    float* Rs = Xs + be;
-    float* Ss = Rs + be;
-    const bool split_ok = !calib && g->use_split && c.resblock == 1 && g->precision == TTSC_PREC_F16X3;
-    auto in16 = [&](const ttsc_conv1d* l) { return ttsc_conv1d_in_channels(l) % 16 == 0; };
-    auto conv = [&](ttsc_conv1d* l, const float* x, const void* xs, int64_t Lin, float* y, void* ys, float ys_scale,
-                    float ys_slope, const float* resid, const ttsc_conv1d_epilogue& e, const int32_t* il, const int32_t* ol) {
-        if (calib && x && !xs) {   // calibration forward: abs-max of this layer's input -> its pre-scale, then the layer
+    auto conv = [&](ttsc_conv1d* l, const float* x, int64_t Lin, float* y, const float* resid, const ttsc_conv1d_epilogue& e, const int32_t* il,
+                    const int32_t* ol) {
+        if (calib) {   // calibration forward: abs-max of this layer's input -> its pre-scale, then the layer
             float m = 0.f;
             if (hipMemsetAsync(calib_stat, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return (int)TTSC_EHIP;
             int arc = ttsc_absmax(x, (int64_t)B * ttsc_conv1d_in_channels(l) * Lin, calib_stat, stream);
@@ -356,19 +344,14 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
             arc = ttsc_conv1d_set_activation_scale(l, calib_scale(m * fabsf(e.in_scale)));
             if (arc) return arc;
         }
-        return ttsc_conv1d_forward_split(l, xs ? nullptr : x, xs, B, Lin, y, ys, ys_scale, ys_slope, resid, &e, il, ol, stream);
+        return ttsc_conv1d_forward_ragged(l, x, B, Lin, y, resid, &e, il, ol, stream);
     };
     const float inv_nk = 1.f / (float)c.num_kernels;
     ttsc_conv1d_epilogue ep{1.f, 1.f, 1.f, TTSC_ACT_NONE, 0};
     int64_t L = T;
     float sum_scale = 1.f;   // pending division by nk of the previous stage's block sum (fp32 consumers)
-    bool s_split = false;    // Ss holds split(lrelu(S * scale, 0.1)) for the next upsampler
-    {
-        ttsc_conv1d* up0 = layer("ups.0");
-        s_split = split_ok && in16(up0) && c.upsample_initial_channel % 8 == 0;
-        rc = conv(layer("conv_pre"), mel, nullptr, T, s_split ? nullptr : S, s_split ? (void*)Ss : nullptr, 1.f, 0.1f, nullptr, ep, lens[0], lens[0]);
-        if (rc) return rc;
-    }
+    rc = conv(layer("conv_pre"), mel, T, S, nullptr, ep, lens[0], lens[0]);
+    if (rc) return rc;
     for (int i = 0; i < c.num_upsamples; ++i) {
         const int ch = g->stage_ch[i];
         ttsc_conv1d* up = layer("ups." + std::to_string(i));
@@ -392,19 +375,12 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
             chain_stage = nd <= 3 && ttsc_rbchain_supported(c1, c2, nd) != 0;
         }
         if (chain_stage) fused_stage = false;
-        const bool stage_split = split_ok && !fused_stage && !chain_stage && ch % 16 == 0;
-        // x = ups[i](lrelu(x / nk_prev, 0.1)); the stage input is needed in fp32 (residual of the first pair) and, in the
-        // split flow, as split(lrelu(x, 0.1)) for the three first convs
+        // x = ups[i](lrelu(x / nk_prev, 0.1))
         ttsc_conv1d_epilogue eu{sum_scale, 0.1f, 1.f, TTSC_ACT_NONE, 0};
-        rc = conv(up, S, s_split ? (const void*)Ss : nullptr, L, X, stage_split ? (void*)Xs : nullptr, 1.f, 0.1f, nullptr, eu, lens[i], lens[i + 1]);
+        rc = conv(up, S, L, X, nullptr, eu, lens[i], lens[i + 1]);
         if (rc) return rc;
         L = ttsc_conv1d_out_len(up, L);
         const int32_t* ln = lens[i + 1];
-        // who consumes this stage's block mean: the next upsampler (slope 0.1) or conv_post (slope 0.01)
-        const bool last_stage = (i == c.num_upsamples - 1);
-        const ttsc_conv1d* nxt = last_stage ? layer("conv_post") : layer("ups." + std::to_string(i + 1));
-        const bool next_split = stage_split && in16(nxt);
-        const float next_slope = last_stage ? 0.01f : 0.1f;
         for (int j = 0; j < c.num_kernels; ++j) {
             const std::string rb = "resblocks." + std::to_string(i * c.num_kernels + j);
             const int nd = c.num_dilations[j];
@@ -435,46 +411,29 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
             }
             for (int m = 0; m < nd; ++m) {
                 const float* src = (m == 0) ? X : R;
-                const void* src_s = stage_split ? (const void*)((m == 0) ? Xs : Rs) : nullptr;
                 const bool last = (m == nd - 1);
                 float* dst = last ? S : R;
                 ttsc_conv1d_epilogue e2{1.f, 0.1f, 1.f, TTSC_ACT_NONE, (last && j > 0) ? 1 : 0};
                 if (c.resblock == 1) {
                     ttsc_conv1d_epilogue e1{1.f, 0.1f, 1.f, TTSC_ACT_NONE, 0};
-                    // conv1: its output only feeds conv2 -> split form only (XT's memory holds the split tensor)
-                    rc = conv(layer(rb + ".convs1." + std::to_string(m)), src, src_s, L, stage_split ? nullptr : XT,
-                              stage_split ? (void*)XT : nullptr, 1.f, 0.1f, nullptr, e1, ln, ln);
+                    rc = conv(layer(rb + ".convs1." + std::to_string(m)), src, L, XT, nullptr, e1, ln, ln);
                     if (rc) return rc;
-                    // conv2 (+ residual): fp32 for the residual stream / block sum, split twin for the next consumer:
-                    //   not last      -> split(lrelu(r, 0.1)) for the next pair's conv1
-                    //   last, j==nk-1 -> split(lrelu(sum/nk, slope_next)) for the next upsampler / conv_post
-                    void* ys = nullptr;
-                    float yscale = 1.f, yslope = 0.1f;
-                    if (stage_split && !last) ys = Rs;
-                    if (next_split && last && j == c.num_kernels - 1) {
-                        ys = Ss;
-                        yscale = inv_nk;
-                        yslope = next_slope;
-                    }
-                    rc = conv(layer(rb + ".convs2." + std::to_string(m)), XT, stage_split ? (const void*)XT : nullptr, L, dst, ys, yscale,
-                              yslope, src, e2, ln, ln);
+                    rc = conv(layer(rb + ".convs2." + std::to_string(m)), XT, L, dst, src, e2, ln, ln);   // + residual
                     if (rc) return rc;
                 } else {
                     // ResBlock2 reads src both as conv input and residual; dst != src unless m>0 && !last (R->R),
                     // where an in-place update would race with neighbouring tiles' halo reads -> ping-pong via XT.
                     float* d2 = dst;
                     if (dst == src) d2 = XT;
-                    rc = conv(layer(rb + ".convs." + std::to_string(m)), src, nullptr, L, d2, nullptr, 1.f, 1.f, src, e2, ln, ln);
+                    rc = conv(layer(rb + ".convs." + std::to_string(m)), src, L, d2, src, e2, ln, ln);
                     if (rc) return rc;
                     if (d2 != dst) std::swap(R, XT);
                 }
             }
         }
         sum_scale = inv_nk;
-        s_split = next_split;
     }
     ttsc_conv1d_epilogue epost{sum_scale, 0.01f, 1.f, TTSC_ACT_TANH, 0};
-    return conv(layer("conv_post"), S, s_split ? (const void*)Ss : nullptr, L, wav, nullptr, 1.f, 1.f, nullptr, epost, lens[c.num_upsamples],
-                lens[c.num_upsamples]);
+    return conv(layer("conv_post"), S, L, wav, nullptr, epost, lens[c.num_upsamples], lens[c.num_upsamples]);
 }
 
