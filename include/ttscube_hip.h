@@ -246,7 +246,7 @@ int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel_dev, const float* xlow
                         void* stream);
 /* Which kernel ran the last decode and whether its hand-offs completed.  Synchronises `stream`, then: -1 = single-workgroup
  * streaming kernel; 2 = tile kernel (8 workgroups step 8 utterances, each owning an eighth of the weight rows; chosen for
- * one-layer networks with a mulaw / raw head when ceil(B/8)*8 <= number of CUs, H <= 512; env TTSC_WR_TILE=0 turns it off);
+ * one-layer networks (any output head) when ceil(B/8)*8 <= number of CUs, H <= 512; env TTSC_WR_TILE=0 turns it off);
  * 1 = the tile kernel gave up on an inter-workgroup hand-off (bounded spin timed out; outputs invalid). */
 int ttsc_wavernn_last_status(ttsc_wavernn* w, void* stream);
 void ttsc_wavernn_destroy(ttsc_wavernn* w);

@@ -14,8 +14,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(params=['tile', 'stream'], autouse=True)
 def wr_kernel(request, monkeypatch):
-    """Every test runs twice: with the multi-workgroup tile kernel allowed (its default: one-layer nets with a discrete head,
-    B <= 256) and with the single-workgroup streaming kernel forced (TTSC_WR_TILE=0) — both must be bit-exact."""
+    """Every test runs twice: with the multi-workgroup tile kernel allowed (its default: one-layer nets, B <= 256) and with the single-workgroup streaming kernel forced (TTSC_WR_TILE=0) — both must be bit-exact."""
     if request.param == 'tile':
         monkeypatch.delenv('TTSC_WR_TILE', raising=False)
     else:
@@ -189,17 +188,16 @@ def _cont_net(z):
 
 @pytest.mark.parametrize('name', CONT)
 def test_continuous_outputs_match_reference_and_oracle(golden_dir, name, wr_kernel):
-    """mol / gm / beta in the persistent kernel: with the reference's own random terms injected the samples follow the
+    """mol / gm / beta in the persistent kernels (tile kernel for one-layer nets, streaming kernel otherwise): with the reference's own random terms injected the samples follow the
     reference run to 1e-5 (mixture index identical at every step) and equal the C oracle BIT FOR BIT (one shared arithmetic
     definition) in noise, Philox and arg-max mode; teacher-forced outputs vs the reference's _train_forward <= 1e-4."""
-    if wr_kernel == 'tile':
-        pytest.skip('continuous outputs run on the streaming kernel')
     z = np.load(os.path.join(golden_dir, name + '.npz'))
     net, sd, X, kw = _cont_net(z)
+    want_kernel = 'tile' if (wr_kernel == 'tile' and kw['num_layers'] == 1) else 'stream'
     xl = z['x_low'] if kw['use_lowres'] else None
     if 'noise' in z.files:
         idx, wav, _ = net.decode(X, mode='noise', noise=z['noise'])
-        assert net.last_kernel == 'stream'
+        assert net.last_kernel == want_kernel
         assert float(np.abs(wav.cpu().numpy() - z['wav']).max()) < 1e-5
         if kw['output'] == 'mol':
             assert np.array_equal(idx.cpu().numpy(), z['idx'])
@@ -237,7 +235,7 @@ def test_reference_default_constructor_decodes():
 
 
 def test_default_kernel_choice_by_batch(monkeypatch):
-    """no env override: the tile kernel takes one-layer networks with a discrete head while every member can be resident (B <= 256),
+    """no env override: the tile kernel takes one-layer networks while every member can be resident (B <= 256),
     a partial last tile included; the streaming kernel takes the rest"""
     monkeypatch.delenv('TTSC_WR_TILE', raising=False)
     sd = O.synthetic_state_dict(H=64, num_layers=1, use_lowres=True, seed=77)

@@ -25,6 +25,7 @@
 #include "common.hpp"
 #include "../../include/ttscube_math.h"
 #include "../../include/ttscube_mulaw_lut.h"
+#include "wavernn_sampler.hpp"
 #include "wavernn_tile.hip"
 
 namespace ttsc {
@@ -355,72 +356,9 @@ __global__ __launch_bounds__(WR_THREADS) void wr_decode_kernel(WrArgs a) {
             for (int u = wave; u < BT; u += WR_THREADS / 64) {
                 const float* y = score + u * S;
                 const size_t o = (size_t)BIDX(u) * a.L + t;
-                float wv = 0.f;
-                int bi = 0;
-                if (a.out_kind == TTSC_WR_OUT_MOL) {
-                    float gi = 0.f;
-                    if (lane <= TTSC_MOL_NMIX) {
-                        if (a.mode == 1) {
-                            gi = a.noise[o * TTSC_MOL_NOISE + lane];
-                        } else if (a.mode == 2) {
-                            const float uu = ttsc_u01_clip(ttsc_philox_word((uint32_t)lane, (uint32_t)t, (uint32_t)BIDX(u), a.seed));
-                            gi = lane < TTSC_MOL_NMIX ? -ttsc_logf(-ttsc_logf(uu)) : ttsc_logistic(uu);
-                        }
-                    }
-                    float v = lane < TTSC_MOL_NMIX ? y[lane] + gi : -INFINITY;
-                    int k = lane;
-#pragma unroll
-                    for (int off = 8; off >= 1; off >>= 1) {
-                        const float ov = __shfl_xor(v, off);
-                        const int ok = __shfl_xor(k, off);
-                        if (ov > v || (ov == v && ok < k)) {   // first maximum wins, like the oracle's sequential scan
-                            v = ov;
-                            k = ok;
-                        }
-                    }
-                    const float lg = __shfl(gi, TTSC_MOL_NMIX);
-                    k = __shfl(k, 0);
-                    const float mean = y[TTSC_MOL_NMIX + k];
-                    float ls = y[2 * TTSC_MOL_NMIX + k];
-                    ls = ls < TTSC_LOG_SCALE_MIN ? TTSC_LOG_SCALE_MIN : ls;
-                    wv = mean + ttsc_expf(ls) * lg;
-                    wv = wv < -1.0f ? -1.0f : wv;
-                    wv = wv > 1.0f ? 1.0f : wv;
-                    bi = k;
-                } else if (a.out_kind == TTSC_WR_OUT_GM) {
-                    float z = 0.f;
-                    if (a.mode == 1)
-                        z = a.noise[o];
-                    else if (a.mode == 2)
-                        z = 0.8f * ttsc_normal_icdf(ttsc_u01(ttsc_philox_word(0u, (uint32_t)t, (uint32_t)BIDX(u), a.seed)));
-                    wv = y[0] + z * ttsc_expf(y[1]);
-                } else {   // beta: lanes 0 / 1 draw the two gamma variates
-                    constexpr int NV = 1 + 2 * TTSC_BETA_TRIES;
-                    const int v = lane & 1;
-                    float nz[NV];
-#pragma unroll
-                    for (int i = 0; i < NV; ++i) nz[i] = 0.f;
-                    if (a.mode == 1) {
-#pragma unroll
-                        for (int i = 0; i < NV; ++i) nz[i] = a.noise[o * TTSC_BETA_NOISE + v * NV + i];
-                    } else if (a.mode == 2) {
-                        nz[0] = ttsc_u01(ttsc_philox_word((uint32_t)(v * 16), (uint32_t)t, (uint32_t)BIDX(u), a.seed));
-#pragma unroll
-                        for (int i = 0; i < TTSC_BETA_TRIES; ++i) {
-                            nz[1 + 2 * i] = ttsc_normal_icdf(ttsc_u01(ttsc_philox_word((uint32_t)(v * 16 + 1 + 2 * i), (uint32_t)t, (uint32_t)BIDX(u), a.seed)));
-                            nz[2 + 2 * i] = ttsc_u01(ttsc_philox_word((uint32_t)(v * 16 + 2 + 2 * i), (uint32_t)t, (uint32_t)BIDX(u), a.seed));
-                        }
-                    } else {
-                        nz[0] = 0.5f;
-                        nz[2] = 0.5f;
-                    }
-                    const float gv = ttsc_gamma_mt(ttsc_expf(y[v]), nz);
-                    const float ga = __shfl(gv, 0), gb = __shfl(gv, 1);
-                    float sx = ga / (ga + gb);
-                    sx = sx < 1.17549435e-38f ? 1.17549435e-38f : sx;
-                    sx = sx > 0.99999994f ? 0.99999994f : sx;
-                    wv = (sx - 0.5f) * 2.0f;
-                }
+                float wv;
+                int bi;
+                wr_sample_continuous(a.out_kind, a.mode, y, a.noise, o, t, BIDX(u), a.seed, lane, wv, bi);
                 if (lane == 0) {
                     if (BOK(u)) {
                         a.out_idx[o] = (uint8_t)bi;
@@ -644,17 +582,17 @@ extern "C" int ttsc_wavernn_set_weight(ttsc_wavernn* w, const char* name, const 
 // ---- tile path (wavernn_tile.hip): 8 workgroups step 8 utterances, each owning 1/8 of the rows -------------
 static size_t tile_lds_bytes(const ttsc_wavernn* w) {
     const auto& c = w->cfg;
-    return ((size_t)c.H * 32 + (size_t)256 * 32 + (size_t)WT_NC * (c.H + 4) + (size_t)WT_NC * 260 + (size_t)3 * (c.H / WT_NC) * WT_NC + 64 + (size_t)3 * (c.H / WT_NC) + 16) * sizeof(float);
+    return ((size_t)c.H * 32 + (size_t)256 * 32 + (size_t)WT_NC * (c.H + 4) + (size_t)WT_NC * 260 + (size_t)3 * (c.H / WT_NC) * WT_NC + 64 + (size_t)3 * (c.H / WT_NC) + 64) * sizeof(float);
 }
 
 static bool tile_supported(const ttsc_wavernn* w, int B) {
     const auto& c = w->cfg;
-    // Default for one-layer networks with a discrete head whenever every member can be resident (B <= 256 on MI355X);
+    // Default for one-layer networks whenever every member can be resident (B <= 256 on MI355X);
     // env TTSC_WR_TILE=0 forces the streaming kernel.  Bit-exact either way.  Measurements: DESIGN.md.
     const char* ev = getenv("TTSC_WR_TILE");
     if (ev && atoi(ev) == 0) return false;
-    if (c.out_kind != TTSC_WR_OUT_MULAW && c.out_kind != TTSC_WR_OUT_RAW) return false;   // discrete heads only
-    if (c.num_layers != 1 || c.H % (4 * WT_NC) != 0 || c.H > 512 || c.S % WT_NC != 0 || c.S > 256) return false;
+    if (c.num_layers != 1 || c.H % (4 * WT_NC) != 0 || c.H > 512 || c.S > 256) return false;
+    if (c.out_kind < 2 && c.S % WT_NC != 0) return false;   // (continuous heads: S = 30 / 2, padded to 32 / 8 rows)
     if (tile_lds_bytes(w) > 160 * 1024) return false;
     const int G = (int)ceil_div(B, WT_NC);
     int dev = 0, cus = 0;
@@ -665,7 +603,7 @@ static bool tile_supported(const ttsc_wavernn* w, int B) {
 // granules (8 bytes) of the exchange area of G tiles + the abort word
 static size_t tile_exchange_granules(const ttsc_wavernn* w, int G) {
     const auto& c = w->cfg;
-    return (size_t)G * 2 * ((size_t)WT_NC * c.H + (size_t)WT_NC * 256 + (size_t)WT_NC * c.S + WT_NC);
+    return (size_t)G * 2 * ((size_t)WT_NC * c.H + (size_t)WT_NC * 256 + (size_t)WT_NC * round_up(c.S, WT_NC) + WT_NC);
 }
 static size_t tile_exchange_bytes(const ttsc_wavernn* w, int B) {
     return tile_exchange_granules(w, (int)ceil_div(B, WT_NC)) * 8 + 256;
@@ -673,7 +611,7 @@ static size_t tile_exchange_bytes(const ttsc_wavernn* w, int B) {
 
 static int tile_pack(ttsc_wavernn* w) {
     const auto& c = w->cfg;
-    const int NC = WT_NC, H = c.H, UPW = H / NC, R3 = 3 * UPW, I0 = w->in0, I0P = (int)round_up(I0, 4), S = c.S, SR = S / NC, PR = 256 / NC;
+    const int NC = WT_NC, H = c.H, UPW = H / NC, R3 = 3 * UPW, I0 = w->in0, I0P = (int)round_up(I0, 4), S = c.S, SP = (int)round_up(S, NC), SR = SP / NC, PR = 256 / NC;
     std::vector<float> whh((size_t)NC * H * R3, 0.f), wih((size_t)NC * I0P * R3, 0.f), bih((size_t)NC * R3), bhh((size_t)NC * R3);
     // the output slice is padded to PR = 32 rows (zero rows beyond SR), so that both resident slices share one layout
     std::vector<float> wpre((size_t)NC * H * PR), bpre((size_t)NC * PR), wout((size_t)NC * 256 * PR, 0.f), bout((size_t)NC * PR, 0.f);
@@ -693,6 +631,7 @@ static int tile_pack(ttsc_wavernn* w) {
         }
         for (int r = 0; r < SR; ++r) {
             const int row = m * SR + r;
+            if (row >= S) continue;   // padding rows of a continuous head stay zero
             for (int k = 0; k < 256; ++k) wout[(size_t)m * 256 * PR + ((size_t)(k >> 2) * PR + r) * 4 + (k & 3)] = w->h_wout[(size_t)row * 256 + k];
             bout[(size_t)m * PR + r] = w->h_bout[row];
         }
@@ -828,11 +767,11 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
         u64* f = (u64*)xbase;
         qa.xh = f; f += (size_t)G * 2 * BU * c.H;
         qa.xpre = f; f += (size_t)G * 2 * BU * 256;
-        qa.xlog = f; f += (size_t)G * 2 * BU * c.S;
+        qa.xlog = f; f += (size_t)G * 2 * BU * round_up(c.S, NC);
         qa.xlx = f; f += (size_t)G * 2 * BU;
         qa.abort_word = (unsigned*)f;
         qa.B = B; qa.T = (int)T; qa.Tl = (int)Tl; qa.H = c.H; qa.UPW = c.H / NC; qa.I0 = w->in0; qa.I0P = (int)round_up(w->in0, 4);
-        qa.use_lowres = c.use_lowres; qa.up = c.upsample; qa.up_low = c.upsample_low; qa.S = c.S; qa.SR = c.S / NC;
+        qa.use_lowres = c.use_lowres; qa.up = c.upsample; qa.up_low = c.upsample_low; qa.S = c.S; qa.SP = (int)round_up(c.S, NC); qa.SR = qa.SP / NC;
         qa.n_mel = c.n_mel; qa.out_kind = c.out_kind; qa.mode = mode; qa.L = a.L; qa.G = G; qa.seed = seed;
         qa.GP = (int)round_up(G, WT_XCDS);
         // all tags (and the abort word) start at zero; the first step carries tag 1
@@ -841,7 +780,8 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
         if (lds > 64 * 1024) {
             static bool attr_set = false;
             if (!attr_set) {
-                hipError_t ae = hipFuncSetAttribute((const void*)wr_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipError_t ae = hipFuncSetAttribute((const void*)wr_tile_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (ae == hipSuccess) ae = hipFuncSetAttribute((const void*)wr_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (ae != hipSuccess) {
                     (void)hipGetLastError();
                     set_error("wr_tile_kernel: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(ae));
@@ -858,7 +798,10 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
             qa.prof = prof_dev;
         }
 #endif
-        hipLaunchKernelGGL(wr_tile_kernel, dim3(qa.GP * NC), dim3(WT_THREADS), lds, s, qa);
+        if (c.out_kind >= 2)
+            hipLaunchKernelGGL(wr_tile_kernel<true>, dim3(qa.GP * NC), dim3(WT_THREADS), lds, s, qa);
+        else
+            hipLaunchKernelGGL(wr_tile_kernel<false>, dim3(qa.GP * NC), dim3(WT_THREADS), lds, s, qa);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             set_error("wr_tile_kernel launch failed: %s", hipGetErrorString(e));

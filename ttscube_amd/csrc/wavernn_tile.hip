@@ -29,6 +29,7 @@
 // 0.75 us per hand-off with agent-scope accesses, same or different XCD; workgroup-scope accesses are NOT coherent across
 // CUs.)  Members of a tile are still placed on one XCD (blockIdx -> XCD is round-robin).
 #include "rnn_chain.hpp"
+#include "wavernn_sampler.hpp"
 
 namespace ttsc {
 
@@ -101,7 +102,7 @@ struct WtArgs {
     const float* bhh;      // [NC][3*UPW]
     const float* wpre;     // rows = 32 (= 256/NC), K = H
     const float* bpre;     // [NC][32]
-    const float* wout;     // rows = 32 (first SR = S/NC real, rest zero), K = 256
+    const float* wout;     // rows = 32 (first SR = SP/NC real, rest zero), K = 256; SP = S rounded up to a multiple of NC (rows >= S zero)
     const float* bout;     // [NC][32]
     const float* lut;
     const float* noise;    // [B, L, S] or null
@@ -112,10 +113,10 @@ struct WtArgs {
     // exchange area (device memory, zeroed before the launch), per tile g, in granules
     u64* xh;               // [G][2][H][8]
     u64* xpre;             // [G][2][256][8]
-    u64* xlog;             // [G][2][8][S]
+    u64* xlog;             // [G][2][8][SP]
     u64* xlx;              // [G][2][8]
     unsigned* abort_word;
-    int B, T, Tl, H, UPW, I0, I0P, use_lowres, up, up_low, S, SR, n_mel, out_kind, mode, L, G, GP;
+    int B, T, Tl, H, UPW, I0, I0P, use_lowres, up, up_low, S, SP, SR, n_mel, out_kind, mode, L, G, GP;
     unsigned long long seed;
     unsigned long long* prof;   // -DTTSC_ABLATE: [workgroup][16] accumulated 100 MHz ticks per segment (thread 0), or null
 };
@@ -278,11 +279,14 @@ __device__ __forceinline__ void mfma_chain_g(f32x4_t (&acc)[NB], const float4* w
 #define WT_TICK(i) do {} while (0)
 #endif
 
+// CONT: continuous output head (MOL / Gaussian / Beta) — a separate instantiation, so that the discrete kernel does not carry
+// the samplers' registers
+template <bool CONT>
 __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
     constexpr int NC = WT_NC, BU = WT_NC, PR = 256 / WT_NC;   // PR = 32 pre-output rows per member
     // LDS: wpre[H/4][32][4] | wout[64][32][4] | hvec[BU][VH] | pvec[BU][VP] | gbuf[3*UPW][BU] | bias[32 + 32 + 3*UPW] | tail_fail, pre_ready
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int H = a.H, UPW = a.UPW, S = a.S, SR = a.SR, NM = a.n_mel, I0P = a.I0P;
+    const int H = a.H, UPW = a.UPW, S = a.S, SP = a.SP, SR = a.SR, NM = a.n_mel, I0P = a.I0P;
     const int R3 = 3 * UPW;
     // tile placement: workgroups are dealt to the XCDs round-robin, so the members of a tile take blockIdx values that are
     // congruent mod 8 (same XCD, same L2); GP = number of tiles rounded up to a multiple of 8, surplus workgroups leave at once
@@ -298,6 +302,7 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
     float* biasL = gbuf + (size_t)R3 * BU;   // bpre[32] | bout[32] | bhh[R3]
     int* tail_fail = reinterpret_cast<int*>(biasL + 64 + R3);
     int* pre_ready = tail_fail + 1;   // helper waves that have staged the pre-output vector (monotonic)
+    float* ybuf = reinterpret_cast<float*>(tail_fail + 4);   // [32]: the output values of utterance m (continuous heads)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int u = tid % BU;            // utterance slot (element-wise work)
     const int j = tid / BU;            // local hidden unit
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
     float hprev = 0.f;   // h_{t-1}[unit m*UPW + j][utterance u]: each (unit, utterance) has exactly one owner thread
     u64* xh = a.xh + (size_t)g * 2 * BU * H;
     u64* xpre = a.xpre + (size_t)g * 2 * BU * 256;
-    u64* xlog = a.xlog + (size_t)g * 2 * BU * S;
+    u64* xlog = a.xlog + (size_t)g * 2 * BU * SP;
     u64* xlx = a.xlx + (size_t)g * 2 * BU;
 
     // resident slices of the pre-output and output layers, h_{-1} = 0 (fma(w, 0, acc) == acc)
@@ -407,17 +412,35 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
             for (int i = 0; i < 4; ++i) {
                 const int s_ = m * SR + trow + i;
                 if (trow + i < SR) {
-                    st_granule(xlog + ((size_t)par * BU + tutt) * S + s_, acc[0][i], tag);
-                    if (a.out_logits && g * BU + tutt < a.B) a.out_logits[((size_t)(g * BU + tutt) * a.L + s) * S + s_] = acc[0][i];
+                    st_granule(xlog + ((size_t)par * BU + tutt) * SP + s_, acc[0][i], tag);
+                    if (a.out_logits && s_ < S && g * BU + tutt < a.B) a.out_logits[((size_t)(g * BU + tutt) * a.L + s) * S + s_] = acc[0][i];
                 }
             }
         }
         WT_TICK(6);
-        if (m < nu) {   // sample utterance m of the tile from its S logits
+        if constexpr (CONT) {
+          if (m < nu) {   // continuous heads (MOL / Gaussian / Beta): S <= 30 output values of utterance m
+            const int bs = g * BU + m;
+            float v[1] = {0.f};
+            if (lane < SP) ok = ld_granules<1>(xlog + ((size_t)par * BU + m) * SP + lane, 1, tag, v, a.abort_word) && ok;
+            if (lane < 32) ybuf[lane] = v[0];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float wv;
+            int bi;
+            const size_t o = (size_t)bs * a.L + s;
+            wr_sample_continuous(a.out_kind, a.mode, ybuf, a.noise, o, s, bs, a.seed, lane, wv, bi);
+            if (lane == 0) {
+                a.out_idx[o] = (uint8_t)bi;
+                a.out_wav[o] = wv;
+                st_granule(xlx + par * BU + m, a.forced_x ? a.forced_x[o] : wv, tag);
+            }
+          }
+        } else if (m < nu) {   // discrete heads: Gumbel-max over the S logits of utterance m
             const int bs = g * BU + m;
             float best = 0.f;
             int bi = 0;
-            const u64* src = xlog + ((size_t)par * BU + m) * S;
+            const u64* src = xlog + ((size_t)par * BU + m) * SP;
             int off[4];
             float v[4];
 #pragma unroll
@@ -448,9 +471,9 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
                 bi = 1 << 20;
             }
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const float os = __shfl_xor(best, off);
-                const int oi = __shfl_xor(bi, off);
+            for (int off2 = 32; off2 >= 1; off2 >>= 1) {
+                const float os = __shfl_xor(best, off2);
+                const int oi = __shfl_xor(bi, off2);
                 if (os > best || (os == best && oi < bi)) {
                     best = os;
                     bi = oi;
