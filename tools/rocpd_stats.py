@@ -1,7 +1,8 @@
 """Summarise a rocprofv3 rocpd sqlite database (kernel trace) into a per-kernel stats CSV (same columns as rocprofv3's
 kernel_stats.csv) and, optionally, a per-launch listing of the last N launches (one forward / one step, in launch order).
 
-    python tools/rocpd_stats.py run_results.db stats.csv [N last.csv]"""
+    python tools/rocpd_stats.py run_results.db stats.csv [N last.csv]
+    python tools/rocpd_stats.py run_results.db stats.csv -MS window_stats.csv     # per-kernel stats of the last MS milliseconds"""
 import sqlite3
 import sys
 
@@ -23,7 +24,21 @@ def main(db, out_csv, n_last=0, last_csv=None):
         for n, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             f.write('"%s",%d,%d,%.1f,%.2f,%d,%d\n' % (n.replace('"', "'"), a[0], a[1], a[1] / a[0], 100.0 * a[1] / tot, a[2], a[3]))
     print('wrote', out_csv, 'kernels:', len(agg), 'total ms: %.3f' % (tot / 1e6))
-    if n_last and last_csv:
+    if n_last < 0 and last_csv:   # steady-state window: everything that started in the last |n_last| ms of the trace
+        t_end = max(r[2] for r in rows)
+        win = [r for r in rows if r[1] >= t_end + n_last * 1e6]
+        agg = {}
+        for r in win:
+            a = agg.setdefault(r[0], [0, 0])
+            a[0] += 1
+            a[1] += r[2] - r[1]
+        tot = sum(a[1] for a in agg.values())
+        with open(last_csv, 'w') as f:
+            f.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage"\n')
+            for n, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                f.write('"%s",%d,%d,%.1f,%.2f\n' % (n.replace('"', "'"), a[0], a[1], a[1] / a[0], 100.0 * a[1] / tot))
+        print('wrote', last_csv, 'window %d ms: %d launches, busy %.3f ms' % (-n_last, len(win), tot / 1e6))
+    elif n_last and last_csv:
         with open(last_csv, 'w') as f:
             f.write('"Name","DurationNs","GridX","GridY","GridZ","WorkgroupX","LdsBytes","Vgprs"\n')
             for r in rows[-n_last:]:

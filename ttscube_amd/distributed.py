@@ -59,7 +59,11 @@ class FlatBucketReducer:
             padded = (total + world - 1) // world * world
             flat = torch.zeros(padded, dtype=torch.float32, device=ps[0].device)
             shard = torch.empty(padded // world, dtype=torch.float32, device=ps[0].device)
-            self._buckets.append((ps, flat, shard, total))
+            views, off = [], 0
+            for p in ps:
+                views.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            self._buckets.append((ps, flat, shard, views))
 
     @torch.no_grad()
     def reduce(self):
@@ -71,15 +75,17 @@ class FlatBucketReducer:
         world = dist.get_world_size(self.group)
         works = []
         self.bytes_exchanged = 0
-        for ps, flat, shard, total in self._buckets:
-            off = 0
-            for p in ps:
-                n = p.numel()
-                if p.grad is not None:
-                    flat[off:off + n].copy_(p.grad.reshape(-1))
-                else:
-                    flat[off:off + n].zero_()
-                off += n
+        for ps, flat, shard, views in self._buckets:
+            # pack: ONE multi-tensor copy per bucket (a per-parameter copy_ is a launch each: ~900 tensors x 3 exchanges per step)
+            dst_l, src_l = [], []
+            for p, v in zip(ps, views):
+                if p.grad is None:
+                    v.zero_()
+                elif p.grad.data_ptr() != v.data_ptr():   # (a gradient that still aliases its view is already in place)
+                    dst_l.append(v)
+                    src_l.append(p.grad)
+            if dst_l:
+                torch._foreach_copy_(dst_l, src_l)
             flat.div_(world)
             if self.use_rs:
                 w1 = dist.reduce_scatter_tensor(shard, flat, group=self.group, async_op=True)
@@ -88,19 +94,16 @@ class FlatBucketReducer:
             works.append(w1)
             self.bytes_exchanged += flat.numel() * 4 * (2 if self.use_rs else 1)
         gathers = []
-        for w1, (ps, flat, shard, total) in zip(works, self._buckets):
+        for w1, (ps, flat, shard, views) in zip(works, self._buckets):
             w1.wait()
             gathers.append(dist.all_gather_into_tensor(flat, shard, group=self.group, async_op=True) if self.use_rs else None)
-        for w2, (ps, flat, shard, total) in zip(gathers, self._buckets):
+        for w2, (ps, flat, shard, views) in zip(gathers, self._buckets):
             if w2 is not None:
                 w2.wait()
-            off = 0
-            for p in ps:
-                n = p.numel()
-                if p.grad is None:
-                    p.grad = torch.empty_like(p)
-                p.grad.copy_(flat[off:off + n].view_as(p))
-                off += n
+            # unpack without copying: the averaged gradient of a parameter IS its slice of the bucket (the optimizer reads it there;
+            # the next zero_grad(set_to_none=True) drops the alias, zero_grad(set_to_none=False) clears the slice)
+            for p, v in zip(ps, views):
+                p.grad = v
 
 
 def broadcast_parameters(module, src=0, group=None):

@@ -3,13 +3,31 @@
 imported at cube/networks/cubegan.py:18-19, used at cubegan.py:144-167) and ``hifigan.meldataset.mel_spectrogram``
 (cubegan.py:21,137-138).  The reference source is absent: restated from Kong, Kim, Bae 2020
 (arXiv:2010.05646, §2.2-2.3, App. A) with the public module/key layout (`discriminators.N.convs.M`, `conv_post`).
-TRAINING-ONLY: these run as plain torch-ROCm modules; they are not on the inference hot path."""
+TRAINING-ONLY: these run as plain torch-ROCm modules; they are not on the inference hot path.
+
+Launch diet (the b = 16 training step is host-bound: ~7 700 launches for ~105 ms of GPU work): when the generated signal carries
+no gradient (the discriminator step) a weight-normed sub-discriminator sees real and generated audio as ONE batch — there are
+no batch statistics, so outputs and gradients are those of two separate calls with half the launches (and one weight
+normalisation instead of two).  The spectrally-normed discriminator keeps its two calls (each call advances its power
+iteration, as in the reference).  In the generator step the real branch needs no graph and the generated branch must not pay
+data gradients for the real half, so the two stay separate."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.utils import spectral_norm, weight_norm
 
 LRELU_SLOPE = 0.1
+
+
+def _pair(d, y, y_hat, batch_ok):
+    """(out_r, fmap_r, out_g, fmap_g) of sub-discriminator d on real / generated audio."""
+    if batch_ok and not y_hat.requires_grad and y.shape == y_hat.shape:
+        n = y.shape[0]
+        out, fmap = d(torch.cat([y, y_hat], dim=0))
+        return out[:n], [f[:n] for f in fmap], out[n:], [f[n:] for f in fmap]
+    y_d_r, fmap_r = d(y)
+    y_d_g, fmap_g = d(y_hat)
+    return y_d_r, fmap_r, y_d_g, fmap_g
 
 
 def get_padding(kernel_size, dilation=1):
@@ -51,8 +69,7 @@ class MultiPeriodDiscriminator(nn.Module):
     def forward(self, y, y_hat):
         y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
         for d in self.discriminators:
-            y_d_r, fmap_r = d(y)
-            y_d_g, fmap_g = d(y_hat)
+            y_d_r, fmap_r, y_d_g, fmap_g = _pair(d, y, y_hat, True)
             y_d_rs.append(y_d_r)
             fmap_rs.append(fmap_r)
             y_d_gs.append(y_d_g)
@@ -97,8 +114,7 @@ class MultiScaleDiscriminator(nn.Module):
             if i != 0:
                 y = self.meanpools[i - 1](y)
                 y_hat = self.meanpools[i - 1](y_hat)
-            y_d_r, fmap_r = d(y)
-            y_d_g, fmap_g = d(y_hat)
+            y_d_r, fmap_r, y_d_g, fmap_g = _pair(d, y, y_hat, i != 0)   # discriminator 0 is spectrally normed
             y_d_rs.append(y_d_r)
             fmap_rs.append(fmap_r)
             y_d_gs.append(y_d_g)
@@ -121,8 +137,8 @@ def discriminator_loss(disc_real_outputs, disc_generated_outputs):
         r_loss = torch.mean((1 - dr) ** 2)
         g_loss = torch.mean(dg ** 2)
         loss = loss + (r_loss + g_loss)
-        r_losses.append(r_loss.item())
-        g_losses.append(g_loss.item())
+        r_losses.append(r_loss.detach())   # tensors, not .item(): 16 host syncs per step would drain the launch queue
+        g_losses.append(g_loss.detach())
     return loss, r_losses, g_losses
 
 

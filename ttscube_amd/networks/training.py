@@ -159,9 +159,12 @@ def cubegan_configure_optimizers(model):
     """cubegan.py:275-311: AdamW(0.8,0.99) x3 + Adam(1e-6) on the dummy; restores `.opt.last` states when present
     (the reference sets `_loaded_optimizer_state` but reads `_loaded_optimizer_states`, so its resume silently skips this)."""
     g, d, t = cubegan_param_groups(model)
-    opt_g = torch.optim.AdamW(g, model._current_lr, betas=[0.8, 0.99])
-    opt_d = torch.optim.AdamW(d, model._current_lr, betas=[0.8, 0.99])
-    opt_t = torch.optim.AdamW(t, model._current_lr, betas=[0.8, 0.99])
+    # fused=True: one multi-tensor kernel per optimizer step instead of ~10 element-wise launches per state update (same
+    # update rule and state_dict layout; device parameters only)
+    fused = all(p.is_cuda for p in itertools.chain(g, d, t))
+    opt_g = torch.optim.AdamW(g, model._current_lr, betas=[0.8, 0.99], fused=fused)
+    opt_d = torch.optim.AdamW(d, model._current_lr, betas=[0.8, 0.99], fused=fused)
+    opt_t = torch.optim.AdamW(t, model._current_lr, betas=[0.8, 0.99], fused=fused)
     opt_b = torch.optim.Adam(model._dummy.parameters(), lr=1e-6)
     if model._loaded_optimizer_states is not None:
         for k, opt in zip(['0', '1', '2', '3'], [opt_g, opt_d, opt_t, opt_b]):
