@@ -19,7 +19,8 @@ from ttscube_amd.hip_layers import Conv1dHip  # noqa: E402
 
 STAGES = {1: (256, 4001), 2: (128, 12004), 3: (64, 48016), 4: (32, 192064)}
 WIDE_BITS = [(0, 'full'), (4, 'no epilogue'), (1, 'no staging in loop'), (2, 'no chunk barrier'), (8, 'no weight prefetch'),
-             (1 | 2, 'no staging, no barrier'), (1 | 2 | 4 | 8, 'MFMA + LDS reads only')]
+             (1 | 2, 'no staging, no barrier'), (1 | 2 | 4 | 8, 'MFMA + LDS reads only'),
+             (32 | (6 << 8), 'skew 2nd workgroup ~24 us'), (32 | 64 | (6 << 8) | (1 << 16), 'skew 24 us + CU spread 0..28 us'), (32 | 64 | (6 << 8) | (2 << 16), 'skew 24 us + CU spread 0..56 us'), (64 | (2 << 16), 'CU spread 0..56 us only')]
 CHAIN_BITS = [(0, 'full'), (1, 'no image conversions'), (2, 'no barriers'), (4, 'no final store'), (8, 'no x load'), (16, 'no weight loads in loop'),
               (4 | 8, 'no HBM traffic'), (1 | 2 | 4 | 8 | 16, 'MFMA + LDS reads only')]
 

@@ -55,6 +55,7 @@ struct ConvArgs {
     int out_act, accumulate;
     int vphase;       // fused ConvTranspose1d phases: GEMM row v = r * vphase + co (vphase = real Cout), output o += r; 0 = off;
                       // -4 = rows interleaved v = co * 4 + r (kernel_size == stride == 4): see epilogue_tile_v4
+    int skew;         // wide kernel: start delay of the second resident workgroup per CU, in units of ~4 us (0 = off)
     int dbg;          // ablation switches, ONLY in -DTTSC_ABLATE builds (tools/ablate.cpp; never in libttscube_hip.so): see TTSC_DBG
     const float* gate;  // data-gradient launches: [B,Cout,Lout] pre-activation saved by the forward; the conv result is
     float gate_slope;   // multiplied by d lrelu/dx = (gate > 0 ? 1 : gate_slope) BEFORE the residual is added; null = off
@@ -597,6 +598,16 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_wide_kernel(ConvArgs a) {
     const float* xb = a.x + (size_t)b * C * a.Lin;
     const int lo = q0 - D * ((K - 1) / 2);
     const half8* wsrc = reinterpret_cast<const half8*>(a.wph) + (size_t)cotg * 128 + lane;
+    // A launch is only 4-6 rounds of workgroups, two resident per CU, all started together: both residents reach their
+    // memory-bound epilogue at the same moment and the matrix pipe idles.  The second resident of every CU (dispatch order:
+    // workgroups 256..511) therefore starts ~24 us late, so that one partner's epilogue falls into the other's tap loop
+    // for the rest of the launch (measured -2 .. -9 % per layer, tools/ablate.py; a wrong guess about the placement only
+    // costs the delay).
+    if (a.skew) {
+        const unsigned lin_id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (lin_id >= 256u && lin_id < 512u)
+            for (int z = 0; z < a.skew; ++z) __builtin_amdgcn_s_sleep(127);
+    }
 
     // ---- weights: global -> LDS by LDS-DMA, one (tap, chunk) step ahead; the two waves that share a row tile (and, at
     // 256 channels, nobody else) read them back as ds_read_b128.  Fetched per wave straight into registers (the first
@@ -923,6 +934,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 2)) void respair32_f16x3_ke
     ea.out_act = TTSC_ACT_NONE;
     ea.accumulate = a.accumulate;
     ea.dbg = 0;
+    ea.skew = 0;
     ea.gate = nullptr;
     ea.gate_slope = 1.f;
     ea.vphase = 0;
@@ -1046,10 +1058,14 @@ static int launch_f16_t(const ConvArgs& a, int B, hipStream_t s) {
 }
 
 template <int C, int K, int D>
-static int launch_f16_wide(const ConvArgs& a, int B, hipStream_t s) {
+static int launch_f16_wide(const ConvArgs& a0, int B, hipStream_t s) {
     constexpr int NT = 256;
     constexpr int SPAN = NT + (K - 1) * D;
-    dim3 grid((unsigned)ceil_div(a.Lout, NT), (unsigned)(C / 128), (unsigned)B);
+    dim3 grid((unsigned)ceil_div(a0.Lout, NT), (unsigned)(C / 128), (unsigned)B);
+    ConvArgs a = a0;
+    // start skew of the second resident workgroup per CU (see the kernel): only when the launch has several full rounds
+    static const int skew_env = getenv("TTSC_CONV_SKEW") ? atoi(getenv("TTSC_CONV_SKEW")) : 6;
+    a.skew = ((size_t)grid.x * grid.y * grid.z >= 1024) ? skew_env : 0;
     constexpr size_t lds = (size_t)2 * (4 * SPAN + 2) * 16 + (size_t)2 * (2 * 2 * 2 * 64) * 16;   // activations + 2 weight slots
     static bool attr = false;
     if (!attr) {
@@ -1551,6 +1567,7 @@ extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, 
         a.in_len = in_len_dev;
         a.out_len = out_len_dev;
         a.dbg = 0;
+        a.skew = 0;
 #ifdef TTSC_ABLATE
         if (const char* ev = getenv("TTSC_CONV_DBG")) a.dbg = atoi(ev);
 #endif
