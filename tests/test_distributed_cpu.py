@@ -40,6 +40,15 @@ def _worker(rank, world, port, q, use_rs):
     assert all(p.grad is None for p in frozen.parameters())        # no gradient anywhere -> stays None (as single-process)
     assert torch.allclose(partial.weight.grad, torch.full((1, 3), 0.5))   # mean of (ones, zeros)
     assert red.bytes_exchanged > 0
+    first = [p.grad.clone() for p in net.parameters()]
+    # second step, both zero_grad styles: the averaged gradients ALIAS the bucket (no unpack copy), so a kept .grad (set_to_none
+    # =False) accumulates in place and is not packed again, a dropped one is re-packed from the fresh tensor
+    for set_to_none in (False, True):
+        net.zero_grad(set_to_none=set_to_none)
+        ((net(xs) - ys) ** 2).mean().backward()
+        red.reduce()
+        for p, g0 in zip(net.parameters(), first):
+            assert torch.allclose(p.grad, g0, atol=1e-7), 'second reduce (set_to_none=%s) changed the averaged gradient' % set_to_none
     q.put((rank, [p.grad.clone() for p in net.parameters()], [p.detach().clone() for p in net.parameters()]))
     dist.barrier()
     dist.destroy_process_group()
