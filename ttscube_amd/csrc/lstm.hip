@@ -111,6 +111,97 @@ __global__ __launch_bounds__(512) void lstm_seq_kernel(LstmArgs a) {
 }
 
 
+// Small hidden sizes (H <= 128: Languasito2's frame-level `_cond_rnn` has H = 64 and runs 300-700 steps per sentence): W_hh of
+// one direction is only 64 / 256 KB, so nothing has to be streamed per step.  One workgroup per (utterance, direction), one THREAD
+// PER GATE ROW (4H threads), each holding its whole row of W_hh in registers for the entire sequence.  A step is: broadcast reads
+// of h from LDS, H fused multiply-adds per thread in four interleaved partial sums (a fixed order, the same for every batch
+// size, so a padded batch still reproduces each utterance run alone bit for bit), gate pre-activations through LDS, the cell /
+// hidden update by the H threads of gate i, two barriers.  The input-projection value of the NEXT step is loaded before the
+// current step's chain.  lstm_seq_kernel (one thread per unit, rows streamed from L2 by a single wave at H = 64) took
+// 3.4 us per step and layer at H = 64; this kernel: tools/bench_lstm.py.
+template <int HH>
+__global__ __launch_bounds__(4 * HH) void lstm_seq_resident_kernel(LstmArgs a) {
+    constexpr int H = HH, H4 = 4 * HH;
+    __shared__ __attribute__((aligned(16))) float hbuf[2][HH];
+    __shared__ float gbuf[4 * HH];
+    const int r = threadIdx.x;            // gate row: gate r / H, unit r % H
+    const int j = r % H;
+    const bool upd = r < H;               // the threads of gate i also own the cell / hidden update of unit j
+    const int b = blockIdx.x, dir = blockIdx.y;
+    const int len = a.lengths ? a.lengths[b] : a.T;
+    float w[HH];
+    {
+        const float4* w4 = reinterpret_cast<const float4*>(a.whh + (size_t)dir * H * H4) + r;   // packed [H/4][4H][4]
+#pragma unroll
+        for (int kb = 0; kb < H / 4; ++kb) {
+            const float4 v = w4[(size_t)kb * H4];
+            w[4 * kb] = v.x;
+            w[4 * kb + 1] = v.y;
+            w[4 * kb + 2] = v.z;
+            w[4 * kb + 3] = v.w;
+        }
+    }
+    float c = (upd && a.c_0) ? a.c_0[((size_t)dir * a.B + b) * H + j] : 0.f;
+    if (upd) hbuf[0][j] = a.h_0 ? a.h_0[((size_t)dir * a.B + b) * H + j] : 0.f;
+    const size_t xstride = (size_t)a.ndir * H4;
+    const float* xb = a.xg + (size_t)b * a.T * xstride + (size_t)dir * H4 + r;
+    auto tpos_of = [&](int s) { return dir == 0 ? s : (len - 1 - s); };
+    float xnext = len > 0 ? xb[(size_t)tpos_of(0) * xstride] : 0.f;
+    __syncthreads();
+    int cur = 0;
+    for (int s = 0; s < a.T; ++s) {
+        const bool ok = s < len;
+        const int tpos = tpos_of(s);
+        const float xcur = xnext;
+        if (s + 1 < len) xnext = xb[(size_t)tpos_of(s + 1) * xstride];
+        if (ok) {
+            const float4* h4 = reinterpret_cast<const float4*>(hbuf[cur]);
+            float p0 = xcur, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < H / 4; ++kb) {
+                const float4 hv = h4[kb];
+                p0 = fmaf(w[4 * kb], hv.x, p0);
+                p1 = fmaf(w[4 * kb + 1], hv.y, p1);
+                p2 = fmaf(w[4 * kb + 2], hv.z, p2);
+                p3 = fmaf(w[4 * kb + 3], hv.w, p3);
+            }
+            gbuf[r] = (p0 + p1) + (p2 + p3);
+        }
+        __syncthreads();
+        if (upd) {
+            if (ok) {
+                const float ig = ttsc_sigmoidf(gbuf[j]);
+                const float fg = ttsc_sigmoidf(gbuf[H + j]);
+                const float gg = ttsc_tanhf(gbuf[2 * H + j]);
+                const float og = ttsc_sigmoidf(gbuf[3 * H + j]);
+                const float cn = fmaf(fg, c, ig * gg);
+                const float hv = og * ttsc_tanhf(cn);
+                c = cn;
+                hbuf[cur ^ 1][j] = hv;
+                a.y[((size_t)b * a.T + tpos) * a.ldy + a.yoff + dir * H + j] = hv;
+                if (a.gates_out) {
+                    float* gp = a.gates_out + ((size_t)b * a.T + tpos) * xstride + (size_t)dir * H4 + j;
+                    gp[0] = ig;
+                    gp[H] = fg;
+                    gp[2 * H] = gg;
+                    gp[3 * H] = og;
+                    a.c_out[((size_t)b * a.T + tpos) * ((size_t)a.ndir * H) + (size_t)dir * H + j] = cn;
+                }
+            } else {
+                hbuf[cur ^ 1][j] = hbuf[cur][j];
+                a.y[((size_t)b * a.T + s) * a.ldy + a.yoff + dir * H + j] = 0.f;   // padded positions read as zeros (each written once)
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (upd) {
+        if (a.h_n) a.h_n[((size_t)dir * a.B + b) * H + j] = hbuf[cur][j];
+        if (a.c_n) a.c_n[((size_t)dir * a.B + b) * H + j] = c;
+    }
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------
 // Backward through time (training of the mel-decoder stacks): one persistent workgroup per
 // (utterance, direction) walks the steps in reverse.  Thread k owns hidden unit k: it turns (dy_t + dh_rec, dc_next) into
@@ -522,6 +613,19 @@ static int lstm_forward_impl(const float* xg_dev, const float* whh_packed_dev, f
     // against the same sentences run alone (tests/test_lstm_gpu.py, tests/test_api_gpu.py); larger batches (G = 2 / 1)
     // agree to ~1e-6 relative.  TTSC_LSTM_SPLIT_INFER=0 keeps inference on the single-workgroup kernel.
     static const bool split_infer = !(getenv("TTSC_LSTM_SPLIT_INFER") && atoi(getenv("TTSC_LSTM_SPLIT_INFER")) == 0);
+    if (H == 64 || H == 128) {   // W_hh resident in registers, one thread per gate row (same kernel for every batch size)
+        dim3 grid((unsigned)B, (unsigned)ndir);
+        if (H == 64)
+            hipLaunchKernelGGL(lstm_seq_resident_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL(lstm_seq_resident_kernel<128>, grid, dim3(512), 0, (hipStream_t)stream, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            set_error("lstm_seq_resident_kernel launch failed: %s", hipGetErrorString(e));
+            return TTSC_EHIP;
+        }
+        return TTSC_OK;
+    }
     const int G = (gates_dev || split_infer) ? lstm_split_members(B, ndir, H) : 1;
     if (G > 1) {
         unsigned* words = lstm_sync_words(B * ndir, (hipStream_t)stream);
