@@ -374,6 +374,126 @@ __global__ __launch_bounds__(512) void lstm_seq_split_kernel(LstmSplitArgs s) {
     }
 }
 
+// The same split with the member's rows of W_hh RESIDENT IN REGISTERS (4 * KL <= 128 weights per thread: H = 256 over 4
+// members) and the state handed over as 8-byte {value, step tag} granules that the consumers poll directly (one agent-scope store
+// per value, no counter, no producer-side drain; ring of two slots per sequence, see wavernn_tile.hip for the argument why two
+// suffice).  Summation order = lstm_seq_split_kernel's (k-ordered chain per k-slice, slices added in order), so results are
+// bit-identical to it; what changes is the step time: no 256 KB weight stream and one round trip instead of three per step.
+typedef unsigned long long lstm_u64;
+
+template <int KL>
+__global__ __launch_bounds__(512) void lstm_seq_split_res_kernel(LstmSplitArgs s, lstm_u64* ring) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // h[H] | part[KS][4][HU]
+    const LstmArgs& a = s.f;
+    const int H = a.H, H4 = 4 * H, HU = s.HU, KS = s.KS;
+    const int tid = threadIdx.x, u = tid % HU, ks = tid / HU;
+    const int m = blockIdx.x, b = blockIdx.y, dir = blockIdx.z;
+    const int j = m * HU + u;
+    float* hs = sm;
+    float* part = sm + H;
+    lstm_u64* rg = ring + (size_t)(b * a.ndir + dir) * 2 * H;
+    const bool owner = ks == 0;
+    const int len = a.lengths ? a.lengths[b] : a.T;
+    float* yb = a.y + (size_t)b * a.T * a.ldy + a.yoff + dir * H;
+    float w[4][KL];
+    {
+        // packed [H/4][4H][4]: row g*H + j, k-block kb holds k = 4*kb .. 4*kb+3
+        const float4* w4 = reinterpret_cast<const float4*>(a.whh + (size_t)dir * H * H4) + j;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int kb = 0; kb < KL / 4; ++kb) {
+                const float4 v = w4[(size_t)(ks * (KL / 4) + kb) * H4 + g * H];
+                w[g][4 * kb] = v.x;
+                w[g][4 * kb + 1] = v.y;
+                w[g][4 * kb + 2] = v.z;
+                w[g][4 * kb + 3] = v.w;
+            }
+    }
+    float c = (owner && a.c_0) ? a.c_0[((size_t)dir * a.B + b) * H + j] : 0.f;
+    float hlast = (owner && a.h_0) ? a.h_0[((size_t)dir * a.B + b) * H + j] : 0.f;
+    if (owner)
+        for (int t = len; t < a.T; ++t) yb[(size_t)t * a.ldy + j] = 0.f;   // pad_packed_sequence: zeros beyond the length
+    for (int st = 0; st < len; ++st) {
+        const int tpos = dir == 0 ? st : (len - 1 - st);
+        float xv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (owner) {   // in flight while the other members finish the previous step
+            const float* xr = a.xg + ((size_t)b * a.T + tpos) * ((size_t)a.ndir * H4) + (size_t)dir * H4 + j;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xv[g] = xr[g * H];
+        }
+        bool fail = false;
+        if (st > 0) {
+            const lstm_u64* src = rg + (size_t)((st - 1) & 1) * H;
+            for (int i = tid; i < H; i += 512) {
+                lstm_u64 gq;
+                unsigned spins = 0;
+                for (;;) {
+                    gq = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(gq >> 32) == (unsigned)st) break;
+                    if (++spins > GS_SPIN_LIMIT || ((spins & 63u) == 0u && __hip_atomic_load(s.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                        __hip_atomic_store(s.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        fail = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                hs[i] = __uint_as_float((unsigned)gq);
+            }
+        } else {
+            for (int i = tid; i < H; i += 512) hs[i] = a.h_0 ? a.h_0[((size_t)dir * a.B + b) * H + i] : 0.f;
+        }
+        if (__syncthreads_or(fail)) return;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        {
+            const float4* h4 = reinterpret_cast<const float4*>(hs + ks * KL);
+#pragma unroll
+            for (int kb = 0; kb < KL / 4; ++kb) {
+                const float4 hv = h4[kb];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float x = acc[g];
+                    x = fmaf(w[g][4 * kb], hv.x, x);
+                    x = fmaf(w[g][4 * kb + 1], hv.y, x);
+                    x = fmaf(w[g][4 * kb + 2], hv.z, x);
+                    x = fmaf(w[g][4 * kb + 3], hv.w, x);
+                    acc[g] = x;
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) part[(ks * 4 + g) * HU + u] = acc[g];
+        __syncthreads();
+        if (owner) {
+            float gs[4] = {xv[0], xv[1], xv[2], xv[3]};
+            for (int q = 0; q < KS; ++q)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gs[g] += part[(q * 4 + g) * HU + u];
+            const float ig = ttsc_sigmoidf(gs[0]);
+            const float fg = ttsc_sigmoidf(gs[1]);
+            const float gg = ttsc_tanhf(gs[2]);
+            const float og = ttsc_sigmoidf(gs[3]);
+            c = fmaf(fg, c, ig * gg);
+            hlast = og * ttsc_tanhf(c);
+            __hip_atomic_store(rg + (size_t)(st & 1) * H + j, ((lstm_u64)(unsigned)(st + 1) << 32) | (lstm_u64)__float_as_uint(hlast), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            yb[(size_t)tpos * a.ldy + j] = hlast;
+            if (a.gates_out) {
+                float* gp = a.gates_out + ((size_t)b * a.T + tpos) * ((size_t)a.ndir * H4) + (size_t)dir * H4 + j;
+                gp[0] = ig;
+                gp[H] = fg;
+                gp[2 * H] = gg;
+                gp[3 * H] = og;
+                a.c_out[((size_t)b * a.T + tpos) * ((size_t)a.ndir * H) + (size_t)dir * H + j] = c;
+            }
+        }
+    }
+    if (owner) {
+        if (a.h_n) a.h_n[((size_t)dir * a.B + b) * H + j] = hlast;
+        if (a.c_n) a.c_n[((size_t)dir * a.B + b) * H + j] = c;
+    }
+}
+
 __global__ __launch_bounds__(512) void lstm_bwd_split_kernel(LstmSplitArgs s) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // dg[4H] | part[KS][HU]
     __shared__ int ok_s;
@@ -638,6 +758,17 @@ static int lstm_forward_impl(const float* xg_dev, const float* whh_packed_dev, f
         sa.HU = H / G;
         sa.KS = 512 / sa.HU;
         const size_t lds = ((size_t)H + (size_t)sa.KS * 4 * sa.HU) * sizeof(float);
+        const int KL = H / sa.KS;
+        static const bool resident = !(getenv("TTSC_LSTM_RESIDENT") && atoi(getenv("TTSC_LSTM_RESIDENT")) == 0);
+        if (resident && KL == 32 && B * ndir <= 4096) {   // 128 weights per thread stay in registers; tagged-granule hand-off
+            static lstm_u64* ring = nullptr;       // [4096 sequences][2 slots][512] granules, per process
+            if (!ring && hipMalloc((void**)&ring, (size_t)4096 * 2 * 512 * sizeof(lstm_u64)) != hipSuccess) {
+                set_error("ttsc_lstm_seq_forward: cannot allocate the hand-off ring");
+                return TTSC_ENOMEM;
+            }
+            TTSC_HIP_CHECK(hipMemsetAsync(ring, 0, (size_t)B * ndir * 2 * H * sizeof(lstm_u64), (hipStream_t)stream));
+            hipLaunchKernelGGL(lstm_seq_split_res_kernel<32>, dim3((unsigned)G, (unsigned)B, (unsigned)ndir), dim3(512), lds, (hipStream_t)stream, sa, ring);
+        } else
         hipLaunchKernelGGL(lstm_seq_split_kernel, dim3((unsigned)G, (unsigned)B, (unsigned)ndir), dim3(512), lds, (hipStream_t)stream, sa);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
