@@ -16,12 +16,16 @@ done
 python tools/pmc_summary.py $O/bench_pmc.csv $O/fetch/p_results.db $O/write/p_results.db $O/sq/p_results.db $O/grbm/p_results.db --note "bench.py --steps 1 --warmup 0 (3 identical forwards, TTSC_HIFIGAN_CALIBRATE=0), one rocprofv3 --pmc pass per counter group; sums over all launches" > $O/pmc_summary.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/e2e -o e -- python tools/bench_e2e.py > $O/e2e.log 2>&1
 python tools/rocpd_stats.py $O/e2e/e_results.db $O/e2e_kernel_stats.csv >> $O/e2e.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/train -o r -- python bench.py --mode train --steps 3 --warmup 1 > $O/train.log 2>&1
-python tools/rocpd_stats.py $O/train/r_results.db $O/train_kernel_stats.csv >> $O/train.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/train -o r -- python bench.py --mode train --steps 4 --warmup 2 > $O/train.log 2>&1
+# per-kernel stats of the whole run (includes MIOpen's one-time find pass) and of the last ~2 steps (steady state)
+python tools/rocpd_stats.py $O/train/r_results.db $O/train_kernel_stats.csv -300 $O/train_last2steps_kernel_stats.csv >> $O/train.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/wr -o v -- python tools/bench_wavernn.py > $O/wavernn.log 2>&1
 python tools/rocpd_stats.py $O/wr/v_results.db $O/wavernn_kernel_stats.csv >> $O/wavernn.log 2>&1
 rm -rf $O/trace $O/fetch $O/write $O/sq $O/grbm $O/e2e $O/train $O/wr
 # the same workload on round 1's kernels only (no wide tiles, no fused chain), for the record
 (TTSC_CONV_WIDE=0 TTSC_HIFIGAN_CHAIN=0 timeout 200 $B --steps 5 --warmup 2) > $O/bench_r1_kernels.log 2>&1
+timeout 300 python bench.py --mode train --steps 6 --warmup 2 2>/dev/null | grep '^{' > $O/bench_train_b16.json
+timeout 400 python bench.py --mode train --train-batch 128 --steps 3 --warmup 1 2>/dev/null | grep '^{' > $O/bench_train_b128.json
+timeout 300 python tools/bench_lstm.py > $O/lstm.log 2>&1
 timeout 600 python bench.py > $O/bench_final.json 2> $O/bench_final.err
 du -sh $O; ls $O; tail -c 300 $O/bench_final.json
