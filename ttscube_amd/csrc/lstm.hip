@@ -302,6 +302,7 @@ struct LstmSplitArgs {
     unsigned* cnt;        // [B * ndir] monotonic counters (zeroed by the host before the launch)
     unsigned* abort_word;
     int G, HU, KS;        // members, hidden units per member, k-slices (HU * KS = 512 threads)
+    int p0;               // lstm_seq_split_res_kernel: first (utterance, direction) pair of this launch (pair = b * ndir + dir)
 };
 
 __global__ __launch_bounds__(512) void lstm_seq_split_kernel(LstmSplitArgs s) {
@@ -387,11 +388,11 @@ __global__ __launch_bounds__(512) void lstm_seq_split_res_kernel(LstmSplitArgs s
     const LstmArgs& a = s.f;
     const int H = a.H, H4 = 4 * H, HU = s.HU, KS = s.KS;
     const int tid = threadIdx.x, u = tid % HU, ks = tid / HU;
-    const int m = blockIdx.x, b = blockIdx.y, dir = blockIdx.z;
+    const int m = blockIdx.x, pair = s.p0 + blockIdx.y, b = pair / a.ndir, dir = pair % a.ndir;
     const int j = m * HU + u;
     float* hs = sm;
     float* part = sm + H;
-    lstm_u64* rg = ring + (size_t)(b * a.ndir + dir) * 2 * H;
+    lstm_u64* rg = ring + (size_t)pair * 2 * H;
     const bool owner = ks == 0;
     const int len = a.lengths ? a.lengths[b] : a.T;
     float* yb = a.y + (size_t)b * a.T * a.ldy + a.yoff + dir * H;
@@ -746,6 +747,46 @@ static int lstm_forward_impl(const float* xg_dev, const float* whh_packed_dev, f
         }
         return TTSC_OK;
     }
+    static const bool resident = !(getenv("TTSC_LSTM_RESIDENT") && atoi(getenv("TTSC_LSTM_RESIDENT")) == 0);
+    if ((gates_dev || split_infer) && resident && H == 256) {
+        // H = 256: four members per (utterance, direction) with their W_hh rows in registers (lstm_seq_split_res_kernel).  All
+        // members of a launch must be resident, so a launch takes cus / 4 pairs; up to three consecutive launches still beat the
+        // streaming kernels (3 us per step and layer per launch against 9.8), and every batch size up to 3 * cus / 8 sentences then
+        // sums in the same order as a sentence run alone.
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 4) {
+            const int pairs = B * ndir, cap = cus / 4;
+            if (pairs <= 3 * cap && pairs <= 4096) {
+                unsigned* words = lstm_sync_words(1, (hipStream_t)stream);
+                TTSC_REQUIRE(words, "ttsc_lstm_seq_forward: cannot allocate the hand-off counters");
+                static lstm_u64* ring = nullptr;       // [4096 pairs][2 slots][256] granules, per process
+                if (!ring && hipMalloc((void**)&ring, (size_t)4096 * 2 * 256 * sizeof(lstm_u64)) != hipSuccess) {
+                    set_error("ttsc_lstm_seq_forward: cannot allocate the hand-off ring");
+                    return TTSC_ENOMEM;
+                }
+                TTSC_HIP_CHECK(hipMemsetAsync(ring, 0, (size_t)pairs * 2 * H * sizeof(lstm_u64), (hipStream_t)stream));
+                LstmSplitArgs sa{};
+                sa.f = a;
+                sa.cnt = words;
+                sa.abort_word = words + 8192;
+                sa.G = 4;
+                sa.HU = H / 4;
+                sa.KS = 512 / sa.HU;
+                const size_t lds = ((size_t)H + (size_t)sa.KS * 4 * sa.HU) * sizeof(float);
+                for (int p0 = 0; p0 < pairs; p0 += cap) {
+                    sa.p0 = p0;
+                    const int n = pairs - p0 < cap ? pairs - p0 : cap;
+                    hipLaunchKernelGGL(lstm_seq_split_res_kernel<32>, dim3(4u, (unsigned)n, 1u), dim3(512), lds, (hipStream_t)stream, sa, ring);
+                }
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess) {
+                    set_error("lstm_seq_split_res_kernel launch failed: %s", hipGetErrorString(e));
+                    return TTSC_EHIP;
+                }
+                return TTSC_OK;
+            }
+        }
+    }
     const int G = (gates_dev || split_infer) ? lstm_split_members(B, ndir, H) : 1;
     if (G > 1) {
         unsigned* words = lstm_sync_words(B * ndir, (hipStream_t)stream);
@@ -758,17 +799,6 @@ static int lstm_forward_impl(const float* xg_dev, const float* whh_packed_dev, f
         sa.HU = H / G;
         sa.KS = 512 / sa.HU;
         const size_t lds = ((size_t)H + (size_t)sa.KS * 4 * sa.HU) * sizeof(float);
-        const int KL = H / sa.KS;
-        static const bool resident = !(getenv("TTSC_LSTM_RESIDENT") && atoi(getenv("TTSC_LSTM_RESIDENT")) == 0);
-        if (resident && KL == 32 && B * ndir <= 4096) {   // 128 weights per thread stay in registers; tagged-granule hand-off
-            static lstm_u64* ring = nullptr;       // [4096 sequences][2 slots][512] granules, per process
-            if (!ring && hipMalloc((void**)&ring, (size_t)4096 * 2 * 512 * sizeof(lstm_u64)) != hipSuccess) {
-                set_error("ttsc_lstm_seq_forward: cannot allocate the hand-off ring");
-                return TTSC_ENOMEM;
-            }
-            TTSC_HIP_CHECK(hipMemsetAsync(ring, 0, (size_t)B * ndir * 2 * H * sizeof(lstm_u64), (hipStream_t)stream));
-            hipLaunchKernelGGL(lstm_seq_split_res_kernel<32>, dim3((unsigned)G, (unsigned)B, (unsigned)ndir), dim3(512), lds, (hipStream_t)stream, sa, ring);
-        } else
         hipLaunchKernelGGL(lstm_seq_split_kernel, dim3((unsigned)G, (unsigned)B, (unsigned)ndir), dim3(512), lds, (hipStream_t)stream, sa);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
