@@ -748,19 +748,21 @@ static int lstm_forward_impl(const float* xg_dev, const float* whh_packed_dev, f
         return TTSC_OK;
     }
     static const bool resident = !(getenv("TTSC_LSTM_RESIDENT") && atoi(getenv("TTSC_LSTM_RESIDENT")) == 0);
-    if ((gates_dev || split_infer) && resident && H == 256) {
-        // H = 256: four members per (utterance, direction) with their W_hh rows in registers (lstm_seq_split_res_kernel).  All
-        // members of a launch must be resident, so a launch takes cus / 4 pairs; up to three consecutive launches still beat the
-        // streaming kernels (3 us per step and layer per launch against 9.8), and every batch size up to 3 * cus / 8 sentences then
-        // sums in the same order as a sentence run alone.
+    if ((gates_dev || split_infer) && resident && (H == 256 || H == 512)) {
+        // H = 256 / 512: G = 4 / 16 members per (utterance, direction), each thread holding 128 weights of W_hh in registers
+        // (lstm_seq_split_res_kernel: 512 threads = HU units x KS k-slices of 32).  All members of a launch must be resident, so a
+        // launch takes cus / G pairs; up to three consecutive launches still beat the streaming kernels (H = 256: 3 us per step
+        // and layer per launch against 9.8), and every batch size up to 3 * cus / (2 G) sentences then sums in the same order as
+        // a sentence run alone.
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 4) {
-            const int pairs = B * ndir, cap = cus / 4;
-            if (pairs <= 3 * cap && pairs <= 4096) {
+            const int Gm = H == 256 ? 4 : 16;
+            const int pairs = B * ndir, cap = cus / Gm;
+            if (cap >= 1 && pairs <= 3 * cap && pairs <= 4096) {
                 unsigned* words = lstm_sync_words(1, (hipStream_t)stream);
                 TTSC_REQUIRE(words, "ttsc_lstm_seq_forward: cannot allocate the hand-off counters");
-                static lstm_u64* ring = nullptr;       // [4096 pairs][2 slots][256] granules, per process
-                if (!ring && hipMalloc((void**)&ring, (size_t)4096 * 2 * 256 * sizeof(lstm_u64)) != hipSuccess) {
+                static lstm_u64* ring = nullptr;       // [4096 pairs][2 slots][H <= 512] granules, per process
+                if (!ring && hipMalloc((void**)&ring, (size_t)4096 * 2 * 512 * sizeof(lstm_u64)) != hipSuccess) {
                     set_error("ttsc_lstm_seq_forward: cannot allocate the hand-off ring");
                     return TTSC_ENOMEM;
                 }
@@ -769,14 +771,14 @@ static int lstm_forward_impl(const float* xg_dev, const float* whh_packed_dev, f
                 sa.f = a;
                 sa.cnt = words;
                 sa.abort_word = words + 8192;
-                sa.G = 4;
-                sa.HU = H / 4;
+                sa.G = Gm;
+                sa.HU = H / Gm;
                 sa.KS = 512 / sa.HU;
                 const size_t lds = ((size_t)H + (size_t)sa.KS * 4 * sa.HU) * sizeof(float);
                 for (int p0 = 0; p0 < pairs; p0 += cap) {
                     sa.p0 = p0;
                     const int n = pairs - p0 < cap ? pairs - p0 : cap;
-                    hipLaunchKernelGGL(lstm_seq_split_res_kernel<32>, dim3(4u, (unsigned)n, 1u), dim3(512), lds, (hipStream_t)stream, sa, ring);
+                    hipLaunchKernelGGL(lstm_seq_split_res_kernel<32>, dim3((unsigned)Gm, (unsigned)n, 1u), dim3(512), lds, (hipStream_t)stream, sa, ring);
                 }
                 hipError_t e = hipGetLastError();
                 if (e != hipSuccess) {
