@@ -68,7 +68,7 @@ def test_lstm_two_utterances_per_workgroup():
     """lstm_seq_kernel<2> (B * ndir > 512 sequences: two utterances share one W_hh stream), ragged, vs torch.nn.LSTM."""
     from ttscube_amd.hip_layers import LSTMHip
     torch.manual_seed(9)
-    m = nn.LSTM(input_size=24, hidden_size=64, num_layers=1, bidirectional=True, batch_first=True)
+    m = nn.LSTM(input_size=24, hidden_size=96, num_layers=1, bidirectional=True, batch_first=True)   # (H = 64 / 128 run the resident kernel)
     B, T = 301, 6
     x = torch.randn(B, T, 24)
     lens = [(b % T) + 1 for b in range(B)]
@@ -77,3 +77,26 @@ def test_lstm_two_utterances_per_workgroup():
         ref, _ = nn.utils.rnn.pad_packed_sequence(m(packed)[0], batch_first=True, total_length=T)
     y = LSTMHip(m.cuda())(x.cuda(), lengths=lens).cpu()
     assert float((y - ref).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize('H,B,T', [(256, 40, 23), (256, 3, 50), (512, 3, 21), (512, 10, 9), (64, 70, 33), (128, 5, 40)])
+def test_lstm_resident_kernels_ragged_vs_torch_and_solo(H, B, T):
+    """Register-resident recurrences: lstm_seq_resident_kernel (H = 64 / 128), lstm_seq_split_res_kernel with 4 (H = 256) / 16
+    (H = 512) members — B = 40 at H = 256 is 80 (utterance, direction) pairs = two consecutive launches, B = 10 at H = 512 two as
+    well.  Ragged batch against torch.nn.LSTM (packed), and bit-identical to each utterance run alone."""
+    from ttscube_amd.hip_layers import LSTMHip
+    torch.manual_seed(H + B + T)
+    m = nn.LSTM(input_size=48, hidden_size=H, num_layers=2, bidirectional=True, batch_first=True)
+    x = torch.randn(B, T, 48)
+    lens = [((7 * b) % T) + 1 for b in range(B)]
+    lens[0] = T
+    with torch.no_grad():
+        packed = nn.utils.rnn.pack_padded_sequence(x, lens, batch_first=True, enforce_sorted=False)
+        ref, _ = nn.utils.rnn.pad_packed_sequence(m(packed)[0], batch_first=True, total_length=T)
+    h = LSTMHip(m.cuda())
+    y = h(x.cuda(), lengths=lens)
+    assert float((y.cpu() - ref).abs().max()) < 3e-5
+    for b in (0, 1, B - 1):
+        solo = h(x[b:b + 1, :lens[b]].cuda())
+        assert torch.equal(y[b, :lens[b]], solo[0])
+        assert bool((y[b, lens[b]:] == 0).all())
