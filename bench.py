@@ -73,7 +73,8 @@ def time_forward(g, mel, steps, warmup):
 
 def extra_legs(g, h, sd, rank_dev, R):
     """Secondary measurements the driver times with the same command: exact-fp32 arithmetic on the same
-    workload, the reference API's own B=1 x 3 s case (BASELINE configs[0] shape on the GPU), and WaveRNN decode (configs[2])."""
+    workload, the reference API's own B=1 x 3 s case (BASELINE configs[0] shape on the GPU), WaveRNN decode (configs[2]), one
+    Cubegan training step (configs[3] per-GPU share) and text features -> audio end to end (configs[4] per-GPU share)."""
     import numpy as np
     import torch
     legs = {}
@@ -133,6 +134,46 @@ def extra_legs(g, h, sd, rank_dev, R):
         del model, opts
     except Exception as e:
         legs['cubegan_training_step_b16'] = {'error': str(e)[:200]}
+    try:   # BASELINE configs[4] per-GPU share: text features -> audio (Languasito2 + generator), 64 random sentences and one sentence
+        import numpy as np
+        from oracle import meldecoder_ref as MO   # synthetic weights only
+        from ttscube_amd.networks.cubegan import Cubegan
+
+        class _Enc:
+            phon2int = {'p%d' % i: i for i in range(50)}
+            speaker2int = {'s0': 0}
+            max_pitch = 300
+            max_duration = 12   # synthetic weights give ~uniform durations: ~6 frames per phoneme
+
+        torch.manual_seed(0)
+        tts = Cubegan(_Enc(), conditioning=None, train=False)
+        esd = tts.state_dict()
+        esd.update({'_languasito.' + k: v for k, v in MO.fill_state_dict(MO.named_shapes(tts._languasito), 5).items()})
+        esd.update({'_generator.' + k: v for k, v in sd.items()})
+        tts.load_state_dict(esd)
+        tts = tts.to(rank_dev).eval()
+        rs = np.random.RandomState(1234)
+        n = 64
+        lens = rs.randint(20, 121, size=n)
+        xc = np.zeros((n, lens.max()), dtype=np.int64)
+        for b, l in enumerate(lens):
+            xc[b, :l] = rs.randint(1, 51, size=l)
+        for tag, xx in (('e2e_64_sentences', xc), ('e2e_single_sentence', xc[:1, :lens[0]])):
+            mk = lambda: {'x_char': torch.from_numpy(xx), 'x_speaker': torch.ones((xx.shape[0], 1), dtype=torch.long)}
+            for _ in range(2):
+                wav, wl = tts.inference(mk(), return_lengths=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                wav, wl = tts.inference(mk(), return_lengths=True)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            assert bool(torch.isfinite(wav).all())
+            legs[tag] = {'ms': dt * 1e3, 'samples': int(sum(wl)), 'samples_per_s': float(sum(wl)) / dt}
+        del tts
+    except Exception as e:
+        legs['e2e_64_sentences'] = {'error': str(e)[:200]}
     return legs
 
 
