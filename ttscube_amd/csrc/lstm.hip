@@ -10,6 +10,13 @@
 // h lives in LDS double-buffered) — no inter-workgroup communication, one workgroup barrier per step.
 // Ragged batches: `lengths[b]` gives pack_padded_sequence semantics (reverse direction starts at len-1, outputs
 // beyond len are zero), so a padded batch reproduces the per-utterance results exactly.
+//
+// Kernel choice (lstm_forward_impl):
+//   H = 64 / 128        lstm_seq_resident_kernel      one thread per gate row, W_hh in registers, no stream at all
+//   H = 256 / 512       lstm_seq_split_res_kernel     4 / 16 workgroups per (utterance, direction), 128 weights per thread in
+//                                                      registers, tagged-granule hand-off; up to three consecutive launches
+//   few sequences, other H   lstm_seq_split_kernel    <= 4 workgroups per sequence streaming their rows, counter hand-off
+//   everything else     lstm_seq_kernel<BT>           one workgroup per (utterance tile, direction), rows streamed from L2
 #include <algorithm>
 
 #include "common.hpp"
