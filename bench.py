@@ -238,6 +238,8 @@ def bench_train(args):
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29517')
     dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    if getattr(args, 'miopen_find', False):
+        torch.backends.cudnn.benchmark = True   # the discriminators' strided / grouped convolutions still run on MIOpen
     b = args.train_batch
     enc = synthetic_encodings()
     torch.manual_seed(1234 + rank)                       # ranks start different on purpose: broadcast must make them equal
@@ -304,6 +306,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--mode', choices=('infer', 'train'), default='infer', help="'train': the Cubegan adversarial training step (BASELINE configs[3])")
     ap.add_argument('--train-batch', type=int, default=16, help='utterances per GPU in --mode train')
+    ap.add_argument('--miopen-find', action='store_true', help="--mode train: let MIOpen search its convolution algorithms exhaustively "
+                    "(torch.backends.cudnn.benchmark): ~12 minutes once per process on a fresh box, then 108 instead of 145 ms per step; "
+                    "what scripts/train_cubegan.py does for real training runs")
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
