@@ -308,7 +308,7 @@ def main():
     ap.add_argument('--train-batch', type=int, default=16, help='utterances per GPU in --mode train')
     ap.add_argument('--miopen-find', action='store_true', help="--mode train: let MIOpen search its convolution algorithms exhaustively "
                     "(torch.backends.cudnn.benchmark): ~12 minutes once per process on a fresh box, then 108 instead of 145 ms per step; "
-                    "what scripts/train_cubegan.py does for real training runs")
+                    "scripts/train_cubegan.py --miopen-find does the same for real training runs")
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)

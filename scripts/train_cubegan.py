@@ -36,9 +36,10 @@ def _train(params):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     dev = torch.device('cuda', local)
-    # The discriminators' strided / grouped convolutions run on MIOpen; let it search its algorithms once (minutes at start-up, then
-    # 108 instead of 145 ms per b=16 step on MI355X).  --no-miopen-find keeps its immediate-mode choices.
-    torch.backends.cudnn.benchmark = not getattr(params, 'no_miopen_find', False)
+    # The discriminators' strided / grouped convolutions run on MIOpen.  --miopen-find lets it search its algorithms exhaustively
+    # (torch.backends.cudnn.benchmark: minutes at start-up, then 108 instead of 145 ms per b=16 step on MI355X).  Opt-in: the search
+    # repeats for every new tensor shape, and the text encoder's torch convolutions see a new length with almost every batch.
+    torch.backends.cudnn.benchmark = bool(getattr(params, 'miopen_find', False))
     torch.cuda.set_device(dev)
     if world > 1:
         dist.init_process_group('nccl', device_id=dev)
@@ -133,7 +134,7 @@ if __name__ == '__main__':
     p.add_argument('--lm', dest='lm', default=None, help='external conditioning (none | fasttext:<lang> | hf:<model>); only none is built')
     p.add_argument('--resume', dest='resume', action='store_true')
     p.add_argument('--epochs', type=int, default=1)
-    p.add_argument('--no-miopen-find', dest='no_miopen_find', action='store_true', help='skip MIOpen\'s exhaustive convolution search at start-up')
+    p.add_argument('--miopen-find', dest='miopen_find', action='store_true', help='let MIOpen search its convolution algorithms exhaustively (see _train)')
     p.add_argument('--synthetic', type=int, default=0, help='ignore the folders and train on N seeded synthetic examples per rank')
     p.add_argument('--generate-epoch', dest='generate_epoch', type=int, default=0, help='synthesise the dev set every N epochs (0 = never)')
     _train(p.parse_args())
