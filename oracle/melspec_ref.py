@@ -8,7 +8,8 @@ definitions on the path.
 
 PARITY UNPINNED for the librosa-dependent part: librosa is not installed here and the reference holds no fixture for it; the
 STFT / Slaney filterbank are restated from librosa's documented definitions (periodic Hann, Slaney mel scale with slaney
-normalisation).  Cross-checked against torch.stft in tests/test_melspec_cpu.py."""
+normalisation).  Cross-checked in tests/test_melspec_cpu.py against torch.stft and against `transformers.audio_utils` (an independent
+restatement of librosa's STFT / Slaney filterbank pipeline): filterbank 1e-9, both mel-spectrogram definitions 1e-7."""
 import numpy as np
 
 
