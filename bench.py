@@ -91,21 +91,27 @@ def extra_legs(g, h, sd, rank_dev, R):
         net = WaveRNN(num_layers=1, layer_size=512, upsample=240, upsample_low=10, use_lowres=True, output='mulaw')
         net.load_state_dict({k: torch.from_numpy(v) for k, v in wsd.items()}, strict=True)
         net = net.to(rank_dev).eval()
-        Bw, Tw = 256, 10
+        Bw, Tw = 256, 100   # C3 = 256 utterances x 100 frames = 24 000 autoregressive steps
         wm, wx = WO.synthetic_inputs(Bw, Tw, seed=6)
         X = {'mel': torch.from_numpy(wm), 'x_low': torch.from_numpy(wx)}
-        net.decode(X, mode='philox', seed=1)
+        net.decode({'mel': X['mel'][:, :4], 'x_low': X['x_low'][:, :96]}, mode='philox', seed=1)   # warm-up (weights packed, clocks up)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         idx, _, _ = net.decode(X, mode='philox', seed=2)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        # oracle on 2 utterances x 2 frames; the first frame (240 samples) is outside the reach of the truncation (the low-res
-        # conv stack looks 9 low-res samples = 90 samples ahead)
-        ridx, _, _ = WO.decode(wsd, wm[:2, :2], wx[:2, :48], num_layers=1, H=512, mode=WO.MODE_PHILOX, seed=2)
-        assert np.array_equal(idx[:2, :240].cpu().numpy(), ridx[:, :240]), 'WaveRNN indices differ from the oracle'
+        # oracle on utterances 0 and 255 over the WHOLE decode (the philox counters carry the utterance index: b_offset)
+        from concurrent.futures import ThreadPoolExecutor
+        chk = (0, Bw - 1)
+        with ThreadPoolExecutor(len(chk)) as ex:
+            refs = list(ex.map(lambda b: WO.decode(wsd, wm[b:b + 1], wx[b:b + 1], num_layers=1, H=512, mode=WO.MODE_PHILOX, seed=2,
+                                                   b_offset=b)[0], chk))
+        idx_h = idx.cpu().numpy()
+        for b, ridx in zip(chk, refs):
+            assert np.array_equal(idx_h[b], ridx[0]), 'WaveRNN indices of utterance %d differ from the oracle' % b
         legs['wavernn_decode_b256'] = {'us_per_step': dt / (Tw * 240) * 1e6, 'samples_per_s': Bw * Tw * 240 / dt, 'H': 512, 'layers': 1,
-                                       'output': 'mulaw', 'indices_bit_exact_vs_oracle': True, 'kernel': net.last_kernel}
+                                       'frames': Tw, 'steps': Tw * 240, 'output': 'mulaw', 'indices_bit_exact_vs_oracle': True,
+                                       'oracle_checked': '%d utterances x %d steps' % (len(chk), Tw * 240), 'kernel': net.last_kernel}
     except Exception as e:
         legs['wavernn_decode_b256'] = {'error': str(e)[:200]}
     try:   # BASELINE configs[3] per-GPU share: one full Cubegan training step (no exchange at N = 1; `--mode train` runs it under RCCL)
@@ -152,12 +158,12 @@ def extra_legs(g, h, sd, rank_dev, R):
         esd.update({'_generator.' + k: v for k, v in sd.items()})
         tts.load_state_dict(esd)
         tts = tts.to(rank_dev).eval()
-        rs = np.random.RandomState(1234)
+        from ttscube_amd.io_utils.synthetic import synthetic_sentences
         n = 64
-        lens = rs.randint(20, 121, size=n)
-        xc = np.zeros((n, lens.max()), dtype=np.int64)
-        for b, l in enumerate(lens):
-            xc[b, :l] = rs.randint(1, 51, size=l)
+        xc, lens = synthetic_sentences(n, seed=1234)
+        lsd = {k[len('_languasito.'):]: v for k, v in esd.items() if k.startswith('_languasito.')}
+        wfold = R.fold_state_dict(sd)
+        to16 = lambda a: np.asarray(a * 32767, dtype=np.int16)
         for tag, xx in (('e2e_64_sentences', xc), ('e2e_single_sentence', xc[:1, :lens[0]])):
             mk = lambda: {'x_char': torch.from_numpy(xx), 'x_speaker': torch.ones((xx.shape[0], 1), dtype=torch.long)}
             for _ in range(2):
@@ -170,7 +176,18 @@ def extra_legs(g, h, sd, rank_dev, R):
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / reps
             assert bool(torch.isfinite(wav).all())
-            legs[tag] = {'ms': dt * 1e3, 'samples': int(sum(wl)), 'samples_per_s': float(sum(wl)) / dt}
+            # never report a time for wrong audio: shortest + longest sentence against the oracle chain (meldecoder_ref -> hifigan_ref):
+            # identical durations, <= 4 LSB int16 (1e-4 of full scale)
+            worst = 0
+            for b in sorted({int(np.argmin(lens[:xx.shape[0]])), int(np.argmax(lens[:xx.shape[0]]))}):
+                with torch.no_grad():
+                    cond, durs, _ = MO.languasito2_inference(lsd, torch.from_numpy(xc[b:b + 1, :lens[b]]), torch.tensor([[1]]), _Enc.max_pitch)
+                    ref = R.generator_forward(wfold, h, cond.permute(0, 2, 1))
+                assert wl[b] == 240 * sum(durs) + 64, 'e2e: durations of sentence %d differ from the oracle' % b
+                dlt = np.abs(to16(wav[b, 0, :wl[b]].cpu().numpy()).astype(np.int32) - to16(ref.numpy().squeeze()).astype(np.int32))
+                worst = max(worst, int(dlt.max()))
+            assert worst <= 4, 'e2e: %d LSB from the oracle chain' % worst
+            legs[tag] = {'ms': dt * 1e3, 'samples': int(sum(wl)), 'samples_per_s': float(sum(wl)) / dt, 'max_lsb_vs_oracle_chain': worst}
         del tts
     except Exception as e:
         legs['e2e_64_sentences'] = {'error': str(e)[:200]}

@@ -65,6 +65,32 @@ static float dot_chain(const float* w, const float* x, int n, float acc) {
     return acc;
 }
 
+/* out[r] = dot_chain(W + r*ld, x, n, bias[r]) for r < rows.  Eight rows advance in lockstep so that the CPU overlaps eight
+ * independent fmaf chains (a single chain is bound by the fma latency); every row is still ONE k-ordered chain seeded with
+ * its bias, i.e. bit-identical to dot_chain. */
+static void matvec_chain(const float* W, int ld, const float* x, int n, const float* bias, int rows, float* out) {
+    int r = 0;
+    for (; r + 8 <= rows; r += 8) {
+        float a0 = bias[r], a1 = bias[r + 1], a2 = bias[r + 2], a3 = bias[r + 3];
+        float a4 = bias[r + 4], a5 = bias[r + 5], a6 = bias[r + 6], a7 = bias[r + 7];
+        const float* w = W + (size_t)r * ld;
+        for (int k = 0; k < n; ++k) {
+            const float xk = x[k];
+            a0 = fmaf(w[k], xk, a0);
+            a1 = fmaf(w[(size_t)ld + k], xk, a1);
+            a2 = fmaf(w[(size_t)2 * ld + k], xk, a2);
+            a3 = fmaf(w[(size_t)3 * ld + k], xk, a3);
+            a4 = fmaf(w[(size_t)4 * ld + k], xk, a4);
+            a5 = fmaf(w[(size_t)5 * ld + k], xk, a5);
+            a6 = fmaf(w[(size_t)6 * ld + k], xk, a6);
+            a7 = fmaf(w[(size_t)7 * ld + k], xk, a7);
+        }
+        out[r] = a0, out[r + 1] = a1, out[r + 2] = a2, out[r + 3] = a3;
+        out[r + 4] = a4, out[r + 5] = a5, out[r + 6] = a6, out[r + 7] = a7;
+    }
+    for (; r < rows; ++r) out[r] = dot_chain(W + (size_t)r * ld, x, n, bias[r]);
+}
+
 /* F.interpolate(x[B,1,Tl], 10*Tl, mode='linear') (align_corners=False), modules.py:353 */
 void wr_interp_linear(const float* x, int Tl, int up, float* out) {
     const int n = Tl * up;
@@ -121,9 +147,11 @@ int wr_noise_width(const wr_cfg* c) {
  * the fed-back sample at step t is forced_x[b][t] (teacher forcing: logits then equal WaveRNN._train_forward).
  * Outputs: out_idx [B,L] uint8, out_wav [B,L] float, out_logits [B,L,S] or NULL.
  */
-int wr_decode(const wr_cfg* c, const wr_weights* w, const float* mel, const float* x_low, int B, int T, int Tl,
-              int mode, const float* noise, uint64_t seed, const float* forced_x, uint8_t* out_idx, float* out_wav,
-              float* out_logits) {
+/* wr_decode_at: the arrays hold utterances b_offset .. b_offset+B-1 of a larger batch — only the counter-based noise depends
+ * on the absolute utterance index (counter word 2), so a few utterances of a big batch can be checked on their own. */
+int wr_decode_at(const wr_cfg* c, const wr_weights* w, const float* mel, const float* x_low, int B, int T, int Tl,
+                 int mode, const float* noise, uint64_t seed, const float* forced_x, int b_offset, uint8_t* out_idx, float* out_wav,
+                 float* out_logits) {
     const int H = c->H, S = c->S, NM = c->n_mel;
     const int I0 = NM + (c->use_lowres ? 21 : 0) + 1;
     const int64_t L = wr_out_len(c, T, Tl);
@@ -133,6 +161,8 @@ int wr_decode(const wr_cfg* c, const wr_weights* w, const float* mel, const floa
     float* x = (float*)malloc(sizeof(float) * (size_t)(I0 > H ? I0 : H));
     float* h = (float*)calloc((size_t)c->num_layers * H, sizeof(float));
     float* hn = (float*)malloc(sizeof(float) * H);
+    float* gi = (float*)malloc(sizeof(float) * 3 * H);
+    float* gh = (float*)malloc(sizeof(float) * 3 * H);
     float* pre = (float*)malloc(sizeof(float) * 256);
     float* logits = (float*)malloc(sizeof(float) * S);
     if (c->use_lowres) {
@@ -164,13 +194,11 @@ int wr_decode(const wr_cfg* c, const wr_weights* w, const float* mel, const floa
             int in_l = I0;
             for (int l = 0; l < c->num_layers; ++l) {
                 float* hl = h + (size_t)l * H;
+                matvec_chain(w->w_ih[l], in_l, x, in_l, w->b_ih[l], 3 * H, gi);   /* rows: r | z | n (torch GRU layout) */
+                matvec_chain(w->w_hh[l], H, hl, H, w->b_hh[l], 3 * H, gh);
                 for (int j = 0; j < H; ++j) {
-                    const float gi_r = dot_chain(w->w_ih[l] + (size_t)(0 * H + j) * in_l, x, in_l, w->b_ih[l][0 * H + j]);
-                    const float gi_z = dot_chain(w->w_ih[l] + (size_t)(1 * H + j) * in_l, x, in_l, w->b_ih[l][1 * H + j]);
-                    const float gi_n = dot_chain(w->w_ih[l] + (size_t)(2 * H + j) * in_l, x, in_l, w->b_ih[l][2 * H + j]);
-                    const float gh_r = dot_chain(w->w_hh[l] + (size_t)(0 * H + j) * H, hl, H, w->b_hh[l][0 * H + j]);
-                    const float gh_z = dot_chain(w->w_hh[l] + (size_t)(1 * H + j) * H, hl, H, w->b_hh[l][1 * H + j]);
-                    const float gh_n = dot_chain(w->w_hh[l] + (size_t)(2 * H + j) * H, hl, H, w->b_hh[l][2 * H + j]);
+                    const float gi_r = gi[j], gi_z = gi[H + j], gi_n = gi[2 * H + j];
+                    const float gh_r = gh[j], gh_z = gh[H + j], gh_n = gh[2 * H + j];
                     const float r = ttsc_sigmoidf(gi_r + gh_r);
                     const float z = ttsc_sigmoidf(gi_z + gh_z);
                     const float rg = r * gh_n;
@@ -182,8 +210,9 @@ int wr_decode(const wr_cfg* c, const wr_weights* w, const float* mel, const floa
                 memcpy(x, hn, sizeof(float) * H);
                 in_l = H;
             }
-            for (int j = 0; j < 256; ++j) pre[j] = ttsc_tanhf(dot_chain(w->w_pre + (size_t)j * H, x, H, w->b_pre[j]));
-            for (int s = 0; s < S; ++s) logits[s] = dot_chain(w->w_out + (size_t)s * 256, pre, 256, w->b_out[s]);
+            matvec_chain(w->w_pre, H, x, H, w->b_pre, 256, pre);
+            for (int j = 0; j < 256; ++j) pre[j] = ttsc_tanhf(pre[j]);
+            matvec_chain(w->w_out, 256, pre, 256, w->b_out, S, logits);
             if (out_logits) memcpy(out_logits + ((size_t)b * L + t) * S, logits, sizeof(float) * S);
             int best = 0;
             float wav;
@@ -195,7 +224,7 @@ int wr_decode(const wr_cfg* c, const wr_weights* w, const float* mel, const floa
                         g = noise[((size_t)b * L + t) * S + s];
                     } else if (mode == MODE_PHILOX) {
                         uint32_t r4[4];
-                        ttsc_philox4x32((uint32_t)(s >> 2), (uint32_t)t, (uint32_t)b, 0u,
+                        ttsc_philox4x32((uint32_t)(s >> 2), (uint32_t)t, (uint32_t)(b + b_offset), 0u,
                                         (uint32_t)seed, (uint32_t)(seed >> 32), r4);
                         g = ttsc_gumbel(r4[s & 3]);
                     }
@@ -217,9 +246,9 @@ int wr_decode(const wr_cfg* c, const wr_weights* w, const float* mel, const floa
                 if (mode == MODE_NOISE) {
                     memcpy(nz, noise + ((size_t)b * L + t) * nw, sizeof(float) * nw);
                 } else if (mode == MODE_PHILOX) {
-                    if (c->out_kind == OUT_MOL) ttsc_noise_mol((uint32_t)t, (uint32_t)b, seed, nz);
-                    else if (c->out_kind == OUT_GM) ttsc_noise_gm((uint32_t)t, (uint32_t)b, seed, nz);
-                    else ttsc_noise_beta((uint32_t)t, (uint32_t)b, seed, nz);
+                    if (c->out_kind == OUT_MOL) ttsc_noise_mol((uint32_t)t, (uint32_t)(b + b_offset), seed, nz);
+                    else if (c->out_kind == OUT_GM) ttsc_noise_gm((uint32_t)t, (uint32_t)(b + b_offset), seed, nz);
+                    else ttsc_noise_beta((uint32_t)t, (uint32_t)(b + b_offset), seed, nz);
                 } else if (c->out_kind == OUT_BETA) {
                     for (int v = 0; v < 2; ++v) nz[v * (1 + 2 * TTSC_BETA_TRIES)] = 0.5f, nz[v * (1 + 2 * TTSC_BETA_TRIES) + 2] = 0.5f;
                 }
@@ -241,9 +270,17 @@ int wr_decode(const wr_cfg* c, const wr_weights* w, const float* mel, const floa
     free(x);
     free(h);
     free(hn);
+    free(gi);
+    free(gh);
     free(pre);
     free(logits);
     return 0;
+}
+
+int wr_decode(const wr_cfg* c, const wr_weights* w, const float* mel, const float* x_low, int B, int T, int Tl,
+              int mode, const float* noise, uint64_t seed, const float* forced_x, uint8_t* out_idx, float* out_wav,
+              float* out_logits) {
+    return wr_decode_at(c, w, mel, x_low, B, T, Tl, mode, noise, seed, forced_x, 0, out_idx, out_wav, out_logits);
 }
 
 /* exported for the math pin test */

@@ -79,7 +79,7 @@ def _f32(a):
 
 
 def decode(sd, mel, x_low=None, num_layers=1, H=512, use_lowres=True, upsample=240, upsample_low=10, output='mulaw',
-           mode=MODE_ARGMAX, noise=None, seed=0, forced_x=None, want_logits=False, prefix=''):
+           mode=MODE_ARGMAX, noise=None, seed=0, forced_x=None, want_logits=False, prefix='', b_offset=0):
     """sd: state_dict-like {name: array} in the reference WaveRNN key layout."""
     L_ = lib()
     mel = _f32(mel)
@@ -123,10 +123,10 @@ def decode(sd, mel, x_low=None, num_layers=1, H=512, use_lowres=True, upsample=2
     if fx is not None:
         assert fx.shape[0] == B and fx.shape[1] >= L
         fx = _f32(fx[:, :L])
-    rc = L_.wr_decode(C.byref(cfg), C.byref(w), mel.ctypes.data_as(C.c_void_p),
+    rc = L_.wr_decode_at(C.byref(cfg), C.byref(w), mel.ctypes.data_as(C.c_void_p),
                       xl.ctypes.data_as(C.c_void_p) if xl is not None else None, B, T, Tl, mode,
                       nz.ctypes.data_as(C.c_void_p) if nz is not None else None, C.c_uint64(seed),
-                      fx.ctypes.data_as(C.c_void_p) if fx is not None else None,
+                      fx.ctypes.data_as(C.c_void_p) if fx is not None else None, C.c_int(b_offset),
                       idx.ctypes.data_as(C.c_void_p), wav.ctypes.data_as(C.c_void_p),
                       logits.ctypes.data_as(C.c_void_p) if logits is not None else None)
     assert rc == 0

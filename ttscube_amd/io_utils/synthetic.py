@@ -25,3 +25,14 @@ def synthetic_encodings(nphones=40, speakers=2):
     enc.speaker2int = {'s%d' % i: i for i in range(speakers)}
     enc.max_pitch, enc.max_duration = 300, 12
     return enc
+
+
+def synthetic_sentences(n, seed=1234, nphones=50, min_ph=20, max_ph=120):
+    """BASELINE configs[4] text side: n random phoneme-id sentences, ids U{1..nphones} (0 = padding, the collate's
+    `id + 1` convention of io_cubegan.py:219-231), lengths U{min_ph..max_ph}.  Returns (x_char [n, max_len] int64 zero-padded, lens)."""
+    rs = np.random.RandomState(seed)
+    lens = rs.randint(min_ph, max_ph + 1, size=n)
+    xc = np.zeros((n, int(lens.max())), dtype=np.int64)
+    for b, l in enumerate(lens):
+        xc[b, :l] = rs.randint(1, nphones + 1, size=l)
+    return xc, lens
