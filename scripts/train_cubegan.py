@@ -9,7 +9,9 @@ restores model AND optimizers (the reference's resume silently drops the optimiz
 train_cubegan.py:135 vs cubegan.py:304).
 
 Data: `--train-folder` / `--dev-folder` hold the reference's processed corpus (<id>.json / .mgc / .pitch / .wav, read by
-io_utils.io_cubegan.CubeganDataset); every rank trains on its own slice `examples[rank::world]`.  `.best` is selected on the
+io_utils.io_cubegan.CubeganDataset); every rank trains on its own slice of exactly ceil(N / world) items (`rank_shard`: wrap-padded
+like DistributedSampler, so all ranks run the same number of steps and gradient exchanges), read and collated by `--num-workers`
+background threads one batch ahead of the GPU step; the dev set is validated in rank shards and the loss sums are all-reduced.  `.best` is selected on the
 DEV-set mel-L1 (Cubegan.validation_step / validation_epoch_end, cubegan.py:191-273), as the reference does.  With
 `--synthetic N` the folders are ignored and N seeded synthetic examples per rank (+ N/4 for the dev set) are used instead —
 that must be asked for explicitly: a missing or empty folder is an error, never a silent fall-back."""
@@ -26,6 +28,7 @@ import yaml
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ttscube_amd.distributed import FlatBucketReducer, broadcast_parameters  # noqa: E402
 from ttscube_amd.io_utils.io_cubegan import CubeganCollate, CubeganEncodings  # noqa: E402
+from ttscube_amd.io_utils.loader import BatchLoader, equal_batches, rank_shard  # noqa: E402
 from ttscube_amd.io_utils.synthetic import synthetic_examples  # noqa: E402
 from ttscube_amd.networks import training as T  # noqa: E402
 from ttscube_amd.networks.cubegan import Cubegan  # noqa: E402
@@ -45,9 +48,10 @@ def _train(params):
         dist.init_process_group('nccl', device_id=dev)
     conditioning = params.lm if params.lm not in (None, 'none') else None
     if params.synthetic:
-        examples = list(synthetic_examples(params.synthetic, 1234 + rank))          # rank-distinct data and crops
-        dev_examples = list(synthetic_examples(max(2, params.synthetic // 4), 4321))
-        enc_source = list(synthetic_examples(params.synthetic, 1234)) if world > 1 else examples
+        trainset = list(synthetic_examples(params.synthetic, 1234 + rank))          # rank-distinct data and crops, same count on every rank
+        devset = list(synthetic_examples(max(2, params.synthetic // 4), 4321))
+        my_items = list(range(len(trainset)))
+        enc_source = list(synthetic_examples(params.synthetic, 1234)) if world > 1 else trainset
     else:
         from ttscube_amd.io_utils.io_cubegan import CubeganDataset
         for folder in (params.train_folder, params.dev_folder):
@@ -56,9 +60,9 @@ def _train(params):
         trainset, devset = CubeganDataset(params.train_folder), CubeganDataset(params.dev_folder)
         if len(trainset) == 0 or len(devset) == 0:
             raise SystemExit('no <id>.json/.mgc/.pitch/.wav items under %s / %s' % (params.train_folder, params.dev_folder))
-        examples = [trainset[i] for i in range(rank, len(trainset), world)]             # this rank's slice of the corpus
-        dev_examples = [devset[i] for i in range(len(devset))]
-        enc_source = [trainset[i] for i in range(len(trainset))] if not params.resume else []
+        my_items = rank_shard(len(trainset), rank, world)             # this rank's slice: same length on every rank
+        enc_source = trainset.meta_items() if not params.resume else []   # JSON + .pitch only: no wav / mgc decode for the encodings
+    my_dev = list(range(rank, len(devset), world))                     # validation shard (sums are all-reduced below)
     enc = CubeganEncodings()
     if params.resume:
         enc.load('{0}.encodings'.format(params.output_base))
@@ -85,18 +89,23 @@ def _train(params):
     val_rng = random.Random(7)
     for epoch in range(params.epochs):
         mel_loss, nb = 0.0, 0
-        random.Random(1000 * epoch + rank).shuffle(examples)
-        for s in range(0, len(examples), params.batch_size):
-            out = T.cubegan_training_step(model, collate.collate_fn(examples[s:s + params.batch_size]), opts, reducers, rng=crop_rng)
+        order = list(my_items)
+        random.Random(1000 * epoch + rank).shuffle(order)
+        for batch in BatchLoader(trainset, equal_batches(order, params.batch_size), collate.collate_fn, params.num_workers):
+            out = T.cubegan_training_step(model, batch, opts, reducers, rng=crop_rng)
             mel_loss += out['loss_mel']
             nb += 1
+        # validation (train_cubegan.py:38-76 + cubegan.py:191-273): mean dev-set mel-L1 -> _val_loss -> .best.  Every rank validates
+        # its shard of the dev set (nobody idles in a barrier long enough to trip the RCCL watchdog); (sum, count) are all-reduced.
+        model.eval()
+        vals = [T.cubegan_validation_step(model, b, rng=val_rng)['loss_mel']
+                for b in BatchLoader(devset, equal_batches(my_dev, params.batch_size), collate.collate_fn, params.num_workers)]
+        model.train()
+        vs = torch.tensor([sum(vals), float(len(vals))], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(vs)
+        model._val_loss = float(vs[0] / max(float(vs[1]), 1.0))
         if rank == 0:
-            # validation (train_cubegan.py:38-76 + cubegan.py:191-273): mean dev-set mel-L1 -> _val_loss -> .best
-            model.eval()
-            vals = [T.cubegan_validation_step(model, collate.collate_fn(dev_examples[s:s + params.batch_size]), rng=val_rng)['loss_mel']
-                    for s in range(0, len(dev_examples), params.batch_size)]
-            model.train()
-            model._val_loss = sum(vals) / max(len(vals), 1)
             if model._val_loss < best:
                 best = model._val_loss
                 model.save('{0}.best'.format(params.output_base))
@@ -109,8 +118,9 @@ def _train(params):
             if params.generate_epoch and epoch % params.generate_epoch == 0 and not params.synthetic:
                 from ttscube_amd.io_utils.runtime import cubegan_synthesize_dataset
                 model.eval()
-                cubegan_synthesize_dataset(model, output_path='generated_files/free/', devset_path=params.dev_folder, limit=-1,
-                                           conditioning=conditioning)
+                # bounded: the other ranks wait in the barrier below while rank 0 synthesises (default 16 files, not the whole dev set)
+                cubegan_synthesize_dataset(model, output_path='generated_files/free/', devset_path=params.dev_folder,
+                                           limit=params.generate_limit, conditioning=conditioning)
                 model.train()
         if world > 1:
             dist.barrier()
@@ -136,5 +146,6 @@ if __name__ == '__main__':
     p.add_argument('--epochs', type=int, default=1)
     p.add_argument('--miopen-find', dest='miopen_find', action='store_true', help='let MIOpen search its convolution algorithms exhaustively (see _train)')
     p.add_argument('--synthetic', type=int, default=0, help='ignore the folders and train on N seeded synthetic examples per rank')
+    p.add_argument('--generate-limit', dest='generate_limit', type=int, default=16, help='dev files synthesised by --generate-epoch (-1 = all)')
     p.add_argument('--generate-epoch', dest='generate_epoch', type=int, default=0, help='synthesise the dev set every N epochs (0 = never)')
     _train(p.parse_args())

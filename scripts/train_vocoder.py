@@ -9,7 +9,8 @@ state_dicts), <base>.last (CubenetVocoder state_dict, prefixes _wavernn_hr. / _w
 
 Data: `--train-folder` / `--dev-folder` hold .wav files; io_utils.io_vocoder.VocoderDataset reads them exactly as the reference's
 (normalise to 0.98 peak, low-rate copy, log10-mel — computed on the GPU here —, `data/cache` files, random hop-aligned crops
-of `--maximum-segment-size` samples).  Every rank trains on its own slice `files[rank::world]`; `.lr.best` / `.hr.best` are
+of `--maximum-segment-size` samples).  Every rank trains on its own slice of exactly ceil(N / world) files (`rank_shard`: wrap-padded,
+so all ranks run the same number of steps and gradient exchanges), loaded by `--num-workers` background threads; `.lr.best` / `.hr.best` are
 selected on the dev-set losses (train_vocoder.py:36-59 of the reference).  `--synthetic N` ignores the folders and uses N seeded
 synthetic items per rank; it must be asked for explicitly — a missing or empty folder is an error."""
 import os
@@ -26,6 +27,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ttscube_amd.distributed import FlatBucketReducer, broadcast_parameters  # noqa: E402
 from ttscube_amd.networks import training as T  # noqa: E402
 from ttscube_amd.io_utils.io_vocoder import VocoderCollate  # noqa: E402
+from ttscube_amd.io_utils.loader import BatchLoader, equal_batches, rank_shard  # noqa: E402
 from ttscube_amd.networks.vocoder import CubenetVocoder  # noqa: E402
 
 
@@ -41,10 +43,10 @@ def _synthetic_items(params, n, seed):
 
 
 class _RankSlice:
-    """items rank, rank + world, ... of a dataset (data-parallel sharding of the file list)"""
+    """this rank's ceil(N / world) items of a dataset (wrap-padded: every rank gets the same count -> same number of steps)"""
 
     def __init__(self, ds, rank, world):
-        self.ds, self.idx = ds, list(range(rank, len(ds), world))
+        self.ds, self.idx = ds, rank_shard(len(ds), rank, world)
 
     def __len__(self):
         return len(self.idx)
@@ -60,7 +62,9 @@ def _datasets(params, rank, world):
     for folder in (params.train_folder, params.dev_folder):
         if not os.path.isdir(folder):
             raise SystemExit('%s does not exist (pass --synthetic N to train on synthetic items)' % folder)
-    kw = dict(target_sample_rate=params.sample_rate, lowres_sample_rate=params.sample_rate_low, hop_size=params.hop_size)
+    from ttscube_amd.io_utils.vocoder import MelVocoder
+    kw = dict(target_sample_rate=params.sample_rate, lowres_sample_rate=params.sample_rate_low, hop_size=params.hop_size,
+              mel_vocoder=MelVocoder('cuda:%d' % int(os.environ.get('LOCAL_RANK', '0'))))   # cache-miss features on THIS rank's GPU
     train = VocoderDataset(params.train_folder, max_segment_size=params.maximum_segment_size, random_start=True, **kw)
     dev = VocoderDataset(params.dev_folder, max_segment_size=params.maximum_segment_size, random_start=False, **kw)
     if len(train) == 0 or len(dev) == 0:
@@ -98,23 +102,26 @@ def _train(params):
         nb = 0
         order = list(range(len(train)))
         random.Random(1000 * epoch + rank).shuffle(order)
-        for s in range(0, len(order), params.batch_size):
-            out = T.vocoder_training_step(model, collate([train[i] for i in order[s:s + params.batch_size]]), opts, reducers)
+        for batch in BatchLoader(train, equal_batches(order, params.batch_size), collate, params.num_workers):
+            out = T.vocoder_training_step(model, batch, opts, reducers)
             tot['lr'] += out['lr']
             tot['hr'] += out['hr']
             nb += 1
+        # validation (WaveRNN.validation_step, modules.py:541-551): teacher-forced loss on the dev set, no gradient; every rank takes
+        # its shard of the dev set and the (sums, count) are all-reduced
+        model.eval()
+        vsum = torch.zeros(3, dtype=torch.float64, device=dev)
+        with torch.no_grad():
+            for b in BatchLoader(dev_items, equal_batches(list(range(rank, len(dev_items), world)), params.batch_size), collate, params.num_workers):
+                b = {k: v.to(dev) for k, v in b.items()}
+                vsum[0] += float(T.wavernn_loss(model._wavernn_hr, {'x': b['x'], 'x_low': b['x_low'], 'mel': b['mel']}))
+                vsum[1] += float(T.wavernn_loss(model._wavernn_lr, {'x': b['x_low'], 'mel': b['mel']}))
+                vsum[2] += 1
+        model.train()
+        if world > 1:
+            dist.all_reduce(vsum)
+        val, nv = {'hr': float(vsum[0]), 'lr': float(vsum[1])}, int(vsum[2])
         if rank == 0:
-            # validation (WaveRNN.validation_step, modules.py:541-551): teacher-forced loss on the dev set, no gradient
-            val = {'lr': 0.0, 'hr': 0.0}
-            nv = 0
-            model.eval()
-            with torch.no_grad():
-                for s in range(0, len(dev_items), params.batch_size):
-                    b = {k: v.to(dev) for k, v in collate([dev_items[i] for i in range(s, min(s + params.batch_size, len(dev_items)))]).items()}
-                    val['hr'] += float(T.wavernn_loss(model._wavernn_hr, {'x': b['x'], 'x_low': b['x_low'], 'mel': b['mel']}))
-                    val['lr'] += float(T.wavernn_loss(model._wavernn_lr, {'x': b['x_low'], 'mel': b['mel']}))
-                    nv += 1
-            model.train()
             for k, net in (('lr', model._wavernn_lr), ('hr', model._wavernn_hr)):
                 v = val[k] / max(nv, 1)
                 if v < best[k]:

@@ -226,6 +226,7 @@ def _chain_call(c1s, c2s, xd, y, accumulate, lens, shape):
     (32, 11, (1, 3, 5), 1999, 2, 0), (32, 11, (1, 3, 5), 3000, 1, 1), (32, 11, (5,), 7, 2, -1), (32, 3, (1, 3), 392, 1, -1),
     (64, 3, (1, 3, 5), 900, 2, 0), (64, 7, (1, 3, 5), 777, 1, 0), (64, 7, (1, 3, 5), 1300, 2, 1), (64, 11, (1, 3, 5), 1100, 1, 1),
     (64, 11, (3,), 600, 2, 0), (64, 3, (5,), 257, 1, 1),
+    (128, 3, (1, 3, 5), 1000, 2, -1), (128, 3, (1, 3, 5), 233, 1, -1), (128, 3, (5,), 470, 2, -1),   # 2 x 4 wave grid, three 1-step weight slots
 ])
 def test_fused_resblock_chain_matches_torch(C, k, dils, L, B, shape):
     """rbchain_f16x3_kernel (resblock.hip) through ttsc_rbchain_forward: the whole ResBlock1
@@ -260,7 +261,7 @@ def test_fused_resblock_chain_not_eligible():
     a1 = (C.c_void_p * 2)(*[c._h for c in c1s])
     a2 = (C.c_void_p * 2)(*[c._h for c in c2s])
     assert _lib.lib().ttsc_rbchain_supported(a1, a2, 2) == 0
-    c1s, c2s, _ = _chain_layers(128, 3, (1,))
+    c1s, c2s, _ = _chain_layers(128, 7, (1,))   # 128 channels: only K = 3 fits the LDS image
     a1 = (C.c_void_p * 1)(c1s[0]._h)
     a2 = (C.c_void_p * 1)(c2s[0]._h)
     assert _lib.lib().ttsc_rbchain_supported(a1, a2, 1) == 0

@@ -119,3 +119,32 @@ def test_trainers_do_not_fall_back_to_synthetic_data(tmp_path):
     p.synthetic = 3
     train, dev = tv._datasets(p, 1, 2)
     assert len(train) == 3 and len(dev) == 2 and train[0][2].shape == (11, 80)
+
+
+def test_rank_shards_have_equal_step_counts_and_loader_prefetches():
+    """ADVICE r2: with N=97 items, world=2, bs=16 the old `items[rank::world]` slices gave 4 vs 3 batches -> one rank would block in
+    an extra gradient exchange.  rank_shard wrap-pads to ceil(N / world) so every rank runs the same number of steps."""
+    from ttscube_amd.io_utils.loader import BatchLoader, equal_batches, rank_shard
+    for n, world, bs in ((97, 2, 16), (5, 8, 2), (64, 8, 16), (1, 4, 3)):
+        shards = [rank_shard(n, r, world) for r in range(world)]
+        assert len({len(s) for s in shards}) == 1 and len(shards[0]) == -(-n // world)
+        assert len({len(equal_batches(s, bs)) for s in shards}) == 1
+        assert set(i for s in shards for i in s) == set(range(n))          # nothing dropped
+    assert rank_shard(0, 0, 2) == []
+
+    class DS:
+        def __getitem__(self, i):
+            if i == 13:
+                raise ValueError('bad item')
+            return i * i
+
+    col = lambda items: sum(items)
+    batches = equal_batches(list(range(10)), 3)
+    for nw in (0, 3):
+        assert list(BatchLoader(DS(), batches, col, num_workers=nw)) == [sum(i * i for i in b) for b in batches]
+    import pytest
+    with pytest.raises(ValueError):
+        list(BatchLoader(DS(), [[1, 2], [13]], col, num_workers=2))
+    it = iter(BatchLoader(DS(), equal_batches(list(range(12)), 2), col, num_workers=2))   # abandoning the iterator must not hang
+    assert next(it) == 1
+    del it

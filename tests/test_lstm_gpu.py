@@ -100,3 +100,29 @@ def test_lstm_resident_kernels_ragged_vs_torch_and_solo(H, B, T):
         solo = h(x[b:b + 1, :lens[b]].cuda())
         assert torch.equal(y[b, :lens[b]], solo[0])
         assert bool((y[b, lens[b]:] == 0).all())
+
+
+def test_two_handles_on_two_streams_do_not_share_handoff_state():
+    """the split recurrences keep their counters / granule rings / abort words per (device, stream)
+    (csrc/util.cpp handoff_area), so two handles driven concurrently on two streams of one device cannot corrupt each other."""
+    from ttscube_amd import _lib
+    from ttscube_amd.hip_layers import LSTMHip
+    torch.manual_seed(11)
+    ma = nn.LSTM(input_size=96, hidden_size=256, num_layers=2, bidirectional=True, batch_first=True).cuda()
+    mb = nn.LSTM(input_size=80, hidden_size=512, num_layers=1, bidirectional=True, batch_first=True).cuda()
+    ha, hb = LSTMHip(ma), LSTMHip(mb)
+    xa, xb = torch.randn(2, 140, 96).cuda(), torch.randn(1, 90, 80).cuda()
+    ra, rb = ha(xa), hb(xb)          # solo, default stream
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for _ in range(6):
+        with torch.cuda.stream(sa):
+            ya = ha(xa)
+        with torch.cuda.stream(sb):
+            yb = hb(xb)
+        outs.append((ya, yb))
+    torch.cuda.synchronize()
+    assert _lib.lib().ttsc_lstm_split_status() == 0
+    for ya, yb in outs:
+        assert torch.equal(ya, ra) and torch.equal(yb, rb)

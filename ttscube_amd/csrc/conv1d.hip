@@ -1043,11 +1043,7 @@ static int launch_f16_t(const ConvArgs& a, int B, hipStream_t s) {
     constexpr int MT = MI * 32;
     dim3 grid((unsigned)ceil_div(a.q_cnt, NT), (unsigned)(a.CoutP / MT), (unsigned)B);
     const size_t lds = (size_t)a.span_pad * 4 * 16 + (size_t)a.ntaps * MI * 2 * 64 * 16;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv_f16x3_kernel<MI, NJ, TMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    if (int rc = ensure_full_lds((const void*)conv_f16x3_kernel<MI, NJ, TMAX>)) return rc;   // once per (device, kernel)
     hipLaunchKernelGGL((conv_f16x3_kernel<MI, NJ, TMAX>), grid, dim3(256), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -1067,11 +1063,7 @@ static int launch_f16_wide(const ConvArgs& a0, int B, hipStream_t s) {
     static const int skew_env = getenv("TTSC_CONV_SKEW") ? atoi(getenv("TTSC_CONV_SKEW")) : 6;
     a.skew = ((size_t)grid.x * grid.y * grid.z >= 1024) ? skew_env : 0;
     constexpr size_t lds = (size_t)2 * (4 * SPAN + 2) * 16 + (size_t)2 * (2 * 2 * 2 * 64) * 16;   // activations + 2 weight slots
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv_f16x3_wide_kernel<C, K, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    if (int rc = ensure_full_lds((const void*)conv_f16x3_wide_kernel<C, K, D>)) return rc;   // once per (device, kernel)
     hipLaunchKernelGGL((conv_f16x3_wide_kernel<C, K, D>), grid, dim3(256), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -1111,13 +1103,8 @@ static int launch_cfg(const ConvArgs& a, int B, hipStream_t s) {
     dim3 block(WM * WN * 64);
     size_t lds = (size_t)2 * KC * a.span_pad * sizeof(float);
     TTSC_REQUIRE(lds <= 160 * 1024, "conv_mfma_kernel: receptive field too large for LDS (%zu bytes)", lds);
-    if (lds > 64 * 1024) {
-        static size_t attr_set = 0;
-        if (lds > attr_set) {
-            TTSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<MI, NJ, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = lds;
-        }
-    }
+    if (lds > 64 * 1024)
+        if (int rc = ensure_full_lds(reinterpret_cast<const void*>(conv_mfma_kernel<MI, NJ, WM, WN>))) return rc;
     hipLaunchKernelGGL((conv_mfma_kernel<MI, NJ, WM, WN>), grid, block, lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -1756,13 +1743,9 @@ extern "C" int ttsc_respair_forward(const ttsc_conv1d* c1, const ttsc_conv1d* c2
     dim3 grid((unsigned)ceil_div(L, NTO), (unsigned)B);
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipSuccess;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)respair32_f16x3_kernel<3, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)respair32_f16x3_kernel<7, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)respair32_f16x3_kernel<11, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    if (int rc = ensure_full_lds((const void*)respair32_f16x3_kernel<3, NW>)) return rc;
+    if (int rc = ensure_full_lds((const void*)respair32_f16x3_kernel<7, NW>)) return rc;
+    if (int rc = ensure_full_lds((const void*)respair32_f16x3_kernel<11, NW>)) return rc;
     if (k == 3)
         hipLaunchKernelGGL((respair32_f16x3_kernel<3, NW>), grid, dim3(64 * NW), lds, s, a);
     else if (k == 7)

@@ -197,11 +197,7 @@ static int launch_wgrad(const WgArgs& a, hipStream_t s) {
     const int tiles = ((a.A + 31) / 32) * ((a.Bc + 31) / 32);
     const int wgs_x = (a.N * a.groups + 3) / 4;
     const size_t lds = (size_t)4 * (32 * WG_PP + 32 * WG_QP) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        TTSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<JT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    if (int rc = ensure_full_lds(reinterpret_cast<const void*>(conv_wgrad_kernel<JT>))) return rc;   // once per (device, kernel)
     hipLaunchKernelGGL(conv_wgrad_kernel<JT>, dim3(wgs_x, tiles), dim3(256), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -325,15 +325,7 @@ static int gru_check_launch(const char* what) {
 
 // members per utterance for the split kernels: power of two, units per member >= 32, all workgroups co-resident
 static int gru_split_members(int B, int H) {
-    static int cus = -1;
-    if (cus < 0) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess)
-            cus = 0;
-        else
-            cus = p.multiProcessorCount;
-    }
+    const int cus = device_cus();   // of the CURRENT device
     int gmax = 4;   // measured on MI355X (H=512, B=16, T=24000): G=2.. see DESIGN.md; 4 is the best trade between row stream and hand-off cost
     if (const char* ev = getenv("TTSC_GRU_SPLIT")) gmax = atoi(ev);
     int G = 1;
@@ -345,28 +337,17 @@ static int gru_split_members(int B, int H) {
     return G;
 }
 
-static unsigned* g_gru_words = nullptr;   // [0..4095] per-utterance counters, [4096] abort word
-
-static unsigned* gru_sync_words(int B, hipStream_t s) {
+// Counters / abort words of the split recurrences: one area per (device, stream) — common.hpp HandoffArea
+static HandoffArea* gru_area(int B, hipStream_t s) {
     if (B > 4096) return nullptr;
-    if (!g_gru_words) {
-        if (hipMalloc((void**)&g_gru_words, 4097 * sizeof(unsigned)) != hipSuccess) return nullptr;
-        if (hipMemset(g_gru_words, 0, 4097 * sizeof(unsigned)) != hipSuccess) return nullptr;
-    }
-    // counters restart at zero; the abort word [4096] is STICKY until ttsc_gru_split_status() has reported it
-    if (hipMemsetAsync(g_gru_words, 0, 4096 * sizeof(unsigned), s) != hipSuccess) return nullptr;
-    return g_gru_words;
+    HandoffArea* ar = handoff_area("gru", s, 4096, 0);
+    if (!ar || ar->rearm(s) != hipSuccess) return nullptr;   // counters and this launch's abort word restart at zero
+    return ar;
 }
 
-// 0 = every hand-off of the most recent split launch completed; 1 = a bounded spin timed out (that launch's results are
-// invalid).  Synchronises the device; meant for tests and debugging.
-extern "C" int32_t ttsc_gru_split_status(void) {
-    if (!g_gru_words) return 0;
-    unsigned v = 0;
-    if (hipMemcpy(&v, g_gru_words + 4096, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    if (v && hipMemset(g_gru_words + 4096, 0, sizeof(unsigned)) != hipSuccess) return -1;   // reported once, then re-armed
-    return (int32_t)(v != 0);
-}
+// 0 = every hand-off of the split GRU launches on this device since the last call completed; 1 = a bounded spin timed out (that
+// launch's results are invalid).  Synchronises the device; meant for tests and debugging.
+extern "C" int32_t ttsc_gru_split_status(void) { return handoff_status("gru"); }
 
 extern "C" int ttsc_gru_pack_whh_device(const float* whh_dev, int32_t H, int32_t transpose, float* out_dev, void* stream) {
     TTSC_REQUIRE(whh_dev && out_dev, "ttsc_gru_pack_whh_device: null argument");
@@ -384,12 +365,12 @@ extern "C" int ttsc_gru_seq_forward(const float* xg_dev, const float* whh_packed
     GruArgs a{xg_dev, whh_packed_dev, bhh_dev, y_dev, saved_dev, h0_dev, B, T, H};
     const int G = gru_split_members(B, H);
     if (G > 1) {
-        unsigned* words = gru_sync_words(B, (hipStream_t)stream);
-        TTSC_REQUIRE(words, "ttsc_gru_seq_forward: cannot allocate the hand-off counters");
+        HandoffArea* ar = gru_area(B, (hipStream_t)stream);
+        TTSC_REQUIRE(ar, "ttsc_gru_seq_forward: cannot allocate the hand-off counters");
         GruSplitArgs sa{};
         sa.f = a;
-        sa.cnt = words;
-        sa.abort_word = words + 4096;
+        sa.cnt = ar->words;
+        sa.abort_word = ar->abort_word();
         sa.G = G;
         sa.HU = H / G;
         sa.KS = 512 / sa.HU;
@@ -408,12 +389,12 @@ extern "C" int ttsc_gru_seq_backward(const float* dy_dev, const float* saved_dev
     GruBwdArgs a{dy_dev, saved_dev, y_dev, h0_dev, whhT_packed_dev, dgi_dev, dgh_dev, B, T, H};
     const int G = gru_split_members(B, H);
     if (G > 1) {
-        unsigned* words = gru_sync_words(B, (hipStream_t)stream);
-        TTSC_REQUIRE(words, "ttsc_gru_seq_backward: cannot allocate the hand-off counters");
+        HandoffArea* ar = gru_area(B, (hipStream_t)stream);
+        TTSC_REQUIRE(ar, "ttsc_gru_seq_backward: cannot allocate the hand-off counters");
         GruSplitArgs sa{};
         sa.bw = a;
-        sa.cnt = words;
-        sa.abort_word = words + 4096;
+        sa.cnt = ar->words;
+        sa.abort_word = ar->abort_word();
         sa.G = G;
         sa.HU = H / G;
         sa.KS = 512 / sa.HU;

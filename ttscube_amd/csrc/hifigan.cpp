@@ -42,6 +42,7 @@ struct ttsc_hifigan {
     std::vector<int> stage_ch;  // channels after upsample i
     bool use_fused = true;      // env TTSC_HIFIGAN_FUSED=0 disables the fused residual-pair kernel (A/B measurements)
     bool use_chain = true;      // env TTSC_HIFIGAN_CHAIN=0 disables the whole-ResBlock fused chain kernel (resblock.hip)
+    bool use_chain128 = true;   // env TTSC_HIFIGAN_CHAIN128=0: keep the 128-channel K=3 block on the layer-by-layer wide kernel (A/B)
     int chain_shape = -1;       // env TTSC_HIFIGAN_CHAIN_SHAPE: tile shape of the chain kernel (-1 = by halo)
     int precision = TTSC_PREC_FP32;
     // Split precision keeps activations as fp16 (hi, lo) pairs, so every layer's input gets a power-of-two pre-scale that
@@ -95,6 +96,7 @@ extern "C" int ttsc_hifigan_create(const ttsc_hifigan_cfg* cfg, ttsc_hifigan** o
     g->cfg = *cfg;
     if (const char* ev = getenv("TTSC_HIFIGAN_FUSED")) g->use_fused = atoi(ev) != 0;
     if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN")) g->use_chain = atoi(ev) != 0;
+    if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN128")) g->use_chain128 = atoi(ev) != 0;
     if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN_SHAPE")) g->chain_shape = atoi(ev);
     if (const char* ev = getenv("TTSC_HIFIGAN_CALIBRATE")) g->auto_calibrate = atoi(ev) != 0;
     int rc = add_layer(g.get(), "conv_pre", cfg->num_mels, cfg->upsample_initial_channel, 7, 1, 3, 1, 0);
@@ -362,17 +364,23 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
                 const std::string rb = "resblocks." + std::to_string(i * c.num_kernels + j);
                 fused_stage = ttsc_respair_supported(layer(rb + ".convs1." + std::to_string(m)), layer(rb + ".convs2." + std::to_string(m))) != 0;
             }
-        // ... or, better, does every ResBlock1 of the stage run as ONE fused chain launch (32 / 64 channels)?
-        bool chain_stage = !calib && (c.resblock == 1) && g->use_chain;
-        for (int j = 0; chain_stage && j < c.num_kernels; ++j) {
+        // ... or, better, which ResBlock1s of the stage run as ONE fused chain launch each (32 / 64 channels: all of them; 128 channels:
+        // the K = 3 block, whose image + halo still fit the LDS)?
+        bool chain_rb[TTSC_HIFIGAN_MAX_RB] = {false};
+        bool chain_stage = !calib && (c.resblock == 1) && g->use_chain;   // every block of the stage chained
+        for (int j = 0; j < c.num_kernels; ++j) {
             const std::string rb = "resblocks." + std::to_string(i * c.num_kernels + j);
             const ttsc_conv1d *c1[TTSC_HIFIGAN_MAX_DIL], *c2[TTSC_HIFIGAN_MAX_DIL];
             const int nd = c.num_dilations[j];
-            for (int m = 0; m < nd; ++m) {
+            bool ok = !calib && (c.resblock == 1) && g->use_chain && nd <= 3;
+            for (int m = 0; ok && m < nd; ++m) {
                 c1[m] = layer(rb + ".convs1." + std::to_string(m));
                 c2[m] = layer(rb + ".convs2." + std::to_string(m));
             }
-            chain_stage = nd <= 3 && ttsc_rbchain_supported(c1, c2, nd) != 0;
+            ok = ok && ttsc_rbchain_supported(c1, c2, nd) != 0;
+            if (ok && ch >= 128 && !g->use_chain128) ok = false;
+            chain_rb[j] = ok;
+            chain_stage = chain_stage && ok;
         }
         if (chain_stage) fused_stage = false;
         // x = ups[i](lrelu(x / nk_prev, 0.1))
@@ -384,7 +392,7 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
         for (int j = 0; j < c.num_kernels; ++j) {
             const std::string rb = "resblocks." + std::to_string(i * c.num_kernels + j);
             const int nd = c.num_dilations[j];
-            if (chain_stage) {
+            if (chain_rb[j]) {
                 // the whole ResBlock1 in one launch: X -> S (+= for the second and third block)
                 const ttsc_conv1d *c1[TTSC_HIFIGAN_MAX_DIL], *c2[TTSC_HIFIGAN_MAX_DIL];
                 for (int m = 0; m < nd; ++m) {

@@ -441,6 +441,7 @@ __global__ __launch_bounds__(512) void lstm_seq_split_res_kernel(LstmSplitArgs s
                     if ((unsigned)(gq >> 32) == (unsigned)st) break;
                     if (++spins > GS_SPIN_LIMIT || ((spins & 63u) == 0u && __hip_atomic_load(s.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                         __hip_atomic_store(s.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(s.abort_word + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sticky copy
                         fail = true;
                         break;
                     }
@@ -621,11 +622,7 @@ extern "C" void ttsc_device_free(void* p) {
 
 // members per (utterance, direction) for the split kernels: power of two <= 4, >= 32 units per member, all workgroups resident
 static int lstm_split_members(int B, int ndir, int H) {
-    static int cus = -1;
-    if (cus < 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-    }
+    const int cus = device_cus();   // of the CURRENT device
     int gmax = 4;
     if (const char* ev = getenv("TTSC_LSTM_SPLIT")) gmax = atoi(ev);
     int G = 1;
@@ -637,27 +634,16 @@ static int lstm_split_members(int B, int ndir, int H) {
     return G;
 }
 
-static unsigned* g_lstm_words = nullptr;   // [0..8191] per-(utterance, direction) counters, [8192] abort word
-
-static unsigned* lstm_sync_words(int n, hipStream_t s) {
-    if (n > 8192) return nullptr;
-    if (!g_lstm_words) {
-        if (hipMalloc((void**)&g_lstm_words, 8193 * sizeof(unsigned)) != hipSuccess) return nullptr;
-        if (hipMemset(g_lstm_words, 0, 8193 * sizeof(unsigned)) != hipSuccess) return nullptr;
-    }
-    // counters restart at zero; the abort word [8192] is STICKY until ttsc_lstm_split_status() has reported it
-    if (hipMemsetAsync(g_lstm_words, 0, 8192 * sizeof(unsigned), s) != hipSuccess) return nullptr;
-    return g_lstm_words;
+// Counters / abort words / granule ring of the split recurrences: one area per (device, stream) — common.hpp HandoffArea
+static HandoffArea* lstm_area(hipStream_t s, size_t ring_bytes) {
+    HandoffArea* ar = handoff_area("lstm", s, 8192, ring_bytes);
+    if (!ar || ar->rearm(s) != hipSuccess) return nullptr;   // counters and this launch's abort word restart at zero
+    return ar;
 }
 
-// 0 = every hand-off of the most recent split LSTM launch completed, 1 = a bounded spin timed out.  Synchronises the device.
-extern "C" int32_t ttsc_lstm_split_status(void) {
-    if (!g_lstm_words) return 0;
-    unsigned v = 0;
-    if (hipMemcpy(&v, g_lstm_words + 8192, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    if (v && hipMemset(g_lstm_words + 8192, 0, sizeof(unsigned)) != hipSuccess) return -1;   // reported once, then re-armed
-    return (int32_t)(v != 0);
-}
+// 0 = every hand-off of the split LSTM launches on this device since the last call completed, 1 = a bounded spin timed out.
+// Synchronises the device.
+extern "C" int32_t ttsc_lstm_split_status(void) { return handoff_status("lstm"); }
 
 static int lstm_forward_impl(const float* xg_dev, const float* whh_packed_dev, float* y_dev, const int32_t* lengths_dev,
                              int32_t B, int32_t T, int32_t H, int32_t ndir, int64_t ldy, int32_t yoff, const float* h0_dev,
@@ -701,12 +687,13 @@ extern "C" int ttsc_lstm_seq_backward(const float* dy_dev, const float* gates_de
     LstmBwdArgs a{dy_dev, gates_dev, c_dev, whhT_packed_dev, dgates_dev, lengths_dev, B, T, H, ndir, (int)ldy, yoff};
     const int G = lstm_split_members(B, ndir, H);
     if (G > 1) {
-        unsigned* words = lstm_sync_words(B * ndir, (hipStream_t)stream);
-        TTSC_REQUIRE(words, "ttsc_lstm_seq_backward: cannot allocate the hand-off counters");
+        TTSC_REQUIRE(B * ndir <= 8192, "ttsc_lstm_seq_backward: too many sequences for the split kernel");
+        HandoffArea* ar = lstm_area((hipStream_t)stream, 0);
+        TTSC_REQUIRE(ar, "ttsc_lstm_seq_backward: cannot allocate the hand-off counters");
         LstmSplitArgs sa{};
         sa.bw = a;
-        sa.cnt = words;
-        sa.abort_word = words + 8192;
+        sa.cnt = ar->words;
+        sa.abort_word = ar->abort_word();
         sa.G = G;
         sa.HU = H / G;
         sa.KS = 512 / sa.HU;
@@ -761,23 +748,23 @@ static int lstm_forward_impl(const float* xg_dev, const float* whh_packed_dev, f
         // launch takes cus / G pairs; up to three consecutive launches still beat the streaming kernels (H = 256: 3 us per step
         // and layer per launch against 9.8), and every batch size up to 3 * cus / (2 G) sentences then sums in the same order as
         // a sentence run alone.
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 4) {
+        const int cus = device_cus();
+        if (cus >= 4) {
             const int Gm = H == 256 ? 4 : 16;
             const int pairs = B * ndir, cap = cus / Gm;
             if (cap >= 1 && pairs <= 3 * cap && pairs <= 4096) {
-                unsigned* words = lstm_sync_words(1, (hipStream_t)stream);
-                TTSC_REQUIRE(words, "ttsc_lstm_seq_forward: cannot allocate the hand-off counters");
-                static lstm_u64* ring = nullptr;       // [4096 pairs][2 slots][H <= 512] granules, per process
-                if (!ring && hipMalloc((void**)&ring, (size_t)4096 * 2 * 512 * sizeof(lstm_u64)) != hipSuccess) {
-                    set_error("ttsc_lstm_seq_forward: cannot allocate the hand-off ring");
+                // granule ring [pairs][2 slots][H]: sized for this launch, grown on demand, one per (device, stream)
+                HandoffArea* ar = lstm_area((hipStream_t)stream, (size_t)pairs * 2 * H * sizeof(lstm_u64));
+                if (!ar) {
+                    set_error("ttsc_lstm_seq_forward: cannot allocate the hand-off counters / ring");
                     return TTSC_ENOMEM;
                 }
+                lstm_u64* ring = reinterpret_cast<lstm_u64*>(ar->buf);
                 TTSC_HIP_CHECK(hipMemsetAsync(ring, 0, (size_t)pairs * 2 * H * sizeof(lstm_u64), (hipStream_t)stream));
                 LstmSplitArgs sa{};
                 sa.f = a;
-                sa.cnt = words;
-                sa.abort_word = words + 8192;
+                sa.cnt = ar->words;
+                sa.abort_word = ar->abort_word();
                 sa.G = Gm;
                 sa.HU = H / Gm;
                 sa.KS = 512 / sa.HU;
@@ -798,12 +785,13 @@ static int lstm_forward_impl(const float* xg_dev, const float* whh_packed_dev, f
     }
     const int G = (gates_dev || split_infer) ? lstm_split_members(B, ndir, H) : 1;
     if (G > 1) {
-        unsigned* words = lstm_sync_words(B * ndir, (hipStream_t)stream);
-        TTSC_REQUIRE(words, "ttsc_lstm_seq_forward: cannot allocate the hand-off counters");
+        TTSC_REQUIRE(B * ndir <= 8192, "ttsc_lstm_seq_forward: too many sequences for the split kernel");
+        HandoffArea* ar = lstm_area((hipStream_t)stream, 0);
+        TTSC_REQUIRE(ar, "ttsc_lstm_seq_forward: cannot allocate the hand-off counters");
         LstmSplitArgs sa{};
         sa.f = a;
-        sa.cnt = words;
-        sa.abort_word = words + 8192;
+        sa.cnt = ar->words;
+        sa.abort_word = ar->abort_word();
         sa.G = G;
         sa.HU = H / G;
         sa.KS = 512 / sa.HU;

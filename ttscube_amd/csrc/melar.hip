@@ -353,11 +353,7 @@ extern "C" int ttsc_melar_set_weights(ttsc_melar* m, const float* w_ih1, int64_t
 // split factor for the AR decoder: 15.5 MB of weights per step make G = 8 the measured optimum for one utterance
 // (G = 1 / 2 / 4 / 8: 12.1 / 9.5 / 8.0 / 5.9 ms for 58 steps), >= 32 units per member, all workgroups co-resident
 static int melar_split_members(int B, int H, int P) {
-    static int cus = -1;
-    if (cus < 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-    }
+    const int cus = device_cus();   // of the CURRENT device
     int gmax = 8;
     if (const char* ev = getenv("TTSC_MELAR_SPLIT")) gmax = atoi(ev);
     int G = 1;
@@ -369,18 +365,9 @@ static int melar_split_members(int B, int H, int P) {
     return G;
 }
 
-static float* g_melar_x = nullptr;       // exchange area [cap][4][H_max = 512] + counters
-static unsigned* g_melar_words = nullptr;  // [0..1023] counters, [1024] sticky abort word
-static int g_melar_cap = 0;
-
-// 0 = every hand-off since the last call completed, 1 = a bounded spin timed out (sticky until read).  Synchronises the device.
-extern "C" int32_t ttsc_melar_split_status(void) {
-    if (!g_melar_words) return 0;
-    unsigned v = 0;
-    if (hipMemcpy(&v, g_melar_words + 1024, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    if (v && hipMemset(g_melar_words + 1024, 0, sizeof(unsigned)) != hipSuccess) return -1;
-    return (int32_t)(v != 0);
-}
+// 0 = every hand-off of the split AR launches on this device since the last call completed, 1 = a bounded spin timed out
+// (sticky until read).  Synchronises the device.  The exchange area [B][4][H] + counters live in one HandoffArea per (device, stream).
+extern "C" int32_t ttsc_melar_split_status(void) { return handoff_status("melar"); }
 
 extern "C" int ttsc_melar_decode(const ttsc_melar* m, const float* xg1_dev, int32_t B, int32_t S, const float* masks_dev,
                                  uint64_t seed, const int32_t* steps_dev, float* y_dev, void* stream) {
@@ -395,25 +382,14 @@ extern "C" int ttsc_melar_decode(const ttsc_melar* m, const float* xg1_dev, int3
     const int G = B <= 1024 ? melar_split_members(B, m->H, m->P) : 1;
     if (G > 1) {
         hipStream_t st = (hipStream_t)stream;
-        if (!g_melar_words) {
-            TTSC_HIP_CHECK(hipMalloc((void**)&g_melar_words, 1025 * sizeof(unsigned)));
-            TTSC_HIP_CHECK(hipMemset(g_melar_words, 0, 1025 * sizeof(unsigned)));
-        }
-        if (B > g_melar_cap) {
-            if (g_melar_x) {
-                TTSC_HIP_CHECK(hipDeviceSynchronize());
-                (void)hipFree(g_melar_x);
-                g_melar_x = nullptr;
-            }
-            TTSC_HIP_CHECK(hipMalloc((void**)&g_melar_x, (size_t)B * 4 * 512 * sizeof(float)));
-            g_melar_cap = B;
-        }
-        TTSC_HIP_CHECK(hipMemsetAsync(g_melar_words, 0, 1024 * sizeof(unsigned), st));   // counters; the abort word stays sticky
+        HandoffArea* ar = handoff_area("melar", st, 1024, (size_t)B * 4 * 512 * sizeof(float));
+        TTSC_REQUIRE(ar, "ttsc_melar_decode: cannot allocate the exchange area");
+        TTSC_HIP_CHECK(ar->rearm(st));   // counters and this launch's abort word restart at zero; the sticky copy stays
         MelArSplitArgs sa{};
         sa.a = a;
-        sa.xh = g_melar_x;
-        sa.cnt = g_melar_words;
-        sa.abort_word = g_melar_words + 1024;
+        sa.xh = reinterpret_cast<float*>(ar->buf);
+        sa.cnt = ar->words;
+        sa.abort_word = ar->abort_word();
         sa.G = G;
         sa.HU = m->H / G;
         sa.KS = 512 / sa.HU;

@@ -57,22 +57,30 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 
 // MI = C/32 row tiles, K taps, CT 32-column tiles per wave, NW waves per workgroup, WPS = waves per SIMD the register
-// allocation has to leave room for (2: two workgroups of 4 waves or one of 8 per CU).
-template <int MI, int K, int CT, int NW, int WPS>
+// allocation has to leave room for (2: two workgroups of 4 waves or one of 8 per CU).  GRP (tap, chunk) steps form one weight
+// group = one LDS slot = one barrier interval; NSLOT slots form a ring.  Two slots of two steps at 32 / 64 channels; at 128
+// channels the image takes 136 KiB of the 160, so the ring is three slots of ONE step (8 KiB each): the group after next travels
+// while the next one — published a whole step earlier — is already being read ahead.
+// WM = waves along the channel axis: a wave owns MI / WM row tiles of its CT column tiles (WM = 1: every wave owns all channels of its
+// columns).  At 128 channels 2 x 4 waves of (2 row tiles x 2 column tiles) read 8 fragments per 12 MFMAs instead of 10 and hold
+// half the weight fragments in registers.
+template <int MI, int K, int CT, int NW, int WPS, int GRP = 2, int NSLOT = 2, int WM = 1>
 __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int C = 32 * MI, NCH = 2 * MI, NG = 4 * MI;
-    constexpr int NCOL = NW * CT * 32;
+    constexpr int WN = NW / WM, MIW = MI / WM;    // waves along time; row tiles per wave
+    static_assert(NW % WM == 0 && MI % WM == 0, "wave grid");
+    constexpr int NCOL = WN * CT * 32;
     constexpr int MARG = (K == 3) ? 8 : (K == 7 ? 16 : 26);   // >= the largest tap offset (dilation 5: 5*(K-1)/2)
     constexpr int PW = NCOL + 2 * MARG;
     constexpr int NTHR = 64 * NW;
     constexpr int STEP_ITEMS = MI * 2 * 64;       // 16-byte items of the weight fragments of one (tap, chunk) step
-    constexpr int GRP = 2;                        // steps per weight group = one LDS slot = one barrier interval
     constexpr int GRP_ITEMS = GRP * STEP_ITEMS;
+    constexpr int AHEAD = NSLOT - 1;              // weight groups in flight ahead of the one being multiplied
     constexpr int NS = K * NCH, NGRP = NS / GRP;
     static_assert(NS % GRP == 0, "weight groups");
     half8* P = reinterpret_cast<half8*>(smem_raw);   // plane (group g, pl) at P + (g*2 + pl) * PW, tile column c at + MARG + c
-    half8* Aw = P + (size_t)NG * 2 * PW;             // weight fragments: [2 slots][GRP_ITEMS]
+    half8* Aw = P + (size_t)NG * 2 * PW;             // weight fragments: [NSLOT slots][GRP_ITEMS]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -80,7 +88,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
     const int q0 = blockIdx.x * a.nto;
     const int lin = a.len ? a.len[b] : a.L;
     if (q0 >= lin) return;
-    const int colw = wv * (CT * 32);                 // first tile column of this wave
+    const int wm = wv / WN;                          // this wave's row-tile group
+    const int mi0 = wm * MIW;                        // its first row tile
+    const int colw = (wv % WN) * (CT * 32);          // first tile column of this wave
     const int pos_w = q0 - a.halo + colw + l31;      // sequence position of this lane's column in column tile 0
     const float* xb = a.x + (size_t)b * C * a.L;
 
@@ -99,7 +109,13 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
                                                  (__attribute__((address_space(3))) void*)(Aw + slot * GRP_ITEMS + blk * 64), 16, 0, 0);
         }
     };
-    stage_group(a.w1[0], 0, 0);
+    // the first AHEAD groups of a convolution leave together (into slots 0 .. AHEAD-1, all retired by the barrier that ended the
+    // previous convolution); the barrier in front of the convolution publishes them
+    auto stage_first = [&](const half8* w) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < AHEAD; ++g) stage_group(w, g, g);
+    };
+    stage_first(a.w1[0]);
 
     // the margins only feed columns that are never stored, but they must hold finite numbers
     for (int i = tid; i < NG * 2 * 2 * MARG; i += NTHR) {
@@ -111,7 +127,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
     }
 
     // residual stream of the tile: C/D layout, channel = 32*mi + (r & 3) + 8*(r >> 2) + 4*half, column = lane & 31
-    f32x16 xres[MI][CT];
+    f32x16 xres[MIW][CT];
     bool pok[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
@@ -120,10 +136,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
         int pc = pos < lin - 1 ? pos : lin - 1;
         pc = pc < 0 ? 0 : pc;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MIW; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ch = 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int ch = 32 * (mi0 + mi) + (r & 3) + 8 * (r >> 2) + 4 * half;
                 xres[mi][ct][r] = TTSC_DBG(a, 8) ? (float)(ch + pc) * 1e-3f : xb[(size_t)ch * a.L + pc];
             }
     }
@@ -137,14 +153,14 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
         const half2v l0 = __builtin_convertvector(p0 - __builtin_convertvector(h0, float2v), half2v);
         const half2v l1 = __builtin_convertvector(p1 - __builtin_convertvector(h1, float2v), half2v);
         const half4 vh = {h0[0], h0[1], h1[0], h1[1]}, vl = {l0[0], l0[1], l1[0], l1[1]};
-        _Float16* ph = reinterpret_cast<_Float16*>(P + (size_t)((mi * 4 + gi) * 2) * PW + MARG + colw + ct * 32 + l31) + 4 * half;
+        _Float16* ph = reinterpret_cast<_Float16*>(P + (size_t)(((mi0 + mi) * 4 + gi) * 2) * PW + MARG + colw + ct * 32 + l31) + 4 * half;
         *reinterpret_cast<half4*>(ph) = vh;
         *reinterpret_cast<half4*>(ph + (size_t)PW * 8) = vl;
     };
     // image <- split(s * lrelu(x)), zero outside the sequence (the convolutions pad with zeros); s = power-of-two pre-scale
     auto xres_to_image = [&](float s) __attribute__((always_inline)) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MIW; ++mi)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -162,9 +178,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
     // acc = sum over taps j and 16-channel chunks c of  W[j][c] x image[c][column + (j - (K-1)/2) * d]   (three split products).
     // Precondition: weight group 0 of `w` sits in slot 0, published by a barrier.  Ends with a barrier (every wave has
     // finished reading the image and the weight slots).
-    auto conv = [&](const half8* w, int d, f32x16 (&acc)[MI][CT]) __attribute__((always_inline)) {
+    auto conv = [&](const half8* w, int d, f32x16 (&acc)[MIW][CT]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MIW; ++mi)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -173,12 +189,12 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
         // Software pipeline, written out and pinned with scheduling barriers because hipcc will not build it (it sinks
         // every LDS read to just before its first use): the activation fragments of step s+1 are read between the MFMAs
         // of step s; the weight fragments of the group's second step are read during its first.
-        half8 Af[2][MI][2];
+        half8 Af[2][MIW][2];
         half8 Bf[2][2][CT];
-        auto readA = [&](half8 (&Aq)[MI][2], int s) __attribute__((always_inline)) {
-            const half8* ap = Aw + ((s / GRP) & 1) * GRP_ITEMS + (s % GRP) * STEP_ITEMS + lane;
+        auto readA = [&](half8 (&Aq)[MIW][2], int s) __attribute__((always_inline)) {
+            const half8* ap = Aw + ((s / GRP) % NSLOT) * GRP_ITEMS + (s % GRP) * STEP_ITEMS + mi0 * 128 + lane;
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
+            for (int mi = 0; mi < MIW; ++mi) {
                 Aq[mi][0] = ap[(mi * 2 + 0) * 64];
                 Aq[mi][1] = ap[(mi * 2 + 1) * 64];
             }
@@ -191,12 +207,13 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
                 Bf[0][1][ct] = bp[PW + ct * 32];
             }
         }
-        constexpr int NM = 3 * MI * CT;   // MFMAs per step
+        constexpr int NM = 3 * MIW * CT;   // MFMAs per step (and wave)
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             if (s % GRP == 0) {
-                if (s / GRP + 1 < NGRP) stage_group(w, s / GRP + 1, (s / GRP + 1) & 1);   // next group: DMA behind this group's MFMAs
-                readA(Af[s & 1], s);
+                // group g + AHEAD leaves now, behind this group's MFMAs: its slot was read last by group g - 1 (retired by the previous barrier)
+                if (s / GRP + AHEAD < NGRP) stage_group(w, s / GRP + AHEAD, (s / GRP + AHEAD) % NSLOT);
+                if (s == 0 || NSLOT < 3) readA(Af[s & 1], s);   // (with three slots the next group was read ahead during the previous step)
             }
             const int jn = (s + 1) / NCH, cn = (s + 1) % NCH;
             const half8* bpn = base + (size_t)(cn * 4) * PW + jn * d;
@@ -205,15 +222,16 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
             // Term order lo_w*hi_x, hi_w*lo_x, hi_w*hi_x; consecutive MFMAs go to different accumulators.
 #pragma unroll
             for (int q = 0; q < NM; ++q) {
-                const int term = q / (MI * CT), mi = (q / CT) % MI, ct = q % CT;
+                const int term = q / (MIW * CT), mi = (q / CT) % MIW, ct = q % CT;
                 acc[mi][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[s & 1][mi][term == 0 ? 1 : 0], Bf[s & 1][term == 1 ? 1 : 0][ct],
                                                                    acc[mi][ct], 0, 0, 0);
                 if (q < 2 * CT && s + 1 < NS) Bf[(s + 1) & 1][q / CT][q % CT] = bpn[(q / CT) * PW + (q % CT) * 32];
-                if (q >= 2 * CT && q < 2 * CT + 2 * MI && (s + 1) % GRP != 0) {   // next step of the same group: its weights
+                // weights of the next step: same group, or (three slots) the next group, published one barrier ago
+                if (q >= 2 * CT && q < 2 * CT + 2 * MIW && s + 1 < NS && ((s + 1) % GRP != 0 || NSLOT >= 3)) {
                     const int i = q - 2 * CT;
-                    Af[(s + 1) & 1][i >> 1][i & 1] = Aw[(((s + 1) / GRP) & 1) * GRP_ITEMS + ((s + 1) % GRP) * STEP_ITEMS + i * 64 + lane];
+                    Af[(s + 1) & 1][i >> 1][i & 1] = Aw[(((s + 1) / GRP) % NSLOT) * GRP_ITEMS + ((s + 1) % GRP) * STEP_ITEMS + mi0 * 128 + i * 64 + lane];
                 }
-                if (q < 2 * CT + 2 * MI) __builtin_amdgcn_sched_barrier(0);
+                if (q < 2 * CT + 2 * MIW) __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_sched_barrier(0);
             if ((s + 1) % GRP == 0 && !TTSC_DBG(a, 2)) __syncthreads();   // publishes the next weight group, retires this one
@@ -223,17 +241,17 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
     xres_to_image(a.xs[0]);
     if (!TTSC_DBG(a, 2)) __syncthreads();
     for (int p = 0; p < a.npairs; ++p) {
-        f32x16 acc[MI][CT];
+        f32x16 acc[MIW][CT];
         conv(a.w1[p], a.d1[p], acc);           // (ends with a barrier: the image may be overwritten in place)
-        stage_group(a.w2[p], 0, 0);            // conv2's first weight group travels while the epilogue runs
+        stage_first(a.w2[p]);                  // conv2's first weight group(s) travel while the epilogue runs
         {
             const float us = a.us1[p];
             const float* bias = a.b1[p];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MIW; ++mi)
 #pragma unroll
                 for (int gi = 0; gi < 4; ++gi) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 32 * mi + 8 * gi + 4 * half) * a.bs1[p];
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 32 * (mi0 + mi) + 8 * gi + 4 * half) * a.bs1[p];
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {
                         float v[4];
@@ -249,15 +267,15 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
         }
         if (!TTSC_DBG(a, 2)) __syncthreads();
         conv(a.w2[p], 1, acc);
-        if (p + 1 < a.npairs) stage_group(a.w1[p + 1], 0, 0);
+        if (p + 1 < a.npairs) stage_first(a.w1[p + 1]);
         {
             const float us = a.us2[p];
             const float* bias = a.b2[p];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MIW; ++mi)
 #pragma unroll
                 for (int gi = 0; gi < 4; ++gi) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 32 * mi + 8 * gi + 4 * half);
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 32 * (mi0 + mi) + 8 * gi + 4 * half);
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -274,7 +292,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
     if (TTSC_DBG(a, 4)) {
         float t = 0.f;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MIW; ++mi)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) t += xres[mi][ct][0] + xres[mi][ct][9];
         if (t == 12345.678f) a.y[0] = 1.f;
@@ -288,12 +306,12 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
         const bool ok = col >= a.halo && col < a.halo + a.nto && pos < lin;
         const int pc = ok ? pos : 0;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
+        for (int mi = 0; mi < MIW; ++mi) {
             float yv[16];
             if (a.accumulate) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int ch = 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int ch = 32 * (mi0 + mi) + (r & 3) + 8 * (r >> 2) + 4 * half;
                     yv[r] = yb[(size_t)ch * a.L + pc];
                 }
             } else {
@@ -302,7 +320,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ch = 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int ch = 32 * (mi0 + mi) + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (ok) yb[(size_t)ch * a.L + pc] = xres[mi][ct][r] + yv[r];
             }
         }
@@ -313,21 +331,17 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
 template __global__ void rbchain_f16x3_kernel<TTSC_RB_PROBE>(ChainArgs);
 }  // namespace ttsc
 #else
-template <int MI, int K, int CT, int NW, int WPS>
+template <int MI, int K, int CT, int NW, int WPS, int GRP = 2, int NSLOT = 2, int WM = 1>
 static int launch_chain(ChainArgs& a, int B, hipStream_t s) {
-    constexpr int NCOL = NW * CT * 32;
+    constexpr int NCOL = (NW / WM) * CT * 32;
     constexpr int MARG = (K == 3) ? 8 : (K == 7 ? 16 : 26);
-    constexpr size_t lds = (size_t)(4 * MI) * 2 * (NCOL + 2 * MARG) * 16 + (size_t)2 * 2 * (MI * 2 * 64) * 16;   // image + 2 weight slots
+    constexpr size_t lds = (size_t)(4 * MI) * 2 * (NCOL + 2 * MARG) * 16 + (size_t)NSLOT * GRP * (MI * 2 * 64) * 16;   // image + weight ring
     static_assert(lds <= 160 * 1024, "activation image exceeds the LDS");
     a.nto = NCOL - 2 * a.halo;
     TTSC_REQUIRE(a.nto >= 64, "rbchain: halo %d leaves no output columns in a %d-column tile", a.halo, NCOL);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)rbchain_f16x3_kernel<MI, K, CT, NW, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    if (int rc = ensure_full_lds((const void*)rbchain_f16x3_kernel<MI, K, CT, NW, WPS, GRP, NSLOT, WM>)) return rc;   // once per (device, kernel)
     dim3 grid((unsigned)ceil_div(a.L, a.nto), (unsigned)B);
-    hipLaunchKernelGGL((rbchain_f16x3_kernel<MI, K, CT, NW, WPS>), grid, dim3(64 * NW), lds, s, a);
+    hipLaunchKernelGGL((rbchain_f16x3_kernel<MI, K, CT, NW, WPS, GRP, NSLOT, WM>), grid, dim3(64 * NW), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("rbchain_f16x3_kernel launch failed: %s", hipGetErrorString(e));
@@ -340,6 +354,9 @@ static int launch_chain(ChainArgs& a, int B, hipStream_t s) {
 // 8 waves x 64 columns (64 channels), one workgroup per CU
 template <int MI, int K>
 static int launch_chain_k(ChainArgs& a, int B, int shape, hipStream_t s) {
+    if constexpr (MI == 4) {   // 128 channels: 2 x 4 waves of (64 channels x 64 columns), the whole LDS (image 136 KiB + three 8-KiB weight slots)
+        return launch_chain<4, K, 2, 8, 2, 1, 3, 2>(a, B, s);
+    }
     if (MI == 1) {
         if (shape == 1) return launch_chain<1, K, 4, 8, 2>(a, B, s);
         return launch_chain<1, K, 4, 4, 2>(a, B, s);
@@ -369,14 +386,15 @@ static int chain_pair_ok(const ttsc_conv1d* c1, const ttsc_conv1d* c2, int C, in
 extern "C" int ttsc_rbchain_supported(const ttsc_conv1d* const* convs1, const ttsc_conv1d* const* convs2, int32_t npairs) {
     if (!convs1 || !convs2 || npairs < 1 || npairs > RB_MAXP || !convs1[0]) return 0;
     const int C = convs1[0]->cfg.in_channels, k = convs1[0]->cfg.kernel_size;
-    if (!(C == 32 || C == 64) || !(k == 3 || k == 7 || k == 11)) return 0;
+    if (!(C == 32 || C == 64 || C == 128) || !(k == 3 || k == 7 || k == 11)) return 0;
+    if (C == 128 && k != 3) return 0;   // the 128-channel image + margins only fits the LDS with K = 3 (halo 24 of 256 columns)
     int halo = 0;
     for (int p = 0; p < npairs; ++p) {
         if (!chain_pair_ok(convs1[p], convs2[p], C, k)) return 0;
         halo += (convs1[p]->cfg.dilation + 1) * (k - 1) / 2;
     }
     // the smallest tile (256 columns at 64 channels, 512 at 32) must keep a useful share of output columns
-    const int ncol = C == 32 ? 512 : 256;
+    const int ncol = C == 32 ? 512 : 256;   // (128 channels: the only tile is 256 columns)
     return ncol - 2 * halo >= ncol / 2 ? 1 : 0;
 }
 
@@ -422,6 +440,7 @@ extern "C" int ttsc_rbchain_forward(const ttsc_conv1d* const* convs1, const ttsc
         shape = (2 * a.halo * 6 > small) ? 1 : 0;
         if (C == 64 && (int64_t)B * ceil_div(L, 2 * small - 2 * a.halo) >= 256) shape = 1;
     }
+    if (C == 128) return launch_chain_k<4, 3>(a, B, shape, s);
     if (C == 32) {
         if (k == 3) return launch_chain_k<1, 3>(a, B, shape, s);
         if (k == 7) return launch_chain_k<1, 7>(a, B, shape, s);

@@ -1,6 +1,12 @@
 // Error state, version and device probing for libttscube_hip.so.
 #include "common.hpp"
 
+#include <map>
+#include <mutex>
+#include <set>
+#include <tuple>
+#include <utility>
+
 namespace ttsc {
 static thread_local char g_err[1024] = "";
 void set_error(const char* fmt, ...) {
@@ -8,6 +14,97 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+static std::mutex g_state_mu;
+
+int device_cus() {
+    static std::map<int, int> cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    std::lock_guard<std::mutex> lk(g_state_mu);
+    auto it = cus.find(dev);
+    if (it != cus.end()) return it->second;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    cus[dev] = n;
+    return n;
+}
+
+int ensure_full_lds(const void* fn) {
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return TTSC_EHIP;
+    std::lock_guard<std::mutex> lk(g_state_mu);
+    if (done.count({dev, fn})) return TTSC_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize, 160 KiB): %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    done.insert({dev, fn});
+    return TTSC_OK;
+}
+
+namespace {
+struct AreaKey {
+    int dev;
+    hipStream_t stream;
+    std::string tag;
+    bool operator<(const AreaKey& o) const { return std::tie(dev, stream, tag) < std::tie(o.dev, o.stream, o.tag); }
+};
+std::map<AreaKey, HandoffArea>& areas() {
+    static std::map<AreaKey, HandoffArea> m;
+    return m;
+}
+}  // namespace
+
+HandoffArea* handoff_area(const char* tag, hipStream_t stream, size_t nwords, size_t buf_bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_state_mu);
+    HandoffArea& a = areas()[AreaKey{dev, stream, tag}];
+    if (a.nwords < nwords) {
+        unsigned old_abort = 0;
+        if (a.words) {   // keep a pending (unreported) abort across the re-allocation
+            if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+            (void)hipMemcpy(&old_abort, a.words + a.nwords + 1, sizeof(unsigned), hipMemcpyDeviceToHost);
+            (void)hipFree(a.words);
+            a.words = nullptr;
+        }
+        if (hipMalloc((void**)&a.words, (nwords + 2) * sizeof(unsigned)) != hipSuccess) return nullptr;
+        if (hipMemset(a.words, 0, (nwords + 2) * sizeof(unsigned)) != hipSuccess) return nullptr;
+        if (old_abort && hipMemcpy(a.words + nwords + 1, &old_abort, sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        a.nwords = nwords;
+    }
+    if (a.buf_bytes < buf_bytes) {
+        if (a.buf) {
+            if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+            (void)hipFree(a.buf);
+            a.buf = nullptr;
+            a.buf_bytes = 0;
+        }
+        if (hipMalloc(&a.buf, buf_bytes) != hipSuccess) return nullptr;
+        a.buf_bytes = buf_bytes;
+    }
+    return &a;   // std::map nodes are address-stable
+}
+
+int handoff_status(const char* tag) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    std::lock_guard<std::mutex> lk(g_state_mu);
+    int any = 0;
+    for (auto& kv : areas()) {
+        if (kv.first.dev != dev || kv.first.tag != tag || !kv.second.words) continue;
+        unsigned v = 0;
+        if (hipMemcpy(&v, kv.second.abort_word() + 1, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;   // synchronises
+        if (v) {
+            any = 1;   // reported once, then re-armed
+            if (hipMemset(kv.second.abort_word() + 1, 0, sizeof(unsigned)) != hipSuccess) return -1;
+        }
+    }
+    return any;
 }
 }  // namespace ttsc
 

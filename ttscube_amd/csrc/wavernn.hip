@@ -778,17 +778,9 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
         TTSC_HIP_CHECK(hipMemsetAsync(xbase, 0, tile_exchange_granules(w, G) * 8 + 64, s));
         const size_t lds = tile_lds_bytes(w);
         if (lds > 64 * 1024) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                hipError_t ae = hipFuncSetAttribute((const void*)wr_tile_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (ae == hipSuccess) ae = hipFuncSetAttribute((const void*)wr_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (ae != hipSuccess) {
-                    (void)hipGetLastError();
-                    set_error("wr_tile_kernel: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(ae));
-                    return TTSC_EHIP;
-                }
-                attr_set = true;
-            }
+            // full 160 KiB once per (device, kernel): a later model with a larger H, or a second device, needs no re-arming
+            if (int rc = ensure_full_lds((const void*)wr_tile_kernel<false>)) return rc;
+            if (int rc = ensure_full_lds((const void*)wr_tile_kernel<true>)) return rc;
         }
 #ifdef TTSC_ABLATE
         unsigned long long* prof_dev = nullptr;

@@ -41,6 +41,12 @@ class CubeganDataset:
     def __len__(self):
         return len(self._examples)
 
+    def meta_items(self):
+        """{'meta', 'pitch'} of every item WITHOUT decoding its wav / mgc: all CubeganEncodings.compute needs (io_cubegan.py:120-137)."""
+        for description in self._examples:
+            base_fn = os.path.join(self._base_path, description['id'])
+            yield {'meta': description, 'pitch': np.array(np.load(open(base_fn + '.pitch', 'rb')), dtype=np.float64)}
+
     @staticmethod
     def _make_absolute_silence(audio, pitch, meta):
         max_phone = max(meta['frame2phon'])
