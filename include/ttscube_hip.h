@@ -142,6 +142,21 @@ int ttsc_weight_norm_backward(const float* dw_dev, const float* v_dev, const flo
 size_t ttsc_bias_grad_workspace_bytes(int32_t B, int32_t C, int64_t L);
 int ttsc_bias_grad(const float* dy_dev, float* db_dev, int32_t B, int32_t C, int64_t L, void* ws_dev, size_t ws_bytes, int32_t ws_is_fresh,
                    void* stream);
+/* torch.optim.AdamW (cube/networks/cubegan.py:275-298: betas (0.8, 0.99)) over ONE flat fp32 arena: parameters, gradients and both
+ * moment estimates of a parameter group are four contiguous, 16-byte-aligned device arrays of n elements (the gradient arena is the
+ * gradient-exchange bucket itself); `step` is the 1-based step count of the bias corrections.  Same update rule and operation order
+ * as torch's single-tensor AdamW (decoupled weight decay, no amsgrad). */
+int ttsc_adamw_step(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int64_t step, void* stream);
+/* GAN loss terms over a LIST of tensors in one launch, value and gradient together — hifigan.models.feature_loss / generator_loss /
+ * discriminator_loss [EXTERNAL; call sites cube/networks/cubegan.py:144-149,160-167]:
+ *   kind 0:  out = sum_k w_k * mean|a_k - b_k|      gb_k = w_k sign(b_k - a_k) / n_k,  ga_k = -gb_k      (feature matching: w = 2)
+ *   kind 1:  out = sum_k w_k * mean (a_k - target)^2   ga_k = 2 w_k (a_k - target) / n_k              (least-squares GAN terms)
+ * a_dev / b_dev / ga_dev / gb_dev: host arrays of nseg device pointers (gradient pointers, or the arrays themselves, may be null);
+ * numel / weight: host arrays.  1 <= nseg <= 64 per call.  out_dev: one float.  Deterministic (fixed-order sums). */
+size_t ttsc_gan_loss_workspace_bytes(int32_t nseg);
+int ttsc_gan_loss(int32_t kind, int32_t nseg, const void* const* a_dev, const void* const* b_dev, void* const* ga_dev, void* const* gb_dev,
+                  const int64_t* numel, const float* weight, float target, float* out_dev, void* ws_dev, size_t ws_bytes, void* stream);
 size_t ttsc_conv_wgrad_workspace_bytes(int32_t N, int32_t A, int32_t B, int64_t LP, int32_t J);
 int ttsc_conv_wgrad(const float* p_dev, const float* q_dev, float* g_dev, int32_t N, int32_t A, int32_t B, int64_t LP, int64_t LQ,
                     int32_t J, int32_t base, int32_t step, float q_scale, float q_slope, void* ws_dev, size_t ws_bytes, void* stream);

@@ -7,6 +7,10 @@
 //   ttsc_weight_norm_forward    w[r,:] = v[r,:] * (g[r] / ||v[r,:]||),  norm[r] = ||v[r,:]||          (one workgroup per row)
 //   ttsc_weight_norm_backward   dg[r] = <dw,v> / n,  dv = (g/n) * dw - v * (g * <dw,v> / n^3)
 //   ttsc_bias_grad              db[c] = sum_{b,t} dy[b,c,t]   (fixed-order two-level sum, last workgroup of a channel finishes)
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+
 #include "common.hpp"
 
 namespace ttsc {
@@ -99,6 +103,121 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
     }
 }
 
+// ---- AdamW over a flat arena ---------------------------------------------------------------------------------------------
+// cube/networks/cubegan.py:275-311 builds three torch.optim.AdamW(betas=(0.8, 0.99)) over ~900 parameter tensors.  Here the
+// parameters of a group, their gradients (the gradient-exchange bucket itself, ttscube_amd/distributed.py) and both moment
+// estimates are four flat fp32 arenas, so one optimizer step is ONE streaming kernel (16-byte accesses, 5 reads + 3 writes per
+// element) instead of a multi-tensor launch chain.  Same update rule and operation order as torch's single-tensor AdamW.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct AdamArgs {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    long n;
+    float decay;      // 1 - lr * weight_decay
+    float om_b1;      // 1 - beta1
+    float b2, om_b2;  // beta2, 1 - beta2
+    float inv_bc2s;   // 1 / sqrt(1 - beta2^t)
+    float eps;
+    float step_size;  // lr / (1 - beta1^t)
+};
+
+__device__ __forceinline__ void adamw_elem(float& p, float g, float& m, float& v, const AdamArgs& a) {
+    p *= a.decay;
+    m = m + (g - m) * a.om_b1;                 // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * a.b2 + (g * g) * a.om_b2;          // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float denom = sqrtf(v) * a.inv_bc2s + a.eps;
+    p = p - a.step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adamw_flat_kernel(AdamArgs a) {
+    const long n4 = a.n >> 2;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 p = reinterpret_cast<f32x4*>(a.p)[i], m = reinterpret_cast<f32x4*>(a.m)[i], v = reinterpret_cast<f32x4*>(a.v)[i];
+        const f32x4 g = reinterpret_cast<const f32x4*>(a.g)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float pe = p[e], me = m[e], ve = v[e];
+            adamw_elem(pe, g[e], me, ve, a);
+            p[e] = pe, m[e] = me, v[e] = ve;
+        }
+        reinterpret_cast<f32x4*>(a.p)[i] = p;
+        reinterpret_cast<f32x4*>(a.m)[i] = m;
+        reinterpret_cast<f32x4*>(a.v)[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {   // tail
+        const long i = (n4 << 2) + threadIdx.x;
+        adamw_elem(a.p[i], a.g[i], a.m[i], a.v[i], a);
+    }
+}
+
+// ---- GAN loss terms over lists of tensors ----------------------------------------------------------------------------------
+// hifigan.models.{feature_loss, generator_loss, discriminator_loss} [EXTERNAL; call sites cube/networks/cubegan.py:144-149,
+// 160-167] walk Python lists of ~50 discriminator outputs / feature maps: a mean, a subtraction, an abs or a square and an add
+// per tensor, forward and backward.  One launch evaluates a whole list AND its gradient:
+//   kind 0  sum_k w_k * mean|a_k - b_k|          (feature matching, w = 2)       d/db = w sign(b - a) / n_k,  d/da = -d/db
+//   kind 1  sum_k w_k * mean (t - a_k)^2         (least squares against target t) d/da = 2 w (a - t) / n_k
+// The segment table {a, b, ga, gb, n, w} travels BY VALUE in the kernel arguments (<= 64 segments = 3 KiB: no host
+// synchronisation, no staging copy).  Partial sums per workgroup are added in a fixed order by the last workgroup (ticket), so
+// the value is deterministic.
+struct LossSeg {
+    const float* a;
+    const float* b;
+    float* ga;
+    float* gb;
+    long n;
+    float w;
+    float target;
+};
+
+constexpr int GAN_LOSS_MAX_SEG = 64;
+struct LossTable {
+    LossSeg seg[GAN_LOSS_MAX_SEG];
+};
+
+__global__ __launch_bounds__(256) void gan_loss_kernel(const LossTable tab, int nseg, int kind, int blocks_per_seg,
+                                                       float* __restrict__ partial, unsigned* __restrict__ ticket, float* __restrict__ out) {
+    __shared__ float red[4];
+    __shared__ bool last;
+    const int si = blockIdx.x / blocks_per_seg, bi = blockIdx.x - si * blocks_per_seg;
+    const LossSeg sg = tab.seg[si];
+    const float scale = sg.w / (float)sg.n;
+    float acc = 0.f;
+    for (long i = (long)bi * 256 + threadIdx.x; i < sg.n; i += (long)blocks_per_seg * 256) {
+        const float a = sg.a[i];
+        if (kind == 0) {
+            const float d = sg.b[i] - a;
+            acc += fabsf(d);
+            const float gsign = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
+            if (sg.gb) sg.gb[i] = gsign;
+            if (sg.ga) sg.ga[i] = -gsign;
+        } else {
+            const float d = a - sg.target;
+            acc += d * d;
+            if (sg.ga) sg.ga[i] = 2.f * scale * d;
+        }
+    }
+    const float s = block_sum(acc, red);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = s * scale;
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last) {   // fixed-order final sum by one workgroup
+        float t = 0.f;
+        for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float tot = block_sum(t, red);
+        if (threadIdx.x == 0) {
+            *out = tot;
+            *ticket = 0u;   // re-armed for the next call
+        }
+    }
+}
+
 }  // namespace ttsc
 
 using namespace ttsc;
@@ -151,4 +270,59 @@ extern "C" int ttsc_bias_grad(const float* dy_dev, float* db_dev, int32_t B, int
     if (ws_is_fresh) TTSC_HIP_CHECK(hipMemsetAsync(ticket, 0, (size_t)C * sizeof(unsigned), s));   // tickets must start at zero
     hipLaunchKernelGGL(bias_grad_kernel, dim3(C, S), dim3(256), 0, s, dy_dev, db_dev, part, ticket, B, C, (int)L, S);
     return check_launch("bias_grad_kernel");
+}
+
+extern "C" int ttsc_adamw_step(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, int64_t step, void* stream) {
+    TTSC_REQUIRE(p_dev && g_dev && m_dev && v_dev && n > 0 && step >= 1, "ttsc_adamw_step: bad argument");
+    TTSC_REQUIRE((((uintptr_t)p_dev | (uintptr_t)g_dev | (uintptr_t)m_dev | (uintptr_t)v_dev) & 15) == 0, "ttsc_adamw_step: arenas must be 16-byte aligned");
+    AdamArgs a;
+    a.p = p_dev;
+    a.g = g_dev;
+    a.m = m_dev;
+    a.v = v_dev;
+    a.n = n;
+    a.decay = 1.f - lr * weight_decay;
+    a.om_b1 = 1.f - beta1;
+    a.b2 = beta2;
+    a.om_b2 = 1.f - beta2;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    a.inv_bc2s = (float)(1.0 / sqrt(bc2));
+    a.eps = eps;
+    a.step_size = (float)((double)lr / bc1);
+    const long n4 = n >> 2;
+    const unsigned blocks = (unsigned)std::min<long>(std::max<long>((n4 + 255) / 256, 1), 2048);
+    hipLaunchKernelGGL(adamw_flat_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("adamw_flat_kernel");
+}
+
+extern "C" size_t ttsc_gan_loss_workspace_bytes(int32_t nseg) {
+    if (nseg <= 0) return 0;
+    return 64 + (size_t)nseg * 64 * sizeof(float);   // ticket + partial sums
+}
+
+extern "C" int ttsc_gan_loss(int32_t kind, int32_t nseg, const void* const* a_dev, const void* const* b_dev, void* const* ga_dev,
+                             void* const* gb_dev, const int64_t* numel, const float* weight, float target, float* out_dev, void* ws_dev,
+                             size_t ws_bytes, void* stream) {
+    TTSC_REQUIRE(kind == 0 || kind == 1, "ttsc_gan_loss: kind must be 0 (L1 between pairs) or 1 (squared distance to a target)");
+    TTSC_REQUIRE(nseg > 0 && nseg <= GAN_LOSS_MAX_SEG && a_dev && numel && weight && out_dev && ws_dev, "ttsc_gan_loss: bad argument (1..%d tensors per call)", GAN_LOSS_MAX_SEG);
+    TTSC_REQUIRE(kind == 1 || b_dev, "ttsc_gan_loss: kind 0 needs the second operand list");
+    TTSC_REQUIRE(ws_bytes >= ttsc_gan_loss_workspace_bytes(nseg), "ttsc_gan_loss: workspace too small");
+    LossTable tab;
+    memset(&tab, 0, sizeof(tab));
+    long nmax = 0;
+    for (int i = 0; i < nseg; ++i) {
+        TTSC_REQUIRE(a_dev[i] && numel[i] > 0, "ttsc_gan_loss: empty segment %d", i);
+        tab.seg[i] = LossSeg{(const float*)a_dev[i], kind == 0 ? (const float*)b_dev[i] : nullptr, ga_dev ? (float*)ga_dev[i] : nullptr,
+                             (kind == 0 && gb_dev) ? (float*)gb_dev[i] : nullptr, (long)numel[i], weight[i], target};
+        TTSC_REQUIRE(kind == 1 || tab.seg[i].b, "ttsc_gan_loss: null operand in segment %d", i);
+        nmax = std::max<long>(nmax, numel[i]);
+    }
+    const int bps = (int)std::min<long>(std::max<long>(nmax / 8192, 1), 64);   // workgroups per segment
+    hipStream_t s = (hipStream_t)stream;
+    unsigned* ticket = (unsigned*)ws_dev;                    // (re-armed by the kernel; zeroed here so that a fresh workspace works too)
+    float* partial = (float*)((char*)ws_dev + 64);
+    TTSC_HIP_CHECK(hipMemsetAsync(ticket, 0, 64, s));
+    hipLaunchKernelGGL(gan_loss_kernel, dim3((unsigned)(nseg * bps)), dim3(256), 0, s, tab, nseg, kind, bps, partial, ticket, out_dev);
+    return check_launch("gan_loss_kernel");
 }

@@ -37,9 +37,14 @@ int ensure_full_lds(const void* fn) {
     if (hipGetDevice(&dev) != hipSuccess) return TTSC_EHIP;
     std::lock_guard<std::mutex> lk(g_state_mu);
     if (done.count({dev, fn})) return TTSC_OK;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // the 160 KiB of a CU cover static + dynamic LDS: leave room for the kernel's own __shared__ arrays
+    hipFuncAttributes fa;
+    hipError_t e = hipFuncGetAttributes(&fa, fn);
+    const int dyn = 160 * 1024 - (e == hipSuccess ? (int)fa.sharedSizeBytes : 0);
+    if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
     if (e != hipSuccess) {
-        set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize, 160 KiB): %s", hipGetErrorString(e));
+        (void)hipGetLastError();   // do not leave the error for an unrelated launch check to find
+        set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize, %d): %s", dyn, hipGetErrorString(e));
         return TTSC_EHIP;
     }
     done.insert({dev, fn});

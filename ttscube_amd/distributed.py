@@ -72,6 +72,12 @@ class FlatBucketReducer:
             return
         if self._buckets is None:
             self._build()
+        else:
+            live = {id(p) for ps, _, _, _ in self._buckets for p in ps}
+            for p in self.params:   # a parameter that got its first gradient after the buckets were laid out would never be exchanged
+                if p.grad is not None and id(p) not in live:
+                    raise RuntimeError('FlatBucketReducer: a parameter of shape %s received its first gradient after the first exchange; '
+                                       'the replicas would diverge silently' % (tuple(p.shape),))
         world = dist.get_world_size(self.group)
         works = []
         self.bytes_exchanged = 0
@@ -104,6 +110,113 @@ class FlatBucketReducer:
             # the next zero_grad(set_to_none=True) drops the alias, zero_grad(set_to_none=False) clears the slice)
             for p, v in zip(ps, views):
                 p.grad = v
+
+
+class ArenaReducer:
+    """Gradient exchange of a `ttscube_amd.optim.FlatAdamW` group, overlapped with the backward pass that produces the gradients.
+
+    The optimizer's gradient arena IS the exchange buffer: it is cut into `bucket_mb` chunks; every live parameter carries a
+    post-accumulate-grad hook, and the moment the last parameter of a chunk has its gradient, that chunk's reduce_scatter is
+    launched (async, on RCCL's stream) while autograd keeps differentiating the layers in front of it — what Lightning's DDP does
+    per backward for the reference (scripts/train_cubegan.py:138-145), here with reduce_scatter + all_gather so that every GPU
+    drives all 7 of its xGMI links.  `reduce()` after backward() launches whatever is still pending, then all_gathers.  All ranks
+    run the same graph, so chunks complete — and collectives are issued — in the same order everywhere.
+    The first step has no arenas yet (liveness is decided from its gradients): `reduce()` builds them and exchanges un-overlapped."""
+
+    def __init__(self, opt, bucket_mb=64, group=None, use_reduce_scatter=True, force=False, overlap=True):
+        self.opt, self.group, self.use_rs, self.force, self.overlap = opt, group, use_reduce_scatter, force, overlap
+        self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
+        self.bytes_exchanged = 0
+        self.launched_early = 0      # chunks whose reduce_scatter left from a gradient hook during the last backward pass
+        self._chunks = None
+        opt.on_build(self._on_build)
+
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and (self.force or dist.get_world_size(self.group) > 1)
+
+    def _on_build(self, opt):
+        world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        n = opt.g.numel()
+        step = max(world, self.bucket_elems // world * world)
+        self._chunks = []
+        for s in range(0, n, step):
+            e = min(n, s + step)
+            assert (e - s) % world == 0 or e == n
+            pad = (e - s + world - 1) // world * world
+            # (the arena is padded to 64 elements per parameter; a ragged last chunk gets its own padded staging view)
+            buf = opt.g[s:e] if pad == e - s else None
+            self._chunks.append({'s': s, 'e': e, 'pad': pad, 'buf': buf, 'shard': torch.empty(pad // world, dtype=torch.float32, device=opt.g.device),
+                                 'need': 0, 'left': 0, 'work': None})
+        self._owners = []
+        for i, o in zip(opt.live, opt.offsets):
+            p = opt.params[i]
+            cs = [k for k, c in enumerate(self._chunks) if c['s'] < o + p.numel() and o < c['e']]
+            for k in cs:
+                self._chunks[k]['need'] += 1
+            self._owners.append(cs)
+            if self.overlap:
+                p.register_post_accumulate_grad_hook(self._make_hook(cs))
+        self.arm()
+
+    def _make_hook(self, cs):
+        def hook(_p):
+            if not self._armed:
+                return
+            for k in cs:
+                c = self._chunks[k]
+                c['left'] -= 1
+                if c['left'] == 0 and c['work'] is None:
+                    self._launch(c)
+                    self.launched_early += 1
+        return hook
+
+    def arm(self):
+        """call before a backward pass (right after zero_grad): chunk counters restart"""
+        self._armed = self._chunks is not None and self._active() and self.overlap
+        if self._chunks is not None:
+            for c in self._chunks:
+                c['left'], c['work'] = c['need'], None
+        self.launched_early = 0
+
+    @torch.no_grad()
+    def _launch(self, c):
+        world = dist.get_world_size(self.group)
+        g = self.opt.g
+        if c['buf'] is None:   # ragged tail: stage into a padded buffer
+            if 'stage' not in c:
+                c['stage'] = torch.zeros(c['pad'], dtype=torch.float32, device=g.device)
+            c['stage'][:c['e'] - c['s']].copy_(g[c['s']:c['e']])
+            flat = c['stage']
+        else:
+            flat = c['buf']
+        flat.div_(world)
+        c['flat'] = flat
+        if self.use_rs:
+            c['work'] = dist.reduce_scatter_tensor(c['shard'], flat, group=self.group, async_op=True)
+        else:
+            c['work'] = dist.all_reduce(flat, group=self.group, async_op=True)
+
+    @torch.no_grad()
+    def reduce(self):
+        if not self._active():
+            return
+        self.opt.ensure_built()
+        self._armed = False
+        self.bytes_exchanged = 0
+        for c in self._chunks:
+            if c['work'] is None:
+                self._launch(c)
+        gathers = []
+        for c in self._chunks:
+            c['work'].wait()
+            gathers.append(dist.all_gather_into_tensor(c['flat'], c['shard'], group=self.group, async_op=True) if self.use_rs else None)
+            self.bytes_exchanged += c['pad'] * 4 * (2 if self.use_rs else 1)
+        for w, c in zip(gathers, self._chunks):
+            if w is not None:
+                w.wait()
+            if c['buf'] is None:
+                self.opt.g[c['s']:c['e']].copy_(c['flat'][:c['e'] - c['s']])
+            c['work'] = None
 
 
 def broadcast_parameters(module, src=0, group=None):

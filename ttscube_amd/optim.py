@@ -1,0 +1,161 @@
+"""AdamW over flat arenas — the optimizers of `Cubegan.configure_optimizers` (cube/networks/cubegan.py:275-311: three
+torch.optim.AdamW(betas=(0.8, 0.99)) over ~900 parameter tensors) as ONE HIP kernel per group and step.
+
+Layout: the live parameters of a group are re-pointed (``p.data``) into one contiguous fp32 arena; their gradients accumulate
+straight into a second arena (``p.grad`` are permanent views of it — that arena is also the gradient-exchange bucket of
+`ttscube_amd.distributed.ArenaReducer`, so nothing is packed or copied before the RCCL exchange); the two moment estimates are
+two more arenas.  `step()` = `ttsc_adamw_step` over the four arenas (csrc/train_ops.hip), `zero_grad()` = one memset.
+
+"Live" = has a gradient on some rank after the first backward pass (decided once, collectively): a parameter nobody
+differentiates keeps ``.grad is None`` and is never touched, exactly like torch.optim.AdamW skips it.  A parameter that turns up
+with a gradient later raises (it would silently never be exchanged).
+
+`state_dict()` / `load_state_dict()` speak torch.optim.AdamW's format ({'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}},
+'param_groups': [...]}), so `<base>.opt.last` files (scripts/train_cubegan.py) stay interchangeable with torch's optimizer."""
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+_ALIGN = 64   # elements: every parameter starts on a 256-byte boundary of the arena
+
+
+class FlatAdamW:
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, group=None):
+        self.params = [p for p in params]
+        self.param_groups = [{'lr': lr, 'betas': tuple(betas), 'eps': eps, 'weight_decay': weight_decay, 'amsgrad': False,
+                              'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                              'params': list(range(len(self.params)))}]
+        self.group = group
+        self.step_count = 0
+        self.live = None          # indices into self.params, set by _build
+        self.offsets = None       # arena offset of every live parameter
+        self.p = self.g = self.m = self.v = None
+        self._pending = None      # state loaded before the arenas exist
+        self._hooks = []          # called once the arenas exist (the reducer registers its gradient hooks there)
+
+    # ---- arenas ----------------------------------------------------------------------------------------------------------
+    @property
+    def built(self):
+        return self.p is not None
+
+    def _build(self):
+        ps = self.params
+        dev = ps[0].device
+        if dev.type != 'cuda':
+            raise _lib.TTSCError('FlatAdamW: parameters live on the CPU; move the model to a HIP device first (no CPU path)')
+        has = torch.tensor([1.0 if (p.grad is not None and p.requires_grad) else 0.0 for p in ps], dtype=torch.float32, device=dev)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(has, op=dist.ReduceOp.MAX, group=self.group)   # live on ANY rank -> live everywhere (same arena layout)
+        self.live = [i for i, h in enumerate(has.tolist()) if h > 0]
+        offs, n = [], 0
+        for i in self.live:
+            offs.append(n)
+            n += (ps[i].numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.offsets, self.numel = offs, n
+        z = lambda: torch.zeros(max(n, _ALIGN), dtype=torch.float32, device=dev)
+        self.p, self.g, self.m, self.v = z(), z(), z(), z()
+        dst_p, src_p, dst_g, src_g = [], [], [], []
+        for i, o in zip(self.live, offs):
+            p = ps[i]
+            if p.dtype != torch.float32:
+                raise _lib.TTSCError('FlatAdamW: fp32 parameters only')
+            vp, vg = self.p[o:o + p.numel()].view_as(p), self.g[o:o + p.numel()].view_as(p)
+            dst_p.append(vp)
+            src_p.append(p.data)
+            if p.grad is not None:
+                dst_g.append(vg)
+                src_g.append(p.grad)
+        with torch.no_grad():
+            torch._foreach_copy_(dst_p, src_p)
+            if dst_g:
+                torch._foreach_copy_(dst_g, src_g)
+        for i, o, vp in zip(self.live, offs, dst_p):
+            p = ps[i]
+            p.data = vp                                             # the parameter now IS its slice of the arena
+            p.grad = self.g[o:o + p.numel()].view_as(p)            # ... and its gradient accumulates into the gradient arena
+        if self._pending is not None:
+            self._apply_state(self._pending)
+            self._pending = None
+        for h in self._hooks:
+            h(self)
+
+    def ensure_built(self):
+        """lay the arenas out now (called after the FIRST backward pass, by the gradient exchange or by step())"""
+        if not self.built:
+            self._build()
+        return self
+
+    def on_build(self, fn):
+        if self.built:
+            fn(self)
+        else:
+            self._hooks.append(fn)
+
+    def _check_no_stragglers(self):
+        live = set(self.live)
+        for i, p in enumerate(self.params):
+            if i not in live and p.grad is not None and p.requires_grad:
+                raise _lib.TTSCError('FlatAdamW: parameter #%d (%s) received its first gradient after the arenas were laid out; it would '
+                                     'never be updated or exchanged. Make every differentiated path active in the first step.'
+                                     % (i, tuple(p.shape)))
+
+    # ---- torch.optim surface -------------------------------------------------------------------------------------------------
+    def zero_grad(self, set_to_none=True):
+        if not self.built:
+            for p in self.params:
+                p.grad = None
+            return
+        self.g.zero_()            # ONE memset; the .grad views stay in place (autograd accumulates into them)
+
+    @torch.no_grad()
+    def step(self):
+        if not self.built:
+            self._build()
+        self._check_no_stragglers()
+        self.step_count += 1
+        pg = self.param_groups[0]
+        with torch.cuda.device(self.p.device):
+            _lib.check(_lib.lib().ttsc_adamw_step(_lib.dev_ptr(self.p), _lib.dev_ptr(self.g), _lib.dev_ptr(self.m), _lib.dev_ptr(self.v),
+                                                  self.numel, float(pg['lr']), float(pg['betas'][0]), float(pg['betas'][1]), float(pg['eps']),
+                                                  float(pg['weight_decay']), self.step_count, _lib.current_stream()), 'ttsc_adamw_step')
+        # the kernel wrote through raw pointers: tell autograd / the weight caches of the inference handles (version counters)
+        torch.autograd.graph.increment_version([self.params[i] for i in self.live])
+
+    def state_dict(self):
+        state = {}
+        if self.built and self.step_count > 0:
+            for i, o in zip(self.live, self.offsets):
+                p = self.params[i]
+                n = p.numel()
+                state[i] = {'step': torch.tensor(float(self.step_count)), 'exp_avg': self.m[o:o + n].view_as(p).clone(),
+                            'exp_avg_sq': self.v[o:o + n].view_as(p).clone()}
+        elif self._pending is not None:
+            state = self._pending['state']
+        return {'state': state, 'param_groups': [dict(g) for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        g = sd['param_groups'][0]
+        for k in ('lr', 'betas', 'eps', 'weight_decay'):
+            if k in g:
+                self.param_groups[0][k] = tuple(g[k]) if k == 'betas' else g[k]
+        if self.built:
+            self._apply_state(sd)
+        else:
+            self._pending = sd
+
+    def _apply_state(self, sd):
+        st = sd['state']
+        steps = []
+        with torch.no_grad():
+            for i, o in zip(self.live, self.offsets):
+                e = st.get(i, st.get(str(i)))
+                if e is None:
+                    continue
+                p = self.params[i]
+                n = p.numel()
+                self.m[o:o + n].view_as(p).copy_(e['exp_avg'])
+                self.v[o:o + n].view_as(p).copy_(e['exp_avg_sq'])
+                steps.append(int(float(e['step'])))
+        if steps:
+            self.step_count = max(steps)
