@@ -238,7 +238,7 @@ def bench_train(args):
     import random
     import torch
     import torch.distributed as dist
-    from ttscube_amd.distributed import FlatBucketReducer, broadcast_parameters
+    from ttscube_amd.distributed import broadcast_parameters
     from ttscube_amd.io_utils.io_cubegan import CubeganCollate
     from ttscube_amd.io_utils.synthetic import synthetic_encodings, synthetic_examples
     from ttscube_amd.networks import training as T
@@ -264,8 +264,7 @@ def bench_train(args):
     model.train()
     broadcast_parameters(model)
     opts = T.cubegan_configure_optimizers(model)
-    g, d, t = T.cubegan_param_groups(model)
-    reducers = tuple(FlatBucketReducer(ps, force=True) for ps in (g, d, t))
+    reducers = T.cubegan_reducers(model, opts, force=True)   # the exchange runs at N = 1 too (a world of one)
     batch = CubeganCollate(enc).collate_fn(list(synthetic_examples(b, 777 + rank, min_ph=30, max_ph=50)))   # rank-distinct data
     crop = random.Random(99 + rank)
 
@@ -299,6 +298,18 @@ def bench_train(args):
     barrier()
     ex_ms = (time.perf_counter() - t1) / 5 * 1e3
     ex_bytes = sum(r.bytes_exchanged for r in reducers)
+    early = [getattr(r, 'launched_early', None) for r in reducers]
+    # exposed exchange time: the same steps without any exchange (only meaningful with one rank: replicas would diverge otherwise)
+    exposed_ms = None
+    if world == 1:
+        for _ in range(2):
+            T.cubegan_training_step(model, batch, opts, None, rng=crop)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            T.cubegan_training_step(model, batch, opts, None, rng=crop)
+        torch.cuda.synchronize()
+        exposed_ms = elapsed / args.steps * 1e3 - (time.perf_counter() - t2) / args.steps * 1e3
     if rank == 0:
         samples = world * b * 12000
         nparam = sum(p.numel() for p in model.parameters())
@@ -311,7 +322,9 @@ def bench_train(args):
                           'global_batch': world * b, 'parallelism': 'dp%d: replicated parameters, 3 flat-bucket RCCL exchanges per step '
                                                                     '(reduce_scatter + all_gather)' % world},
                'exchange': {'bytes_per_step_per_rank': ex_bytes, 'ms_per_step_alone': ex_ms,
-                            'algorithm_GBs': ex_bytes / (ex_ms * 1e-3) / 1e9 if ex_ms > 0 else None, 'replicas_identical': same},
+                            'algorithm_GBs': ex_bytes / (ex_ms * 1e-3) / 1e9 if ex_ms > 0 else None, 'replicas_identical': same,
+                            'exposed_ms_per_step': exposed_ms, 'chunks_launched_during_backward': early, 'note': 'reduce_scatters leave from bucket-ready gradient hooks during backward(); '
+                            'exposed = step time with the three exchanges minus step time without them (N = 1 only)'},
                'losses': {k: round(float(v), 5) for k, v in out.items()},
                'roofline': None, 'cpu_baseline': None}
         print(json.dumps(res))

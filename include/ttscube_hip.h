@@ -33,6 +33,7 @@ extern "C" {
 #define TTSC_EHIP (-2)     /* HIP runtime error (message has hipGetErrorString) */
 #define TTSC_ESTATE (-3)   /* weights missing / handle not ready */
 #define TTSC_ENOMEM (-4)   /* workspace too small */
+#define TTSC_ERANGE (-5)   /* split-precision generator: non-finite output even after re-calibration (non-finite input / weights) */
 
 const char* ttsc_version(void);
 const char* ttsc_last_error(void);
@@ -93,6 +94,9 @@ int32_t ttsc_conv1d_in_channels(const ttsc_conv1d* c);
  * staged and is divided out of the accumulator in the epilogue — both exact; 1 = off.  Ignored by TTSC_PREC_FP32. */
 int ttsc_conv1d_set_activation_scale(ttsc_conv1d* c, float scale);
 float ttsc_conv1d_get_activation_scale(const ttsc_conv1d* c);
+/* out_channels == 1 layers (conv_post): `flag_dev` (device, 4 bytes, or NULL = off) is OR-ed with 1 by the forward kernel when it emits a
+ * non-finite sample — the range guard of the split-precision generator (ttsc_hifigan_forward). */
+int ttsc_conv1d_set_nonfinite_flag(ttsc_conv1d* c, uint32_t* flag_dev);
 /* out_dev[0] = max(out_dev[0], max_i |x_i|) over n device floats (out_dev zeroed by the caller); feeds the calibration below */
 int ttsc_absmax(const float* x_dev, int64_t n, float* out_dev, void* stream);
 /* x_dev [B,Cin,Lin] -> y_dev [B,Cout,Lout]; resid_dev NULL or [B,Cout,Lout]; ep NULL = plain conv */
@@ -205,12 +209,21 @@ int ttsc_hifigan_forward_ragged(ttsc_hifigan* g, const float* mel_dev, int32_t B
 /* algorithmic FLOPs (2 x MAC) of one forward at (B, T): the roofline numerator used by bench.py */
 /* Activation pre-scales of the split-precision path: one layer-by-layer forward on `mel` with an abs-max reduction in front of
  * every convolution; every layer's input scale becomes the power of two that puts that maximum in [2^9, 2^10) (six binades of
- * head-room below fp16's 65504, full 22-bit accuracy for values down to 2^-13 of the maximum).  ttsc_hifigan_forward runs it by
- * itself on the first call after the weights or the precision changed (env TTSC_HIFIGAN_CALIBRATE=0: all scales stay 1); call it
- * explicitly to re-calibrate on other data.  wav_dev / workspace as for the forward (wav_dev receives that forward's output). */
+ * head-room below fp16's 65504, full 22-bit accuracy for values down to 2^-13 of the maximum).  The first ttsc_hifigan_forward
+ * after the weights or the precision changed calibrates by itself — by default on a FIXED built-in probe mel (log-mel range
+ * [-5, 1]), so the scales depend on the weights alone and a handle's output never depends on which utterance came first
+ * (env TTSC_HIFIGAN_CALIBRATE=input: on that call's own input; =0: all scales stay 1).  Call this function to calibrate on other
+ * data.  wav_dev / workspace as for the forward (wav_dev receives that forward's output).
+ * Range guard: every split-precision forward checks (one stream synchronisation) whether conv_post emitted a non-finite sample —
+ * an fp16 overflow in any layer reaches the waveform as NaN; it then re-calibrates on that input, reruns, and returns TTSC_ERANGE
+ * only if the output is still non-finite.  ttsc_hifigan_recalibrations counts the reruns (env TTSC_HIFIGAN_RANGE_CHECK=0: off). */
 int ttsc_hifigan_calibrate(ttsc_hifigan* g, const float* mel_dev, int32_t B, int64_t T, float* wav_dev, void* workspace_dev,
                            size_t workspace_bytes, void* stream);
 int ttsc_hifigan_get_activation_scale(const ttsc_hifigan* g, const char* layer_name, float* scale_out);
+/* Restores persisted scales (the file a checkpoint keeps beside it): ALL n layers of the generator by name, powers of two.  Pending
+ * weights are uploaded first; the handle then counts as calibrated until its weights change. */
+int ttsc_hifigan_set_activation_scales(ttsc_hifigan* g, const char* const* layer_names, const float* scales, int32_t n);
+int32_t ttsc_hifigan_recalibrations(const ttsc_hifigan* g);
 int ttsc_hifigan_algorithmic_flops(const ttsc_hifigan* g, int32_t B, int64_t T, double* flops_out);
 void ttsc_hifigan_destroy(ttsc_hifigan* g);
 

@@ -26,7 +26,7 @@ import torch.distributed as dist
 import yaml
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ttscube_amd.distributed import FlatBucketReducer, broadcast_parameters  # noqa: E402
+from ttscube_amd.distributed import broadcast_parameters  # noqa: E402
 from ttscube_amd.io_utils.io_cubegan import CubeganCollate, CubeganEncodings  # noqa: E402
 from ttscube_amd.io_utils.loader import BatchLoader, equal_batches, rank_shard  # noqa: E402
 from ttscube_amd.io_utils.synthetic import synthetic_examples  # noqa: E402
@@ -81,8 +81,7 @@ def _train(params):
     model = model.to(dev)
     broadcast_parameters(model)
     opts = T.cubegan_configure_optimizers(model)
-    g, d, t = T.cubegan_param_groups(model)
-    reducers = (FlatBucketReducer(g), FlatBucketReducer(d), FlatBucketReducer(t)) if world > 1 else None
+    reducers = T.cubegan_reducers(model, opts) if world > 1 else None   # reduce_scatters leave from bucket-ready gradient hooks
     collate = CubeganCollate(enc)
     crop_rng = random.Random(99 + rank)
     best = 9999.0

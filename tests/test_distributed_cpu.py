@@ -90,6 +90,82 @@ def test_flat_bucket_allreduce_matches_single_process_gradient(use_rs):
         assert torch.allclose(p.grad, gr, atol=1e-6)
 
 
+def _arena_worker(rank, world, port, q, overlap):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ttscube_amd.distributed import ArenaReducer, broadcast_parameters
+    from ttscube_amd.optim import FlatAdamW
+    torch.manual_seed(100 + rank)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 50), torch.nn.Tanh(), torch.nn.Linear(50, 33), torch.nn.Tanh(), torch.nn.Linear(33, 3))
+    frozen = torch.nn.Linear(2, 2)                      # never differentiated: stays out of the arenas, .grad stays None
+    broadcast_parameters(net)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(8, 7, generator=g)
+    y = torch.randn(8, 3, generator=g)
+    xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+    opt = FlatAdamW(list(net.parameters()) + list(frozen.parameters()), lr=1e-3, betas=(0.8, 0.99))
+    red = ArenaReducer(opt, bucket_mb=0.0008, overlap=overlap)   # ~200-element chunks: several per layer, parameters straddle them
+    early = []
+    grads = None
+    for step in range(3):
+        opt.zero_grad()
+        red.arm()
+        ((net(xs) - ys) ** 2).mean().backward()
+        red.reduce()                                      # step 0 lays the arenas out (no hooks yet), later steps overlap
+        early.append(red.launched_early)
+        grads = [p.grad.clone() for p in net.parameters()]
+    assert all(p.grad is None for p in frozen.parameters())
+    assert all(p.grad.data_ptr() >= opt.g.data_ptr() for p in net.parameters())     # gradients live in the arena, parameters too
+    assert all(p.data_ptr() >= opt.p.data_ptr() and p.data_ptr() < opt.p.data_ptr() + opt.p.numel() * 4 for p in net.parameters())
+    # a parameter that starts receiving gradients after the layout is an error, not a silent divergence
+    frozen(torch.ones(1, 2)).sum().backward()
+    try:
+        opt._check_no_stragglers()
+        late = False
+    except Exception:
+        late = True
+    q.put((rank, grads, [p.detach().clone() for p in net.parameters()], early, late, red.bytes_exchanged))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('overlap', [True, False])
+def test_arena_reducer_with_bucket_ready_hooks_matches_single_process_gradient(overlap):
+    """the exchange over FlatAdamW's gradient arena with the reduce_scatters launched from post-accumulate-grad hooks
+    while backward() is still running gives the gradient of the global batch, identically on both ranks."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_arena_worker, args=(r, world, port, q, overlap)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, grads, params, early, late, nbytes = q.get(timeout=120)
+        res[r] = (grads, params, early, late, nbytes)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)                       # the same averaged gradient, bit for bit, on both ranks
+    net = torch.nn.Sequential(torch.nn.Linear(7, 50), torch.nn.Tanh(), torch.nn.Linear(50, 33), torch.nn.Tanh(), torch.nn.Linear(33, 3))
+    with torch.no_grad():
+        for p, v in zip(net.parameters(), res[0][1]):
+            p.copy_(v)
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.randn(8, 7, generator=g), torch.randn(8, 3, generator=g)
+    ((net(x) - y) ** 2).mean().backward()
+    for p, gr in zip(net.parameters(), res[0][0]):
+        assert torch.allclose(p.grad, gr, atol=1e-6)
+    for r in range(world):
+        early, late, nbytes = res[r][2], res[r][3], res[r][4]
+        assert late and nbytes > 0
+        assert early[0] == 0                           # first step: layout, exchange after backward
+        assert (early[1] > 0 and early[2] > 0) if overlap else (early[1] == 0 and early[2] == 0)
+
+
 def test_utterance_sharding_is_a_partition():
     from ttscube_amd.api import TTSCube
     items = list(range(13))

@@ -191,3 +191,44 @@ def test_calibration_is_sticky_and_explicit():
         assert torch.equal(solo[0], a[1])
         y = g.calibrate((mel * 30.0).cuda())
         assert y.shape == a.shape and g.activation_scale('conv_pre') < 1.0 * 2 ** 10
+
+
+def test_split_precision_guard_and_weight_only_scales(tmp_path):
+    """VERDICT r2 #5 / ADVICE r2: (i) default scales come from a fixed built-in probe, so a handle's output does not depend on which
+    input it saw first; (ii) an input far outside the calibrated range trips the guard word of conv_post, the forward re-calibrates
+    and reruns — correct audio, not garbage; (iii) a non-finite input is an error, not silent NaN audio; (iv) scales persist."""
+    from ttscube_amd._lib import TTSCError
+    h = dict(R.CONFIG_V1)
+    sd = R.synthetic_state_dict(h, seed=51)
+    mel = R.synthetic_mel(2, 24, seed=52)
+    ga, gb = _gen(h, sd), _gen(h, sd)
+    with torch.no_grad():
+        ga(torch.zeros_like(mel).cuda())                   # an unrepresentative first input (silence warm-up) ...
+        a = ga(mel.cuda())
+        b = gb(mel.cuda())                                 # ... against a handle that sees the utterance first
+        assert torch.equal(a, b) and ga.activation_scales() == gb.activation_scales()
+        assert ga.recalibrations == 0
+        # (ii) calibrate on a 100x quieter signal, then feed one 3000x louder than that
+        ga.calibrate((mel * 0.01).cuda())
+        s_small = ga.activation_scale('conv_pre')
+        loud = mel * 30.0
+        out = ga(loud.cuda()).cpu()
+        assert ga.recalibrations == 1 and ga.activation_scale('conv_pre') < s_small
+        ref = R.generator_forward(R.fold_state_dict(sd), h, loud)
+        assert bool(torch.isfinite(out).all()) and _rel_rms(out, ref) < 2e-5
+        assert torch.equal(ga(loud.cuda()).cpu(), out) and ga.recalibrations == 1     # scales now fit: no second rerun
+        # (iii)
+        bad = mel.clone()
+        bad[0, 3, 5] = float('nan')
+        with pytest.raises(TTSCError, match='non-finite'):
+            gb(bad.cuda())
+        assert torch.equal(gb(mel.cuda()), b)              # the handle is still usable (re-calibrated on the next clean input if needed)
+        # (iv) persisted scales: a fresh handle restores them instead of calibrating
+        rec = ga.export_scales()
+        gc = _gen(h, sd)
+        gc.import_scales(rec)
+        assert torch.equal(gc(loud.cuda()).cpu(), out) and gc.activation_scales() == rec['scales'] and gc.recalibrations == 0
+        # a record of OTHER weights is ignored (fingerprint mismatch): the handle calibrates on the probe as usual
+        gd = _gen(h, R.synthetic_state_dict(h, seed=53))
+        gd.import_scales(rec)
+        assert bool(torch.isfinite(gd(mel.cuda())).all())

@@ -258,3 +258,80 @@ def test_hip_gru_autograd_matches_torch(cfg):
     assert _rel(y1, y0) < 1e-5
     for a_, b_, p in zip(g1, g0, [x] + params):
         assert a_.shape == b_.shape and _rel(a_, b_) < 1e-4, (tuple(p.shape), _rel(a_, b_))
+
+
+def test_flat_adamw_matches_torch_adamw_and_speaks_its_state_dict():
+    """ttsc_adamw_step over flat arenas == torch.optim.AdamW(betas=(0.8, 0.99)) step for step (cubegan.py:275-298), parameters and
+    gradients alias the arenas, version counters move (weight caches of the inference handles see the update), and the state_dict
+    round-trips through torch's optimizer."""
+    from ttscube_amd.optim import FlatAdamW
+    torch.manual_seed(3)
+    mk = lambda: torch.nn.Sequential(torch.nn.Linear(37, 129), torch.nn.Tanh(), torch.nn.Linear(129, 5)).cuda()
+    a, b = mk(), mk()
+    b.load_state_dict(a.state_dict())
+    extra = torch.nn.Parameter(torch.zeros(3, device='cuda'))     # never differentiated: must stay untouched, as torch leaves it
+    oa = FlatAdamW(list(a.parameters()) + [extra], lr=2e-4, betas=(0.8, 0.99))
+    ob = torch.optim.AdamW(b.parameters(), lr=2e-4, betas=(0.8, 0.99))
+    x = torch.randn(16, 37, device='cuda')
+    for step in range(5):
+        for net, opt in ((a, oa), (b, ob)):
+            opt.zero_grad()
+            (net(x).tanh().pow(2).mean() * (1 + step)).backward()
+            opt.step()
+            opt.param_groups[0]['lr'] = 2e-4 / (1 + 1e-5 * (step + 1))
+        for p, q in zip(a.parameters(), b.parameters()):
+            assert float((p - q).abs().max()) < 2e-7, step
+    assert extra.grad is None and float(extra.abs().sum()) == 0
+    v0 = [p._version for p in a.parameters()]
+    oa.zero_grad(); a(x).sum().backward(); oa.step()
+    assert all(p._version > v for p, v in zip(a.parameters(), v0))
+    # state_dict: torch layout -> torch optimizer -> back
+    sd = oa.state_dict()
+    assert set(sd['state'].keys()) == {0, 1, 2, 3} and float(sd['state'][0]['step']) == 6.0
+    oc = torch.optim.AdamW(a.parameters(), lr=1.0)
+    oc.load_state_dict({'state': sd['state'], 'param_groups': [dict(sd['param_groups'][0], params=[0, 1, 2, 3])]})
+    assert torch.equal(oc.state_dict()['state'][2]['exp_avg'], sd['state'][2]['exp_avg'])
+    c = mk()
+    c.load_state_dict(a.state_dict())
+    od = FlatAdamW(list(c.parameters()), lr=1.0)
+    od.load_state_dict(sd)                                       # before the arenas exist: applied at the first step
+    for net, opt in ((a, oa), (c, od)):
+        opt.zero_grad(); net(x).pow(2).mean().backward(); opt.step()
+    for p, q in zip(a.parameters(), c.parameters()):
+        assert torch.equal(p, q)
+    with pytest.raises(Exception):
+        FlatAdamW([torch.nn.Parameter(torch.zeros(4))]).step()   # CPU parameters: no CPU path
+
+
+def test_fused_gan_losses_match_torch_formulations():
+    from ttscube_amd.hifigan import discriminators as D
+    from ttscube_amd.hifigan import losses_hip as H
+    g = torch.Generator().manual_seed(5)
+    shapes = [(4, 32, 700, 2), (4, 128, 234, 2), (4, 1, 77, 3), (4, 1024, 9, 5), (4, 16, 12000)]
+    mk = lambda: [[torch.randn(s, generator=g).cuda().requires_grad_(True) for s in shapes[:3]], [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in shapes[3:]]]
+    fr, fg = mk(), mk()
+    fr2 = [[t.detach() for t in sub] for sub in fr]               # generator step: the real branch carries no graph
+    flat = lambda ll: [t for sub in ll for t in sub]
+    l0 = D.feature_loss(fr2, fg)
+    g0 = torch.autograd.grad(l0 * 1.7, flat(fg))
+    l1 = H.feature_loss(fr2, fg)
+    g1 = torch.autograd.grad(l1 * 1.7, flat(fg))
+    assert abs(float(l0) - float(l1)) < 1e-5 * abs(float(l0))
+    for u, v in zip(g0, g1):
+        assert float((u - v).abs().max()) <= 1e-6 * float(u.abs().max()) + 1e-12
+    outs_r, outs_g = flat(mk()), flat(mk())
+    d0 = D.discriminator_loss(outs_r, outs_g)[0]
+    d1 = H.discriminator_loss(outs_r, outs_g)[0]
+    assert abs(float(d0) - float(d1)) < 1e-5 * abs(float(d0))
+    for u, v in zip(torch.autograd.grad(d0, outs_r + outs_g), torch.autograd.grad(d1, outs_r + outs_g)):
+        assert float((u - v).abs().max()) <= 1e-6 * float(u.abs().max()) + 1e-12
+    n0, n1 = D.generator_loss(outs_g)[0], H.generator_loss(outs_g)[0]
+    assert abs(float(n0) - float(n1)) < 1e-5 * abs(float(n0))
+    for u, v in zip(torch.autograd.grad(n0, outs_g), torch.autograd.grad(n1, outs_g)):
+        assert float((u - v).abs().max()) <= 1e-6 * float(u.abs().max()) + 1e-12
+    # slices of a batched tensor (the discriminator step runs real + generated as one batch): views must work
+    big = torch.randn(8, 64, 100, generator=g).cuda().requires_grad_(True)
+    s0 = D.discriminator_loss([big[:4]], [big[4:]])[0]
+    s1 = H.discriminator_loss([big[:4]], [big[4:]])[0]
+    ga, gb = torch.autograd.grad(s0, big)[0], torch.autograd.grad(s1, big)[0]
+    assert abs(float(s0) - float(s1)) < 1e-5 * abs(float(s0)) and float((ga - gb).abs().max()) < 1e-9

@@ -57,6 +57,7 @@ struct ConvArgs {
                       // -4 = rows interleaved v = co * 4 + r (kernel_size == stride == 4): see epilogue_tile_v4
     int skew;         // wide kernel: start delay of the second resident workgroup per CU, in units of ~4 us (0 = off)
     int dbg;          // ablation switches, ONLY in -DTTSC_ABLATE builds (tools/ablate.cpp; never in libttscube_hip.so): see TTSC_DBG
+    unsigned* nf_flag;  // conv_cout1_kernel: set to 1 when a non-finite output sample is produced (split-precision range guard), or null
     const float* gate;  // data-gradient launches: [B,Cout,Lout] pre-activation saved by the forward; the conv result is
     float gate_slope;   // multiplied by d lrelu/dx = (gate > 0 ? 1 : gate_slope) BEFORE the residual is added; null = off
 };
@@ -1027,6 +1028,15 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs a) {
         t = apply_act(t, a.out_act);
         res[e] = t + (a.accumulate && ok ? yb[q + e] : 0.f);
     }
+    if (a.nf_flag) {
+        // range guard of the split-precision generator: an fp16 overflow anywhere upstream reaches the waveform as NaN (the hi and
+        // lo halves of an overflowed value are +inf and -inf, their products cancel to NaN), so one test per output sample on this
+        // HBM-bound kernel covers every layer (hifigan.cpp re-calibrates and reruns when the word is set)
+        bool bad = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bad = bad || (q + e < a.Lout && !(fabsf(res[e]) <= 3.0e38f));
+        if (bad) atomicOr(a.nf_flag, 1u);
+    }
     if (q + 3 < a.Lout && (((uintptr_t)(yb + q)) & 15) == 0) {
         const f32x4 o = {res[0], res[1], res[2], res[3]};
         *reinterpret_cast<f32x4*>(yb + q) = o;
@@ -1503,6 +1513,12 @@ extern "C" int ttsc_conv1d_set_activation_scale(ttsc_conv1d* c, float scale) {
 }
 extern "C" float ttsc_conv1d_get_activation_scale(const ttsc_conv1d* c) { return c ? c->act_scale : 0.f; }
 
+extern "C" int ttsc_conv1d_set_nonfinite_flag(ttsc_conv1d* c, uint32_t* flag_dev) {
+    TTSC_REQUIRE(c, "ttsc_conv1d_set_nonfinite_flag: null argument");
+    c->nf_flag = flag_dev;
+    return TTSC_OK;
+}
+
 namespace ttsc {
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
     float m = 0.f;
@@ -1547,6 +1563,7 @@ extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, 
         a.x = x;
         a.y = y;
         a.resid = resid;
+        a.nf_flag = nullptr;
         a.wp = ph.wp_dev;
         a.wph = ph.wph_dev;
         a.w_unscale = c->w_unscale;
@@ -1614,6 +1631,7 @@ extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, 
         if (use_cout1) {
             // one output channel (conv_post): vector-ALU kernel, bound by the single read of its input
             a.wp = w_plain;
+            a.nf_flag = c->nf_flag;
             dim3 grid((unsigned)ceil_div(Lout, 1024), (unsigned)B);
             hipLaunchKernelGGL(conv_cout1_kernel, grid, dim3(256), 0, s, a);
             hipError_t e = hipGetLastError();

@@ -29,5 +29,6 @@ struct ttsc_conv1d {
     const float* bias_ext = nullptr;  // device-weight mode: the caller's bias tensor
     float* w_plain_dev = nullptr;     // out_channels == 1: weights in torch layout [1][Cin][K] for conv_cout1_kernel
     const float* w_plain_ext = nullptr;   // device-weight mode: the caller's weight tensor (same layout)
+    unsigned* nf_flag = nullptr;          // out_channels == 1: device word that conv_cout1_kernel ORs with 1 when it emits a non-finite sample
 };
 

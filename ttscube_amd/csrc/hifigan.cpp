@@ -17,6 +17,7 @@
 // HBM layout: four activation buffers carved from the caller's workspace (X: stage input, XT: inner
 // activation of a residual pair, R: running residual stream, S: sum over residual blocks), each
 // [B, C_i, L_i] fp32 channel-major, sized for the largest stage.
+#include <cmath>
 #include <cstdlib>
 #include <map>
 #include <memory>
@@ -46,11 +47,28 @@ struct ttsc_hifigan {
     int chain_shape = -1;       // env TTSC_HIFIGAN_CHAIN_SHAPE: tile shape of the chain kernel (-1 = by halo)
     int precision = TTSC_PREC_FP32;
     // Split precision keeps activations as fp16 (hi, lo) pairs, so every layer's input gets a power-of-two pre-scale that
-    // centres it in fp16's range (ttsc_conv1d_set_activation_scale).  The scales come from ONE calibration forward — the
-    // first forward after the weights changed, on that call's own input, run layer by layer with an abs-max reduction in
-    // front of every convolution — and stay fixed afterwards (env TTSC_HIFIGAN_CALIBRATE=0: all scales 1).
-    bool auto_calibrate = true;
+    // centres it in fp16's range (ttsc_conv1d_set_activation_scale).  The scales come from ONE calibration forward, run layer
+    // by layer with an abs-max reduction in front of every convolution, and stay fixed until the weights change.
+    //   calib_mode 1 (default, env TTSC_HIFIGAN_CALIBRATE unset / "probe"): calibrated on a FIXED built-in probe mel (log-mel
+    //       range [-5, 1] of cube/io_utils/vocoder.py:96-98: noise frames, all-floor frames, all-ceiling frames) the first time
+    //       the weights are used — the scales are a function of the weights alone, so a handle's output never depends on which
+    //       utterance it saw first;
+    //   calib_mode 2 ("input"): calibrated on the first forward's own input (round 2's behaviour);
+    //   calib_mode 0 ("0"): all scales 1.
+    // Every forward is guarded: conv_post raises a device word when it emits a non-finite sample (= an fp16 overflow anywhere
+    // upstream, see conv_cout1_kernel); the forward then re-calibrates on the offending input and reruns, and only reports
+    // TTSC_ERANGE when the output is still non-finite (non-finite input or weights).  env TTSC_HIFIGAN_RANGE_CHECK=0 switches
+    // the guard (one stream synchronisation per forward) off.
+    int calib_mode = 1;
     bool calibrated = false;
+    bool range_check = true;
+    int recalibrations = 0;          // forwards that tripped the guard and were rerun after re-calibration
+    unsigned* flag_dev = nullptr;    // the guard word
+    unsigned* flag_host = nullptr;   // pinned copy
+    ~ttsc_hifigan() {
+        if (flag_dev) (void)hipFree(flag_dev);
+        if (flag_host) (void)hipHostFree(flag_host);
+    }
     // pack + upload every layer whose host copy changed; returns the name of the first incomplete layer (or "")
     int flush_weights(std::string* missing) {
         for (auto& kv : layers) {
@@ -98,7 +116,11 @@ extern "C" int ttsc_hifigan_create(const ttsc_hifigan_cfg* cfg, ttsc_hifigan** o
     if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN")) g->use_chain = atoi(ev) != 0;
     if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN128")) g->use_chain128 = atoi(ev) != 0;
     if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN_SHAPE")) g->chain_shape = atoi(ev);
-    if (const char* ev = getenv("TTSC_HIFIGAN_CALIBRATE")) g->auto_calibrate = atoi(ev) != 0;
+    if (const char* ev = getenv("TTSC_HIFIGAN_CALIBRATE")) {
+        const std::string v(ev);
+        g->calib_mode = (v == "0" || v == "off") ? 0 : (v == "input" || v == "2") ? 2 : 1;
+    }
+    if (const char* ev = getenv("TTSC_HIFIGAN_RANGE_CHECK")) g->range_check = atoi(ev) != 0;
     int rc = add_layer(g.get(), "conv_pre", cfg->num_mels, cfg->upsample_initial_channel, 7, 1, 3, 1, 0);
     if (rc) return rc;
     int ch = cfg->upsample_initial_channel;
@@ -130,6 +152,12 @@ extern "C" int ttsc_hifigan_create(const ttsc_hifigan_cfg* cfg, ttsc_hifigan** o
         g->stage_ch.push_back(ch);
     }
     rc = add_layer(g.get(), "conv_post", ch, 1, 7, 1, 3, 1, 0);
+    if (rc) return rc;
+    TTSC_HIP_CHECK(hipMalloc((void**)&g->flag_dev, 64));
+    TTSC_HIP_CHECK(hipMemset(g->flag_dev, 0, 64));
+    TTSC_HIP_CHECK(hipHostMalloc((void**)&g->flag_host, 64, hipHostMallocDefault));
+    *g->flag_host = 0u;
+    rc = ttsc_conv1d_set_nonfinite_flag(g->layers.at("conv_post")->c, g->flag_dev);
     if (rc) return rc;
     *out = g.release();
     return TTSC_OK;
@@ -267,6 +295,77 @@ extern "C" int ttsc_hifigan_calibrate(ttsc_hifigan* g, const float* mel, int32_t
     return rc;
 }
 
+// The built-in calibration probe: one utterance of 96 mel frames covering the log-mel range the generator is fed with
+// (floor -5 = cube/io_utils/vocoder.py:96-98 / the collate's pad value, ceiling ~1): 32 frames of clip(N(-2,1)), 16 all-floor,
+// 16 all-ceiling, 32 frames of clip(N(-1,1.5)).  Generated by a fixed integer recurrence (no library RNG: identical everywhere).
+static void probe_mel(int num_mels, int T, std::vector<float>& out) {
+    out.assign((size_t)num_mels * T, 0.f);
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    auto u01 = [&]() {
+        st = st * 6364136223846793005ull + 1442695040888963407ull;
+        return ((double)((st >> 11) & ((1ull << 53) - 1)) + 0.5) / (double)(1ull << 53);
+    };
+    auto normal = [&]() { return sqrt(-2.0 * log(u01())) * cos(6.283185307179586 * u01()); };
+    for (int t = 0; t < T; ++t)
+        for (int m = 0; m < num_mels; ++m) {
+            double v;
+            if (t < 32) v = -2.0 + normal();
+            else if (t < 48) v = -5.0;
+            else if (t < 64) v = 1.0;
+            else v = -1.0 + 1.5 * normal();
+            v = v < -5.0 ? -5.0 : (v > 1.0 ? 1.0 : v);
+            out[(size_t)m * T + t] = (float)v;
+        }
+}
+
+// weight-only calibration: the probe through ttsc_hifigan_calibrate on private buffers (once per weight change)
+static int calibrate_on_probe(ttsc_hifigan* g, void* stream) {
+    const int T = 96;
+    std::vector<float> h;
+    probe_mel(g->cfg.num_mels, T, h);
+    const size_t wsb = ttsc_hifigan_workspace_bytes(g, 1, T);
+    const int64_t Lout = ttsc_hifigan_out_len(g, T);
+    float *mel = nullptr, *wav = nullptr;
+    void* ws = nullptr;
+    int rc = TTSC_OK;
+    if (hipMalloc((void**)&mel, h.size() * sizeof(float)) != hipSuccess || hipMalloc((void**)&wav, (size_t)Lout * sizeof(float)) != hipSuccess ||
+        hipMalloc(&ws, wsb) != hipSuccess) {
+        set_error("ttsc_hifigan: cannot allocate the calibration probe buffers");
+        rc = TTSC_ENOMEM;
+    }
+    if (!rc && hipMemcpy(mel, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = TTSC_EHIP;
+    if (!rc) rc = ttsc_hifigan_calibrate(g, mel, 1, T, wav, ws, wsb, stream);
+    if (!rc && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = TTSC_EHIP;
+    if (mel) (void)hipFree(mel);
+    if (wav) (void)hipFree(wav);
+    if (ws) (void)hipFree(ws);
+    return rc;
+}
+
+extern "C" int ttsc_hifigan_set_activation_scales(ttsc_hifigan* g, const char* const* layers, const float* scales, int32_t n) {
+    TTSC_REQUIRE(g && layers && scales && n > 0, "ttsc_hifigan_set_activation_scales: null argument");
+    {
+        std::string missing;
+        int frc = g->flush_weights(&missing);   // the scales belong to the weights that are about to be used
+        if (frc == TTSC_ESTATE) {
+            set_error("ttsc_hifigan_set_activation_scales: weights missing (first: '%s')", missing.c_str());
+            return TTSC_ESTATE;
+        }
+        if (frc) return frc;
+    }
+    TTSC_REQUIRE((size_t)n == g->layers.size(), "ttsc_hifigan_set_activation_scales: %d scales for %zu layers", n, g->layers.size());
+    for (int i = 0; i < n; ++i) {
+        auto it = g->layers.find(layers[i] ? layers[i] : "");
+        TTSC_REQUIRE(it != g->layers.end(), "ttsc_hifigan_set_activation_scales: unknown layer '%s'", layers[i] ? layers[i] : "(null)");
+        int rc = ttsc_conv1d_set_activation_scale(it->second->c, scales[i]);
+        if (rc) return rc;
+    }
+    g->calibrated = true;
+    return TTSC_OK;
+}
+
+extern "C" int32_t ttsc_hifigan_recalibrations(const ttsc_hifigan* g) { return g ? g->recalibrations : -1; }
+
 extern "C" int ttsc_hifigan_get_activation_scale(const ttsc_hifigan* g, const char* layer, float* out) {
     TTSC_REQUIRE(g && layer && out, "ttsc_hifigan_get_activation_scale: null argument");
     auto it = g->layers.find(layer);
@@ -277,7 +376,27 @@ extern "C" int ttsc_hifigan_get_activation_scale(const ttsc_hifigan* g, const ch
 
 extern "C" int ttsc_hifigan_forward_ragged(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, const int32_t* frames,
                                            float* wav, void* ws, size_t ws_bytes, void* stream) {
-    return hifigan_run(g, mel, B, T, frames, wav, ws, ws_bytes, stream, nullptr);
+    TTSC_REQUIRE(g, "ttsc_hifigan_forward: null argument");
+    const bool guard = g->range_check && g->precision == TTSC_PREC_F16X3 && g->calib_mode != 0;   // (mode 0 is a measurement switch: scales stay 1)
+    hipStream_t s = (hipStream_t)stream;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (guard) TTSC_HIP_CHECK(hipMemsetAsync(g->flag_dev, 0, sizeof(unsigned), s));
+        int rc = hifigan_run(g, mel, B, T, frames, wav, ws, ws_bytes, stream, nullptr);
+        if (rc || !guard) return rc;
+        TTSC_HIP_CHECK(hipMemcpyAsync(g->flag_host, g->flag_dev, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        TTSC_HIP_CHECK(hipStreamSynchronize(s));
+        if (*g->flag_host == 0u) return TTSC_OK;
+        if (attempt == 1) break;
+        // a non-finite sample left conv_post: some layer's input overflowed the fp16 range its pre-scale was calibrated for
+        // (or the input itself is non-finite).  Re-derive the scales on THIS input and run the forward again.
+        g->recalibrations++;
+        rc = ttsc_hifigan_calibrate(g, mel, B, T, wav, ws, ws_bytes, stream);
+        if (rc) return rc;
+    }
+    g->calibrated = false;   // the scales derived from a non-finite input are meaningless: the next forward calibrates afresh
+    set_error("ttsc_hifigan_forward: non-finite output even after re-calibrating the split-precision scales on this input "
+              "(non-finite values in the input or the weights?)");
+    return TTSC_ERANGE;
 }
 
 static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, const int32_t* frames, float* wav, void* ws, size_t ws_bytes,
@@ -299,8 +418,8 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
         return TTSC_ENOMEM;
     }
     const bool calib = calib_stat != nullptr;
-    if (!calib && !g->calibrated && g->auto_calibrate && g->precision == TTSC_PREC_F16X3) {
-        int crc = ttsc_hifigan_calibrate(g, mel, B, T, wav, ws, ws_bytes, stream);   // first forward after new weights
+    if (!calib && !g->calibrated && g->calib_mode != 0 && g->precision == TTSC_PREC_F16X3) {   // first forward after new weights
+        int crc = g->calib_mode == 1 ? calibrate_on_probe(g, stream) : ttsc_hifigan_calibrate(g, mel, B, T, wav, ws, ws_bytes, stream);
         if (crc) return crc;
     }
     const auto& c = g->cfg;

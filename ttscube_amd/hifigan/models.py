@@ -180,6 +180,26 @@ class Generator(nn.Module):
                 _lib.check(L.ttsc_hifigan_set_weight(self._handle, (name + suffix).encode(), C.c_void_p(t.data_ptr()),
                                                      shape, t.dim()), 'ttsc_hifigan_set_weight(%s)' % (name + suffix))
         self._sig = sig
+        pend, self._pending_scales = getattr(self, '_pending_scales', None), None
+        if pend is not None and self._precision == 'f16x3' and abs(pend['fingerprint'] - self.weight_fingerprint()) <= 1e-9 * abs(pend['fingerprint']):
+            self.load_activation_scales(pend['scales'])    # persisted beside the checkpoint these weights came from
+
+    def weight_fingerprint(self):
+        """sum |w| over the folded weights (float64): ties a persisted scale file to the weights it was calibrated for"""
+        with torch.no_grad():
+            return float(sum(l.folded_weight().double().abs().sum() for _, l in self._named_convs()))
+
+    def export_scales(self):
+        """JSON-able record of the split-precision calibration (None unless the f16x3 handle exists and is calibrated)"""
+        if self._handle is None or self._precision != 'f16x3':
+            return None
+        return {'precision': 'f16x3', 'fingerprint': self.weight_fingerprint(), 'scales': self.activation_scales()}
+
+    def import_scales(self, rec):
+        """queue a record written by export_scales(); applied at the next weight upload if the fingerprint matches"""
+        if rec and rec.get('precision') == 'f16x3':
+            self._pending_scales = rec
+            self._sig = None
 
     def __del__(self):
         try:
@@ -236,8 +256,9 @@ class Generator(nn.Module):
 
     def calibrate(self, x):
         """(Re)derive the split-precision path's per-layer activation pre-scales from `x` [B, num_mels, T] (ttsc_hifigan_calibrate:
-        one layer-by-layer forward with an abs-max reduction per layer).  The first forward after loading weights does this
-        by itself on its own input; call it to re-calibrate on more representative data.  Returns that forward's output."""
+        one layer-by-layer forward with an abs-max reduction per layer).  The first forward after loading weights calibrates
+        by itself on a fixed built-in probe mel (so the scales depend on the weights alone); call this to calibrate on other
+        data.  Returns that forward's output."""
         L = _lib.lib()
         self._sync()
         x = x.detach().float().contiguous()
@@ -257,6 +278,24 @@ class Generator(nn.Module):
         out = C.c_float()
         _lib.check(_lib.lib().ttsc_hifigan_get_activation_scale(self._handle, layer_name.encode(), C.byref(out)), 'get_activation_scale')
         return out.value
+
+    def activation_scales(self):
+        """{layer name: power-of-two pre-scale} of the split-precision path — what `Cubegan.save` keeps beside a checkpoint"""
+        self._sync()
+        return {name: self.activation_scale(name) for name, _ in self._named_convs()}
+
+    def load_activation_scales(self, scales):
+        """restore persisted scales (all layers); the handle then skips its own calibration until the weights change"""
+        self._sync()
+        names = [n for n, _ in self._named_convs()]
+        arr_n = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        arr_s = (C.c_float * len(names))(*[float(scales[n]) for n in names])
+        _lib.check(_lib.lib().ttsc_hifigan_set_activation_scales(self._handle, arr_n, arr_s, len(names)), 'ttsc_hifigan_set_activation_scales')
+
+    @property
+    def recalibrations(self):
+        """forwards that tripped the range guard (a non-finite sample left conv_post) and were rerun after re-calibration"""
+        return 0 if self._handle is None else int(_lib.lib().ttsc_hifigan_recalibrations(self._handle))
 
     def remove_weight_norm(self):
         self.conv_pre.remove_weight_norm()

@@ -75,10 +75,20 @@ class Cubegan(nn.Module):
     @torch.jit.ignore
     def save(self, path):
         torch.save(self.state_dict(), path)
+        # the generator's split-precision calibration travels beside the checkpoint (<path>.scales.json): a reloaded model then
+        # reproduces this handle's arithmetic without calibrating again
+        rec = self._generator.export_scales()
+        if rec is not None:
+            import json
+            json.dump(rec, open(path + '.scales.json', 'w'))
 
     @torch.jit.ignore
     def load(self, path):
         self.load_state_dict(torch.load(path, map_location='cpu'), strict=False)
+        import json
+        import os
+        if os.path.exists(path + '.scales.json'):
+            self._generator.import_scales(json.load(open(path + '.scales.json')))
 
     @staticmethod
     def _compute_lr(initial_lr, delta, step):

@@ -61,6 +61,10 @@ def wavernn_loss(net, X):
 import itertools
 import random
 
+# True: every piece of the training steps that has a native counterpart runs as its torch-op formulation instead (torch.optim.AdamW,
+# per-tensor GAN loss expressions): the reference the native step is held to by tests/test_baseline_configs_gpu.py.  Never set in production.
+TORCH_REFERENCE = False
+
 import torch.nn.functional as F
 
 from ..hifigan.models import ResBlock1
@@ -159,12 +163,16 @@ def cubegan_configure_optimizers(model):
     """cubegan.py:275-311: AdamW(0.8,0.99) x3 + Adam(1e-6) on the dummy; restores `.opt.last` states when present
     (the reference sets `_loaded_optimizer_state` but reads `_loaded_optimizer_states`, so its resume silently skips this)."""
     g, d, t = cubegan_param_groups(model)
-    # fused=True: one multi-tensor kernel per optimizer step instead of ~10 element-wise launches per state update (same
-    # update rule and state_dict layout; device parameters only)
-    fused = all(p.is_cuda for p in itertools.chain(g, d, t))
-    opt_g = torch.optim.AdamW(g, model._current_lr, betas=[0.8, 0.99], fused=fused)
-    opt_d = torch.optim.AdamW(d, model._current_lr, betas=[0.8, 0.99], fused=fused)
-    opt_t = torch.optim.AdamW(t, model._current_lr, betas=[0.8, 0.99], fused=fused)
+    on_gpu = all(p.is_cuda for p in itertools.chain(g, d, t))
+    if on_gpu and not TORCH_REFERENCE:
+        # one HIP kernel per group and step over flat parameter / gradient / moment arenas (ttscube_amd/optim.py); the gradient arena
+        # doubles as the RCCL exchange buffer (distributed.ArenaReducer).  state_dict layout == torch.optim.AdamW's.
+        from ..optim import FlatAdamW
+        mk = lambda ps: FlatAdamW(ps, model._current_lr, betas=(0.8, 0.99))
+    else:
+        # fused=True: one multi-tensor kernel per optimizer step instead of ~10 element-wise launches per state update
+        mk = lambda ps: torch.optim.AdamW(ps, model._current_lr, betas=[0.8, 0.99], fused=on_gpu)
+    opt_g, opt_d, opt_t = mk(g), mk(d), mk(t)
     opt_b = torch.optim.Adam(model._dummy.parameters(), lr=1e-6)
     if model._loaded_optimizer_states is not None:
         for k, opt in zip(['0', '1', '2', '3'], [opt_g, opt_d, opt_t, opt_b]):
@@ -174,11 +182,31 @@ def cubegan_configure_optimizers(model):
     return opt_g, opt_d, opt_t, opt_b
 
 
+def cubegan_reducers(model, optimizers, force=False, overlap=True, bucket_mb=64):
+    """The three gradient exchanges of a Cubegan step, in the order `cubegan_training_step` expects (generator side, discriminators,
+    text side).  Over a FlatAdamW group the exchange runs on the optimizer's own gradient arena and its reduce_scatters leave from
+    bucket-ready gradient hooks while backward() is still running (distributed.ArenaReducer); over a torch optimizer it is the
+    copy-in FlatBucketReducer."""
+    from ..distributed import ArenaReducer, FlatBucketReducer
+    from ..optim import FlatAdamW
+    out = []
+    for opt, ps in zip(optimizers[:3], cubegan_param_groups(model)):
+        if isinstance(opt, FlatAdamW):
+            out.append(ArenaReducer(opt, bucket_mb=bucket_mb, force=force, overlap=overlap))
+        else:
+            out.append(FlatBucketReducer(ps, bucket_mb=bucket_mb, force=force))
+    return tuple(out)
+
+
 def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
     """Cubegan.training_step (cubegan.py:85-189): discriminator step, generator step (adv + feature + 45 x mel-L1),
     text step (duration CE + pitch/vuv L1); one gradient exchange per backward pass (reducers = (g, d, t))."""
-    from ..hifigan.discriminators import discriminator_loss, feature_loss, generator_loss
+    if TORCH_REFERENCE:
+        from ..hifigan.discriminators import discriminator_loss, feature_loss, generator_loss
+    else:   # value + gradient of a whole list of discriminator outputs / feature maps in one launch (hifigan/losses_hip.py)
+        from ..hifigan.losses_hip import discriminator_loss, feature_loss, generator_loss
     from ..io_utils.melspec import mel_spectrogram   # DFT / mel GEMMs + element-wise kernels on HIP, forward and backward
+    arm = lambda i: reducers and hasattr(reducers[i], 'arm') and reducers[i].arm()   # bucket-ready hooks restart with every backward pass
     opt_g, opt_d, opt_t, opt_b = optimizers
     rng = rng or random
     dev = model.get_device()
@@ -212,6 +240,7 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
     y_g_hat_mel = mel_spectrogram(y_g_hat.squeeze(1), 1024, 80, 24000, 240, 1024, 0, 12000)
     opt_b.zero_grad()
     opt_d.zero_grad()
+    arm(1)
     y_df_hat_r, y_df_hat_g, _, _ = model._mpd(y, y_g_hat.detach())
     loss_disc_f, _, _ = discriminator_loss(y_df_hat_r, y_df_hat_g)
     y_ds_hat_r, y_ds_hat_g, _, _ = model._msd(y, y_g_hat.detach())
@@ -222,6 +251,7 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
         reducers[1].reduce()
     opt_d.step()
     opt_g.zero_grad()
+    arm(0)
     loss_mel = F.l1_loss(y_mel, y_g_hat_mel) * 45
     # the generator step only needs the discriminators' DATA gradients: the reference also accumulates their weight
     # gradients here and throws them away at the next opt_d.zero_grad() (cubegan.py:137,157-170); freezing the
@@ -242,6 +272,7 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
         reducers[0].reduce()
     opt_g.step()
     opt_t.zero_grad()
+    arm(2)
     loss_text = loss_pitch + loss_duration
     loss_text.backward()
     if reducers:

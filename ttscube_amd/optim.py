@@ -41,9 +41,7 @@ class FlatAdamW:
 
     def _build(self):
         ps = self.params
-        dev = ps[0].device
-        if dev.type != 'cuda':
-            raise _lib.TTSCError('FlatAdamW: parameters live on the CPU; move the model to a HIP device first (no CPU path)')
+        dev = ps[0].device   # (the layout itself is device-agnostic — the gloo tests build it on the CPU; step() needs the HIP kernel)
         has = torch.tensor([1.0 if (p.grad is not None and p.requires_grad) else 0.0 for p in ps], dtype=torch.float32, device=dev)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             dist.all_reduce(has, op=dist.ReduceOp.MAX, group=self.group)   # live on ANY rank -> live everywhere (same arena layout)
@@ -113,6 +111,8 @@ class FlatAdamW:
         if not self.built:
             self._build()
         self._check_no_stragglers()
+        if self.p.device.type != 'cuda':
+            raise _lib.TTSCError('FlatAdamW.step: parameters live on the CPU; move the model to a HIP device first (no CPU path)')
         self.step_count += 1
         pg = self.param_groups[0]
         with torch.cuda.device(self.p.device):
