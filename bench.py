@@ -332,9 +332,130 @@ def bench_train(args):
     dist.destroy_process_group()
 
 
+def bench_e2e(args):
+    """`--mode e2e`: BASELINE configs[4] — full synthesize(): phoneme ids -> BiLSTM mel decoder (Languasito2) -> HiFi-GAN, random
+    sentences (20..120 phonemes) sharded over the GPUs of one node, 64 sentences per GPU (N = 8: the 512 sentences of the config),
+    no collective on the data path (`TTSCube.shard`, cube/api.py:45-66 is the B = 1 loop this replaces).  A step = one pass over this
+    rank's shard as length-bucketed padded batches.  Per-phase device time (text stacks / alignment / frame stacks / generator) from
+    HIP events; never a time for wrong audio: the shortest and the longest sentence of every rank are checked against the oracle
+    chain (meldecoder_ref -> hifigan_ref: identical durations, <= 4 LSB int16)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from oracle import hifigan_ref as R          # synthetic weights + the post-run check only
+    from oracle import meldecoder_ref as MO
+    from ttscube_amd.api import TTSCube
+    from ttscube_amd.io_utils.synthetic import synthetic_sentences
+    from ttscube_amd.networks.cubegan import Cubegan
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    class _Enc:
+        phon2int = {'p%d' % i: i for i in range(50)}
+        speaker2int = {'s0': 0}
+        max_pitch = 300
+        max_duration = 12   # synthetic weights give ~uniform durations: ~6 frames per phoneme
+
+    h = dict(R.CONFIG_V1)
+    gsd = R.synthetic_state_dict(h, seed=1234)
+    torch.manual_seed(0)
+    tts = Cubegan(_Enc(), conditioning=None, train=False)
+    sd = tts.state_dict()
+    lsd = MO.fill_state_dict(MO.named_shapes(tts._languasito), 5)
+    sd.update({'_languasito.' + k: v for k, v in lsd.items()})
+    sd.update({'_generator.' + k: v for k, v in gsd.items()})
+    tts.load_state_dict(sd)
+    tts = tts.to(dev).eval()
+    per_gpu, bs = args.sentences_per_gpu, args.e2e_batch
+    xc, lens = synthetic_sentences(per_gpu * world, seed=1234)
+    mine = TTSCube.shard(list(range(per_gpu * world)), rank, world)
+    order = sorted(mine, key=lambda i: int(lens[i]))                  # length buckets: neighbours in length share a padded batch
+    batches = [order[s:s + bs] for s in range(0, len(order), bs)]
+
+    def run(timers=None):
+        outs, n = {}, 0
+        for b in batches:
+            L = int(max(lens[i] for i in b))
+            X = {'x_char': torch.from_numpy(xc[b][:, :L]), 'x_speaker': torch.ones((len(b), 1), dtype=torch.long)}
+            wav, wl = tts.inference(X, return_lengths=True, timers=timers)
+            n += int(sum(wl))
+            outs.update({i: (wav[k, 0, :wl[k]], wl[k]) for k, i in enumerate(b)})
+        return outs, n
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        outs, nsamp = run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        outs, nsamp = run()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # per-phase device time of one more (untimed) pass
+    tm = []
+    run(tm)
+    torch.cuda.synchronize()
+    phases = {}
+    for (n0, e0), (n1, e1) in zip(tm[:-1], tm[1:]):
+        if n1 != 'start':
+            phases[n1] = phases.get(n1, 0.0) + e0.elapsed_time(e1)
+    # oracle check: shortest + longest sentence of this rank
+    to16 = lambda a: np.asarray(a * 32767, dtype=np.int16)
+    wfold = R.fold_state_dict(gsd)
+    worst = 0
+    for i in sorted({order[0], order[-1]}):
+        with torch.no_grad():
+            cond, durs, _ = MO.languasito2_inference(lsd, torch.from_numpy(xc[i:i + 1, :lens[i]]), torch.tensor([[1]]), _Enc.max_pitch)
+            ref = R.generator_forward(wfold, h, cond.permute(0, 2, 1))
+        w, wl = outs[i]
+        assert wl == 240 * sum(durs) + 64, 'e2e: durations of sentence %d differ from the oracle' % i
+        worst = max(worst, int(np.abs(to16(w.cpu().numpy()).astype(np.int32) - to16(ref.numpy().squeeze()).astype(np.int32)).max()))
+    assert worst <= 4, 'e2e: %d LSB from the oracle chain on rank %d' % (worst, rank)
+    agg = torch.tensor([elapsed, float(nsamp), float(worst)], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = agg.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = agg.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, nsamp_all, worst = float(mx[0]), float(sm[1]), int(mx[2])
+    else:
+        nsamp_all = float(nsamp)
+    if rank == 0:
+        value = nsamp_all * args.steps / elapsed
+        print(json.dumps({
+            'metric': 'audio samples/sec (end-to-end synthesize(): phonemes -> BiLSTM mel decoder -> HiFi-GAN)', 'value': value, 'unit': 'samples/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': max(1, args.warmup), 'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 (generator: split fp16 hi/lo x3 MFMA)', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[4]: %d random sentences per GPU (20-120 phonemes, %d in all), Languasito2 + HiFi-GAN V1, '
+                                   'length-bucketed padded batches of %d' % (per_gpu, per_gpu * world, bs),
+                       'global_batch': per_gpu * world, 'parallelism': 'utterance shards (TTSCube.shard), no collective'},
+            'rtf_24k': value / world / 24000.0, 'sentences_per_s': per_gpu * world * args.steps / elapsed,
+            'phase_ms_rank0': {k: round(v, 3) for k, v in phases.items()}, 'samples_per_step_rank0': int(nsamp),
+            'max_lsb_vs_oracle_chain': worst, 'oracle_checked': '2 sentences per rank (shortest, longest)', 'roofline': None, 'cpu_baseline': None}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--mode', choices=('infer', 'train'), default='infer', help="'train': the Cubegan adversarial training step (BASELINE configs[3])")
+    ap.add_argument('--mode', choices=('infer', 'train', 'e2e'), default='infer',
+                    help="'train': the Cubegan adversarial training step (BASELINE configs[3]); 'e2e': text -> audio, sentences sharded over the GPUs (configs[4])")
+    ap.add_argument('--sentences-per-gpu', type=int, default=64, help='--mode e2e: sentences in every rank\'s shard')
+    ap.add_argument('--e2e-batch', type=int, default=64, help='--mode e2e: sentences per padded batch')
     ap.add_argument('--train-batch', type=int, default=16, help='utterances per GPU in --mode train')
     ap.add_argument('--miopen-find', action='store_true', help="--mode train: let MIOpen search its convolution algorithms exhaustively "
                     "(torch.backends.cudnn.benchmark): ~12 minutes once per process on a fresh box, then 108 instead of 145 ms per step; "
@@ -349,6 +470,8 @@ def main():
     args = ap.parse_args()
     if args.mode == 'train':
         return bench_train(args)
+    if args.mode == 'e2e':
+        return bench_e2e(args)
 
     import torch
     import torch.distributed as dist
@@ -437,7 +560,8 @@ def main():
             'rtf_24k': value / world / 24000.0, 'rtf_22k05': value / world / 22050.0,
             'per_gpu_samples_s': value / world,
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak, 'traffic': traffic, 'traffic_unit': 'HBM bytes per step (rocprofv3 PMC, profiles/r02_bench_hbm_pmc.csv)',
+                         'frac': achieved / peak, 'traffic': traffic, 'traffic_unit': 'HBM bytes per step (rocprofv3 PMC, %s)' % os.path.relpath(TRAFFIC_CSV, ROOT),
+                         'traffic_source': 'committed PMC summary of this workload (builder-run rocprofv3 passes), NOT measured in this run',
                          'kernel': kname,
                          'flops_per_step': flops_step, 'device_ms_per_step': dev_ms / args.steps,
                          'mfma_executed_tflops': executed, 'mfma_dense_peak_tflops': PEAK_F16_MFMA_TFLOPS if precision == 'f16x3' else PEAK_FP32_MFMA_TFLOPS,

@@ -88,12 +88,13 @@ def generator_forward(w, h, mel, return_stages=False):
     rds = h['resblock_dilation_sizes']
     nk = len(rks)
     rb = resblock1 if str(h.get('resblock', '1')) == '1' else resblock2
-    stages = []
+    stages, ups_out = [], []
     x = F.conv1d(mel, w['conv_pre.weight'], w['conv_pre.bias'], padding=3)
     stages.append(x)
     for i, (u, k) in enumerate(zip(rates, ksz)):
         x = F.leaky_relu(x, LRELU_SLOPE)
         x = F.conv_transpose1d(x, w['ups.%d.weight' % i], w['ups.%d.bias' % i], stride=u, padding=(k - u) // 2)
+        ups_out.append(x)
         xs = None
         for j in range(nk):
             r = rb(w, 'resblocks.%d' % (i * nk + j), x, rks[j], rds[j])
@@ -103,6 +104,8 @@ def generator_forward(w, h, mel, return_stages=False):
     x = F.leaky_relu(x)  # default slope 0.01 (H8)
     x = F.conv1d(x, w['conv_post.weight'], w['conv_post.bias'], padding=3)
     x = torch.tanh(x)
+    if return_stages == 'all':   # + every upsampler's output (tests/test_oracle_hifigan.py: layer-by-layer pin against the surrogate)
+        return x, stages, ups_out
     if return_stages:
         return x, stages
     return x

@@ -55,3 +55,30 @@ def test_weight_norm_fold_matches_torch():
         torch.nn.utils.remove_weight_norm(m)
         assert torch.allclose(m.weight, w, atol=1e-7)
         assert torch.allclose(m(x), y, atol=1e-6)
+
+
+def test_oracle_full_v1_matches_surrogate_layer_by_layer(golden_dir):
+    """The FULL config_v1 generator (512 channels) stage by stage against the independent implementation: conv_pre output, every
+    upsampler's output, every stage's block mean and the waveform (tools/gen_golden_hifigan.py::full_v1).  The reference's own
+    generator source is absent, so this is the strongest pin available for oracle/hifigan_ref.py."""
+    import json
+    import torch
+    import torch.nn.functional as F
+    z = np.load(os.path.join(golden_dir, 'hifigan_full_v1.npz'))
+    h = json.loads(str(z['cfg_json']))
+    assert h['upsample_initial_channel'] == 512
+    w = R.fold_state_dict(R.synthetic_state_dict(h, seed=int(z['seed']), weight_norm=True))
+    assert abs(float(sum(v.double().abs().sum() for v in w.values())) - float(z['weights_abs_sum'])) < 1e-6 * float(z['weights_abs_sum'])
+    rel = lambda a, b: float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+    for T in (7, 30):
+        mel = torch.from_numpy(z['mel/%d' % T])
+        wav, stages, ups = R.generator_forward(w, h, mel, return_stages='all')
+        assert float((wav[:, 0] - torch.from_numpy(z['wav/%d' % T])).pow(2).mean().sqrt()) < 2e-6
+        if T != 7:
+            continue
+        assert rel(stages[0], torch.from_numpy(z['stage/conv_pre'])) < 1e-6
+        n = len(h['upsample_rates'])
+        for i in range(n):
+            assert rel(ups[i], torch.from_numpy(z['stage/ups_out.%d' % i])) < 2e-6, i
+            slope = 0.1 if i < n - 1 else 0.01
+            assert rel(F.leaky_relu(stages[i + 1], slope), torch.from_numpy(z['stage/stage_lrelu.%d' % i])) < 2e-6, i

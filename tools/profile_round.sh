@@ -7,7 +7,8 @@ O=gpurun_out/$R
 mkdir -p $O; cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 B="python bench.py --no-extra --no-cpu-baseline"
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- $B --steps 5 --warmup 1 > $O/bench_trace.log 2>&1
-python tools/rocpd_stats.py $O/trace/t_results.db $O/bench_kernel_stats.csv 48 $O/bench_last_forward.csv >> $O/bench_trace.log 2>&1
+python tools/rocpd_stats.py $O/trace/t_results.db $O/bench_kernel_stats.csv fwd:ttsc:: $O/bench_last_forward.csv >> $O/bench_trace.log 2>&1
+python tools/roofline_table.py $O/bench_last_forward.csv $O/roofline.md >> $O/bench_trace.log 2>&1
 # PMC passes: calibration off so that every forward of the run is the same launch sequence (3 forwards each)
 for P in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" "grbm:GRBM_COUNT GRBM_GUI_ACTIVE"; do
   N=${P%%:*}; C=${P#*:}

@@ -51,15 +51,19 @@ class Cubegan(nn.Module):
         self._loss_l1 = nn.L1Loss()
         self.automatic_optimization = False
 
-    def inference(self, X, return_lengths=False):
+    def inference(self, X, return_lengths=False, timers=None):
         """cubegan.py:74-83: text -> conditioning (predicted durations/pitch) -> waveform [B,1,L] in (-1,1).
         With a padded batch (B>1, new capability) `return_lengths=True` also returns each utterance's sample count."""
         with torch.no_grad():
-            cond, _, flens = self._languasito.inference(X, return_aux=True, check_status=False)
+            cond, _, flens = self._languasito.inference(X, return_aux=True, check_status=False, timers=timers)
             if cond.shape[1] == 0:
                 cond = torch.zeros((cond.shape[0], 1, cond.shape[2]), device=self.get_device())
                 flens = [1] * cond.shape[0]
             wav = self._generator(cond.permute(0, 2, 1).contiguous(), frames=flens if cond.shape[0] > 1 else None)
+            if timers is not None:   # phase boundaries for bench.py --mode e2e (see Languasito2.inference)
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                timers.append(('generator', ev))
         _lib.check_split_status('Cubegan.inference')   # the BiLSTM recurrences may run split over several workgroups
         if return_lengths:
             return wav, [self._generator.out_len(f) if f > 0 else 0 for f in flens]

@@ -479,10 +479,17 @@ class Languasito2(nn.Module):
             h = torch.cat([h, sel], dim=-1)
         return h.contiguous()
 
-    def inference(self, X, hf_cond=None, return_aux=False, check_status=True):
+    def inference(self, X, hf_cond=None, return_aux=False, check_status=True, timers=None):
         """modules.py:1001-1009.  X: 'x_char' long [B,N] (0 = pad), 'x_speaker' long [B,1].  Returns conditioning [B,F,80]
         (zero rows beyond each utterance's own frame count); X['y_frame2phone'] / X['y_pitch'] are (re)written like
-        the reference does."""
+        the reference does.  `timers` (optional list): (phase name, HIP event) pairs are appended at the phase boundaries
+        ('text' = phoneme-level stacks + duration head, 'alignment' = durations -> frame map + row expansion, 'frames' = frame-level
+        stacks) — bench.py --mode e2e reports them."""
+        def mark(name):
+            if timers is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                timers.append((name, ev))
         X.pop('y_frame2phone', None)
         dev = self._get_device()
         x_char = X['x_char'].to(dev)
@@ -490,13 +497,16 @@ class Languasito2(nn.Module):
         B, N = x_char.shape
         lengths = _char_lengths(X, x_char)
         with torch.no_grad():
+            mark('start')
             hcs = self._text_stack('t', x_char, x_speaker, lengths, X, hf_cond)
             hd = self._lstm('_dur_rnn')(hcs, lengths=lengths)
             out_dur = linear_hip(hd, self._dur_output.linear_layer.weight, self._dur_output.linear_layer.bias)
+            mark('text')
             # duration head -> frame->phone map on the device (the reference goes through the host here, modules.py:946-953)
             f2p = align_durations(out_dur, lengths)
             X['y_frame2phone'] = f2p
             hexp, flens = _expand_rows(hcs, f2p)
+            mark('alignment')
             F_ = hexp.shape[1]
             if F_ == 0:
                 X['y_pitch'] = torch.zeros((B, 0), device=dev)
@@ -515,6 +525,7 @@ class Languasito2(nn.Module):
             if B > 1:
                 fmask = (torch.arange(F_, device=dev)[None, :] < torch.as_tensor(flens, device=dev)[:, None]).float()
                 cond = cond * fmask[:, :, None]
+            mark('frames')
         if check_status:   # (Cubegan.inference polls once for the whole synthesis instead)
             _lib.check_split_status('Languasito2.inference')
         return (cond, f2p.durations(), flens) if return_aux else cond
