@@ -224,6 +224,12 @@ int ttsc_hifigan_get_activation_scale(const ttsc_hifigan* g, const char* layer_n
  * weights are uploaded first; the handle then counts as calibrated until its weights change. */
 int ttsc_hifigan_set_activation_scales(ttsc_hifigan* g, const char* const* layer_names, const float* scales, int32_t n);
 int32_t ttsc_hifigan_recalibrations(const ttsc_hifigan* g);
+/* Range guard mode: 1 (default) = every forward synchronises its stream, re-calibrates + reruns when tripped; 2 = deferred: forwards
+ * never wait, the guard word stays sticky on the device until ttsc_hifigan_range_status() (which synchronises `stream`) reads and
+ * clears it: 1 = some forward since the last call emitted a non-finite sample — its output must be discarded / recomputed —, 0 = all
+ * clean; 0 = guard off. */
+int ttsc_hifigan_set_range_check(ttsc_hifigan* g, int32_t mode);
+int32_t ttsc_hifigan_range_status(ttsc_hifigan* g, void* stream);
 int ttsc_hifigan_algorithmic_flops(const ttsc_hifigan* g, int32_t B, int64_t T, double* flops_out);
 void ttsc_hifigan_destroy(ttsc_hifigan* g);
 

@@ -3,8 +3,8 @@ cases; these run the shapes the metric is quoted on and check them against the o
 
   C3  WaveRNN decode, B = 256 utterances, H = 512, T = 100 frames = 24 000 autoregressive steps (cube/networks/modules.py:453-503):
       sample indices AND waveform bit-exact against oracle/wavernn_ref.c on utterances {0, 7, 128, 255} over the WHOLE decode (the
-      counter-based noise carries the utterance index, so the oracle runs those four alone); one two-layer net (the reference
-      class default, modules.py:392-400) on the streaming kernel.
+      counter-based noise carries the utterance index, so the oracle runs those four alone); the same for a two-layer net (the
+      reference class default, modules.py:392-400), also on the tile kernel.
   C5  per-GPU share of the end-to-end path: 64 ragged sentences (20..120 phonemes) through Cubegan.inference (cubegan.py:74-83):
       {shortest, longest, 2 random} against the meldecoder_ref -> hifigan_ref oracle chain (identical durations, <= 4 LSB int16),
       all 64 against their solo runs.
@@ -32,7 +32,7 @@ def _wavernn(H, N, sd):
     return net.cuda().eval()
 
 
-@pytest.mark.parametrize('N,T,check,kernel', [(1, 100, (0, 7, 128, 255), 'tile'), (2, 100, (3, 200), 'stream')])
+@pytest.mark.parametrize('N,T,check,kernel', [(1, 100, (0, 7, 128, 255), 'tile'), (2, 100, (3, 200), 'tile')])
 def test_c3_wavernn_b256_h512_full_length_bit_exact(N, T, check, kernel):
     B, H, seed = 256, 512, 0x5EED00C3
     sd = O.synthetic_state_dict(H=H, num_layers=N, use_lowres=True, seed=31 + N)

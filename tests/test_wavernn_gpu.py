@@ -78,7 +78,7 @@ def test_matches_oracle_bit_exact(H, N, lowres, B, T, mode, wr_kernel):
     ridx, rwav, rlog = O.decode(sd, mel, x_low if lowres else None, num_layers=N, H=H, use_lowres=lowres, upsample=up,
                                 mode=omode, noise=noise, seed=0xC0FFEE12345, want_logits=True)
     idx, wav, logits = net.decode(X, mode=mode, noise=noise, seed=0xC0FFEE12345, want_logits=True)
-    assert net.last_kernel == ('tile' if (wr_kernel == 'tile' and N == 1 and B <= 256) else 'stream')
+    assert net.last_kernel == ('tile' if (wr_kernel == 'tile' and N <= 2 and B <= 256) else 'stream')
     assert np.array_equal(idx.cpu().numpy(), ridx), 'first index mismatch at %s' % (np.argwhere(idx.cpu().numpy() != ridx)[:3],)
     assert np.array_equal(wav.cpu().numpy(), rwav)
     assert np.array_equal(logits.cpu().numpy(), rlog)  # logits themselves are bit-exact
@@ -188,12 +188,12 @@ def _cont_net(z):
 
 @pytest.mark.parametrize('name', CONT)
 def test_continuous_outputs_match_reference_and_oracle(golden_dir, name, wr_kernel):
-    """mol / gm / beta in the persistent kernels (tile kernel for one-layer nets, streaming kernel otherwise): with the reference's own random terms injected the samples follow the
+    """mol / gm / beta in the persistent kernels (tile kernel for one- and two-layer nets, streaming kernel otherwise): with the reference's own random terms injected the samples follow the
     reference run to 1e-5 (mixture index identical at every step) and equal the C oracle BIT FOR BIT (one shared arithmetic
     definition) in noise, Philox and arg-max mode; teacher-forced outputs vs the reference's _train_forward <= 1e-4."""
     z = np.load(os.path.join(golden_dir, name + '.npz'))
     net, sd, X, kw = _cont_net(z)
-    want_kernel = 'tile' if (wr_kernel == 'tile' and kw['num_layers'] == 1) else 'stream'
+    want_kernel = 'tile' if (wr_kernel == 'tile' and kw['num_layers'] <= 2) else 'stream'
     xl = z['x_low'] if kw['use_lowres'] else None
     if 'noise' in z.files:
         idx, wav, _ = net.decode(X, mode='noise', noise=z['noise'])
@@ -246,3 +246,14 @@ def test_default_kernel_choice_by_batch(monkeypatch):
         assert net.last_kernel == want
         ridx, _, _ = O.decode(sd, mel, x_low, num_layers=1, H=64, mode=O.MODE_PHILOX, seed=9)
         assert np.array_equal(idx.cpu().numpy(), ridx)
+    # two-layer networks (the reference class default) run on the tile kernel too; TTSC_WR_TILE2=0 is the A/B switch back
+    sd2 = O.synthetic_state_dict(H=128, num_layers=2, use_lowres=True, seed=78)
+    net2 = _net(128, 2, True, sd2)
+    mel, x_low = O.synthetic_inputs(11, 1, seed=5)
+    X = {'mel': torch.from_numpy(mel), 'x_low': torch.from_numpy(x_low)}
+    ridx, _, rlog = O.decode(sd2, mel, x_low, num_layers=2, H=128, mode=O.MODE_PHILOX, seed=3, want_logits=True)
+    idx, _, logits = net2.decode(X, mode='philox', seed=3, want_logits=True)
+    assert net2.last_kernel == 'tile' and np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(logits.cpu().numpy(), rlog)
+    monkeypatch.setenv('TTSC_WR_TILE2', '0')
+    idx, _, _ = net2.decode(X, mode='philox', seed=3)
+    assert net2.last_kernel == 'stream' and np.array_equal(idx.cpu().numpy(), ridx)

@@ -57,11 +57,13 @@ struct ttsc_hifigan {
     //   calib_mode 0 ("0"): all scales 1.
     // Every forward is guarded: conv_post raises a device word when it emits a non-finite sample (= an fp16 overflow anywhere
     // upstream, see conv_cout1_kernel); the forward then re-calibrates on the offending input and reruns, and only reports
-    // TTSC_ERANGE when the output is still non-finite (non-finite input or weights).  env TTSC_HIFIGAN_RANGE_CHECK=0 switches
-    // the guard (one stream synchronisation per forward) off.
+    // TTSC_ERANGE when the output is still non-finite (non-finite input or weights).  range_check: 1 = as described (one stream
+    // synchronisation per forward; default), 2 = deferred: the forward never waits, the guard word stays sticky on the device and
+    // ttsc_hifigan_range_status() reads and clears it whenever the caller can afford the synchronisation (pipelined callers whose
+    // host work for the next batch overlaps this forward), 0 = off (env TTSC_HIFIGAN_RANGE_CHECK).
     int calib_mode = 1;
     bool calibrated = false;
-    bool range_check = true;
+    int range_check = 1;
     int recalibrations = 0;          // forwards that tripped the guard and were rerun after re-calibration
     unsigned* flag_dev = nullptr;    // the guard word
     unsigned* flag_host = nullptr;   // pinned copy
@@ -120,7 +122,7 @@ extern "C" int ttsc_hifigan_create(const ttsc_hifigan_cfg* cfg, ttsc_hifigan** o
         const std::string v(ev);
         g->calib_mode = (v == "0" || v == "off") ? 0 : (v == "input" || v == "2") ? 2 : 1;
     }
-    if (const char* ev = getenv("TTSC_HIFIGAN_RANGE_CHECK")) g->range_check = atoi(ev) != 0;
+    if (const char* ev = getenv("TTSC_HIFIGAN_RANGE_CHECK")) g->range_check = atoi(ev);
     int rc = add_layer(g.get(), "conv_pre", cfg->num_mels, cfg->upsample_initial_channel, 7, 1, 3, 1, 0);
     if (rc) return rc;
     int ch = cfg->upsample_initial_channel;
@@ -366,6 +368,27 @@ extern "C" int ttsc_hifigan_set_activation_scales(ttsc_hifigan* g, const char* c
 
 extern "C" int32_t ttsc_hifigan_recalibrations(const ttsc_hifigan* g) { return g ? g->recalibrations : -1; }
 
+extern "C" int ttsc_hifigan_set_range_check(ttsc_hifigan* g, int32_t mode) {
+    TTSC_REQUIRE(g && mode >= 0 && mode <= 2, "ttsc_hifigan_set_range_check: mode must be 0 (off), 1 (synchronous) or 2 (deferred)");
+    g->range_check = mode;
+    return TTSC_OK;
+}
+
+// Deferred guard: 1 when any forward since the last call emitted a non-finite sample (the word is then cleared and the handle
+// marked un-calibrated, so the next forward calibrates afresh), 0 otherwise, < 0 on a HIP error.  Synchronises `stream`.
+extern "C" int32_t ttsc_hifigan_range_status(ttsc_hifigan* g, void* stream) {
+    if (!g) return TTSC_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemcpyAsync(g->flag_host, g->flag_dev, sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        set_error("ttsc_hifigan_range_status: reading the guard word failed");
+        return TTSC_EHIP;
+    }
+    if (*g->flag_host == 0u) return 0;
+    if (hipMemsetAsync(g->flag_dev, 0, sizeof(unsigned), s) != hipSuccess) return TTSC_EHIP;
+    g->calibrated = false;
+    return 1;
+}
+
 extern "C" int ttsc_hifigan_get_activation_scale(const ttsc_hifigan* g, const char* layer, float* out) {
     TTSC_REQUIRE(g && layer && out, "ttsc_hifigan_get_activation_scale: null argument");
     auto it = g->layers.find(layer);
@@ -377,8 +400,9 @@ extern "C" int ttsc_hifigan_get_activation_scale(const ttsc_hifigan* g, const ch
 extern "C" int ttsc_hifigan_forward_ragged(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, const int32_t* frames,
                                            float* wav, void* ws, size_t ws_bytes, void* stream) {
     TTSC_REQUIRE(g, "ttsc_hifigan_forward: null argument");
-    const bool guard = g->range_check && g->precision == TTSC_PREC_F16X3 && g->calib_mode != 0;   // (mode 0 is a measurement switch: scales stay 1)
     hipStream_t s = (hipStream_t)stream;
+    if (g->range_check == 2) return hifigan_run(g, mel, B, T, frames, wav, ws, ws_bytes, stream, nullptr);   // deferred: sticky word, see ttsc_hifigan_range_status
+    const bool guard = g->range_check == 1 && g->precision == TTSC_PREC_F16X3 && g->calib_mode != 0;   // (mode 0 is a measurement switch: scales stay 1)
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (guard) TTSC_HIP_CHECK(hipMemsetAsync(g->flag_dev, 0, sizeof(unsigned), s));
         int rc = hifigan_run(g, mel, B, T, frames, wav, ws, ws_bytes, stream, nullptr);

@@ -428,10 +428,12 @@ struct ttsc_wavernn {
     float* lc_b[3] = {nullptr, nullptr, nullptr};
     // host copies (torch layout) kept for the tile kernel's per-member packing
     std::vector<float> h_wih0, h_whh0, h_bih0, h_bhh0, h_wpre, h_bpre, h_wout, h_bout;
+    std::vector<float> h_wih1, h_whh1, h_bih1, h_bhh1;   // second GRU layer (the reference class default is num_layers = 2)
     float *c_whh = nullptr, *c_wih = nullptr, *c_bih = nullptr, *c_bhh = nullptr, *c_wpre = nullptr, *c_bpre = nullptr, *c_wout = nullptr,
           *c_bout = nullptr;
     float *q_whh = nullptr, *q_wih = nullptr, *q_bih = nullptr, *q_bhh = nullptr, *q_wpre = nullptr, *q_bpre = nullptr, *q_wout = nullptr,
           *q_bout = nullptr;   // tile kernel (wavernn_tile.hip): 8 row slices of every matrix
+    float *q_whh2 = nullptr, *q_wih2 = nullptr, *q_bih2 = nullptr, *q_bhh2 = nullptr;   // ... and of the second GRU layer
     bool tile_dirty = true;
     int last_kind = 0;         // 0 streaming kernel, 2 tile kernel
     unsigned* last_abort_word = nullptr;   // device word set by the tile kernel when a hand-off timed out
@@ -501,7 +503,8 @@ extern "C" void ttsc_wavernn_destroy(ttsc_wavernn* w) {
         if (w->b_hh[l]) (void)hipFree(w->b_hh[l]);
     }
     for (float* p : {w->wt_pre, w->b_pre, w->wt_out, w->b_out, w->lut, w->lc_w[0], w->lc_w[1], w->lc_w[2], w->lc_b[0], w->lc_b[1], w->lc_b[2],
-                     w->c_whh, w->c_wih, w->c_bih, w->c_bhh, w->c_wpre, w->c_bpre, w->c_wout, w->c_bout})
+                     w->c_whh, w->c_wih, w->c_bih, w->c_bhh, w->c_wpre, w->c_bpre, w->c_wout, w->c_bout, w->q_whh2, w->q_wih2, w->q_bih2, w->q_bhh2,
+                     w->q_whh, w->q_wih, w->q_bih, w->q_bhh, w->q_wpre, w->q_bpre, w->q_wout, w->q_bout})
         if (p) (void)hipFree(p);
     delete w;
 }
@@ -530,18 +533,22 @@ extern "C" int ttsc_wavernn_set_weight(ttsc_wavernn* w, const char* name, const 
             TTSC_REQUIRE(shape_is(shape, nd, {3 * H, in_l}), "ttsc_wavernn_set_weight: '%s' expects [%d,%d]", name, 3 * H, in_l);
             rc = (l == 0) ? upload_transposed(&w->wt_ih[l], host, 3 * H, in_l) : upload_packed4(&w->wt_ih[l], host, 3 * H, in_l);
             if (l == 0) w->h_wih0.assign(host, host + (size_t)3 * H * in_l);
+            if (l == 1) w->h_wih1.assign(host, host + (size_t)3 * H * in_l);
         } else if (k == "weight_hh_l0") {
             TTSC_REQUIRE(shape_is(shape, nd, {3 * H, H}), "ttsc_wavernn_set_weight: '%s' expects [%d,%d]", name, 3 * H, H);
             rc = upload_packed4(&w->wt_hh[l], host, 3 * H, H);
             if (l == 0) w->h_whh0.assign(host, host + (size_t)3 * H * H);
+            if (l == 1) w->h_whh1.assign(host, host + (size_t)3 * H * H);
         } else if (k == "bias_ih_l0") {
             TTSC_REQUIRE(shape_is(shape, nd, {3 * H}), "ttsc_wavernn_set_weight: '%s' expects [%d]", name, 3 * H);
             rc = upload(&w->b_ih[l], host, 3 * H);
             if (l == 0) w->h_bih0.assign(host, host + 3 * H);
+            if (l == 1) w->h_bih1.assign(host, host + 3 * H);
         } else if (k == "bias_hh_l0") {
             TTSC_REQUIRE(shape_is(shape, nd, {3 * H}), "ttsc_wavernn_set_weight: '%s' expects [%d]", name, 3 * H);
             rc = upload(&w->b_hh[l], host, 3 * H);
             if (l == 0) w->h_bhh0.assign(host, host + 3 * H);
+            if (l == 1) w->h_bhh1.assign(host, host + 3 * H);
         } else {
             TTSC_REQUIRE(false, "ttsc_wavernn_set_weight: unknown key '%s'", name);
         }
@@ -582,7 +589,9 @@ extern "C" int ttsc_wavernn_set_weight(ttsc_wavernn* w, const char* name, const 
 // ---- tile path (wavernn_tile.hip): 8 workgroups step 8 utterances, each owning 1/8 of the rows -------------
 static size_t tile_lds_bytes(const ttsc_wavernn* w) {
     const auto& c = w->cfg;
-    return ((size_t)c.H * 32 + (size_t)256 * 32 + (size_t)WT_NC * (c.H + 4) + (size_t)WT_NC * 260 + (size_t)3 * (c.H / WT_NC) * WT_NC + 64 + (size_t)3 * (c.H / WT_NC) + 64) * sizeof(float);
+    size_t n = (size_t)c.H * 32 + (size_t)256 * 32 + (size_t)WT_NC * (c.H + 4) + (size_t)WT_NC * 260 + (size_t)3 * (c.H / WT_NC) * WT_NC + 64 + (size_t)3 * (c.H / WT_NC) + 64;
+    if (c.num_layers == 2) n += (size_t)WT_NC * (c.H + 4) + (size_t)3 * (c.H / WT_NC) * WT_NC + (size_t)6 * (c.H / WT_NC);   // h2 vector, W_hh2 h2 products, b_ih2 | b_hh2
+    return n * sizeof(float);
 }
 
 static bool tile_supported(const ttsc_wavernn* w, int B) {
@@ -591,7 +600,11 @@ static bool tile_supported(const ttsc_wavernn* w, int B) {
     // env TTSC_WR_TILE=0 forces the streaming kernel.  Bit-exact either way.  Measurements: DESIGN.md.
     const char* ev = getenv("TTSC_WR_TILE");
     if (ev && atoi(ev) == 0) return false;
-    if (c.num_layers != 1 || c.H % (4 * WT_NC) != 0 || c.H > 512 || c.S > 256) return false;
+    if (c.num_layers > 2 || c.H % (4 * WT_NC) != 0 || c.H > 512 || c.S > 256) return false;
+    if (c.num_layers == 2) {
+        const char* e2 = getenv("TTSC_WR_TILE2");   // A/B switch: two-layer nets back on the streaming kernel
+        if (e2 && atoi(e2) == 0) return false;
+    }
     if (c.out_kind < 2 && c.S % WT_NC != 0) return false;   // (continuous heads: S = 30 / 2, padded to 32 / 8 rows)
     if (tile_lds_bytes(w) > 160 * 1024) return false;
     const int G = (int)ceil_div(B, WT_NC);
@@ -603,7 +616,7 @@ static bool tile_supported(const ttsc_wavernn* w, int B) {
 // granules (8 bytes) of the exchange area of G tiles + the abort word
 static size_t tile_exchange_granules(const ttsc_wavernn* w, int G) {
     const auto& c = w->cfg;
-    return (size_t)G * 2 * ((size_t)WT_NC * c.H + (size_t)WT_NC * 256 + (size_t)WT_NC * round_up(c.S, WT_NC) + WT_NC);
+    return (size_t)G * 2 * ((size_t)c.num_layers * WT_NC * c.H + (size_t)WT_NC * 256 + (size_t)WT_NC * round_up(c.S, WT_NC) + WT_NC);
 }
 static size_t tile_exchange_bytes(const ttsc_wavernn* w, int B) {
     return tile_exchange_granules(w, (int)ceil_div(B, WT_NC)) * 8 + 256;
@@ -645,6 +658,24 @@ static int tile_pack(ttsc_wavernn* w) {
     if ((rc = upload(&w->q_bpre, bpre.data(), bpre.size()))) return rc;
     if ((rc = upload(&w->q_wout, wout.data(), wout.size()))) return rc;
     if ((rc = upload(&w->q_bout, bout.data(), bout.size()))) return rc;
+    if (c.num_layers == 2) {   // second GRU layer: input = h1 (K = H), same member slices and packing
+        std::vector<float> whh2((size_t)NC * H * R3), wih2((size_t)NC * H * R3), bih2((size_t)NC * R3), bhh2((size_t)NC * R3);
+        for (int m = 0; m < NC; ++m)
+            for (int q = 0; q < 3; ++q)
+                for (int j = 0; j < UPW; ++j) {
+                    const int row = q * H + m * UPW + j, lr = q * UPW + j;
+                    for (int k = 0; k < H; ++k) {
+                        whh2[(size_t)m * H * R3 + ((size_t)(k >> 2) * R3 + lr) * 4 + (k & 3)] = w->h_whh1[(size_t)row * H + k];
+                        wih2[(size_t)m * H * R3 + ((size_t)(k >> 2) * R3 + lr) * 4 + (k & 3)] = w->h_wih1[(size_t)row * H + k];
+                    }
+                    bih2[(size_t)m * R3 + lr] = w->h_bih1[row];
+                    bhh2[(size_t)m * R3 + lr] = w->h_bhh1[row];
+                }
+        if ((rc = upload(&w->q_whh2, whh2.data(), whh2.size()))) return rc;
+        if ((rc = upload(&w->q_wih2, wih2.data(), wih2.size()))) return rc;
+        if ((rc = upload(&w->q_bih2, bih2.data(), bih2.size()))) return rc;
+        if ((rc = upload(&w->q_bhh2, bhh2.data(), bhh2.size()))) return rc;
+    }
     w->tile_dirty = false;
     return TTSC_OK;
 }
@@ -763,9 +794,11 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
         qa.mel = mel; qa.interp = a.interp; qa.feats = a.feats;
         qa.whh = w->q_whh; qa.wih = w->q_wih; qa.bih = w->q_bih; qa.bhh = w->q_bhh;
         qa.wpre = w->q_wpre; qa.bpre = w->q_bpre; qa.wout = w->q_wout; qa.bout = w->q_bout;
+        qa.whh2 = w->q_whh2; qa.wih2 = w->q_wih2; qa.bih2 = w->q_bih2; qa.bhh2 = w->q_bhh2; qa.NL = c.num_layers;
         qa.lut = w->lut; qa.noise = noise; qa.forced_x = forced_x; qa.out_idx = idx; qa.out_wav = wav; qa.out_logits = logits;
         u64* f = (u64*)xbase;
         qa.xh = f; f += (size_t)G * 2 * BU * c.H;
+        if (c.num_layers == 2) { qa.xh2 = f; f += (size_t)G * 2 * BU * c.H; }
         qa.xpre = f; f += (size_t)G * 2 * BU * 256;
         qa.xlog = f; f += (size_t)G * 2 * BU * round_up(c.S, NC);
         qa.xlx = f; f += (size_t)G * 2 * BU;
@@ -779,8 +812,10 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
         const size_t lds = tile_lds_bytes(w);
         if (lds > 64 * 1024) {
             // full 160 KiB once per (device, kernel): a later model with a larger H, or a second device, needs no re-arming
-            if (int rc = ensure_full_lds((const void*)wr_tile_kernel<false>)) return rc;
-            if (int rc = ensure_full_lds((const void*)wr_tile_kernel<true>)) return rc;
+            if (int rc = ensure_full_lds((const void*)wr_tile_kernel<false, false>)) return rc;
+            if (int rc = ensure_full_lds((const void*)wr_tile_kernel<true, false>)) return rc;
+            if (int rc = ensure_full_lds((const void*)wr_tile_kernel<false, true>)) return rc;
+            if (int rc = ensure_full_lds((const void*)wr_tile_kernel<true, true>)) return rc;
         }
 #ifdef TTSC_ABLATE
         unsigned long long* prof_dev = nullptr;
@@ -790,10 +825,17 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
             qa.prof = prof_dev;
         }
 #endif
-        if (c.out_kind >= 2)
-            hipLaunchKernelGGL(wr_tile_kernel<true>, dim3(qa.GP * NC), dim3(WT_THREADS), lds, s, qa);
-        else
-            hipLaunchKernelGGL(wr_tile_kernel<false>, dim3(qa.GP * NC), dim3(WT_THREADS), lds, s, qa);
+        const dim3 tg(qa.GP * NC), tb(WT_THREADS);
+        if (c.num_layers == 2) {
+            if (c.out_kind >= 2)
+                hipLaunchKernelGGL((wr_tile_kernel<true, true>), tg, tb, lds, s, qa);
+            else
+                hipLaunchKernelGGL((wr_tile_kernel<false, true>), tg, tb, lds, s, qa);
+        } else if (c.out_kind >= 2) {
+            hipLaunchKernelGGL((wr_tile_kernel<true, false>), tg, tb, lds, s, qa);
+        } else {
+            hipLaunchKernelGGL((wr_tile_kernel<false, false>), tg, tb, lds, s, qa);
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             set_error("wr_tile_kernel launch failed: %s", hipGetErrorString(e));

@@ -104,6 +104,11 @@ struct WtArgs {
     const float* bpre;     // [NC][32]
     const float* wout;     // rows = 32 (first SR = SP/NC real, rest zero), K = 256; SP = S rounded up to a multiple of NC (rows >= S zero)
     const float* bout;     // [NC][32]
+    // second GRU layer (NL == 2; input = h1, K = H): same member slices and packing as whh
+    const float* whh2;
+    const float* wih2;
+    const float* bih2;     // [NC][3*UPW]
+    const float* bhh2;     // [NC][3*UPW]
     const float* lut;
     const float* noise;    // [B, L, S] or null
     const float* forced_x; // [B, L] or null
@@ -112,11 +117,12 @@ struct WtArgs {
     float* out_logits;
     // exchange area (device memory, zeroed before the launch), per tile g, in granules
     u64* xh;               // [G][2][H][8]
+    u64* xh2;              // [G][2][H][8]   state of the second layer (NL == 2)
     u64* xpre;             // [G][2][256][8]
     u64* xlog;             // [G][2][8][SP]
     u64* xlx;              // [G][2][8]
     unsigned* abort_word;
-    int B, T, Tl, H, UPW, I0, I0P, use_lowres, up, up_low, S, SP, SR, n_mel, out_kind, mode, L, G, GP;
+    int B, T, Tl, H, UPW, I0, I0P, use_lowres, up, up_low, S, SP, SR, n_mel, out_kind, mode, L, G, GP, NL;
     unsigned long long seed;
     unsigned long long* prof;   // -DTTSC_ABLATE: [workgroup][16] accumulated 100 MHz ticks per segment (thread 0), or null
 };
@@ -266,6 +272,36 @@ __device__ __forceinline__ void mfma_chain_g(f32x4_t (&acc)[NB], const float4* w
     }
 }
 
+// One 64-row block of a member's (3*UPW rows) x (8 utterances) product  out[row][utt] = bias[row] + sum_k W[row][k] v[utt][k]  on one
+// wave: two 4-utterance accumulators per lane, weights streamed from global memory.  NOT inlined on purpose: the two-layer kernel
+// runs three such products per step and three inlined copies of the software-pipelined chain (two register sets of weight words
+// each) push the kernel ~90 VGPRs into scratch; one out-of-line copy keeps it in registers.
+// bias / v / out live in LDS: typed as address-space-3 pointers so that the out-of-line body still uses ds_read / ds_write (a generic
+// pointer would turn every h read of the chain into a flat load).
+typedef __attribute__((address_space(3))) float lds_float;
+typedef __attribute__((address_space(1))) float glb_float;   // (likewise global: a generic pointer would make the weight stream flat loads,
+                                                             // whose lgkmcnt accounting serialises them with the LDS reads of the chain)
+__device__ __noinline__ void wt_row_block(const glb_float* W_g, const lds_float* bias_l, const lds_float* v_l, lds_float* out_l, int r0,
+                                         int R3, int VH, int H, int BU) {
+    const float* W = (const float*)W_g;
+    const float* bias = (const float*)bias_l;
+    const float* v = (const float*)v_l;
+    float* out = (float*)out_l;
+    const int lane = threadIdx.x & 63;
+    const int mrow = 4 * (lane >> 2), mutt = lane & 3;
+    f32x4_t acc[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[nb][i] = bias[min(r0 + mrow + i, R3 - 1)];
+    mfma_chain_g<2, 8>(acc, reinterpret_cast<const float4*>(W) + min(r0 + lane, R3 - 1), R3, v + mutt * VH, VH, H);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (r0 + mrow + i < R3) out[(r0 + mrow + i) * BU + mutt + 4 * nb] = acc[nb][i];
+}
+
 #ifdef TTSC_ABLATE
 #define WT_TICK(i)                                                     \
     do {                                                               \
@@ -280,8 +316,12 @@ __device__ __forceinline__ void mfma_chain_g(f32x4_t (&acc)[NB], const float4* w
 #endif
 
 // CONT: continuous output head (MOL / Gaussian / Beta) — a separate instantiation, so that the discrete kernel does not carry
-// the samplers' registers
-template <bool CONT>
+// the samplers' registers.
+// L2: two GRU layers (the reference class default, cube/networks/modules.py:392-400).  Member m also owns its H/8 units of the
+// second layer.  Per step the second layer adds ONE product to the critical path — W_ih2 . h1_t, which needs this step's h1 —
+// and one hand-off (h2_t); its recurrent product W_hh2 . h2_{t-1} rides with W_hh1 . h1_{t-1} on waves 1..3 behind the tail of
+// the previous step.  All three products stream their member slice from L2 / Infinity Cache (1.18 MB per member and step).
+template <bool CONT, bool L2>
 __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
     constexpr int NC = WT_NC, BU = WT_NC, PR = 256 / WT_NC;   // PR = 32 pre-output rows per member
     // LDS: wpre[H/4][32][4] | wout[64][32][4] | hvec[BU][VH] | pvec[BU][VP] | gbuf[3*UPW][BU] | bias[32 + 32 + 3*UPW] | tail_fail, pre_ready
@@ -303,6 +343,12 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
     int* tail_fail = reinterpret_cast<int*>(biasL + 64 + R3);
     int* pre_ready = tail_fail + 1;   // helper waves that have staged the pre-output vector (monotonic)
     float* ybuf = reinterpret_cast<float*>(tail_fail + 4);   // [32]: the output values of utterance m (continuous heads)
+    // second layer: h2 vector of the 8 utterances | W_hh2 h2 products | b_ih2, b_hh2   (W_ih2 h1 products reuse gbuf: the
+    // first layer's gate math has consumed it by then)
+    float* hvec2 = ybuf + 60;
+    float* gbuf2 = hvec2 + (size_t)BU * VH;
+    float* bias2 = gbuf2 + (size_t)R3 * BU;   // bih2[R3] | bhh2[R3]
+    float* hvecT = L2 ? hvec2 : hvec;         // what the tail (pre-output layer) reads: the LAST layer's state
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int u = tid % BU;            // utterance slot (element-wise work)
     const int j = tid / BU;            // local hidden unit
@@ -335,7 +381,11 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
     const int nblk = (R3 + 63) >> 6;
     float pmel[3] = {0, 0, 0}, plow[3] = {0, 0, 0};
     float hprev = 0.f;   // h_{t-1}[unit m*UPW + j][utterance u]: each (unit, utterance) has exactly one owner thread
+    float hprev2 = 0.f;  // the same for the second layer
     u64* xh = a.xh + (size_t)g * 2 * BU * H;
+    u64* xh2 = L2 ? a.xh2 + (size_t)g * 2 * BU * H : nullptr;
+    const float* Whh2 = L2 ? a.whh2 + (size_t)m * H * R3 : nullptr;
+    const float* Wih2 = L2 ? a.wih2 + (size_t)m * H * R3 : nullptr;
     u64* xpre = a.xpre + (size_t)g * 2 * BU * 256;
     u64* xlog = a.xlog + (size_t)g * 2 * BU * SP;
     u64* xlx = a.xlx + (size_t)g * 2 * BU;
@@ -354,6 +404,10 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
         if (tid == 0) {
             *tail_fail = 0;
             *pre_ready = 0;
+        }
+        if (L2) {
+            for (int i = tid; i < BU * VH; i += WT_THREADS) hvec2[i] = 0.f;
+            for (int i = tid; i < 2 * R3; i += WT_THREADS) bias2[i] = i < R3 ? a.bih2[(size_t)m * R3 + i] : a.bhh2[(size_t)m * R3 + i - R3];
         }
     }
     __syncthreads();
@@ -386,7 +440,7 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
             f32x4_t acc[1];
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[0][i] = bpre_m[trow + i];
-            mfma_chain<1, 4>(acc, reinterpret_cast<const float4*>(wpreL) + (lane & 31), PR, hvec + tutt * VH, 0, H);
+            mfma_chain<1, 4>(acc, reinterpret_cast<const float4*>(wpreL) + (lane & 31), PR, hvecT + tutt * VH, 0, H);
 #pragma unroll
             for (int i = 0; i < 4; ++i) st_granule(xpre + ((size_t)par * 256 + m * PR + trow + i) * BU + tutt, ttsc_tanhf(acc[0][i]), tag);
         }
@@ -503,17 +557,22 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
             if (t > 0) stage_pre(t - 1);
         } else if (wave - 1 < nblk) {
             const int r0 = (wave - 1) * 64;
-            f32x4_t acc[2];
+            if (L2) {   // (two-layer kernel: out-of-line block, see wt_row_block) recurrent products of BOTH layers for this step
+                wt_row_block((const glb_float*)Whh, (const lds_float*)bhh_m, (const lds_float*)hvec, (lds_float*)gbuf, r0, R3, VH, H, BU);
+                wt_row_block((const glb_float*)Whh2, (const lds_float*)(bias2 + R3), (const lds_float*)hvec2, (lds_float*)gbuf2, r0, R3, VH, H, BU);
+            } else {
+                f32x4_t acc[2];
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+                for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[nb][i] = bhh_m[min(r0 + mrow + i, R3 - 1)];
-            mfma_chain_g<2, 8>(acc, reinterpret_cast<const float4*>(Whh) + min(r0 + lane, R3 - 1), R3, hvec + mutt * VH, VH, H);
+                    for (int i = 0; i < 4; ++i) acc[nb][i] = bhh_m[min(r0 + mrow + i, R3 - 1)];
+                mfma_chain_g<2, 8>(acc, reinterpret_cast<const float4*>(Whh) + min(r0 + lane, R3 - 1), R3, hvec + mutt * VH, VH, H);
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+                for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (r0 + mrow + i < R3) gbuf[(r0 + mrow + i) * BU + mutt + 4 * nb] = acc[nb][i];
+                    for (int i = 0; i < 4; ++i)
+                        if (r0 + mrow + i < R3) gbuf[(r0 + mrow + i) * BU + mutt + 4 * nb] = acc[nb][i];
+            }
         }
         // ---- cached prefixes of the layer-0 input chain (same order as wavernn.hip: mel | low-res feats | interp | last_x) ----
         if (gru_thr) {
@@ -586,6 +645,48 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
         }
         if (__syncthreads_or((!ok) || *tail_fail)) return;   // also publishes hvec
         WT_TICK(3);
+        if (L2) {
+            // ---- second layer, critical part: W_ih2 . h1_t  (needs this step's h1; 3*UPW rows x 8 utterances on waves 1..3) ----
+            if (wave >= 1 && wave - 1 < nblk) wt_row_block((const glb_float*)Wih2, (const lds_float*)bias2, (const lds_float*)hvec, (lds_float*)gbuf, (wave - 1) * 64, R3, VH, H, BU);   // (gbuf is free: the first layer's gates are done)
+            __syncthreads();
+            // ---- gate math of the second layer, h2_t hand-off and staging ----
+            if (gru_thr) {
+                float gi[3], gh[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    gi[q] = gbuf[(q * UPW + j) * BU + u];
+                    gh[q] = gbuf2[(q * UPW + j) * BU + u];
+                }
+                const float r = ttsc_sigmoidf(gi[0] + gh[0]);
+                const float z = ttsc_sigmoidf(gi[1] + gh[1]);
+                const float rg = r * gh[2];
+                const float nn = ttsc_tanhf(gi[2] + rg);
+                const float d = hprev2 - nn;
+                hprev2 = fmaf(z, d, nn);
+                st_granule(xh2 + ((size_t)par * H + m * UPW + j) * BU + u, hprev2, (unsigned)t + 1u);
+            }
+            {
+                const u64* src = xh2 + (size_t)par * H * BU;
+                for (int i0 = tid; i0 < BU * H; i0 += 8 * WT_THREADS) {
+                    if (i0 + 7 * WT_THREADS < BU * H) {
+                        float v[8];
+                        ok = ld_granules<8>(src + i0, WT_THREADS, (unsigned)t + 1u, v, a.abort_word) && ok;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const int i = i0 + r * WT_THREADS;
+                            hvec2[(i & 7) * VH + (i >> 3)] = v[r];
+                        }
+                    } else {
+                        for (int i = i0; i < BU * H; i += WT_THREADS) {
+                            float v[1];
+                            ok = ld_granules<1>(src + i, 1, (unsigned)t + 1u, v, a.abort_word) && ok;
+                            hvec2[(i & 7) * VH + (i >> 3)] = v[0];
+                        }
+                    }
+                }
+            }
+            if (__syncthreads_or(!ok)) return;   // publishes hvec2
+        }
         if (++fr_phase == a.up) { fr_phase = 0; ++fr; }
         if (++lo_phase == a.up_low) { lo_phase = 0; ++lo; }
     }

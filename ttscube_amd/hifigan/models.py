@@ -220,10 +220,14 @@ class Generator(nn.Module):
         _lib.check(_lib.lib().ttsc_hifigan_algorithmic_flops(self._handle, B, T, C.byref(out)), 'algorithmic_flops')
         return out.value
 
-    def forward(self, x, frames=None):
+    def forward(self, x, frames=None, check='sync'):
         """x: [B, num_mels, T] fp32 on a HIP device -> [B, 1, L].  frames (optional, list[int] per utterance): valid mel
         frames of a padded batch — every layer then masks beyond the utterance's own length, so
-        y[b, 0, :out_len(frames[b])] equals that utterance run alone (ragged batching; not in the reference, B=1)."""
+        y[b, 0, :out_len(frames[b])] equals that utterance run alone (ragged batching; not in the reference, B=1).
+        check: the split-precision range guard — 'sync' (default): this call waits for its own result and, if a non-finite sample
+        came out, re-calibrates and reruns by itself; 'deferred': no wait — the previous deferred call's verdict is collected at
+        the start of this one (raises if it was bad), the last one's by `finish_range_check()`: for pipelined callers whose host
+        work for the next batch overlaps the generator."""
         if not x.is_cuda:
             raise _lib.TTSCError('Generator.forward: input must live on a HIP device (got %s); no CPU path' % x.device)
         # differentiable path only when a gradient is actually wanted: the input carries one, or the module is in training mode.
@@ -231,11 +235,32 @@ class Generator(nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or (self.training and any(p.requires_grad for p in self.parameters()))):
             from .autograd import generator_forward_with_grad
             return generator_forward_with_grad(self, x)
-        return self._forward_hip(x, frames)
+        return self._forward_hip(x, frames, check)
 
-    def _forward_hip(self, x, frames=None):
+    def finish_range_check(self):
+        """collect the verdict of the deferred range guard (synchronises the current stream); raises if a forward since the last
+        collection emitted non-finite audio"""
+        if self._handle is None or not getattr(self, '_deferred_pending', False):
+            return
+        self._deferred_pending = False
+        st = int(_lib.lib().ttsc_hifigan_range_status(self._handle, _lib.current_stream()))
+        if st < 0:
+            _lib.check(st, 'ttsc_hifigan_range_status')
+        if st:
+            raise _lib.TTSCError('Generator: a forward run with check="deferred" produced non-finite audio (an activation left the fp16 range its '
+                                 'pre-scale was calibrated for, or the input was non-finite); rerun that batch with check="sync"')
+
+    def _forward_hip(self, x, frames=None, check='sync'):
         L = _lib.lib()
         self._sync()
+        assert check in ('sync', 'deferred', None)
+        with torch.cuda.device(x.device):
+            self.finish_range_check()             # (verdict of the previous deferred call, before anything new is enqueued)
+        mode = {'sync': 1, 'deferred': 2, None: 0}[check]
+        if mode != getattr(self, '_range_mode', 1):
+            _lib.check(L.ttsc_hifigan_set_range_check(self._handle, mode), 'ttsc_hifigan_set_range_check')
+            self._range_mode = mode
+        self._deferred_pending = mode == 2
         x = x.detach().float().contiguous()
         B, _, T = x.shape
         Lout = self.out_len(T)

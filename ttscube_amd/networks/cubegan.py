@@ -51,7 +51,7 @@ class Cubegan(nn.Module):
         self._loss_l1 = nn.L1Loss()
         self.automatic_optimization = False
 
-    def inference(self, X, return_lengths=False, timers=None):
+    def inference(self, X, return_lengths=False, timers=None, check='sync'):
         """cubegan.py:74-83: text -> conditioning (predicted durations/pitch) -> waveform [B,1,L] in (-1,1).
         With a padded batch (B>1, new capability) `return_lengths=True` also returns each utterance's sample count."""
         with torch.no_grad():
@@ -59,7 +59,9 @@ class Cubegan(nn.Module):
             if cond.shape[1] == 0:
                 cond = torch.zeros((cond.shape[0], 1, cond.shape[2]), device=self.get_device())
                 flens = [1] * cond.shape[0]
-            wav = self._generator(cond.permute(0, 2, 1).contiguous(), frames=flens if cond.shape[0] > 1 else None)
+            # check: the generator's split-precision range guard ('sync' waits for this batch and reruns it if needed; 'deferred' lets a
+            # pipelined caller keep the host ahead of the GPU — see hifigan.models.Generator.forward)
+            wav = self._generator(cond.permute(0, 2, 1).contiguous(), frames=flens if cond.shape[0] > 1 else None, check=check)
             if timers is not None:   # phase boundaries for bench.py --mode e2e (see Languasito2.inference)
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record()
