@@ -56,6 +56,8 @@ typedef struct {
     int32_t padding;
     int32_t dilation;    /* ConvTranspose1d: must be 1 */
     int32_t transposed;  /* 0 = Conv1d (weight [Cout,Cin,K]), 1 = ConvTranspose1d (weight [Cin,Cout,K]) */
+    int32_t groups;      /* Conv1d only: torch's `groups` (weight [Cout, Cin/groups, K]); 0 or 1 = dense.  TTSC_PREC_FP32 only — the
+                          * grouped k=41 layers of the multi-scale discriminator (training, row f1) */
 } ttsc_conv1d_cfg;
 
 enum { TTSC_ACT_NONE = 0, TTSC_ACT_TANH = 1, TTSC_ACT_RELU = 2, TTSC_ACT_SIGMOID = 3 };
@@ -162,6 +164,11 @@ size_t ttsc_gan_loss_workspace_bytes(int32_t nseg);
 int ttsc_gan_loss(int32_t kind, int32_t nseg, const void* const* a_dev, const void* const* b_dev, void* const* ga_dev, void* const* gb_dev,
                   const int64_t* numel, const float* weight, float target, float* out_dev, void* ws_dev, size_t ws_bytes, void* stream);
 size_t ttsc_conv_wgrad_workspace_bytes(int32_t N, int32_t A, int32_t B, int64_t LP, int32_t J);
+/* grouped variant (torch Conv1d groups): P [N,A,LP], Q [N,groups*Bg,LQ], G [A,Bg,J] — row a only meets the Bg channels of its own
+ * group.  Workspace: ttsc_conv_wgrad_workspace_bytes(N, A, Bg, LP, J). */
+int ttsc_conv_wgrad_grouped(const float* p_dev, const float* q_dev, float* g_dev, int32_t N, int32_t A, int32_t Bg, int32_t groups, int64_t LP,
+                            int64_t LQ, int32_t J, int32_t base, int32_t step, float q_scale, float q_slope, void* ws_dev, size_t ws_bytes,
+                            void* stream);
 int ttsc_conv_wgrad(const float* p_dev, const float* q_dev, float* g_dev, int32_t N, int32_t A, int32_t B, int64_t LP, int64_t LQ,
                     int32_t J, int32_t base, int32_t step, float q_scale, float q_slope, void* ws_dev, size_t ws_bytes, void* stream);
 

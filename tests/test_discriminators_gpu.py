@@ -1,0 +1,108 @@
+"""GPU: the HiFi-GAN discriminators on the HIP convolution kernels (hifigan/disc_hip.py) against their
+torch-op formulation (hifigan/discriminators.py): strided / grouped Conv1d values and gradients, MPD and MSD outputs, feature maps
+and parameter gradients."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+@pytest.mark.parametrize('Cin,Cout,K,s,p,G,N,L', [
+    (1, 32, 5, 3, 2, 1, 6, 601), (32, 128, 5, 3, 2, 1, 4, 200), (512, 1024, 5, 3, 2, 1, 3, 70), (1024, 1024, 5, 1, 2, 1, 2, 30),
+    (128, 128, 41, 2, 20, 4, 2, 1500), (128, 256, 41, 2, 20, 16, 2, 700), (256, 512, 41, 4, 20, 16, 2, 401), (512, 1024, 41, 4, 20, 16, 1, 200),
+    (256, 256, 41, 1, 20, 16, 2, 150), (64, 128, 7, 1, 3, 2, 2, 333), (48, 48, 3, 2, 1, 3, 3, 100), (1024, 1, 3, 1, 1, 1, 2, 40), (1, 128, 15, 1, 7, 1, 2, 900),
+])
+def test_strided_grouped_conv_matches_torch(Cin, Cout, K, s, p, G, N, L):
+    from ttscube_amd.hifigan.disc_hip import HipStridedConv
+    g = torch.Generator().manual_seed(Cin + Cout + K + s)
+    x = torch.randn(N, Cin, L, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(Cout, Cin // G, K, generator=g) / (Cin // G * K) ** 0.5).cuda().requires_grad_(True)
+    b = (torch.randn(Cout, generator=g) * 0.1).cuda().requires_grad_(True)
+    for slope in (1.0, 0.1):
+        ref = F.conv1d(F.leaky_relu(x, slope) if slope != 1.0 else x, w, b, stride=s, padding=p, groups=G)
+        h = HipStridedConv(Cin, Cout, K, s, p, G)
+        y = h(x, w, b, in_slope=slope)
+        assert y.shape == ref.shape and _rel(y, ref) < 3e-6, (slope, tuple(y.shape), tuple(ref.shape))
+        gy = torch.randn(ref.shape, generator=g).cuda()
+        g0 = torch.autograd.grad(ref, (x, w, b), gy)
+        g1 = torch.autograd.grad(y, (x, w, b), gy)
+        for u, v, name in zip(g1, g0, 'xwb'):
+            assert u.shape == v.shape and _rel(u, v) < 1e-5, (name, slope, _rel(u, v))
+
+
+@pytest.mark.parametrize('Cin,Cout,K,s,pad,P,B,H', [(1, 32, 5, 3, 2, 2, 3, 500), (32, 128, 5, 3, 2, 3, 2, 201), (128, 512, 5, 3, 2, 11, 2, 61),
+                                                     (512, 1024, 5, 3, 2, 7, 2, 23), (1024, 1024, 5, 1, 2, 5, 2, 9), (1024, 1, 3, 1, 1, 11, 2, 6)])
+def test_period_folded_conv_matches_conv2d(Cin, Cout, K, s, pad, P, B, H):
+    """MPD's Conv2d((K, 1), (s, 1)) on [B, C, H, P] == the dilation-P Conv1d on the flat [B, C, H * P] signal"""
+    from ttscube_amd.hifigan.disc_hip import HipStridedConv
+    g = torch.Generator().manual_seed(Cin + P)
+    x = torch.randn(B, Cin, H, P, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(Cout, Cin, K, 1, generator=g) / (Cin * K) ** 0.5).cuda().requires_grad_(True)
+    b = (torch.randn(Cout, generator=g) * 0.1).cuda().requires_grad_(True)
+    ref = F.conv2d(F.leaky_relu(x, 0.1), w, b, stride=(s, 1), padding=(pad, 0))
+    y = HipStridedConv(Cin, Cout, K, s, pad, period=P)(x.flatten(2), w.squeeze(-1), b, in_slope=0.1).view(B, Cout, -1, P)
+    assert y.shape == ref.shape and _rel(y, ref) < 3e-6
+    gy = torch.randn(ref.shape, generator=g).cuda()
+    for u, v, name in zip(torch.autograd.grad(y, (x, w, b), gy), torch.autograd.grad(ref, (x, w, b), gy), 'xwb'):
+        assert u.shape == v.shape and _rel(u, v) < 1e-5, (name, _rel(u, v))
+
+
+def test_group_shapes_that_do_not_tile_are_rejected():
+    from ttscube_amd._lib import TTSCError
+    from ttscube_amd.hifigan.disc_hip import HipStridedConv
+    with pytest.raises(TTSCError, match='per group'):
+        HipStridedConv(64, 96, 7, 1, 3, 2)        # 48 output channels per group: neither a multiple nor a divisor of a 32-row tile
+
+
+@pytest.mark.parametrize('which', ['mpd', 'msd'])
+def test_native_discriminators_match_torch_modules(which):
+    from ttscube_amd.hifigan import discriminators as D
+    from ttscube_amd.hifigan import disc_hip as H
+    torch.manual_seed(7)
+    m = (D.MultiPeriodDiscriminator() if which == 'mpd' else D.MultiScaleDiscriminator()).cuda()
+    B, T = 2, 6000
+    g = torch.Generator().manual_seed(8)
+    y = (torch.rand(B, 1, T, generator=g) - 0.5).cuda()
+    y_hat = (torch.rand(B, 1, T, generator=g) - 0.5).cuda().requires_grad_(True)
+    with torch.no_grad():
+        for _ in range(4):                          # spectral norm: let the power iteration settle (a fresh module's u, v are random),
+            m(y, y_hat)
+    m.eval()                                        # ... then freeze it: no iteration between the two evaluations compared below
+    fwd = H.mpd_forward if which == 'mpd' else H.msd_forward
+    params = [p for p in m.parameters() if p.requires_grad]
+
+    def losses(outs):
+        rs, gs, fr, fg = outs
+        ld = D.discriminator_loss(rs, gs)[0]
+        lg = D.generator_loss(gs)[0] + D.feature_loss(fr, fg)
+        return ld, lg
+
+    ref = m(y, y_hat)
+    nat = fwd(m, y, y_hat)
+    for i, d in enumerate(m.discriminators):
+        for a, b_ in ((nat[0][i], ref[0][i]), (nat[1][i], ref[1][i])):
+            assert a.shape == b_.shape and _rel(a, b_) < 2e-5, (which, i)
+        for fa, fb in zip(nat[2][i] + nat[3][i], ref[2][i] + ref[3][i]):   # same layout as the reference modules, MPD's [B, C, H, p] included
+            assert fa.shape == fb.shape and _rel(fa, fb) < 2e-5, (which, i, tuple(fa.shape))
+    ld0, lg0 = losses(ref)
+    ld1, lg1 = losses(nat)
+    assert abs(float(ld0) - float(ld1)) < 1e-4 * abs(float(ld0)) and abs(float(lg0) - float(lg1)) < 1e-4 * abs(float(lg0))
+    gp0 = torch.autograd.grad(ld0, params, retain_graph=True)
+    gp1 = torch.autograd.grad(ld1, params, retain_graph=True)
+    names = [n for n, p_ in m.named_parameters() if p_.requires_grad]
+    bad = [(n, _rel(a, b_), bool(torch.isfinite(a).all()), bool(torch.isfinite(b_).all())) for n, a, b_ in zip(names, gp1, gp0)
+           if not (_rel(a, b_) < 2e-3)]   # (sums of ~1e5 signed terms per element, fp32, in two different orders)
+    assert not bad, ('parameter gradients of the discriminator loss (name, rel, native finite, torch finite)', bad[:6])
+    gx0 = torch.autograd.grad(lg0, y_hat)[0]
+    gx1 = torch.autograd.grad(lg1, y_hat)[0]
+    assert _rel(gx1, gx0) < 1e-4          # what the generator receives through the discriminators
+    # discriminator step: generated audio carries no graph -> real + generated run as ONE batch; same values
+    nat_d = fwd(m, y, y_hat.detach(), want_fmap=False)
+    ld2 = D.discriminator_loss(nat_d[0], nat_d[1])[0]
+    assert abs(float(ld2) - float(ld0)) < 1e-4 * abs(float(ld0)) and nat_d[2][0] == []

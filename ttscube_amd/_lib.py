@@ -14,7 +14,7 @@ class TTSCError(RuntimeError):
 
 class Conv1dCfg(C.Structure):
     _fields_ = [('in_channels', C.c_int32), ('out_channels', C.c_int32), ('kernel_size', C.c_int32),
-                ('stride', C.c_int32), ('padding', C.c_int32), ('dilation', C.c_int32), ('transposed', C.c_int32)]
+                ('stride', C.c_int32), ('padding', C.c_int32), ('dilation', C.c_int32), ('transposed', C.c_int32), ('groups', C.c_int32)]
 
 
 class Conv1dEpilogue(C.Structure):
@@ -79,6 +79,8 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p]),
     'ttsc_conv1d_destroy': (None, [C.c_void_p]),
     'ttsc_conv1d_set_weight_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ttsc_conv_wgrad_grouped': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
+                                          C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
     'ttsc_conv_wgrad': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
     'ttsc_conv1d_set_weight_device_dgrad': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

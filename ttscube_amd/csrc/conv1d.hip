@@ -45,7 +45,9 @@ struct ConvArgs {
     const float* bias;  // [Cout] or null
     const int* in_len;  // [B] per-utterance valid input length (ragged batches) or null
     const int* out_len; // [B] per-utterance valid output length or null (tiles wholly beyond it are skipped)
-    int Cin, CinP, Cout, CoutP;
+    int Cin, CinP, Cout, CoutP;   // Cin = input channels a workgroup stages (grouped: those of its rows' groups), CinP = rounded up to 16
+    int CinTot;                   // channels of the input tensor (batch stride); == Cin unless grouped
+    int groups, cin_g, cout_g;    // grouped Conv1d (fp32 kernel only): the workgroup's first input channel = (its first row / cout_g) * cin_g
     int Lin, Lout;
     int ntaps, tap_base, tap_step;
     int out_stride, out_off;
@@ -198,7 +200,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const float* xb = a.x + (size_t)b * a.Cin * a.Lin;
+    // grouped convolution: this workgroup's rows only meet the input channels of their own group(s)
+    const int cin0 = a.groups > 1 ? ((blockIdx.y * (WM * MI * 32)) / a.cout_g) * a.cin_g : 0;
+    const float* xb = a.x + ((size_t)b * a.CinTot + cin0) * a.Lin;
     const int lo = q0 + a.min_shift;  // x position of LDS column 0
     const int cipN = a.CinP >> 1;
     const int nchunks = a.CinP / KC;
@@ -1153,13 +1157,34 @@ extern "C" int ttsc_conv1d_create(const ttsc_conv1d_cfg* cfg, ttsc_conv1d** out)
     } else {
         TTSC_REQUIRE(cfg->stride == 1, "ttsc_conv1d_create: Conv1d supports stride 1 only");
     }
+    const int groups = cfg->groups > 1 ? cfg->groups : 1;
+    if (groups > 1) {
+        TTSC_REQUIRE(!cfg->transposed, "ttsc_conv1d_create: groups need a Conv1d");
+        TTSC_REQUIRE(cfg->in_channels % groups == 0 && cfg->out_channels % groups == 0, "ttsc_conv1d_create: channels (%d, %d) not divisible by groups %d",
+                     cfg->in_channels, cfg->out_channels, groups);
+    }
     ttsc_conv1d* c = new ttsc_conv1d();
     c->cfg = *cfg;
+    c->cfg.groups = groups;
     c->vfused = cfg->transposed && (cfg->out_channels % 32 == 0) && cfg->stride > 1;
     c->CoutV = c->vfused ? cfg->stride * cfg->out_channels : cfg->out_channels;
     c->MT = pick_mt(c->CoutV);
+    c->groups = groups;
+    c->cin_g = cfg->in_channels / groups;
+    c->cout_g = cfg->out_channels / groups;
+    c->cin_tile = cfg->in_channels;
+    if (groups > 1) {
+        // an M tile must not straddle a group boundary unless it holds whole groups
+        c->MT = c->cout_g >= 128 && c->cout_g % 128 == 0 ? 128 : (c->cout_g >= 64 && c->cout_g % 64 == 0 ? 64 : 32);
+        if (!(c->cout_g % c->MT == 0 || c->MT % c->cout_g == 0)) {
+            delete c;
+            set_error("ttsc_conv1d_create: %d output channels per group do not tile into 32-row blocks", cfg->out_channels / groups);
+            return TTSC_EINVAL;
+        }
+        c->cin_tile = (c->MT > c->cout_g ? c->MT / c->cout_g : 1) * c->cin_g;
+    }
     c->NT = c->MT == 128 ? 128 : (c->MT == 64 ? 256 : 512);
-    c->CinP = (int)round_up(cfg->in_channels, KC);
+    c->CinP = (int)round_up(c->cin_tile, KC);
     c->CoutP = (int)round_up(c->CoutV, c->MT);
     *out = c;
     return TTSC_OK;
@@ -1210,7 +1235,11 @@ static void pack_phase(const ttsc_conv1d* c, const float* w, const std::vector<i
                         ok = ok && kk < K;
                     }
                     float v = 0.f;
-                    if (ok) v = g.transposed ? w[((size_t)ci * Cout + co) * K + kk] : w[((size_t)co * Cin + ci) * K + kk];
+                    if (c->groups > 1) {   // ci counts from the first input channel of the row tile's group(s); weight [Cout, cin_g, K]
+                        const int gco = co / c->cout_g, cig = ((co / c->MT) * c->MT / c->cout_g) * c->cin_g + ci;
+                        ok = co < Cout && ci < c->cin_tile && cig / c->cin_g == gco;
+                        if (ok) v = w[((size_t)co * c->cin_g + (cig - gco * c->cin_g)) * K + kk];
+                    } else if (ok) v = g.transposed ? w[((size_t)ci * Cout + co) * K + kk] : w[((size_t)co * Cin + ci) * K + kk];
                     out[(((size_t)j * cipN + cip) * cotN + cot) * 64 + lane] = v;
                 }
     }
@@ -1267,7 +1296,7 @@ extern "C" int ttsc_conv1d_set_precision(ttsc_conv1d* c, int32_t precision) {
     const int halo = c->cfg.transposed ? (c->cfg.kernel_size + c->cfg.stride - 1) / c->cfg.stride - 1
                                        : (c->cfg.kernel_size - 1) * c->cfg.dilation;
     const int taps = c->cfg.transposed ? (c->cfg.kernel_size + c->cfg.stride - 1) / c->cfg.stride : c->cfg.kernel_size;
-    if (precision == TTSC_PREC_F16X3 && (halo > 64 || taps > 16)) precision = TTSC_PREC_FP32;
+    if (precision == TTSC_PREC_F16X3 && (halo > 64 || taps > 16 || c->groups > 1)) precision = TTSC_PREC_FP32;   // (grouped layers: fp32 kernel only)
     if (precision == c->precision) return TTSC_OK;
     TTSC_REQUIRE(!c->dev_weights, "ttsc_conv1d_set_precision: weights were set from device memory; switch the precision first");
     c->precision = precision;
@@ -1277,7 +1306,7 @@ extern "C" int ttsc_conv1d_set_precision(ttsc_conv1d* c, int32_t precision) {
 extern "C" int ttsc_conv1d_set_weight(ttsc_conv1d* c, const float* w, const float* bias) {
     TTSC_REQUIRE(c && w, "ttsc_conv1d_set_weight: null argument");
     const auto& g0 = c->cfg;
-    c->w_host.assign(w, w + (size_t)g0.in_channels * g0.out_channels * g0.kernel_size);
+    c->w_host.assign(w, w + (size_t)c->cin_g * g0.out_channels * g0.kernel_size);   // torch layout: [Cout, Cin / groups, K]
     c->has_bias = bias != nullptr;
     if (bias) c->b_host.assign(bias, bias + g0.out_channels);
     c->dev_weights = false;
@@ -1292,6 +1321,7 @@ struct PackArgs {
     float* out;
     int Cin, Cout, K, CoutV, cipN, cotN, ntaps, k0, kstep, transposed, vfused, stride;
     int flipT;   // source is the forward weight [Cin(this), Cout(this), K] of the layer this handle differentiates
+    int groups, cin_g, cout_g, cin_tile, MT;   // grouped Conv1d: see ttsc_conv1d (conv_internal.hpp)
 };
 __global__ void pack_w_kernel(PackArgs p) {
     const long total = (long)p.ntaps * p.cipN * p.cotN * 64;
@@ -1313,7 +1343,14 @@ __global__ void pack_w_kernel(PackArgs p) {
             ok = ok && kk < p.K;
         }
         float v = 0.f;
-        if (ok) {
+        if (p.groups > 1) {
+            // ci counts from the first input channel of the row tile's group(s).  Forward weight [Cout, cin_g, K]; as the data
+            // gradient of a grouped layer the source is THAT layer's weight [Cin(this), cout_g(this), K], flipped in k.
+            const int gco = co / p.cout_g, cig = ((co / p.MT) * p.MT / p.cout_g) * p.cin_g + ci;
+            if (co < p.Cout && ci < p.cin_tile && cig / p.cin_g == gco)
+                v = p.flipT ? p.w[((size_t)cig * p.cout_g + (co - gco * p.cout_g)) * p.K + (p.K - 1 - kk)]
+                            : p.w[((size_t)co * p.cin_g + (cig - gco * p.cin_g)) * p.K + kk];
+        } else if (ok) {
             if (p.flipT)
                 v = p.w[((size_t)ci * p.Cout + co) * p.K + (p.K - 1 - kk)];
             else
@@ -1341,7 +1378,7 @@ static int set_weight_device_impl(ttsc_conv1d* c, const float* w_dev, const floa
     const auto& g = c->cfg;
     if (c->phases.empty() || (bias_dev != nullptr) != (c->bias_dev != nullptr)) {
         // first call: lay out the phase buffers (zero weights), later calls only overwrite them
-        c->w_host.assign((size_t)g.in_channels * g.out_channels * g.kernel_size, 0.f);
+        c->w_host.assign((size_t)c->cin_g * g.out_channels * g.kernel_size, 0.f);   // (cin_g == in_channels unless grouped)
         c->has_bias = bias_dev != nullptr;
         c->b_host.assign(g.out_channels, 0.f);
         int rc = conv_repack(c);
@@ -1365,6 +1402,11 @@ static int set_weight_device_impl(ttsc_conv1d* c, const float* w_dev, const floa
         p.vfused = c->vfused ? 1 : 0;
         p.stride = g.stride;
         p.flipT = flipT;
+        p.groups = c->groups;
+        p.cin_g = c->cin_g;
+        p.cout_g = c->cout_g;
+        p.cin_tile = c->cin_tile;
+        p.MT = c->MT;
         const long total = (long)p.ntaps * p.cipN * p.cotN * 64;
         const int blocks = (int)std::min<long>((total + 255) / 256, 2048);
         hipLaunchKernelGGL(pack_w_kernel, dim3(blocks), dim3(256), 0, s, p);
@@ -1580,7 +1622,11 @@ extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, 
             TTSC_REQUIRE(!(ep && ep->gate_dev), "ttsc_conv1d_forward: the gate epilogue is not available on this transposed layer");
             TTSC_REQUIRE(((uintptr_t)y % 16 == 0) && (!resid || (uintptr_t)resid % 16 == 0), "ttsc_conv1d_forward: y / resid must be 16-byte aligned for ConvTranspose1d(k=4, s=4)");
         }
-        a.Cin = g.in_channels;
+        a.Cin = c->groups > 1 ? c->cin_tile : g.in_channels;
+        a.CinTot = g.in_channels;
+        a.groups = c->groups;
+        a.cin_g = c->cin_g;
+        a.cout_g = c->cout_g;
         a.CinP = c->CinP;
         a.Cout = g.out_channels;
         a.CoutP = c->CoutP;
@@ -1615,7 +1661,7 @@ extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, 
         a.span_pad = a.span + 1;
         a.in_scale = ep ? ep->in_scale : 1.f;
         const float* w_plain = c->dev_weights ? c->w_plain_ext : c->w_plain_dev;
-        const bool use_cout1 = !g.transposed && g.out_channels == 1 && g.in_channels <= 64 && g.kernel_size <= 16 && g.dilation == 1 &&
+        const bool use_cout1 = !g.transposed && c->groups == 1 && g.out_channels == 1 && g.in_channels <= 64 && g.kernel_size <= 16 && g.dilation == 1 &&
                                w_plain && !(ep && ep->gate_dev);
         if (c->precision == TTSC_PREC_F16X3 && !use_cout1) {   // activation pre-scale (exact powers of two, see ttsc_conv1d_set_activation_scale)
             a.in_scale *= c->act_scale;

@@ -29,6 +29,9 @@ struct ttsc_conv1d {
     const float* bias_ext = nullptr;  // device-weight mode: the caller's bias tensor
     float* w_plain_dev = nullptr;     // out_channels == 1: weights in torch layout [1][Cin][K] for conv_cout1_kernel
     const float* w_plain_ext = nullptr;   // device-weight mode: the caller's weight tensor (same layout)
+    // grouped Conv1d (torch `groups`, fp32 path only): channels per group, and the input channels ONE M tile stages — the groups its
+    // MT rows belong to (a 32-row tile over 16-row groups stages two groups; the packed weights are block-diagonal inside the tile)
+    int groups = 1, cin_g = 0, cout_g = 0, cin_tile = 0;
     unsigned* nf_flag = nullptr;          // out_channels == 1: device word that conv_cout1_kernel ORs with 1 when it emits a non-finite sample
 };
 

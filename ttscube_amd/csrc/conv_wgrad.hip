@@ -34,6 +34,7 @@ struct WgArgs {
     int CH;            // chunks per wave
     int groups;        // position groups per batch item = ceil(chunks / CH)
     int minoff, span;  // Q window of one chunk: positions t0 + minoff .. t0 + minoff + 64 + span
+    int cg_n, Ag, Btot; // grouped convolution: cg_n conv groups of Ag rows (A = cg_n * Ag) x Bc columns each; Q has Btot = cg_n * Bc channels
 };
 
 constexpr int WG_TK = 64;
@@ -47,8 +48,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgArgs a) {
     const int half = lane >> 5, l31 = lane & 31;
     float* pl = sm + wave * (32 * WG_PP + 32 * WG_QP);
     float* ql = pl + 32 * WG_PP;
-    const int tb_n = (a.Bc + 31) >> 5;
-    const int a0 = (blockIdx.y / tb_n) * 32, b0 = (blockIdx.y % tb_n) * 32;
+    // tile -> (conv group, row tile, column tile): rows a0.. of the group's Ag rows, columns b0.. of ITS Bc input channels
+    const int tb_n = (a.Bc + 31) >> 5, ta_n = (a.Ag + 31) >> 5;
+    const int cg = blockIdx.y / (ta_n * tb_n), ti = blockIdx.y % (ta_n * tb_n);
+    const int a0 = cg * a.Ag + (ti / tb_n) * 32, a_end = (cg + 1) * a.Ag, b0 = (ti % tb_n) * 32;
     const int grp = blockIdx.x * 4 + wave;            // position group of this wave
     const bool live = grp < a.N * a.groups;
     const int n = live ? grp / a.groups : 0;
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgArgs a) {
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
     const float* Pn = a.P + (size_t)n * a.A * a.LP;
-    const float* Qn = a.Q + (size_t)n * a.Bc * a.LQ;
+    const float* Qn = a.Q + ((size_t)n * a.Btot + (size_t)cg * a.Bc) * a.LQ;
     // `load` only ISSUES the global loads (clamped addresses, no use of the values): any arithmetic on a loaded value placed
     // here makes hipcc wait for that load before issuing the next ones.  Masking and the leaky-relu prologue happen in
     // `commit`, one MFMA phase later.
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgArgs a) {
         const int t0 = c * WG_TK;
         const int tp = min(t0 + lane, a.LP - 1);
 #pragma unroll
-        for (int r = 0; r < 32; ++r) pr[r] = Pn[(unsigned)(min(a0 + r, a.A - 1) * a.LP + tp)];
+        for (int r = 0; r < 32; ++r) pr[r] = Pn[(unsigned)(min(a0 + r, a_end - 1) * a.LP + tp)];
         const int q_a = min(max(t0 + a.minoff + lane, 0), a.LQ - 1);
 #pragma unroll
         for (int r = 0; r < 32; ++r) q0r[r] = Qn[(unsigned)(min(b0 + r, a.Bc - 1) * a.LQ + q_a)];
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgArgs a) {
         const int t0 = c * WG_TK;
         const bool pok = t0 + lane < a.LP;
 #pragma unroll
-        for (int r = 0; r < 32; ++r) pl[r * WG_PP + lane] = (pok && a0 + r < a.A) ? pr[r] : 0.f;
+        for (int r = 0; r < 32; ++r) pl[r * WG_PP + lane] = (pok && a0 + r < a_end) ? pr[r] : 0.f;
         const int q_a = t0 + a.minoff + lane;
         const bool qa_ok = q_a >= 0 && q_a < a.LQ;
 #pragma unroll
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgArgs a) {
             const float v = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
             const int r = e >> 6, ln = e & 63;
             const int arow = a0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), bcol = b0 + (ln & 31);
-            if (arow < a.A && bcol < a.Bc) dst[(size_t)arow * a.Bc + bcol] = v;
+            if (arow < a_end && bcol < a.Bc) dst[(size_t)arow * a.Bc + bcol] = v;
         }
     }
 }
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 template <int JT>
 static int launch_wgrad(const WgArgs& a, hipStream_t s) {
-    const int tiles = ((a.A + 31) / 32) * ((a.Bc + 31) / 32);
+    const int tiles = a.cg_n * ((a.Ag + 31) / 32) * ((a.Bc + 31) / 32);
     const int wgs_x = (a.N * a.groups + 3) / 4;
     const size_t lds = (size_t)4 * (32 * WG_PP + 32 * WG_QP) * sizeof(float);
     if (int rc = ensure_full_lds(reinterpret_cast<const void*>(conv_wgrad_kernel<JT>))) return rc;   // once per (device, kernel)
@@ -233,7 +236,14 @@ extern "C" size_t ttsc_conv_wgrad_workspace_bytes(int32_t N, int32_t A, int32_t 
 extern "C" int ttsc_conv_wgrad(const float* p_dev, const float* q_dev, float* g_dev, int32_t N, int32_t A, int32_t Bc, int64_t LP,
                                int64_t LQ, int32_t J, int32_t base, int32_t step, float q_scale, float q_slope, void* ws_dev,
                                size_t ws_bytes, void* stream) {
+    return ttsc_conv_wgrad_grouped(p_dev, q_dev, g_dev, N, A, Bc, 1, LP, LQ, J, base, step, q_scale, q_slope, ws_dev, ws_bytes, stream);
+}
+
+extern "C" int ttsc_conv_wgrad_grouped(const float* p_dev, const float* q_dev, float* g_dev, int32_t N, int32_t A, int32_t Bc, int32_t cgroups,
+                                       int64_t LP, int64_t LQ, int32_t J, int32_t base, int32_t step, float q_scale, float q_slope, void* ws_dev,
+                                       size_t ws_bytes, void* stream) {
     TTSC_REQUIRE(p_dev && q_dev && g_dev, "ttsc_conv_wgrad: null argument");
+    TTSC_REQUIRE(cgroups >= 1 && A % cgroups == 0, "ttsc_conv_wgrad: %d rows do not split into %d groups", A, cgroups);
     TTSC_REQUIRE(N > 0 && A > 0 && Bc > 0 && LP > 0 && LQ > 0 && J > 0, "ttsc_conv_wgrad: bad shape N=%d A=%d B=%d LP=%lld LQ=%lld J=%d", N, A, Bc,
                  (long long)LP, (long long)LQ, J);
     TTSC_REQUIRE(LP < (1ll << 30) && LQ < (1ll << 30), "ttsc_conv_wgrad: length too large");
@@ -255,6 +265,9 @@ extern "C" int ttsc_conv_wgrad(const float* p_dev, const float* q_dev, float* g_
     a.step = step;
     a.q_scale = q_scale;
     a.q_slope = q_slope;
+    a.cg_n = cgroups;
+    a.Ag = A / cgroups;
+    a.Btot = cgroups * Bc;
     int splits;
     wgrad_split(N, A, Bc, LP, &a.chunks, &a.CH, &a.groups, &splits);
     for (int j0 = 0; j0 < J; j0 += 12) {

@@ -27,10 +27,11 @@ from ..hip_layers import Conv1dHip
 class TrainConv:
     """Per-layer state of the native training path: forward handle, data-gradient handle, index maps."""
 
-    def __init__(self, Cin, Cout, K, stride=1, padding=0, dilation=1, transposed=False):
+    def __init__(self, Cin, Cout, K, stride=1, padding=0, dilation=1, transposed=False, groups=1):
         self.Cin, self.Cout, self.K = Cin, Cout, K
         self.stride, self.padding, self.dilation, self.transposed = stride, padding, dilation, transposed
-        self.fwd = Conv1dHip(Cin, Cout, K, stride=stride, padding=padding, dilation=dilation, transposed=transposed)
+        self.groups = groups
+        self.fwd = Conv1dHip(Cin, Cout, K, stride=stride, padding=padding, dilation=dilation, transposed=transposed, groups=groups)
         self._dgrad = None
         self._maps = None
         self._bg_ws = {}
@@ -42,7 +43,7 @@ class TrainConv:
                 pd = self.dilation * (self.K - 1) - self.padding
                 if pd < 0:
                     raise _lib.TTSCError('TrainConv: padding larger than the receptive field is not supported')
-                self._dgrad = Conv1dHip(self.Cout, self.Cin, self.K, padding=pd, dilation=self.dilation)
+                self._dgrad = Conv1dHip(self.Cout, self.Cin, self.K, padding=pd, dilation=self.dilation, groups=self.groups)
             else:
                 self._dgrad = Conv1dHip(self.stride * self.Cout, self.Cin, self.taps_t()[2], padding=0)
         return self._dgrad
@@ -112,16 +113,18 @@ def _bias_grad(tc, dy):
     return db
 
 
-def _wgrad(P, Q, A, Bc, J, base, step, q_scale, q_slope):
-    G = torch.empty((A, Bc, J), dtype=torch.float32, device=P.device)
+def _wgrad(P, Q, A, Bc, J, base, step, q_scale, q_slope, groups=1):
+    """G [A, Bc / groups, J]: weight gradient of a (grouped) Conv1d, torch layout"""
+    Bg = Bc // groups
+    G = torch.empty((A, Bg, J), dtype=torch.float32, device=P.device)
     N, _, LP = P.shape
     LQ = Q.shape[2]
     L = _lib.lib()
-    nbytes = int(L.ttsc_conv_wgrad_workspace_bytes(N, A, Bc, LP, J))
+    nbytes = int(L.ttsc_conv_wgrad_workspace_bytes(N, A, Bg, LP, J))
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=P.device)
     with torch.cuda.device(P.device):
-        _lib.check(L.ttsc_conv_wgrad(_lib.dev_ptr(P), _lib.dev_ptr(Q), _lib.dev_ptr(G), N, A, Bc, LP, LQ, J, base, step,
-                                     q_scale, q_slope, _lib.dev_ptr(ws), nbytes, _lib.current_stream()), 'ttsc_conv_wgrad')
+        _lib.check(L.ttsc_conv_wgrad_grouped(_lib.dev_ptr(P), _lib.dev_ptr(Q), _lib.dev_ptr(G), N, A, Bg, groups, LP, LQ, J, base, step,
+                                             q_scale, q_slope, _lib.dev_ptr(ws), nbytes, _lib.current_stream()), 'ttsc_conv_wgrad')
     return G
 
 
@@ -152,7 +155,7 @@ class HipConvFn(torch.autograd.Function):
                 h.set_weight_device_dgrad(w)
                 dx = h(dy, out_scale=sc, gate=x if sl != 1.0 else None, gate_slope=sl)
             if ctx.needs_input_grad[1]:
-                dw = _wgrad(dy, x, tc.Cout, tc.Cin, tc.K, -tc.padding, tc.dilation, sc, sl)
+                dw = _wgrad(dy, x, tc.Cout, tc.Cin, tc.K, -tc.padding, tc.dilation, sc, sl, tc.groups)
         else:
             m_lo, _, M = tc.taps_t()
             dyp = tc.deinterleave(dy, Lin)

@@ -1,0 +1,136 @@
+"""HiFi-GAN discriminators on the HIP convolution kernels: `MultiPeriodDiscriminator` and
+`MultiScaleDiscriminator` of hifigan.models [EXTERNAL; call sites cube/networks/cubegan.py:144-149,160-167] with forward, data
+gradient and weight gradient of every convolution on `conv_mfma_kernel` / `conv_wgrad_kernel` (hifigan/autograd.py::HipConvFn),
+leaky-relu fused into the next layer's staging pass, weight-norm on the fused kernels.  Parameters stay in the torch modules of
+`discriminators.py` (same state_dict keys), which remain the torch-op formulation these functions are tested against.
+
+How the discriminators' convolutions map onto the stride-1, 1-D kernels:
+  * strided Conv1d(stride s) = stride-1 convolution over the phase-de-interleaved input  xr[n, (g, r, ci), m] = x[n, (g, ci), s m + r - p]
+    with ceil(K / s) taps  W'[co, (r, ci), j] = w[co, ci, s j + r]  (zero beyond K): s * Cin_g input channels per group;
+  * MPD's Conv2d((k, 1), stride (s, 1)) over the period-folded signal [B, C, T / p, p] never mixes the p columns: on the FLAT signal
+    (index h p + w, i.e. the audio's own time order) it is a Conv1d with DILATION p — the de-interleave above runs over h with the
+    p columns kept inside each block — so the batch stays B sequences of T / s^i samples (B p sequences of a few dozen frames would
+    leave the kernel's 64..128-column tiles mostly empty), and the feature maps are the reference's [B, C, H, p] tensors as views;
+  * MSD's grouped k = 41 layers use the kernels' group support (block-diagonal M tiles, `ttsc_conv_wgrad_grouped`)."""
+import torch
+import torch.nn.functional as F
+
+from .. import _lib
+from .autograd import HipWeightNormFn, TrainConv, hip_conv
+
+LRELU_SLOPE = 0.1
+
+
+class HipStridedConv:
+    """differentiable Conv1d(Cin -> Cout, K, stride, padding, groups) on the HIP kernels"""
+
+    def __init__(self, Cin, Cout, K, stride=1, padding=0, groups=1, period=1):
+        """period > 1: the signal is a period-folded image flattened as h * period + w and the convolution runs over h only
+        (MPD's (K, 1) kernels): taps `period` samples apart, stride / padding counted in rows of `period` samples."""
+        self.Cin, self.Cout, self.K, self.s, self.p, self.G, self.P = Cin, Cout, K, stride, padding, groups, period
+        self.J = -(-K // stride)
+        if stride == 1:
+            self.tc = TrainConv(Cin, Cout, K, padding=padding * period, dilation=period, groups=groups)
+        else:
+            self.tc = TrainConv(stride * Cin, Cout, self.J, padding=0, dilation=period, groups=groups)
+
+    def __call__(self, x, w, b, in_slope=1.0):
+        if self.s == 1:
+            return hip_conv(self.tc, x, w.contiguous(), b, in_slope=in_slope)
+        s, K, J, G, P = self.s, self.K, self.J, self.G, self.P
+        N, Cin, LP = x.shape
+        L = LP // P                                                     # rows of P samples
+        Lout = (L + 2 * self.p - K) // s + 1
+        M = Lout + J - 1
+        xp = F.pad(x, (self.p * P, (s * M - L - self.p) * P))           # (a negative right pad crops)
+        xr = xp.view(N, G, Cin // G, M, s, P).permute(0, 1, 4, 2, 3, 5).reshape(N, s * Cin, M * P)
+        wp = F.pad(w, (0, s * J - K)).view(self.Cout, Cin // G, J, s).permute(0, 3, 1, 2).reshape(self.Cout, s * (Cin // G), J)
+        # leaky-relu commutes with the de-interleave (and lrelu(0) = 0 keeps the zero padding): it rides in the kernel's staging pass
+        return hip_conv(self.tc, xr, wp.contiguous(), b, in_slope=in_slope)
+
+
+def _weight(l):
+    """the layer's effective weight, differentiable w.r.t. its parameters: weight-norm on the fused kernel, spectral norm through
+    torch's own pre-forward hook (power iteration included, as a module call would do)"""
+    if hasattr(l, 'weight_orig'):
+        for hook in l._forward_pre_hooks.values():
+            hook(l, (None,))
+        return l.weight
+    if hasattr(l, 'weight_g'):   # torch.nn.utils.weight_norm keeps a stale plain `weight` attribute beside (weight_g, weight_v): never read it
+        return HipWeightNormFn.apply(l.weight_v, l.weight_g)
+    return l.weight
+
+
+def _layers(d, kind):
+    cache = getattr(d, '_hip_layers', None)
+    if cache is None:
+        cache = []
+        for l in list(d.convs) + [d.conv_post]:
+            if kind == 'p':
+                cache.append(HipStridedConv(l.in_channels, l.out_channels, l.kernel_size[0], l.stride[0], l.padding[0], period=d.period))
+            else:
+                cache.append(HipStridedConv(l.in_channels, l.out_channels, l.kernel_size[0], l.stride[0], l.padding[0], l.groups))
+        object.__setattr__(d, '_hip_layers', cache)
+    return cache
+
+
+def _run(d, kind, x, want_fmap):
+    """x [N, 1, L] -> (scores [N, L'], fmap list; MPD: feature maps as [N, C, H, period] views, the reference's layout).  Layer i's leaky-relu is applied by layer i+1's staging pass; the activated
+    feature maps are only materialised when the caller needs them (the generator step's feature-matching loss)."""
+    hl = _layers(d, kind)
+    mods = list(d.convs) + [d.conv_post]
+    fmap = []
+    slope = 1.0
+    for i, (l, h) in enumerate(zip(mods, hl)):
+        w = _weight(l)
+        if w.dim() == 4:
+            w = w.squeeze(-1)
+        x = h(x, w, l.bias, in_slope=slope)
+        slope = LRELU_SLOPE
+        if want_fmap:
+            f = F.leaky_relu(x, LRELU_SLOPE) if i < len(mods) - 1 else x
+            fmap.append(f.view(f.shape[0], f.shape[1], -1, d.period) if kind == 'p' else f)
+    return torch.flatten(x, 1, -1), fmap
+
+
+def _fold(x, p):
+    """[B, 1, T] reflect-padded to a multiple of the period (DiscriminatorP.forward); the fold itself is implicit: index h p + w"""
+    t = x.shape[2]
+    return F.pad(x, (0, p - (t % p)), 'reflect') if t % p != 0 else x
+
+
+def _pair(d, kind, y, y_hat, batch_ok, want_fmap):
+    if batch_ok and not y_hat.requires_grad and y.shape == y_hat.shape:   # discriminator step: real + generated as one batch
+        n = y.shape[0]
+        out, fmap = _run(d, kind, torch.cat([y, y_hat], dim=0), want_fmap)
+        return out[:n], [f[:n] for f in fmap], out[n:], [f[n:] for f in fmap]
+    out_r, fmap_r = _run(d, kind, y, want_fmap)
+    out_g, fmap_g = _run(d, kind, y_hat, want_fmap)
+    return out_r, fmap_r, out_g, fmap_g
+
+
+def mpd_forward(mpd, y, y_hat, want_fmap=True):
+    """MultiPeriodDiscriminator.forward(y, y_hat) on the HIP kernels: (y_d_rs, y_d_gs, fmap_rs, fmap_gs)"""
+    if not y.is_cuda:
+        raise _lib.TTSCError('discriminators: inputs must live on a HIP device; no CPU path')
+    res = ([], [], [], [])
+    for d in mpd.discriminators:
+        r = _pair(d, 'p', _fold(y, d.period), _fold(y_hat, d.period), True, want_fmap)
+        for acc, v in zip(res, (r[0], r[2], r[1], r[3])):
+            acc.append(v)
+    return res
+
+
+def msd_forward(msd, y, y_hat, want_fmap=True):
+    """MultiScaleDiscriminator.forward(y, y_hat) on the HIP kernels"""
+    if not y.is_cuda:
+        raise _lib.TTSCError('discriminators: inputs must live on a HIP device; no CPU path')
+    res = ([], [], [], [])
+    for i, d in enumerate(msd.discriminators):
+        if i != 0:
+            y = msd.meanpools[i - 1](y)
+            y_hat = msd.meanpools[i - 1](y_hat)
+        r = _pair(d, 's', y, y_hat, i != 0, want_fmap)   # discriminator 0 is spectrally normed: two calls, two power iterations
+        for acc, v in zip(res, (r[0], r[2], r[1], r[3])):
+            acc.append(v)
+    return res

@@ -14,10 +14,11 @@ ACT = {None: _lib.ACT_NONE, 'none': _lib.ACT_NONE, 'tanh': _lib.ACT_TANH, 'relu'
 
 
 class Conv1dHip:
-    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, transposed=False):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, transposed=False, groups=1):
         L = _lib.lib()
         _lib.require_gpu()
-        self.cfg = _lib.Conv1dCfg(in_channels, out_channels, kernel_size, stride, padding, dilation, int(transposed))
+        self.groups = int(groups)
+        self.cfg = _lib.Conv1dCfg(in_channels, out_channels, kernel_size, stride, padding, dilation, int(transposed), self.groups)
         self._h = C.c_void_p()
         _lib.check(L.ttsc_conv1d_create(C.byref(self.cfg), C.byref(self._h)), 'ttsc_conv1d_create')
 
@@ -35,7 +36,7 @@ class Conv1dHip:
     def set_weight(self, weight, bias=None):
         w = weight.detach().float().cpu().contiguous()
         exp = ((self.cfg.in_channels, self.cfg.out_channels) if self.cfg.transposed else
-               (self.cfg.out_channels, self.cfg.in_channels)) + (self.cfg.kernel_size,)
+               (self.cfg.out_channels, self.cfg.in_channels // self.groups)) + (self.cfg.kernel_size,)
         if tuple(w.shape) != exp:
             raise _lib.TTSCError('Conv1dHip.set_weight: expected weight shape %s, got %s' % (exp, tuple(w.shape)))
         b = None
@@ -50,7 +51,7 @@ class Conv1dHip:
     def set_weight_device(self, weight, bias=None):
         """Training: (re)pack the fragments from the live fp32 device tensors on the current stream (no host copy)."""
         exp = ((self.cfg.in_channels, self.cfg.out_channels) if self.cfg.transposed else
-               (self.cfg.out_channels, self.cfg.in_channels)) + (self.cfg.kernel_size,)
+               (self.cfg.out_channels, self.cfg.in_channels // self.groups)) + (self.cfg.kernel_size,)
         if tuple(weight.shape) != exp or not weight.is_cuda or weight.dtype != torch.float32 or not weight.is_contiguous():
             raise _lib.TTSCError('Conv1dHip.set_weight_device: need a contiguous fp32 device tensor of shape %s' % (exp,))
         if bias is not None and (bias.numel() != self.cfg.out_channels or not bias.is_cuda or bias.dtype != torch.float32):
@@ -63,7 +64,7 @@ class Conv1dHip:
     def set_weight_device_dgrad(self, fwd_weight):
         """Training: this handle is the data gradient of a Conv1d whose weight is `fwd_weight` [Cin(this), Cout(this), K]; the
         flipped / transposed view is read directly by the packing kernel."""
-        exp = (self.cfg.in_channels, self.cfg.out_channels, self.cfg.kernel_size)
+        exp = (self.cfg.in_channels, self.cfg.out_channels // self.groups, self.cfg.kernel_size)   # the forward layer's [Cout, Cin / groups, K]
         if tuple(fwd_weight.shape) != exp or not fwd_weight.is_cuda or fwd_weight.dtype != torch.float32 or not fwd_weight.is_contiguous():
             raise _lib.TTSCError('Conv1dHip.set_weight_device_dgrad: need a contiguous fp32 device tensor of shape %s' % (exp,))
         with torch.cuda.device(fwd_weight.device):

@@ -64,6 +64,8 @@ import random
 # True: every piece of the training steps that has a native counterpart runs as its torch-op formulation instead (torch.optim.AdamW,
 # per-tensor GAN loss expressions): the reference the native step is held to by tests/test_baseline_configs_gpu.py.  Never set in production.
 TORCH_REFERENCE = False
+# None / True: MPD and MSD run on the HIP convolution kernels (hifigan/disc_hip.py); False: the torch-op modules (A/B measurements)
+NATIVE_DISCRIMINATORS = None if __import__('os').environ.get('TTSC_NATIVE_DISC', '1') != '0' else False
 
 import torch.nn.functional as F
 
@@ -207,6 +209,13 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
         from ..hifigan.losses_hip import discriminator_loss, feature_loss, generator_loss
     from ..io_utils.melspec import mel_spectrogram   # DFT / mel GEMMs + element-wise kernels on HIP, forward and backward
     arm = lambda i: reducers and hasattr(reducers[i], 'arm') and reducers[i].arm()   # bucket-ready hooks restart with every backward pass
+    if TORCH_REFERENCE or NATIVE_DISCRIMINATORS is False:
+        mpd = lambda a_, b_, fm=True: model._mpd(a_, b_)
+        msd = lambda a_, b_, fm=True: model._msd(a_, b_)
+    else:   # every convolution of MPD / MSD (forward, data gradient, weight gradient) on the HIP kernels (hifigan/disc_hip.py)
+        from ..hifigan.disc_hip import mpd_forward, msd_forward
+        mpd = lambda a_, b_, fm=True: mpd_forward(model._mpd, a_, b_, want_fmap=fm)
+        msd = lambda a_, b_, fm=True: msd_forward(model._msd, a_, b_, want_fmap=fm)
     opt_g, opt_d, opt_t, opt_b = optimizers
     rng = rng or random
     dev = model.get_device()
@@ -241,9 +250,9 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
     opt_b.zero_grad()
     opt_d.zero_grad()
     arm(1)
-    y_df_hat_r, y_df_hat_g, _, _ = model._mpd(y, y_g_hat.detach())
+    y_df_hat_r, y_df_hat_g, _, _ = mpd(y, y_g_hat.detach(), False)   # (the discriminator step reads no feature maps)
     loss_disc_f, _, _ = discriminator_loss(y_df_hat_r, y_df_hat_g)
-    y_ds_hat_r, y_ds_hat_g, _, _ = model._msd(y, y_g_hat.detach())
+    y_ds_hat_r, y_ds_hat_g, _, _ = msd(y, y_g_hat.detach(), False)
     loss_disc_s, _, _ = discriminator_loss(y_ds_hat_r, y_ds_hat_g)
     loss_disc_all = loss_disc_s + loss_disc_f
     loss_disc_all.backward()
@@ -260,8 +269,8 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
     for p in d_params:
         p.requires_grad_(False)
     try:
-        y_df_hat_r, y_df_hat_g, fmap_f_r, fmap_f_g = model._mpd(y, y_g_hat)
-        y_ds_hat_r, y_ds_hat_g, fmap_s_r, fmap_s_g = model._msd(y, y_g_hat)
+        y_df_hat_r, y_df_hat_g, fmap_f_r, fmap_f_g = mpd(y, y_g_hat)
+        y_ds_hat_r, y_ds_hat_g, fmap_s_r, fmap_s_g = msd(y, y_g_hat)
         loss_gen_all = (generator_loss(y_ds_hat_g)[0] + generator_loss(y_df_hat_g)[0] + feature_loss(fmap_s_r, fmap_s_g)
                         + feature_loss(fmap_f_r, fmap_f_g) + loss_mel)
         loss_gen_all.backward(retain_graph=True)
