@@ -160,6 +160,12 @@ int ttsc_adamw_step(float* p_dev, const float* g_dev, float* m_dev, float* v_dev
  *   kind 1:  out = sum_k w_k * mean (a_k - target)^2   ga_k = 2 w_k (a_k - target) / n_k              (least-squares GAN terms)
  * a_dev / b_dev / ga_dev / gb_dev: host arrays of nseg device pointers (gradient pointers, or the arrays themselves, may be null);
  * numel / weight: host arrays.  1 <= nseg <= 64 per call.  out_dev: one float.  Deterministic (fixed-order sums). */
+/* nn.Embedding of the mel decoder's text stacks (cube/networks/modules.py:869-872) in training: out[i,:] = table[idx[i],:] (rows outside
+ * [0,V) read as zero) and its gradient gtable[v,:] = sum_{i: idx[i]==v} gout[i,:] (every row written; row `skip_row` — padding_idx — gets
+ * zeros; -1 = none).  Deterministic summation order. */
+int ttsc_rows_gather(const float* table_dev, const int32_t* idx_dev, float* out_dev, int64_t n, int32_t C, int32_t V, void* stream);
+int ttsc_rows_scatter_add(const float* gout_dev, const int32_t* idx_dev, float* gtable_dev, int64_t n, int32_t C, int32_t V, int32_t skip_row,
+                          void* stream);
 size_t ttsc_gan_loss_workspace_bytes(int32_t nseg);
 int ttsc_gan_loss(int32_t kind, int32_t nseg, const void* const* a_dev, const void* const* b_dev, void* const* ga_dev, void* const* gb_dev,
                   const int64_t* numel, const float* weight, float target, float* out_dev, void* ws_dev, size_t ws_bytes, void* stream);

@@ -89,6 +89,8 @@ SIGNATURES = {
                                             C.c_int64, C.c_void_p]),
     'ttsc_adamw_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_float, C.c_int64, C.c_void_p]),
+    'ttsc_rows_gather': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    'ttsc_rows_scatter_add': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     'ttsc_gan_loss_workspace_bytes': (C.c_size_t, [C.c_int32]),
     'ttsc_gan_loss': (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                 C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

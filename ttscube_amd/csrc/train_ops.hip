@@ -218,6 +218,31 @@ __global__ __launch_bounds__(256) void gan_loss_kernel(const LossTable tab, int 
     }
 }
 
+// ---- embedding rows (text stacks of the mel decoder, cube/networks/modules.py:869-872) -----------------------------------------
+// forward: out[i, :] = table[idx[i], :];  backward: gtable[v, :] = sum_{i: idx[i] == v} gout[i, :], one workgroup per table row walking
+// the index list in order (deterministic; the tables have a few dozen rows and a batch a few hundred indices).
+__global__ __launch_bounds__(256) void rows_gather_kernel(const float* __restrict__ table, const int* __restrict__ idx, float* __restrict__ out,
+                                                          long n, int C, int V) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n * C; e += (long)gridDim.x * blockDim.x) {
+        const long i = e / C;
+        const int c = (int)(e - i * C);
+        const int v = idx[i];
+        out[e] = (v >= 0 && v < V) ? table[(size_t)v * C + c] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void rows_scatter_add_kernel(const float* __restrict__ gout, const int* __restrict__ idx, float* __restrict__ gtable,
+                                                               long n, int C, int skip_row) {
+    const int v = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = 0.f;
+        if (v != skip_row)
+            for (long i = 0; i < n; ++i)
+                if (idx[i] == v) acc += gout[(size_t)i * C + c];
+        gtable[(size_t)v * C + c] = acc;
+    }
+}
+
 }  // namespace ttsc
 
 using namespace ttsc;
@@ -325,4 +350,18 @@ extern "C" int ttsc_gan_loss(int32_t kind, int32_t nseg, const void* const* a_de
     TTSC_HIP_CHECK(hipMemsetAsync(ticket, 0, 64, s));
     hipLaunchKernelGGL(gan_loss_kernel, dim3((unsigned)(nseg * bps)), dim3(256), 0, s, tab, nseg, kind, bps, partial, ticket, out_dev);
     return check_launch("gan_loss_kernel");
+}
+
+extern "C" int ttsc_rows_gather(const float* table_dev, const int32_t* idx_dev, float* out_dev, int64_t n, int32_t C, int32_t V, void* stream) {
+    TTSC_REQUIRE(table_dev && idx_dev && out_dev && n > 0 && C > 0 && V > 0, "ttsc_rows_gather: bad argument");
+    const unsigned blocks = (unsigned)std::min<long>((n * C + 255) / 256, 2048);
+    hipLaunchKernelGGL(rows_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table_dev, idx_dev, out_dev, (long)n, C, V);
+    return check_launch("rows_gather_kernel");
+}
+
+extern "C" int ttsc_rows_scatter_add(const float* gout_dev, const int32_t* idx_dev, float* gtable_dev, int64_t n, int32_t C, int32_t V,
+                                     int32_t skip_row, void* stream) {
+    TTSC_REQUIRE(gout_dev && idx_dev && gtable_dev && n > 0 && C > 0 && V > 0, "ttsc_rows_scatter_add: bad argument");
+    hipLaunchKernelGGL(rows_scatter_add_kernel, dim3((unsigned)V), dim3(256), 0, (hipStream_t)stream, gout_dev, idx_dev, gtable_dev, (long)n, C, skip_row);
+    return check_launch("rows_scatter_add_kernel");
 }

@@ -119,12 +119,25 @@ def languasito_forward_train(lang, X):
     dev = lang._get_device()
     x_char, x_speaker = X['x_char'].to(dev), X['x_speaker'].to(dev)
 
+    if TORCH_REFERENCE:
+        embed = lambda emb, idx: emb(idx)
+        linear = F.linear
+
+        def cnn(name, h):
+            for layer in getattr(lang, name):
+                if hasattr(layer, 'conv'):
+                    h = torch.tanh(F.conv1d(h, layer.conv.weight, layer.conv.bias, padding=1))
+            return h
+    else:   # embeddings, char-CNN and output Linears on the HIP kernels too (networks/text_autograd.py)
+        from .text_autograd import char_cnn_train, hip_embedding, hip_linear
+        embed, linear = hip_embedding, hip_linear
+        cnn = lambda name, h: char_cnn_train(lang, name, h)
+
     def stack(which):
-        h = getattr(lang, '_phon_emb_' + which)(x_char).permute(0, 2, 1)
-        for layer in getattr(lang, '_char_cnn_' + which):
-            h = torch.tanh(F.conv1d(h, layer.conv.weight, layer.conv.bias, padding=1)) if hasattr(layer, 'conv') else h
+        h = embed(getattr(lang, '_phon_emb_' + which), x_char).permute(0, 2, 1)
+        h = cnn('_char_cnn_' + which, h)
         h = lstm_forward_train(getattr(lang, '_char_rnn_' + which), h.permute(0, 2, 1))
-        spk = getattr(lang, '_speaker_emb_' + which)(x_speaker)
+        spk = embed(getattr(lang, '_speaker_emb_' + which), x_speaker)
         return torch.cat([h, spk.repeat(1, h.shape[1], 1)], dim=-1)
 
     def expand(x, alignments):
@@ -137,14 +150,14 @@ def languasito_forward_train(lang, X):
 
     hcs = stack('t')
     hd = lstm_forward_train(lang._dur_rnn, hcs)
-    out_dur = F.linear(hd, lang._dur_output.linear_layer.weight, lang._dur_output.linear_layer.bias)
+    out_dur = linear(hd, lang._dur_output.linear_layer.weight, lang._dur_output.linear_layer.bias)
     hp = lstm_forward_train(lang._pitch_rnn, expand(hcs, X['y_frame2phone']))
-    op = F.linear(hp, lang._pitch_output.linear_layer.weight, lang._pitch_output.linear_layer.bias)
+    op = linear(hp, lang._pitch_output.linear_layer.weight, lang._pitch_output.linear_layer.bias)
     g = expand(stack('g'), X['y_frame2phone'])
     pitch = X['y_pitch'].to(dev).float().unsqueeze(2) / lang._max_pitch
     m = min(g.shape[1], pitch.shape[1])
     g = lstm_forward_train(lang._cond_rnn, torch.cat([g[:, :m], pitch[:, :m]], dim=-1))
-    cond = F.linear(g, lang._cond_output.linear_layer.weight, lang._cond_output.linear_layer.bias)
+    cond = linear(g, lang._cond_output.linear_layer.weight, lang._cond_output.linear_layer.bias)
     return out_dur, torch.sigmoid(op[:, :, 0]), torch.sigmoid(op[:, :, 1]), cond
 
 
