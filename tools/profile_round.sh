@@ -2,7 +2,7 @@
 # Round profile passes on the GPU box (run through gpurun): kernel traces and PMC passes of the headline bench, the e2e path,
 # the training step and WaveRNN.  The rocpd databases are summarised here and deleted (gpurun returns <= 64 MiB).
 #   usage: bash tools/profile_round.sh r02
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/$R
 mkdir -p $O; cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 B="python bench.py --no-extra --no-cpu-baseline"
@@ -26,7 +26,11 @@ rm -rf $O/trace $O/fetch $O/write $O/sq $O/grbm $O/e2e $O/train $O/wr
 # the same workload on round 1's kernels only (no wide tiles, no fused chain), for the record
 (TTSC_CONV_WIDE=0 TTSC_HIFIGAN_CHAIN=0 timeout 200 $B --steps 5 --warmup 2) > $O/bench_r1_kernels.log 2>&1
 timeout 300 python bench.py --mode train --steps 6 --warmup 2 2>/dev/null | grep '^{' > $O/bench_train_b16.json
+if [ -n "$FULL" ]; then
 timeout 400 python bench.py --mode train --train-batch 128 --steps 3 --warmup 1 2>/dev/null | grep '^{' > $O/bench_train_b128.json
 timeout 300 python tools/bench_lstm.py > $O/lstm.log 2>&1
+fi
+timeout 300 python bench.py --mode e2e --steps 5 --warmup 2 2>/dev/null | grep '^{' > $O/bench_e2e.json
+(timeout 120 python tools/bench_wavernn.py --frames 20 --layers 2; TTSC_WR_TILE2=0 timeout 120 python tools/bench_wavernn.py --frames 4 --layers 2) > $O/wavernn_n2.log 2>&1
 timeout 600 python bench.py > $O/bench_final.json 2> $O/bench_final.err
 du -sh $O; ls $O; tail -c 300 $O/bench_final.json

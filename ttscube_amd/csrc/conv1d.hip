@@ -1745,17 +1745,22 @@ extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, 
                 a.span_pad = a.span + 1;
             };
             const long want = 512;
+            // ... and, among the tiles that fill the machine, not one that is mostly padding: the deep layers of the discriminators see
+            // sequences of 50-200 positions (a 128-column tile over 149 positions computes 256), so a narrower tile is taken whenever it
+            // cuts the padded columns by more than an eighth (this kernel is bound by its MFMA count, not by operand reuse)
+            auto padded = [&](int nt) { return (long)ceil_div(a.q_cnt, nt) * nt; };
+            auto narrower_pays = [&](int nt_big, int nt_small) { return padded(nt_small) * 8 < padded(nt_big) * 7; };
             if (c->MT == 128) {
-                if (wgs(128, 128) >= want) { set_nt(128); rc = launch_cfg<2, 2, 2, 2>(a, B, s); }
-                else if (wgs(64, 128) >= want) { set_nt(128); rc = launch_cfg<1, 2, 2, 2>(a, B, s); }
+                if (wgs(128, 128) >= want && !narrower_pays(128, 64)) { set_nt(128); rc = launch_cfg<2, 2, 2, 2>(a, B, s); }
+                else if (wgs(64, 128) >= want && !narrower_pays(128, 64)) { set_nt(128); rc = launch_cfg<1, 2, 2, 2>(a, B, s); }
                 else { set_nt(64); rc = launch_cfg<1, 1, 2, 2>(a, B, s); }
             } else if (c->MT == 64) {
-                if (wgs(64, 256) >= want) { set_nt(256); rc = launch_cfg<2, 2, 1, 4>(a, B, s); }
-                else if (wgs(64, 128) >= want) { set_nt(128); rc = launch_cfg<1, 2, 2, 2>(a, B, s); }
+                if (wgs(64, 256) >= want && !narrower_pays(256, 128)) { set_nt(256); rc = launch_cfg<2, 2, 1, 4>(a, B, s); }
+                else if (wgs(64, 128) >= want && !narrower_pays(128, 64)) { set_nt(128); rc = launch_cfg<1, 2, 2, 2>(a, B, s); }
                 else { set_nt(64); rc = launch_cfg<1, 1, 2, 2>(a, B, s); }
             } else {
-                if (wgs(32, 512) >= want) { set_nt(512); rc = launch_cfg<1, 4, 1, 4>(a, B, s); }
-                else if (wgs(32, 256) >= want) { set_nt(256); rc = launch_cfg<1, 2, 1, 4>(a, B, s); }
+                if (wgs(32, 512) >= want && !narrower_pays(512, 256)) { set_nt(512); rc = launch_cfg<1, 4, 1, 4>(a, B, s); }
+                else if (wgs(32, 256) >= want && !narrower_pays(256, 128)) { set_nt(256); rc = launch_cfg<1, 2, 1, 4>(a, B, s); }
                 else { set_nt(128); rc = launch_cfg<1, 1, 1, 4>(a, B, s); }
             }
         }
