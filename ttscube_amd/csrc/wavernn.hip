@@ -776,7 +776,7 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
     }
     a.seed = seed;
     TTSC_REQUIRE(a.L > 0, "ttsc_wavernn_decode: nothing to decode (L=%d)", a.L);
-    if (tile_supported(w, B)) {
+    if (tile_supported(w, B) && a.L < (1 << 24)) {   // (candidate granules carry a 24-bit step tag)
         const int NC = WT_NC, BU = WT_NC;
         if (w->tile_dirty) {
             int prc = tile_pack(w);

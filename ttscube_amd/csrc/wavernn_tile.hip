@@ -343,6 +343,7 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
     int* tail_fail = reinterpret_cast<int*>(biasL + 64 + R3);
     int* pre_ready = tail_fail + 1;   // helper waves that have staged the pre-output vector (monotonic)
     float* ybuf = reinterpret_cast<float*>(tail_fail + 4);   // [32]: the output values of utterance m (continuous heads)
+    float* lxv = ybuf + 32;   // [8]: the fed-back samples of the 8 utterances (discrete heads: every member derives them itself)
     // second layer: h2 vector of the 8 utterances | W_hh2 h2 products | b_ih2, b_hh2   (W_ih2 h1 products reuse gbuf: the
     // first layer's gate math has consumed it by then)
     float* hvec2 = ybuf + 60;
@@ -466,9 +467,49 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
             for (int i = 0; i < 4; ++i) {
                 const int s_ = m * SR + trow + i;
                 if (trow + i < SR) {
-                    st_granule(xlog + ((size_t)par * BU + tutt) * SP + s_, acc[0][i], tag);
+                    if constexpr (CONT) st_granule(xlog + ((size_t)par * BU + tutt) * SP + s_, acc[0][i], tag);
                     if (a.out_logits && s_ < S && g * BU + tutt < a.B) a.out_logits[((size_t)(g * BU + tutt) * a.L + s) * S + s_] = acc[0][i];
                 }
+            }
+            if constexpr (!CONT) {
+                // Discrete heads: the Gumbel-max is taken HIERARCHICALLY.  This member reduces its SR classes of every utterance to one
+                // candidate (score, class) — first maximum wins, as in the sequential scan of the oracle — and publishes 8 candidates
+                // instead of 8 x SR logits; every member then reduces the 8 x 8 candidates itself (below), so all of them know all
+                // eight samples and the fed-back value needs no hand-off of its own (three edges per step instead of four).
+                const int bs = g * BU + tutt, s0 = m * SR + trow;   // s0 is a multiple of 4: one Philox block covers this lane's classes
+                float gn[4] = {0.f, 0.f, 0.f, 0.f};
+                if (a.mode == 1 && bs < a.B) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (trow + i < SR && s0 + i < S) gn[i] = a.noise[((size_t)bs * a.L + s) * S + s0 + i];
+                } else if (a.mode == 2) {
+                    uint32_t r4[4];
+                    ttsc_philox4x32((uint32_t)(s0 >> 2), (uint32_t)s, (uint32_t)bs, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gn[i] = ttsc_gumbel(r4[i]);
+                }
+                float best = -INFINITY;
+                int bi = 1 << 20;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float sc = acc[0][i] + gn[i];
+                    if (trow + i < SR && s0 + i < S && (bi == (1 << 20) || sc > best)) {
+                        best = sc;
+                        bi = s0 + i;
+                    }
+                }
+#pragma unroll
+                for (int off2 = 4; off2 <= 16; off2 <<= 1) {   // the 8 lanes that hold this utterance's other row groups
+                    const float os = __shfl_xor(best, off2);
+                    const int oi = __shfl_xor(bi, off2);
+                    if (oi < (1 << 20) && (bi == (1 << 20) || os > best || (os == best && oi < bi))) {
+                        best = os;
+                        bi = oi;
+                    }
+                }
+                if (((lane & 31) >> 2) == 0)   // candidate granule {score, (tag << 8) | class}: xlog area, [parity][utterance][member]
+                    __hip_atomic_store(xlog + ((size_t)par * BU + tutt) * SP + m, ((u64)((tag << 8) | (unsigned)(bi & 255)) << 32) | (u64)__float_as_uint(best),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         WT_TICK(6);
@@ -490,42 +531,25 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
                 st_granule(xlx + par * BU + m, a.forced_x ? a.forced_x[o] : wv, tag);
             }
           }
-        } else if (m < nu) {   // discrete heads: Gumbel-max over the S logits of utterance m
-            const int bs = g * BU + m;
-            float best = 0.f;
-            int bi = 0;
-            const u64* src = xlog + ((size_t)par * BU + m) * SP;
-            int off[4];
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) off[r] = min(lane + 64 * r, S - 1);   // S is a multiple of 8 <= 256
-            ok = ld_granules_at<4>(src, off, tag, v, a.abort_word) && ok;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int s_ = lane + 64 * r;
-                if (s_ < S) {
-                    float g_ = 0.f;
-                    const size_t o = ((size_t)bs * a.L + s) * S + s_;
-                    if (a.mode == 1) {
-                        g_ = a.noise[o];
-                    } else if (a.mode == 2) {
-                        uint32_t r4[4];
-                        ttsc_philox4x32((uint32_t)(s_ >> 2), (uint32_t)s, (uint32_t)bs, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r4);
-                        g_ = ttsc_gumbel(r4[s_ & 3]);
-                    }
-                    const float sc = v[r] + g_;
-                    if (r == 0 || sc > best) {
-                        best = sc;
-                        bi = s_;
-                    }
+        } else {   // discrete heads: every member reduces the 8 (members) x 8 (utterances) candidates; lane -> (utterance l >> 3, member l & 7)
+            const int cu = lane >> 3, cm = lane & 7;
+            const u64* src = xlog + ((size_t)par * BU + cu) * SP + cm;
+            u64 gq;
+            unsigned spins = 0;
+            for (;;) {
+                gq = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(gq >> 40) == (tag & 0xFFFFFFu)) break;
+                if (++spins > WT_SPIN_LIMIT || ((spins & 63u) == 0u && __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    __hip_atomic_store(a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = false;
+                    break;
                 }
+                __builtin_amdgcn_s_sleep(1);
             }
-            if (lane >= S) {   // S < 64: idle lanes must lose every comparison
-                best = -INFINITY;
-                bi = 1 << 20;
-            }
+            float best = __uint_as_float((unsigned)gq);
+            int bi = (int)((gq >> 32) & 255u);
 #pragma unroll
-            for (int off2 = 32; off2 >= 1; off2 >>= 1) {
+            for (int off2 = 1; off2 <= 4; off2 <<= 1) {   // classes of a lower member are lower: "first maximum wins" = lower class on ties
                 const float os = __shfl_xor(best, off2);
                 const int oi = __shfl_xor(bi, off2);
                 if (os > best || (os == best && oi < bi)) {
@@ -533,12 +557,19 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
                     bi = oi;
                 }
             }
-            if (lane == 0) {
+            if (cm == 0) {
+                const int bs = g * BU + cu;
                 const float wv = a.out_kind == 0 ? a.lut[bi] : (((float)bi / 255.0f) - 0.5f) * 2.0f;
-                const size_t o = (size_t)bs * a.L + s;
-                a.out_idx[o] = (uint8_t)bi;
-                a.out_wav[o] = wv;
-                st_granule(xlx + par * BU + m, a.forced_x ? a.forced_x[o] : wv, tag);
+                float fed = wv;
+                if (bs < a.B) {
+                    const size_t o = (size_t)bs * a.L + s;
+                    if (a.forced_x) fed = a.forced_x[o];
+                    if (cu == m) {   // the utterance's own member writes its outputs
+                        a.out_idx[o] = (uint8_t)bi;
+                        a.out_wav[o] = wv;
+                    }
+                }
+                lxv[cu] = fed;   // read by the gate math of the next step after the join barrier
             }
         }
         WT_TICK(7);
@@ -604,7 +635,11 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
         bool ok = true;
         if (gru_thr) {
             float lx[1] = {0.f};
-            if (t > 0 && u < nu) ok = ld_granules<1>(xlx + (par ^ 1) * BU + u, 1, (unsigned)t, lx, a.abort_word);
+            if constexpr (CONT) {
+                if (t > 0 && u < nu) ok = ld_granules<1>(xlx + (par ^ 1) * BU + u, 1, (unsigned)t, lx, a.abort_word);
+            } else if (t > 0) {
+                lx[0] = lxv[u];   // written by wave 0 in the tail of step t-1, before the join barrier
+            }
             float gi[3], gh[3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
