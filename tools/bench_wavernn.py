@@ -20,7 +20,11 @@ def main():
     ap.add_argument('--layers', type=int, default=1)
     ap.add_argument('--H', type=int, default=512)
     ap.add_argument('--ablate', action='store_true', help='load the measurement build (make -C ttscube_amd/csrc ablate); with TTSC_WT_PROF=1 the tile kernel prints its per-phase times')
+    ap.add_argument('--lib', default=None, help='load this build of the library instead (A/B experiments)')
     a = ap.parse_args()
+    if a.lib:
+        from ttscube_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(a.lib)
     if a.ablate:
         from ttscube_amd import _lib
         _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), 'libttscube_hip_ablate.so')

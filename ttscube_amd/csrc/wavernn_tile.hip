@@ -36,6 +36,9 @@ namespace ttsc {
 constexpr int WT_NC = 8;          // members per tile = utterances per tile
 constexpr int WT_THREADS = 512;
 constexpr int WT_XCDS = 8;
+#ifndef WT_STREAM_UN
+#define WT_STREAM_UN 8   // k-blocks of the recurrent weight stream in flight per wave (16-byte words per lane)
+#endif
 constexpr unsigned WT_SPIN_LIMIT = 1u << 20;   // bounded spins: a member that is not resident must not hang the GPU
 
 typedef unsigned long long u64;
@@ -294,7 +297,7 @@ __device__ __noinline__ void wt_row_block(const glb_float* W_g, const lds_float*
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[nb][i] = bias[min(r0 + mrow + i, R3 - 1)];
-    mfma_chain_g<2, 8>(acc, reinterpret_cast<const float4*>(W) + min(r0 + lane, R3 - 1), R3, v + mutt * VH, VH, H);
+    mfma_chain_g<2, WT_STREAM_UN>(acc, reinterpret_cast<const float4*>(W) + min(r0 + lane, R3 - 1), R3, v + mutt * VH, VH, H);
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
                 for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[nb][i] = bhh_m[min(r0 + mrow + i, R3 - 1)];
-                mfma_chain_g<2, 8>(acc, reinterpret_cast<const float4*>(Whh) + min(r0 + lane, R3 - 1), R3, hvec + mutt * VH, VH, H);
+                mfma_chain_g<2, WT_STREAM_UN>(acc, reinterpret_cast<const float4*>(Whh) + min(r0 + lane, R3 - 1), R3, hvec + mutt * VH, VH, H);
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
