@@ -199,6 +199,54 @@ __device__ __forceinline__ void mfma_chain(f32x4_t (&acc)[NB], const float4* w4,
     }
 }
 
+// One k-ordered fmaf chain per LANE on the vector ALU, both operands in LDS (w4[kb * wstride] = four consecutive k of the lane's row, h = the
+// lane's utterance): a dependent v_fma_f32 issues every ~7 clocks against ~14 for the 4x4x1 matrix instruction, so for the short chains that
+// sit on the critical path of a step (the pre-output layer) the vector ALU halves the latency — same fused multiply-adds, same order, same
+// bits.  Operands are prefetched UN k-blocks ahead (two register sets).
+template <int UN>
+__device__ __forceinline__ float fma_chain_lds(const float4* w4, int wstride, const float* h, int K, float acc) {
+    const int KB = K >> 2;
+    float4 wa[UN], ha[UN], wb[UN], hb[UN];
+    auto load = [&](float4 (&w)[UN], float4 (&hv)[UN], int kb0) {
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            w[q] = w4[(size_t)(kb0 + q) * wstride];
+            hv[q] = *reinterpret_cast<const float4*>(h + 4 * (kb0 + q));
+        }
+    };
+    auto run = [&](const float4 (&w)[UN], const float4 (&hv)[UN]) {
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            acc = fmaf(w[q].x, hv[q].x, acc);
+            acc = fmaf(w[q].y, hv[q].y, acc);
+            acc = fmaf(w[q].z, hv[q].z, acc);
+            acc = fmaf(w[q].w, hv[q].w, acc);
+        }
+    };
+    const int NBt = KB / UN;   // KB is a multiple of UN (H % 32 == 0, UN = 8)
+    load(wa, ha, 0);
+    int bi = 0;
+    for (; bi + 2 < NBt; bi += 2) {
+        load(wb, hb, (bi + 1) * UN);
+        __builtin_amdgcn_sched_barrier(0);
+        run(wa, ha);
+        __builtin_amdgcn_sched_barrier(0);
+        load(wa, ha, (bi + 2) * UN);
+        __builtin_amdgcn_sched_barrier(0);
+        run(wb, hb);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (bi + 1 < NBt) {
+        load(wb, hb, (bi + 1) * UN);
+        __builtin_amdgcn_sched_barrier(0);
+        run(wa, ha);
+        run(wb, hb);
+    } else {
+        run(wa, ha);
+    }
+    return acc;
+}
+
 // The same chain with the weight words streamed from global memory: their prefetch distance is one batch of UN k-blocks
 // (L2 latency), while the h words (LDS latency) are read only two k-blocks ahead — which keeps the register count of the
 // two-accumulator recurrent blocks at ~100 instead of ~200.
@@ -435,18 +483,36 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
         if (lane == 0) __hip_atomic_fetch_add(pre_ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
-    // The tail of step s on wave 0 (hvec holds h_s): pre slice, output slice, sample of utterance m.  Tag of step s = s + 1.
+    // The member's pre-output slice of step s — 32 rows x 8 utterances = 256 chains of H terms — on the vector ALU of waves 4..7, one chain per
+    // lane (fma_chain_lds), published as granules; the same waves then gather everybody's slices (stage_pre).  On the matrix pipe of wave 0
+    // this chain took 4.9 us of the 15.6 us step (512 dependent 4x4x1 instructions); here it takes about half.
+    auto pre_valu = [&](int s) {
+        const int hl = tid - 4 * 64;   // 0..255
+        const int row = hl & 31, utt = hl >> 5;
+        const float v = fma_chain_lds<8>(reinterpret_cast<const float4*>(wpreL) + row, PR, hvecT + utt * VH, H, bpre_m[row]);
+        st_granule(xpre + ((size_t)(s & 1) * 256 + m * PR + row) * BU + utt, ttsc_tanhf(v), (unsigned)s + 1u);
+    };
+
+    // The tail of step s on wave 0 (hvec holds h_s): output slice, candidates / sample.  Tag of step s = s + 1.
     auto tail = [&](int s) -> bool {
         const int par = s & 1;
         const unsigned tag = (unsigned)s + 1u;
         bool ok = true;
-        {   // pre-output: 32 rows x 8 utterances
-            f32x4_t acc[1];
+        // While waves 4..7 compute and gather the pre-output vector, this wave draws the step's Gumbel noise for its classes (it depends on
+        // (class, step, utterance) only): off the critical path instead of behind the output chain.
+        float gn[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (!CONT) {
+            const int bs = g * BU + tutt, s0 = m * SR + trow;   // s0 is a multiple of 4: one Philox block covers this lane's classes
+            if (a.mode == 1 && bs < a.B) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[0][i] = bpre_m[trow + i];
-            mfma_chain<1, 4>(acc, reinterpret_cast<const float4*>(wpreL) + (lane & 31), PR, hvecT + tutt * VH, 0, H);
+                for (int i = 0; i < 4; ++i)
+                    if (trow + i < SR && s0 + i < S) gn[i] = a.noise[((size_t)bs * a.L + s) * S + s0 + i];
+            } else if (a.mode == 2) {
+                uint32_t r4[4];
+                ttsc_philox4x32((uint32_t)(s0 >> 2), (uint32_t)s, (uint32_t)bs, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) st_granule(xpre + ((size_t)par * 256 + m * PR + trow + i) * BU + tutt, ttsc_tanhf(acc[0][i]), tag);
+                for (int i = 0; i < 4; ++i) gn[i] = ttsc_gumbel(r4[i]);
+            }
         }
         WT_TICK(4);
         {   // the full pre-output vector of the 8 utterances is staged by the helper waves (stage_pre): wait for the four of them
@@ -479,18 +545,7 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
                 // candidate (score, class) — first maximum wins, as in the sequential scan of the oracle — and publishes 8 candidates
                 // instead of 8 x SR logits; every member then reduces the 8 x 8 candidates itself (below), so all of them know all
                 // eight samples and the fed-back value needs no hand-off of its own (three edges per step instead of four).
-                const int bs = g * BU + tutt, s0 = m * SR + trow;   // s0 is a multiple of 4: one Philox block covers this lane's classes
-                float gn[4] = {0.f, 0.f, 0.f, 0.f};
-                if (a.mode == 1 && bs < a.B) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (trow + i < SR && s0 + i < S) gn[i] = a.noise[((size_t)bs * a.L + s) * S + s0 + i];
-                } else if (a.mode == 2) {
-                    uint32_t r4[4];
-                    ttsc_philox4x32((uint32_t)(s0 >> 2), (uint32_t)s, (uint32_t)bs, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r4);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) gn[i] = ttsc_gumbel(r4[i]);
-                }
+                const int s0 = m * SR + trow;
                 float best = -INFINITY;
                 int bi = 1 << 20;
 #pragma unroll
@@ -588,7 +643,10 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
         if (wave == 0) {
             if (t > 0 && !tail(t - 1)) *tail_fail = 1;
         } else if (wave >= 4) {
-            if (t > 0) stage_pre(t - 1);
+            if (t > 0) {
+                pre_valu(t - 1);
+                stage_pre(t - 1);
+            }
         } else if (wave - 1 < nblk) {
             const int r0 = (wave - 1) * 64;
             if (L2) {   // (two-layer kernel: out-of-line block, see wt_row_block) recurrent products of BOTH layers for this step
@@ -728,7 +786,10 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
         if (++fr_phase == a.up) { fr_phase = 0; ++fr; }
         if (++lo_phase == a.up_low) { lo_phase = 0; ++lo; }
     }
-    if (wave >= 4) stage_pre(a.L - 1);
+    if (wave >= 4) {
+        pre_valu(a.L - 1);
+        stage_pre(a.L - 1);
+    }
     if (wave == 0) tail(a.L - 1);
 #ifdef TTSC_ABLATE
     if (a.prof && tid == 0)
