@@ -376,3 +376,24 @@ def test_conv1d_f16x3_activation_prescale(xscale, act_scale):
     assert rel < 2e-6, (xscale, rel)
     with pytest.raises(Exception):
         conv.set_activation_scale(3.0)       # not a power of two
+
+
+@pytest.mark.parametrize('cin,cout,k,s,L,B', [(512, 256, 16, 5, 300, 2), (512, 256, 16, 5, 37, 1), (256, 128, 16, 3, 600, 2), (256, 128, 16, 3, 259, 1)])
+def test_conv_transpose1d_tall_tile_kernel(cin, cout, k, s, L, B, monkeypatch):
+    """conv_f16x3_tall_kernel (256 / 128 virtual rows per workgroup; the first two upsamplers of HiFi-GAN V1), forced on for problems too
+    small to pick it by itself (TTSC_CONV_WIDE=2), against torch and against the general kernel (TTSC_CONV_TALL=0 is read once per process, so
+    the comparison kernel is the fp32 path)"""
+    from ttscube_amd.hip_layers import Conv1dHip
+    monkeypatch.setenv('TTSC_CONV_WIDE', '2')
+    pad = (k - s) // 2
+    w = _mk((cin, cout, k), 11, 1.0 / (cin * k / s) ** 0.5)
+    b = _mk((cout,), 12, 0.1)
+    x = _mk((B, cin, L), 13)
+    conv = Conv1dHip(cin, cout, k, stride=s, padding=pad, transposed=True).set_precision('f16x3')
+    conv.set_weight(w, b)
+    y = conv(x.cuda(), in_slope=0.1).cpu()
+    ref = F.conv_transpose1d(F.leaky_relu(x, 0.1), w, b, stride=s, padding=pad)
+    assert y.shape == ref.shape and float((y - ref).abs().max()) < F16X3_TOL
+    conv.set_precision('fp32')
+    y32 = conv(x.cuda(), in_slope=0.1).cpu()
+    assert float((y - y32).abs().max()) < F16X3_TOL

@@ -38,6 +38,33 @@ def timed(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
+GEN_BITS = [(0, 'full'), (4, 'no epilogue'), (1, 'no staging commit'), (8, 'no global loads in loop'), (1 | 8, 'no staging at all'), (2, 'no MFMA loop'),
+            (1 | 4 | 8, 'MFMA + LDS reads only')]
+
+
+def ups_ablation(a):
+    """conv_pre / upsampler i at config[1] sizes (B x T = 64 x 800) on conv_f16x3_kernel with parts switched off (TTSC_CONV_DBG)"""
+    cfg = {-2: (80, 512, 7, 1, 800), 0: (512, 256, 16, 5, 800), 1: (256, 128, 16, 3, 4001), 2: (128, 64, 4, 4, 12004), 3: (64, 32, 4, 4, 48016)}[a.ups]
+    Cin, Cout, k, u, L = cfg
+    if a.ups == -2:
+        c = Conv1dHip(Cin, Cout, k, padding=3).set_precision('f16x3')
+        w = torch.randn(Cout, Cin, k) / (Cin * k) ** 0.5
+    else:
+        c = Conv1dHip(Cin, Cout, k, stride=u, padding=(k - u) // 2, transposed=True).set_precision('f16x3')
+        w = torch.randn(Cin, Cout, k) / (Cin * k / u) ** 0.5
+    c.set_weight(w, torch.randn(Cout) * 0.1)
+    x = torch.randn(a.B, Cin, L, device='cuda')
+    y = torch.empty((a.B, Cout, c.out_len(L)), device='cuda')
+    flops = 2.0 * a.B * L * Cin * Cout * k
+    base = None
+    for bit, name in GEN_BITS:
+        os.environ['TTSC_CONV_DBG'] = str(bit)
+        ms = timed(lambda: c(x, out=y, in_slope=0.1), a.iters)
+        base = base or ms
+        print('%s full=%s %-28s %7.3f ms  %5.1f%% of full  %6.1f TF/s  (in %.0f MB, out %.0f MB)' % (
+            'conv_pre' if a.ups == -2 else 'ups.%d' % a.ups, 'y' if bit == 0 else 'n', name, ms, 100 * ms / base, flops / ms / 1e9, x.numel() * 4 / 1e6, y.numel() * 4 / 1e6), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--stage', type=int, default=1)
@@ -45,8 +72,11 @@ def main():
     ap.add_argument('--B', type=int, default=64)
     ap.add_argument('--shape', type=int, default=-1)
     ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--ups', type=int, default=-1, help='ablate upsampler i of config_v1 (-2: conv_pre) on the general split kernel instead of a ResBlock')
     a = ap.parse_args()
     L_ = _lib.lib()
+    if a.ups != -1:
+        return ups_ablation(a)
     Cc, L = STAGES[a.stage]
     k = a.k
     x = torch.randn(a.B, Cc, L, device='cuda')

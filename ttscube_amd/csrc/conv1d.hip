@@ -1087,6 +1087,182 @@ static int launch_f16_wide(const ConvArgs& a0, int B, hipStream_t s) {
     return TTSC_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Tall-tile variant for the first two upsamplers (ConvTranspose1d 512 -> 256, k16 s5 and 256 -> 128, k16 s3).  As GEMMs they are 1280 / 768
+// "virtual rows" (phase, channel) x CIN * J deep over the INPUT positions, J = ceil(K / stride) taps reading x[q - j].  The general kernel
+// runs them as 20 / 12 M tiles of 64 rows that each load, leaky-relu and split the same input window: the ablation (tools/ablate.py --ups)
+// puts 45 % of their time into that staging.  Here a workgroup owns 256 rows x 128 input positions (2 x 2 waves of 4 x 2 MFMA tiles: the
+// same 24 MFMAs per 12 fragment reads as the wide kernel), so the window is staged 5 / 3 times instead of 20 / 12, on the wide kernel's
+// skeleton: weights by LDS-DMA one tap ahead, activations double-buffered, conversion of chunk c+1 spread over the last taps of chunk c.
+// (MI, NJ) = (4, 2): 256 rows x 128 positions (ups.0: 1280 rows); (2, 4): 128 rows x 256 positions (ups.1: 384 rows = 3 tiles instead of 6).
+template <int CIN, int J, int MI, int NJ>
+__global__ __launch_bounds__(256, 2) void conv_f16x3_tall_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int WM = 2, WN = 2, NT = WN * NJ * 32;
+    constexpr int SPAN = NT + (J - 1);
+    constexpr int SPANP = (SPAN + 63) & ~63;
+    constexpr int BUFSZ = 4 * SPAN + 2;
+    constexpr int NCHUNK = CIN / 16;
+    constexpr int AITEMS = WM * MI * 2 * 64;        // weight items of one (tap, chunk) for the workgroup's 256 rows (16 KB)
+    static_assert(J % 2 == 0 && NCHUNK % 2 == 0, "slot parity: an even number of taps per chunk, chunks in pairs");
+    half8* Xp = reinterpret_cast<half8*>(smem_raw);   // [2 buffers][plane (h, pl)][SPAN]
+    half8* Aw = Xp + 2 * BUFSZ;                       // [2 slots][AITEMS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z;
+    const int q0 = a.q_lo + blockIdx.x * NT;          // first INPUT position of the tile
+    const int lin = a.in_len ? a.in_len[b] : a.Lin;
+    if (a.out_len && (long)q0 * a.out_stride + a.out_off >= a.out_len[b]) return;
+    const int cotg = blockIdx.y * (WM * MI);
+    const int cotN = a.CoutP >> 5;
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const float* xb = a.x + (size_t)b * CIN * a.Lin;
+    const int lo = q0 - (J - 1);                      // x position of LDS column 0 (tap j reads column (q - q0) + J - 1 - j)
+    const half8* wsrc = reinterpret_cast<const half8*>(a.wph) + (size_t)cotg * 128 + lane;
+    auto stage_A = [&](int c, int j, int slot) __attribute__((always_inline)) {
+        const half8* wj = wsrc + (size_t)(j * NCHUNK + c) * ((size_t)cotN * 128);
+#pragma unroll
+        for (int i = 0; i < AITEMS / 64 / 4; ++i) {
+            const int blk = wave + i * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wj + blk * 64),
+                                             (__attribute__((address_space(3))) void*)(Aw + slot * AITEMS + blk * 64), 16, 0, 0);
+        }
+    };
+    constexpr int XIT = (2 * SPANP + 255) / 256;
+    static_assert(XIT <= J, "one staging item per tap");
+    float xr[XIT][8];
+    unsigned xoff[XIT];
+    int xslot[XIT];
+    bool xok[XIT];
+#pragma unroll
+    for (int e = 0; e < XIT; ++e) {
+        const int i = tid + e * 256;
+        const int h = i >= SPANP ? 1 : 0;
+        const int p = i - h * SPANP;
+        const int pos = lo + p;
+        xok[e] = pos >= 0 && pos < lin;
+        int pc = pos > lin - 1 ? lin - 1 : pos;
+        pc = pc < 0 ? 0 : pc;
+        xoff[e] = (unsigned)(h * 8 * a.Lin + pc);
+        xslot[e] = (p < SPAN && i < 2 * SPANP) ? (h * 2) * SPAN + p : 4 * SPAN;
+    }
+    auto x_issue_item = [&](int e, int c) __attribute__((always_inline)) {
+        const float* rc = xb + (size_t)(c * 16) * a.Lin;
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) xr[e][ch] = rc[(size_t)ch * a.Lin + xoff[e]];
+    };
+    auto x_commit_item = [&](int e, half8* buf) __attribute__((always_inline)) {
+        half8 vh, vl;
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+            float v = xok[e] ? xr[e][ch] * a.in_scale : 0.f;
+            v = fmaxf(v, v * a.in_slope);
+            const _Float16 hh = (_Float16)v;
+            vh[ch] = hh;
+            vl[ch] = (_Float16)(v - (float)hh);
+        }
+        buf[xslot[e]] = vh;
+        buf[xslot[e] + (xslot[e] < 4 * SPAN ? SPAN : 1)] = vl;
+    };
+    const half8* xbase = Xp + (unsigned)((half * 2) * SPAN + wn * (NJ * 32) + l31);
+    const half8* abase = Aw + (unsigned)(wm * (MI * 128) + lane);
+    auto chunk = [&](int c, auto buf_tag) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        half8* nxt = Xp + (1 - BUF) * BUFSZ;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int slot = j & 1;   // (J is even: every chunk starts on slot 0)
+            if (j + 1 < J)
+                stage_A(c, j + 1, slot ^ 1);
+            else
+                stage_A(c + 1 < NCHUNK ? c + 1 : c, 0, slot ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            half8 ah[MI], al[MI], bh[NJ], bl[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                ah[i] = abase[slot * AITEMS + i * 128];
+                al[i] = abase[slot * AITEMS + i * 128 + 64];
+            }
+#pragma unroll
+            for (int n = 0; n < NJ; ++n) {
+                bh[n] = xbase[BUF * BUFSZ + (J - 1 - j) + n * 32];
+                bl[n] = xbase[BUF * BUFSZ + SPAN + (J - 1 - j) + n * 32];
+            }
+            const int e = J - 1 - j;
+            if (e < XIT) {
+                x_commit_item(e, nxt);
+                x_issue_item(e, c + 2 < NCHUNK ? c + 2 : NCHUNK - 1);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[n], acc[i][n], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[n], acc[i][n], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[n], acc[i][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        }
+    };
+    stage_A(0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < XIT; ++e) x_issue_item(e, 0);
+#pragma unroll
+    for (int e = 0; e < XIT; ++e) x_commit_item(e, Xp);
+#pragma unroll
+    for (int e = 0; e < XIT; ++e) x_issue_item(e, 1);
+    __syncthreads();
+    for (int c = 0; c < NCHUNK; c += 2) {
+        chunk(c, std::integral_constant<int, 0>());
+        chunk(c + 1, std::integral_constant<int, 1>());
+    }
+    // epilogue: virtual row tile -> (phase r, real channel tile); output position o = q * stride + r - padding
+    const int q_hi = a.q_lo + a.q_cnt;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int n = 0; n < NJ; ++n) {
+            const int q = q0 + wn * (NJ * 32) + n * 32 + l31;
+            int cb = (cotg + wm * MI + i) * 32;
+            const int r = cb / a.vphase;
+            cb -= r * a.vphase;
+            const long oo = (long)q * a.out_stride + a.out_off + r;
+            const bool ok = (q < q_hi) && (oo >= 0) && (oo < a.Lout) && (r < a.out_stride);
+            epilogue_tile(acc[i][n], a, b, cb, oo, ok, half, a.w_unscale);
+        }
+    }
+}
+
+template <int CIN, int J, int MI, int NJ>
+static int launch_f16_tall(const ConvArgs& a, int B, hipStream_t s) {
+    constexpr int NT = 2 * NJ * 32, SPAN = NT + (J - 1), MT = 2 * MI * 32;
+    dim3 grid((unsigned)ceil_div(a.q_cnt, NT), (unsigned)(a.CoutP / MT), (unsigned)B);
+    constexpr size_t lds = (size_t)2 * (4 * SPAN + 2) * 16 + (size_t)2 * (2 * MI * 2 * 64) * 16;
+    if (int rc = ensure_full_lds((const void*)conv_f16x3_tall_kernel<CIN, J, MI, NJ>)) return rc;
+    hipLaunchKernelGGL((conv_f16x3_tall_kernel<CIN, J, MI, NJ>), grid, dim3(256), lds, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("conv_f16x3_tall_kernel launch failed: %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    return TTSC_OK;
+}
+
 template <int C, int K>
 static int launch_f16_wide_d(const ConvArgs& a, int B, int d, hipStream_t s) {
     if (d == 1) return launch_f16_wide<C, K, 1>(a, B, s);
@@ -1710,7 +1886,14 @@ extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, 
                                     (g.kernel_size == 3 || g.kernel_size == 7 || g.kernel_size == 11) &&
                                     (g.dilation == 1 || g.dilation == 3 || g.dilation == 5) &&
                                     g.padding == g.dilation * (g.kernel_size - 1) / 2;
-            if (wide_env && wide_shape && (wide_env == 2 || (long)ceil_div(a.Lout, 256) * (g.out_channels / 128) * B >= want16)) {
+            // the first upsamplers of the V1 generator: tall tiles (256 virtual rows x 128 input positions)
+            static const bool tall_on = !(getenv("TTSC_CONV_TALL") && atoi(getenv("TTSC_CONV_TALL")) == 0);
+            const bool tall0 = g.in_channels == 512 && ph.ntaps == 4 && c->CoutP % 256 == 0;    // ups.0: 256-row tiles
+            const bool tall1 = g.in_channels == 256 && ph.ntaps == 6 && c->CoutP % 128 == 0;    // ups.1: 128-row tiles
+            const bool tall_shape = tall_on && c->vfused && a.vphase > 0 && !a.gate && c->CinP == g.in_channels && (tall0 || tall1);
+            if (tall_shape && (wide_env == 2 || (long)ceil_div(a.q_cnt, tall0 ? 128 : 256) * (c->CoutP / (tall0 ? 256 : 128)) * B >= want16)) {
+                rc = tall0 ? launch_f16_tall<512, 4, 4, 2>(a, B, s) : launch_f16_tall<256, 6, 2, 4>(a, B, s);
+            } else if (wide_env && wide_shape && (wide_env == 2 || (long)ceil_div(a.Lout, 256) * (g.out_channels / 128) * B >= want16)) {
                 if (g.out_channels == 256)
                     rc = launch_f16_wide_k<256>(a, B, g.dilation, s);
                 else
