@@ -55,17 +55,20 @@ def self_check(g, mel, out, h, sd, tol=1e-4):
     return rms
 
 
-def time_forward(g, mel, steps, warmup):
-    """(device ms per forward, last output) of `steps` forwards after `warmup`, HIP events on the launch stream."""
+def time_forward(g, mel, steps, warmup, check='sync'):
+    """(device ms per forward, last output) of `steps` forwards after `warmup`, HIP events on the launch stream.  check='deferred': the
+    range guard's verdicts are collected at the next call / before the clock stops instead of by a stream synchronisation per call."""
     import torch
     with torch.no_grad():
         for _ in range(warmup):
-            out = g(mel)
+            out = g(mel, check=check)
+        g.finish_range_check()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(steps):
-            out = g(mel)
+            out = g(mel, check=check)
+        g.finish_range_check()
         e1.record()
         torch.cuda.synchronize()
     return e0.elapsed_time(e1) / steps, out
@@ -80,8 +83,10 @@ def extra_legs(g, h, sd, rank_dev, R):
     legs = {}
     try:
         mel1 = R.synthetic_mel(1, 300, seed=77).to(rank_dev)
-        ms, o1 = time_forward(g, mel1, 50, 20)
-        legs['single_utterance_3s'] = {'ms': ms, 'samples_per_s': o1.shape[2] / (ms * 1e-3), 'rms_vs_oracle': self_check(g, mel1, o1, h, sd)}
+        ms, o1 = time_forward(g, mel1, 50, 20, check='deferred')   # 50 back-to-back calls: pipelined, guard verdicts collected in the timed region
+        ms_sync, _ = time_forward(g, mel1, 50, 5)                   # ... and with the default per-call synchronisation (what a caller who reads the audio back sees)
+        legs['single_utterance_3s'] = {'ms': ms, 'ms_with_per_call_sync': ms_sync, 'samples_per_s': o1.shape[2] / (ms * 1e-3),
+                                       'rms_vs_oracle': self_check(g, mel1, o1, h, sd)}
     except Exception as e:   # a secondary leg must never take the headline number down
         legs['single_utterance_3s'] = {'error': str(e)[:200]}
     try:

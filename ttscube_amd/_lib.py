@@ -204,3 +204,27 @@ def check_split_status(where):
     if bad:
         raise TTSCError('%s: split %s recurrence aborted on a hand-off timeout (are other kernels occupying the CUs? '
                         'TTSC_LSTM_SPLIT=1 / TTSC_GRU_SPLIT=1 select the single-workgroup kernels)' % (where, '/'.join(bad)))
+
+
+class DevLengths(list):
+    """A list of per-utterance lengths that also carries its int32 device copy (`.dev`): the host list keeps every existing use working, the
+    kernels take `.dev` — ONE host-to-device copy per synthesis call instead of one synchronous pageable copy (each a stream drain) per layer."""
+
+    def __init__(self, values, dev_tensor=None, device=None):
+        super().__init__(int(v) for v in values)
+        if dev_tensor is None:
+            import torch
+            dev_tensor = torch.tensor(list(self), dtype=torch.int32).pin_memory().to(device, non_blocking=True)
+        self.dev = dev_tensor
+
+
+def lengths_dev(lengths, device):
+    """int32 device tensor of `lengths` (a DevLengths' own copy, a device tensor as is, else a fresh — synchronous — upload)"""
+    import torch
+    if lengths is None:
+        return None
+    if isinstance(lengths, DevLengths) and lengths.dev.device == torch.device(device):
+        return lengths.dev
+    if torch.is_tensor(lengths) and lengths.is_cuda:
+        return lengths.to(torch.int32).contiguous()
+    return torch.as_tensor(lengths, dtype=torch.int32, device=device).contiguous()

@@ -196,7 +196,7 @@ class LSTMHip:
         H, nd = self.H, self.ndir
         len_dev = None
         if lengths is not None:
-            len_dev = torch.as_tensor(lengths, dtype=torch.int32, device=x.device).contiguous()
+            len_dev = _lib.lengths_dev(lengths, x.device)
         hn = torch.empty((self.num_layers * nd, B, H), dtype=torch.float32, device=x.device) if return_state else None
         cn = torch.empty_like(hn) if return_state else None
         cur = x.float().contiguous()

@@ -295,7 +295,7 @@ def _cnn_forward(stack, emb, lengths):
     B, N, _ = emb.shape
     mask = None
     if lengths is not None and B > 1:
-        mask = (torch.arange(N, device=emb.device)[None, :] < torch.as_tensor(lengths, device=emb.device)[:, None]).float()[:, None, :]
+        mask = (torch.arange(N, device=emb.device)[None, :] < _lib.lengths_dev(lengths, emb.device)[:, None]).float()[:, None, :]
     h = emb.float().permute(0, 2, 1).contiguous()
     if mask is not None:
         h = h * mask
@@ -361,12 +361,12 @@ def align_durations(out_dur, lengths):
     durs = torch.empty((B, N), dtype=torch.int32, device=dev)
     f2p = torch.empty((B, fcap), dtype=torch.int32, device=dev)
     flen = torch.empty((B,), dtype=torch.int32, device=dev)
-    len_t = torch.as_tensor(lengths, dtype=torch.int32, device=dev) if lengths is not None else None
+    len_t = _lib.lengths_dev(lengths, dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().ttsc_align_durations(_lib.dev_ptr(out_dur), _lib.dev_ptr(len_t) if len_t is not None else None, B, N, D,
                                                    _lib.dev_ptr(durs), _lib.dev_ptr(f2p), _lib.dev_ptr(flen), fcap, _lib.current_stream()),
                    'ttsc_align_durations')
-    return Alignment(f2p, flen, flen.cpu().tolist(), durs)
+    return Alignment(f2p, flen, _lib.DevLengths(flen.cpu().tolist(), dev_tensor=flen), durs)   # (frame counts: host list + the device copy the kernel wrote)
 
 
 def _expand_rows(x, alignments, stride=1):
@@ -376,7 +376,7 @@ def _expand_rows(x, alignments, stride=1):
     alignments a collate supplies — host data to begin with)."""
     if isinstance(alignments, Alignment):
         al = alignments
-        flens = [n // stride for n in al.flens]
+        flens = al.flens if stride == 1 else [n // stride for n in al.flens]   # (stride 1 keeps the device copy of the counts)
         m = max(flens) if flens else 0
         if m == 0:
             return x[:, :0], [0] * len(flens)
@@ -495,7 +495,7 @@ class Languasito2(nn.Module):
         x_char = X['x_char'].to(dev)
         x_speaker = X['x_speaker'].to(dev)
         B, N = x_char.shape
-        lengths = _char_lengths(X, x_char)
+        lengths = _lib.DevLengths(_char_lengths(X, x_char), device=dev)   # one upload; every layer below takes the device copy
         with torch.no_grad():
             mark('start')
             hcs = self._text_stack('t', x_char, x_speaker, lengths, X, hf_cond)
@@ -523,7 +523,7 @@ class Languasito2(nn.Module):
             g = self._lstm('_cond_rnn')(g, lengths=flens)
             cond = linear_hip(g, self._cond_output.linear_layer.weight, self._cond_output.linear_layer.bias)
             if B > 1:
-                fmask = (torch.arange(F_, device=dev)[None, :] < torch.as_tensor(flens, device=dev)[:, None]).float()
+                fmask = (torch.arange(F_, device=dev)[None, :] < _lib.lengths_dev(flens, dev)[:, None]).float()
                 cond = cond * fmask[:, :, None]
             mark('frames')
         if check_status:   # (Cubegan.inference polls once for the whole synthesis instead)
