@@ -1,0 +1,95 @@
+"""Split-precision training convolution (csrc/conv_train.hip, C ABI `ttsc_conv_train`) against torch's float64 conv1d on the same inputs:
+forward with leaky-relu prologue / bias / residual, data gradient with the gate epilogue, sequences folded into the tile columns
+(lengths that do not divide a tile, batches that end inside one), and inputs 1e-6 .. 1e4 in magnitude — the range words are measured on
+the device per launch, nothing is calibrated.  Tolerance: 2e-6 of the output's largest magnitude (22-bit operands, fp32 accumulation)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(x, w, b, resid, gate, padding, dilation, flip, **kw):
+    from ttscube_amd.hifigan.autograd import _conv_split
+    if flip:
+        Cin, Cout, K = w.shape[0], w.shape[1], w.shape[2]
+    else:
+        Cout, Cin, K = w.shape
+    return _conv_split(x, w, b, resid, gate, Cin, Cout, K, padding, dilation, flip, **kw)
+
+
+def _ref(x, w, b, resid, gate, padding, dilation, flip, in_scale=1.0, in_slope=1.0, out_scale=1.0, gate_slope=1.0):
+    x, w = x.double(), w.double()
+    if flip:
+        w = w.permute(1, 0, 2).flip(2)
+    a = F.leaky_relu(x * in_scale, in_slope) if in_slope != 1.0 else x * in_scale
+    y = F.conv1d(a, w, b.double() if b is not None else None, padding=padding, dilation=dilation)
+    if gate is not None:
+        y = y * torch.where(gate.double() > 0, 1.0, gate_slope)
+    if resid is not None:
+        y = y + resid.double()
+    return y * out_scale
+
+
+CASES = [  # B, Cin, Cout, K, L, padding, dilation
+    (3, 48, 80, 5, 77, 2, 1),
+    (4, 64, 96, 5, 210, 14, 7),      # MPD period 7: (5, 1) kernel over the flat signal
+    (2, 96, 64, 2, 333, 0, 3),       # de-interleaved strided layer: 2 taps, no padding
+    (5, 32, 32, 3, 50, 1, 1),
+    (2, 128, 128, 11, 300, 25, 5),   # generator ResBlock, widest receptive field
+    (1, 16, 33, 7, 1000, 3, 1),      # ragged channel counts
+    (7, 1024, 64, 5, 22, 4, 2),      # deep discriminator layer: many channels, a sliver of positions
+]
+
+
+@pytest.mark.parametrize('B,Cin,Cout,K,L,pad,d', CASES)
+@pytest.mark.parametrize('mag', [1.0, 1e-6, 1e4])
+def test_forward_matches_float64(B, Cin, Cout, K, L, pad, d, mag):
+    g = torch.Generator().manual_seed(B * 1000 + Cin + K)
+    x = (torch.randn(B, Cin, L, generator=g) * mag).cuda()
+    w = (torch.randn(Cout, Cin, K, generator=g) / (Cin * K) ** 0.5).cuda()
+    b = (torch.randn(Cout, generator=g) * mag).cuda()
+    Lout = L + 2 * pad - d * (K - 1)
+    r = (torch.randn(B, Cout, Lout, generator=g) * mag).cuda()
+    y = _run(x, w, b, r, None, pad, d, 0, in_scale=0.5, in_slope=0.1)
+    ref = _ref(x, w, b, r, None, pad, d, 0, in_scale=0.5, in_slope=0.1)
+    assert y.shape == ref.shape
+    assert float((y.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize('B,Cin,Cout,K,L,pad,d', CASES)
+def test_data_gradient_matches_autograd(B, Cin, Cout, K, L, pad, d):
+    """flip = 1 on the forward weight + gate epilogue == d/dx of conv(leaky_relu(sc * x))"""
+    g = torch.Generator().manual_seed(B + Cin * 7 + K)
+    x = torch.randn(B, Cin, L, generator=g, dtype=torch.float64).cuda().requires_grad_(True)
+    w = (torch.randn(Cout, Cin, K, generator=g, dtype=torch.float64) / (Cin * K) ** 0.5).cuda()
+    sc, sl = 0.7, 0.1
+    y = F.conv1d(F.leaky_relu(x * sc, sl), w, padding=pad, dilation=d)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64).cuda() * 1e-5     # gradients are small numbers
+    (dx_ref,) = torch.autograd.grad(y, x, dy)
+    pd = d * (K - 1) - pad
+    if Cout < 16 or Cin < 32:
+        pytest.skip('the data gradient of this shape stays on the fp32 kernel')
+    dx = _run(dy.float(), w.float().contiguous(), None, None, x.detach().float(), pd, d, 1, out_scale=sc, gate_slope=sl)
+    assert dx.shape == dx_ref.shape
+    assert float((dx.double() - dx_ref).abs().max()) <= 2e-6 * float(dx_ref.abs().max())
+
+
+def test_zero_and_non_finite_inputs_are_visible():
+    x = torch.zeros(2, 32, 40).cuda()
+    w = torch.randn(32, 32, 3).cuda()
+    assert float(_run(x, w, None, None, None, 1, 1, 0).abs().max()) == 0.0
+    x[1, 3, 7] = float('inf')
+    y = _run(x, w, None, None, None, 1, 1, 0)
+    assert not bool(torch.isfinite(y[1]).all()) and bool(torch.isfinite(y[0]).all())
+    x[1, 3, 7] = float('nan')
+    assert bool(torch.isnan(_run(x, w, None, None, None, 1, 1, 0)[1]).any())
+
+
+def test_unsupported_shapes_are_refused():
+    from ttscube_amd import _lib
+    assert not _lib.lib().ttsc_conv_train_supported(1, 32, 5, 1)       # discriminator input layer
+    assert not _lib.lib().ttsc_conv_train_supported(1024, 1, 3, 1)     # conv_post
+    assert not _lib.lib().ttsc_conv_train_supported(64, 64, 41, 1)     # MSD's k = 41 layers (grouped, fp32 kernel)
+    with pytest.raises(_lib.TTSCError):
+        _run(torch.zeros(1, 1, 64).cuda(), torch.zeros(32, 1, 5).cuda(), None, None, None, 2, 1, 0)

@@ -99,9 +99,26 @@ def test_native_discriminators_match_torch_modules(which):
     bad = [(n, _rel(a, b_), bool(torch.isfinite(a).all()), bool(torch.isfinite(b_).all())) for n, a, b_ in zip(names, gp1, gp0)
            if not (_rel(a, b_) < 2e-3)]   # (sums of ~1e5 signed terms per element, fp32, in two different orders)
     assert not bad, ('parameter gradients of the discriminator loss (name, rel, native finite, torch finite)', bad[:6])
-    gx0 = torch.autograd.grad(lg0, y_hat)[0]
-    gx1 = torch.autograd.grad(lg1, y_hat)[0]
-    assert _rel(gx1, gx0) < 1e-4          # what the generator receives through the discriminators
+    # what the generator receives through the discriminators.  The loss is not smooth (leaky-relu gates, the L1 feature loss): a forward pass
+    # that differs in the 6th digit flips a few gates / signs, and torch's own fp32 gradient sits ~1e-3 (max norm) from the float64 one for
+    # that reason alone.  So (a) against float64, the native gradient may be at most 4x as far as torch-fp32 is; (b) on the SAME forward
+    # graph the split-precision data gradients must agree with the exact-fp32 kernels' to 2e-6.
+    from ttscube_amd.hifigan import autograd as A
+    gx0 = torch.autograd.grad(lg0, y_hat, retain_graph=True)[0]
+    gx1 = torch.autograd.grad(lg1, y_hat, retain_graph=True)[0]
+    m64 = (D.MultiPeriodDiscriminator() if which == 'mpd' else D.MultiScaleDiscriminator()).cuda()
+    m64.load_state_dict(m.state_dict())
+    m64 = m64.double().eval()
+    yh64 = y_hat.detach().double().requires_grad_(True)
+    gx64 = torch.autograd.grad(losses(m64(y.double(), yh64))[1], yh64)[0]
+    assert _rel(gx1, gx64) < 4 * _rel(gx0, gx64) + 1e-4, (_rel(gx1, gx64), _rel(gx0, gx64))
+    if A.SPLIT_TRAIN:
+        try:
+            A.SPLIT_TRAIN = False
+            gx2 = torch.autograd.grad(lg1, y_hat, retain_graph=True)[0]    # same graph, data gradients on the fp32 kernel
+        finally:
+            A.SPLIT_TRAIN = True
+        assert _rel(gx1, gx2) < 2e-6
     # discriminator step: generated audio carries no graph -> real + generated run as ONE batch; same values
     nat_d = fwd(m, y, y_hat.detach(), want_fmap=False)
     ld2 = D.discriminator_loss(nat_d[0], nat_d[1])[0]

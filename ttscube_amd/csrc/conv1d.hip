@@ -20,541 +20,9 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "conv_kernels.hpp"
 
 namespace ttsc {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// Ablation switches exist only in the measurement build (-DTTSC_ABLATE, tools/ablate.cpp); the product library compiles
-// them to constants, so no environment variable can make a shipped kernel skip work.
-#ifdef TTSC_ABLATE
-#define TTSC_DBG(args, bit) (((args).dbg & (bit)) != 0)
-#else
-#define TTSC_DBG(args, bit) false
-#endif
-
-static constexpr int KC = 16;  // input channels staged per LDS chunk
-
-struct ConvArgs {
-    const float* x;
-    float* y;
-    const float* resid;
-    const float* wp;    // fp32 path: [ntaps][CinP/2][CoutP/32][64]
-    const void* wph;    // f16x3 path: [ntaps][CinP/16][CoutP/32][2 (hi,lo)][64 lanes][8 half]
-    float w_unscale;    // f16x3 path: weights are stored multiplied by 2^s; the epilogue multiplies by 2^-s
-    const float* bias;  // [Cout] or null
-    const int* in_len;  // [B] per-utterance valid input length (ragged batches) or null
-    const int* out_len; // [B] per-utterance valid output length or null (tiles wholly beyond it are skipped)
-    int Cin, CinP, Cout, CoutP;   // Cin = input channels a workgroup stages (grouped: those of its rows' groups), CinP = rounded up to 16
-    int CinTot;                   // channels of the input tensor (batch stride); == Cin unless grouped
-    int groups, cin_g, cout_g;    // grouped Conv1d (fp32 kernel only): the workgroup's first input channel = (its first row / cout_g) * cin_g
-    int Lin, Lout;
-    int ntaps, tap_base, tap_step;
-    int out_stride, out_off;
-    int q_lo, q_cnt;
-    int span, span_pad, min_shift;
-    float in_scale, in_slope, out_scale;
-    int out_act, accumulate;
-    int vphase;       // fused ConvTranspose1d phases: GEMM row v = r * vphase + co (vphase = real Cout), output o += r; 0 = off;
-                      // -4 = rows interleaved v = co * 4 + r (kernel_size == stride == 4): see epilogue_tile_v4
-    int skew;         // wide kernel: start delay of the second resident workgroup per CU, in units of ~4 us (0 = off)
-    int dbg;          // ablation switches, ONLY in -DTTSC_ABLATE builds (tools/ablate.cpp; never in libttscube_hip.so): see TTSC_DBG
-    unsigned* nf_flag;  // conv_cout1_kernel: set to 1 when a non-finite output sample is produced (split-precision range guard), or null
-    const float* gate;  // data-gradient launches: [B,Cout,Lout] pre-activation saved by the forward; the conv result is
-    float gate_slope;   // multiplied by d lrelu/dx = (gate > 0 ? 1 : gate_slope) BEFORE the residual is added; null = off
-};
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == TTSC_ACT_TANH) return tanhf(v);
-    if (act == TTSC_ACT_RELU) return fmaxf(v, 0.f);
-    if (act == TTSC_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
-    return v;
-}
-
-// Epilogue of one 32x32 MFMA tile held by a wave: bias + residual + scale + activation (+ running sum) and store.
-// All residual / running-sum loads of the tile are issued BEFORE the first store: `resid` and `y` may alias
-// (in-place residual stream), which otherwise forces the compiler to order every load behind the previous store and
-// serialises 16 dependent round trips per tile.  Each lane only reads the addresses it writes, so this is safe.
-// C/D layout of v_mfma_*_32x32: column (time) = lane & 31, row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-__device__ __forceinline__ void epilogue_tile(const f32x16& acc, const ConvArgs& a, int b, int co_base, long o, bool qok,
-                                              int half, float acc_scale) {
-    // NOTE: the optional operands are tested once per row group (wave-uniform branches around straight-line load
-    // groups).  A per-element `ptr ? ptr[i] : 0` makes hipcc branch around every single load and wait for each one in turn.
-    // The tile is processed as four groups of four rows (= the four 8-channel items a lane contributes to): all loads
-    // of a group are issued before its stores, and only ~4 values per operand are live at a time (register pressure).
-    const long o_c = qok ? o : 0;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        float rv[4], yv[4], bv[4], res[4];
-        size_t idx[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int co = co_base + 8 * g + 4 * half + e;
-            const int co_c = co < a.Cout ? co : a.Cout - 1;
-            idx[e] = ((size_t)b * a.Cout + co_c) * a.Lout + o_c;
-        }
-        if (a.bias) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int co = co_base + 8 * g + 4 * half + e;
-                bv[e] = a.bias[co < a.Cout ? co : a.Cout - 1];
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bv[e] = 0.f;
-        }
-        if (a.resid) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) rv[e] = a.resid[idx[e]];
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) rv[e] = 0.f;
-        }
-        if (a.accumulate) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) yv[e] = a.y[idx[e]];
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) yv[e] = 0.f;
-        }
-        if (a.gate) {   // backward of the fused leaky-relu prologue (training only)
-            float gv[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gv[e] = a.gate[idx[e]];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                res[e] = ((acc[4 * g + e] * acc_scale + bv[e]) * (gv[e] > 0.f ? 1.f : a.gate_slope) + rv[e]) * a.out_scale + yv[e];
-        } else if (a.out_act == TTSC_ACT_NONE) {   // the common case gets its own straight-line copy (no inlined tanh/exp bodies)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) res[e] = (acc[4 * g + e] * acc_scale + bv[e] + rv[e]) * a.out_scale + yv[e];
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) res[e] = apply_act((acc[4 * g + e] * acc_scale + bv[e] + rv[e]) * a.out_scale, a.out_act) + yv[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int co = co_base + 8 * g + 4 * half + e;
-            if (qok && co < a.Cout) a.y[idx[e]] = res[e];
-        }
-    }
-}
-
-// Epilogue of a 32x32 tile of a ConvTranspose1d with kernel_size == stride == 4 whose GEMM rows are interleaved as
-// v = co * 4 + r (phase r of output channel co): the four consecutive accumulator registers of a lane are the four phases of
-// ONE output channel at ONE input position q, i.e. four CONSECUTIVE output samples o = 4q .. 4q+3 — one 16-byte store per
-// lane, 512 contiguous bytes per half-wave.  (With rows ordered r * Cout + co every lane writes single floats at a 16-byte
-// stride and the four phases arrive in four separate store instructions: 1.2 ms instead of ~0.4 ms for the last upsampler.)
-__device__ __forceinline__ void epilogue_tile_v4(const f32x16& acc, const ConvArgs& a, int b, int row_base, int q, bool qok, int half,
-                                                 float acc_scale) {
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int co = (row_base >> 2) + 2 * g + half;
-        const bool ok = qok && co < a.Cout;
-        const int co_c = co < a.Cout ? co : a.Cout - 1;
-        const size_t idx = ((size_t)b * a.Cout + co_c) * a.Lout + (size_t)(ok ? q : 0) * 4;
-        const float bv = a.bias ? a.bias[co_c] : 0.f;
-        f32x4 rv = {0.f, 0.f, 0.f, 0.f}, yv = {0.f, 0.f, 0.f, 0.f};
-        if (a.resid) rv = *reinterpret_cast<const f32x4*>(a.resid + idx);
-        if (a.accumulate) yv = *reinterpret_cast<const f32x4*>(a.y + idx);
-        f32x4 res;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float t = (acc[4 * g + e] * acc_scale + bv + rv[e]) * a.out_scale;
-            res[e] = (a.out_act == TTSC_ACT_NONE ? t : apply_act(t, a.out_act)) + yv[e];
-        }
-        if (ok) *reinterpret_cast<f32x4*>(a.y + idx) = res;
-    }
-}
-
-template <int MI, int NJ, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64, 2) void conv_mfma_kernel(ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];  // [2][KC][span_pad]  (double-buffered activation chunk)
-    constexpr int NT = WN * NJ * 32;
-    constexpr int NTHREADS = WM * WN * 64;
-    constexpr int SPC = NT + 64;                                   // staged positions per channel covered by the register prefetch
-    constexpr int NWAVES = WM * WN;
-    constexpr int SMAIN = KC * NT / NTHREADS;                      // prefetch registers per thread: tile columns
-    constexpr int SHALO = KC / NWAVES;                             //                                halo strip
-    static_assert(KC * NT % NTHREADS == 0 && KC % NWAVES == 0, "staging split");
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave / WN;
-    const int wn = wave % WN;
-    const int b = blockIdx.z;
-    const int q0 = a.q_lo + blockIdx.x * NT;
-    const int lin = a.in_len ? a.in_len[b] : a.Lin;   // positions >= lin read as zero (== that utterance run alone)
-    if (a.out_len && (long)q0 * a.out_stride + a.out_off >= a.out_len[b]) return;  // padding-only tile
-    const int cot0 = (blockIdx.y * WM + wm) * MI;  // first 32-row tile of this wave
-    const int cotN = a.CoutP >> 5;
-    const int half = lane >> 5;
-    const int l31 = lane & 31;
-
-    f32x16 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // grouped convolution: this workgroup's rows only meet the input channels of their own group(s)
-    const int cin0 = a.groups > 1 ? ((blockIdx.y * (WM * MI * 32)) / a.cout_g) * a.cin_g : 0;
-    const float* xb = a.x + ((size_t)b * a.CinTot + cin0) * a.Lin;
-    const int lo = q0 + a.min_shift;  // x position of LDS column 0
-    const int cipN = a.CinP >> 1;
-    const int nchunks = a.CinP / KC;
-    const int bufsz = KC * a.span_pad;
-    const bool wide = a.span > SPC;   // receptive field beyond the prefetch window: extra columns are staged synchronously
-
-    // ---- software pipeline -------------------------------------------------------------------------------------
-    // Left to itself hipcc issues every global load right before its use and waits vmcnt(0) for it: one L2 round trip
-    // per MFMA and per staged element, which only many resident workgroups can hide.  Training crops and short
-    // utterances run at <= 1 workgroup per CU, so both operand streams are pipelined explicitly:
-    //   * activations: chunk c+1 is fetched into registers (sreg) while chunk c is multiplied; LDS is double-buffered,
-    //     one barrier per chunk;
-    //   * weights: the 8*MI fragments of (chunk, tap) g+1 are in flight while (chunk, tap) g is multiplied (wa / wb).
-    // The fmaf chain order (chunk, tap, channel pair) is unchanged, results stay bit-identical.
-    // prefetch registers: the NT tile columns of the 16 channels (e = tid + i*NTHREADS -> channel e / NT, column e % NT,
-    // powers of two) plus a 64-column halo strip (channel = wave + i*NWAVES, column = NT + lane)
-    float sreg[SMAIN + SHALO];
-    // sload only ISSUES the loads (clamped addresses); masking, scaling and the leaky-relu happen in scommit, so that no
-    // use of a loaded value sits between the loads (hipcc would wait for each one in turn)
-    auto sload = [&](int cc) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < SMAIN; ++i) {
-            const int e = tid + i * NTHREADS;
-            const int c = e / NT, p = e % NT;
-            const int ci = min(cc + c, a.Cin - 1), pos = min(max(lo + p, 0), a.Lin - 1);
-            sreg[i] = xb[(unsigned)(ci * a.Lin + pos)];
-        }
-#pragma unroll
-        for (int i = 0; i < SHALO; ++i) {
-            const int c = wave + i * NWAVES, p = NT + lane;
-            const int ci = min(cc + c, a.Cin - 1), pos = min(max(lo + p, 0), a.Lin - 1);
-            sreg[SMAIN + i] = xb[(unsigned)(ci * a.Lin + pos)];
-        }
-    };
-    auto scommit = [&](float* buf, int cc) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < SMAIN; ++i) {
-            const int e = tid + i * NTHREADS;
-            const int c = e / NT, p = e % NT;
-            const int ci = cc + c, pos = lo + p;
-            float v = sreg[i] * a.in_scale;
-            v = v > 0.f ? v : v * a.in_slope;
-            if (p < a.span) buf[c * a.span_pad + p] = (ci < a.Cin && pos >= 0 && pos < lin) ? v : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < SHALO; ++i) {
-            const int c = wave + i * NWAVES, p = NT + lane;
-            const int ci = cc + c, pos = lo + p;
-            float v = sreg[SMAIN + i] * a.in_scale;
-            v = v > 0.f ? v : v * a.in_slope;
-            if (p < a.span) buf[c * a.span_pad + p] = (ci < a.Cin && pos >= 0 && pos < lin) ? v : 0.f;
-        }
-        if (wide) {
-            for (int c = wave; c < KC; c += NWAVES) {
-                const int ci = cc + c;
-                for (int p = SPC + lane; p < a.span; p += 64) {
-                    const int pos = lo + p;
-                    float v = 0.f;
-                    if (ci < a.Cin && pos >= 0 && pos < lin) {
-                        v = xb[(size_t)ci * a.Lin + pos] * a.in_scale;
-                        v = v > 0.f ? v : v * a.in_slope;
-                    }
-                    buf[c * a.span_pad + p] = v;
-                }
-            }
-        }
-    };
-    auto loadA = [&](float (&w)[KC / 2][MI], int ch, int j) __attribute__((always_inline)) {
-        const float* wj = a.wp + ((size_t)(j * cipN + ch * (KC / 2)) * cotN + cot0) * 64 + lane;
-#pragma unroll
-        for (int cp = 0; cp < KC / 2; ++cp)
-#pragma unroll
-            for (int i = 0; i < MI; ++i) w[cp][i] = wj[((size_t)cp * cotN + i) * 64];
-    };
-    int chC = 0, jC = 0;   // compute cursor
-    auto step = [&](const float (&w)[KC / 2][MI]) __attribute__((always_inline)) {
-        if (jC == 0 && chC > 0) {   // chunk switch: publish the prefetched activations, fetch the chunk after
-            scommit(xs + (chC & 1) * bufsz, chC * KC);
-            __syncthreads();
-            if (chC + 1 < nchunks) sload((chC + 1) * KC);
-        }
-        const int shift = a.tap_base + jC * a.tap_step - a.min_shift;  // >= 0
-        const float* bj = xs + (chC & 1) * bufsz + half * a.span_pad + wn * (NJ * 32) + l31 + shift;
-#pragma unroll
-        for (int cp = 0; cp < KC / 2; ++cp) {
-            float bf[NJ];
-#pragma unroll
-            for (int n = 0; n < NJ; ++n) bf[n] = bj[(2 * cp) * a.span_pad + n * 32];
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int n = 0; n < NJ; ++n)
-                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cp][i], bf[n], acc[i][n], 0, 0, 0);
-        }
-        if (++jC == a.ntaps) {
-            jC = 0;
-            ++chC;
-        }
-    };
-    int chL = 0, jL = 0;   // weight-load cursor (one (chunk, tap) ahead of the compute cursor)
-    auto advL = [&]() __attribute__((always_inline)) {
-        if (++jL == a.ntaps) {
-            jL = 0;
-            ++chL;
-        }
-    };
-    float wa[KC / 2][MI], wb[KC / 2][MI];
-    const int total = nchunks * a.ntaps;
-    loadA(wa, 0, 0);
-    advL();
-    sload(0);
-    scommit(xs, 0);
-    __syncthreads();
-    if (nchunks > 1) sload(KC);
-    for (int g = 0; g < total; g += 2) {
-        if (g + 1 < total) {
-            loadA(wb, chL, jL);
-            advL();
-        }
-        step(wa);
-        if (g + 2 < total) {
-            loadA(wa, chL, jL);
-            advL();
-        }
-        if (g + 1 < total) step(wb);
-    }
-
-    // ---- epilogue: bias + residual + scale + activation (+ running sum) --------------------------
-    const int q_hi = a.q_lo + a.q_cnt;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-#pragma unroll
-        for (int n = 0; n < NJ; ++n) {
-            const int q = q0 + wn * (NJ * 32) + n * 32 + l31;
-            const long o = (long)q * a.out_stride + a.out_off;
-            const bool qok = (q < q_hi) && (o >= 0) && (o < a.Lout);
-            int cb = (cot0 + i) * 32;
-            long oo = o;
-            bool ok = qok;
-            if (a.vphase) {   // virtual row tile -> (phase r, real channel tile); tiles never straddle phases (Cout % 32 == 0)
-                const int r = cb / a.vphase;
-                cb -= r * a.vphase;
-                oo += r;
-                ok = (q < q_hi) && (oo >= 0) && (oo < a.Lout) && (r < a.out_stride);
-            }
-            epilogue_tile(acc[i][n], a, b, cb, oo, ok, half, 1.f);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Split-precision path: every fp32 value v is carried as two halves  v = hi + lo  (hi = fp16(v), lo = fp16(v - hi),
-// 22 significant bits) and the product is evaluated as  hi_w*hi_x + hi_w*lo_x + lo_w*hi_x  on
-// v_mfma_f32_32x32x16_f16 with fp32 accumulation: fp16 x fp16 products are exact in fp32, the dropped lo*lo term is
-// 2^-22 relative, so the result carries ~fp32 accuracy at 16/3 = 5.3x the fp32-MFMA rate.  Weights are pre-scaled by a
-// power of two so that their low halves stay in fp16's normal range (unscaled exactly in the epilogue).
-// Activations are expected within fp16 range (|x| < 65504).
-//
-// Workgroup = 4 waves side by side along N (time); all four share the M tile, so the weight fragments are staged
-// ONCE per workgroup through LDS (double-buffered, prefetched one tap ahead) instead of once per wave from L2.
-// Activation tile: LDS [position][16 channels] fp16 (hi and lo planes), so a B fragment (8 consecutive channels of
-// one position) is a single 16-byte ds_read; the fp32 -> (hi,lo) split and the leaky-relu prologue happen while staging.
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-
-template <int MI, int NJ, int TMAX>
-__global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int NT = 4 * NJ * 32;
-    constexpr int AFR = MI * 2 * 64;  // half8 items of one (tap, chunk) weight block of this workgroup's M tile
-    // activation tile: four planes [channel-half h][hi|lo][position] of 16-byte items (8 fp16 channels), so that the 32
-    // lanes of a half-wave read 32 CONSECUTIVE 16-byte slots (conflict-free ds_read_b128) and staging writes likewise
-    half8* Xp = reinterpret_cast<half8*>(smem_raw);            // plane (h, pl) at Xp + (h*2 + pl) * span_pad
-    half8* Ap = Xp + (size_t)4 * a.span_pad;                    // [ntaps][AFR]: ALL taps of the current channel chunk
-
-    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.z;
-    const int q0 = a.q_lo + blockIdx.x * NT;
-    const int lin = a.in_len ? a.in_len[b] : a.Lin;
-    if (a.out_len && (long)q0 * a.out_stride + a.out_off >= a.out_len[b]) return;
-    const int cot0 = blockIdx.y * MI;
-    const int cotN = a.CoutP >> 5;
-    const int nchunks = a.CinP >> 4;
-
-    f32x16 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const float* xb = a.x + (size_t)b * a.Cin * a.Lin;
-    const int lo = q0 + a.min_shift;
-    const half8* wsrc = reinterpret_cast<const half8*>(a.wph);
-
-    // Both operands are software-pipelined through registers ONE CHANNEL CHUNK ahead: the global loads of chunk c+1
-    // (activation window and the weight fragments of all taps) are issued before the MFMA loop of chunk c and
-    // committed to LDS after it, so their latency hides behind ntaps*MI*NJ*3 MFMAs and the tap loop itself has no
-    // barrier and no global access.  Addresses are clamped and loads unconditional (selects zero the padding) so the
-    // compiler never branches around a load.
-    constexpr int APT = (TMAX * AFR + 255) / 256;  // weight items per thread per chunk
-    const int a_items = a.ntaps * AFR;
-    half8 areg[APT];
-    auto a_issue = [&](int c) {
-#pragma unroll
-        for (int e = 0; e < APT; ++e) {
-            int idx = tid + e * 256;
-            idx = idx < a_items ? idx : a_items - 1;
-            const int j = idx / AFR, r = idx - j * AFR;
-            areg[e] = wsrc[((size_t)(j * nchunks + c) * cotN + cot0) * 128 + r];
-        }
-    };
-    auto a_commit = [&]() {
-#pragma unroll
-        for (int e = 0; e < APT; ++e) {
-            const int idx = tid + e * 256;
-            if (idx < a_items) Ap[idx] = areg[e];
-        }
-    };
-    // ---- activation staging: fp32 [B,C,L]; work item = (position p, channel group h of 8): 8 dword loads, leaky-relu + hi/lo
-    // split in x_commit
-    constexpr int XIT = ((NT + 64) * 2 + 255) / 256;
-    const int spanp = (a.span + 63) & ~63;
-    float xr[XIT][8];
-    unsigned xoff[XIT];
-    int xslot[XIT];   // LDS item index, or -1
-    bool xok[XIT];
-    int xh[XIT];      // channel half (0/1)
-#pragma unroll
-    for (int e = 0; e < XIT; ++e) {
-        const int i = tid + e * 256;
-        const int h = i / spanp;              // spanp is a multiple of 64: cheap shifts would do, this runs once
-        const int p = i - h * spanp;
-        const int pos = lo + p;
-        xok[e] = pos >= 0 && pos < lin;
-        int pc = pos > lin - 1 ? lin - 1 : pos;
-        pc = pc < 0 ? 0 : pc;
-        xoff[e] = (unsigned)pc;
-        xh[e] = h;
-        xslot[e] = (p < a.span && h < 2) ? (h * 2) * a.span_pad + p : -1;
-    }
-    auto x_issue = [&](int c) {
-#pragma unroll
-        for (int ch = 0; ch < 8; ++ch) {
-            // the two channel rows (h = 0 / 1) of this step are wave-uniform scalars: sgpr base + vgpr offset
-            const int c0 = c * 16 + ch, c1 = c * 16 + 8 + ch;
-            const float* r0 = xb + (size_t)(c0 < a.Cin ? c0 : a.Cin - 1) * a.Lin;
-            const float* r1 = xb + (size_t)(c1 < a.Cin ? c1 : a.Cin - 1) * a.Lin;
-#pragma unroll
-            for (int e = 0; e < XIT; ++e) xr[e][ch] = (xh[e] ? r1 : r0)[xoff[e]];
-        }
-    };
-    auto x_commit = [&](int c) {
-#pragma unroll
-        for (int e = 0; e < XIT; ++e) {
-            if (xslot[e] >= 0) {
-                const int cb = c * 16 + xh[e] * 8;
-                half8 vh, vl;
-#pragma unroll
-                for (int ch = 0; ch < 8; ++ch) {
-                    float v = (xok[e] && cb + ch < a.Cin) ? xr[e][ch] * a.in_scale : 0.f;
-                    v = fmaxf(v, v * a.in_slope);   // leaky-relu for slopes in [0,1] (1 = identity)
-                    const _Float16 hh = (_Float16)v;
-                    vh[ch] = hh;
-                    vl[ch] = (_Float16)(v - (float)hh);
-                }
-                Xp[xslot[e]] = vh;
-                Xp[xslot[e] + a.span_pad] = vl;
-            }
-        }
-    };
-
-    x_issue(0);
-    a_issue(0);
-    for (int c = 0; c < nchunks; ++c) {
-        if (c) __syncthreads();  // everyone finished reading chunk c-1 from LDS
-        if (!TTSC_DBG(a, 1)) {
-            x_commit(c);
-            a_commit();
-        }
-        __syncthreads();
-        if (c + 1 < nchunks && !TTSC_DBG(a, 8)) {
-            x_issue(c + 1);
-            a_issue(c + 1);
-        }
-        if (TTSC_DBG(a, 2)) continue;
-        // per-lane LDS bases are loop invariants; inside the tap loop only `shift` / the tap's block offset are added
-        // (32-bit LDS addressing, immediate offsets for the fragment index) — VALU work per MFMA matters here because
-        // VALU and MFMA issue from the same in-order wave
-        const half8* xh = Xp + (unsigned)((half * 2 + 0) * a.span_pad + wn * (NJ * 32) + l31);
-        const half8* xl = Xp + (unsigned)((half * 2 + 1) * a.span_pad + wn * (NJ * 32) + l31);
-        const half8* al_base = Ap + lane;
-        int shift = a.tap_base - a.min_shift;
-        for (int j = 0; j < a.ntaps; ++j, shift += a.tap_step) {
-            const half8* Ab = al_base + j * AFR;
-            half8 ah[MI], al[MI], bh[NJ], bl[NJ];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                ah[i] = Ab[(i * 2 + 0) * 64];
-                al[i] = Ab[(i * 2 + 1) * 64];
-            }
-#pragma unroll
-            for (int n = 0; n < NJ; ++n) {
-                bh[n] = xh[shift + n * 32];
-                bl[n] = xl[shift + n * 32];
-            }
-            // three product terms; consecutive MFMAs go to DIFFERENT accumulators (no back-to-back dependency)
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[n], acc[i][n], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[n], acc[i][n], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[n], acc[i][n], 0, 0, 0);
-        }
-    }
-
-    const int q_hi = a.q_lo + a.q_cnt;
-    if (TTSC_DBG(a, 4)) {
-        if (acc[0][0][0] == 12345.678f) a.y[0] = 1.f;  // keep the accumulators alive
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-#pragma unroll
-        for (int n = 0; n < NJ; ++n) {
-            const int q = q0 + wn * (NJ * 32) + n * 32 + l31;
-            const long o = (long)q * a.out_stride + a.out_off;
-            const bool qok = (q < q_hi) && (o >= 0) && (o < a.Lout);
-            int cb = (cot0 + i) * 32;
-            long oo = o;
-            bool ok = qok;
-            if (a.vphase == -4) {   // interleaved rows (phase, channel): four consecutive samples per lane
-                epilogue_tile_v4(acc[i][n], a, b, cb, q, (q < q_hi) && (q >= 0) && ((long)q * 4 + 3 < a.Lout), half, a.w_unscale);
-                continue;
-            }
-            if (a.vphase) {   // virtual row tile -> (phase r, real channel tile); tiles never straddle phases (Cout % 32 == 0)
-                const int r = cb / a.vphase;
-                cb -= r * a.vphase;
-                oo += r;
-                ok = (q < q_hi) && (oo >= 0) && (oo < a.Lout) && (r < a.out_stride);
-            }
-            epilogue_tile(acc[i][n], a, b, cb, oo, ok, half, a.w_unscale);
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Wide-tile variant for the square layers of the wide stages (Cin = Cout in {128, 256}, K in {3, 7, 11}, dilation 1/3/5).
@@ -1790,6 +1258,8 @@ extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, 
         a.out_len = out_len_dev;
         a.dbg = 0;
         a.skew = 0;
+        a.fold_S = a.fold_B = 0;
+        a.amax = nullptr;
 #ifdef TTSC_ABLATE
         if (const char* ev = getenv("TTSC_CONV_DBG")) a.dbg = atoi(ev);
 #endif
@@ -1927,12 +1397,14 @@ extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, 
                 a.span = nt + (last < 0 ? -last : last);
                 a.span_pad = a.span + 1;
             };
-            const long want = 512;
+            static const long want_env = getenv("TTSC_CONV_WANT") ? atol(getenv("TTSC_CONV_WANT")) : 512;
+            static const int narrow_env = getenv("TTSC_CONV_NARROW") ? atoi(getenv("TTSC_CONV_NARROW")) : 1;
+            const long want = want_env;
             // ... and, among the tiles that fill the machine, not one that is mostly padding: the deep layers of the discriminators see
             // sequences of 50-200 positions (a 128-column tile over 149 positions computes 256), so a narrower tile is taken whenever it
             // cuts the padded columns by more than an eighth (this kernel is bound by its MFMA count, not by operand reuse)
             auto padded = [&](int nt) { return (long)ceil_div(a.q_cnt, nt) * nt; };
-            auto narrower_pays = [&](int nt_big, int nt_small) { return padded(nt_small) * 8 < padded(nt_big) * 7; };
+            auto narrower_pays = [&](int nt_big, int nt_small) { return narrow_env && padded(nt_small) * 8 < padded(nt_big) * 7; };
             if (c->MT == 128) {
                 if (wgs(128, 128) >= want && !narrower_pays(128, 64)) { set_nt(128); rc = launch_cfg<2, 2, 2, 2>(a, B, s); }
                 else if (wgs(64, 128) >= want && !narrower_pays(128, 64)) { set_nt(128); rc = launch_cfg<1, 2, 2, 2>(a, B, s); }

@@ -1,0 +1,213 @@
+// Split-precision convolutions for the TRAINING step: forward and data gradient of every dense Conv1d of the
+// generator and of the MPD / MSD discriminators on v_mfma_f32_32x32x16_f16 (fp32 carried as fp16 hi + lo, three products, fp32
+// accumulation: 22 significant bits, see conv_kernels.hpp) instead of the exact-fp32 MFMA kernel (157 TF/s peak, 45-90 TF/s measured on
+// these shapes, profiles/r03_disc_layers_fp32.log).  What inference does with calibrated, sticky per-layer scales cannot work here:
+// activations AND gradients move every step and span many orders of magnitude between layers.  So
+//   * the range is measured on the device for every launch: one reduction launch writes max |x| and max |w| (amax_kernel), the weight
+//     packing and the convolution derive their power-of-two scales from those words in-kernel — no host round trip, no state;
+//   * the weights are split and laid out in fragment order from the live torch parameter by pack_wh_kernel (also for the data gradient:
+//     roles of the channel dimensions swapped, taps reversed);
+//   * the batch is folded into the GEMM's column dimension (ConvArgs::fold_S): the deep discriminator layers are 1024 x 1024 x 5 weights
+//     over 100 .. 1 200 positions per sequence; one tile per (sequence, 64 rows) re-streams 1.3 MB of weights for a sliver of columns.
+// The weight gradient stays on the exact-fp32 kernel (conv_wgrad.hip).
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.hpp"
+#include "conv_kernels.hpp"
+
+namespace ttsc {
+
+// amax[0] = max |x|, amax[1] = max |w| (caller zeroes both words first; non-negative floats order like their bit patterns)
+__global__ __launch_bounds__(256) void amax2_kernel(const float* __restrict__ x, long nx, int bx, const float* __restrict__ w, long nw,
+                                                    unsigned* __restrict__ out) {
+    const bool is_w = (int)blockIdx.x >= bx;
+    const float* src = is_w ? w : x;
+    const long n = is_w ? nw : nx;
+    const long first = (long)(is_w ? blockIdx.x - bx : blockIdx.x) * 256 + threadIdx.x;
+    const long stride = (long)(is_w ? gridDim.x - bx : bx) * 256;
+    float m = 0.f;
+    const long n4 = (((uintptr_t)src & 15) == 0) ? n / 4 : 0;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    for (long i = first; i < n4; i += stride) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    for (long i = n4 * 4 + first; i < n; i += stride) m = fmaxf(m, fabsf(src[i]));
+    // (fmaxf drops NaN elements: they reach the output through the data path itself; an inf makes the word inf -> scale 1, visible likewise)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    // one atomic per workgroup: thousands of same-address atomics serialise in L2 (the first version, one per wave, took 59 us flat)
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        if (m > 0.f) atomicMax(out + (is_w ? 1 : 0), __float_as_uint(m));
+    }
+}
+
+struct PackHArgs {
+    const float* w;      // flip == 0: [Cout][Cin][K];  flip == 1: the forward weight [Cin][Cout][K] of the layer being differentiated
+    _Float16* out;       // [K][CinP/16][CoutP/32][2 (hi, lo)][64 lanes][8 half]
+    const float* amax;   // amax[1] = max |w|
+    int Cin, Cout, K, nch, cotN, flip;
+};
+__global__ __launch_bounds__(256) void pack_wh_kernel(PackHArgs p) {
+    const float scale = pow2_to(p.amax[1], SPLIT_W_TARGET);
+    const long total = (long)p.K * p.nch * p.cotN * 64;   // one thread per (tap, chunk, row tile, lane): 8 channels
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int lane = (int)(i & 63);
+        long t = i >> 6;
+        const int cot = (int)(t % p.cotN);
+        t /= p.cotN;
+        const int ch = (int)(t % p.nch);
+        const int j = (int)(t / p.nch);
+        const int co = cot * 32 + (lane & 31);
+        half8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ci = ch * 16 + 8 * (lane >> 5) + e;
+            float v = 0.f;
+            if (co < p.Cout && ci < p.Cin)
+                v = p.flip ? p.w[((size_t)ci * p.Cout + co) * p.K + (p.K - 1 - j)] : p.w[((size_t)co * p.Cin + ci) * p.K + j];
+            v *= scale;
+            const _Float16 h = (_Float16)v;
+            hi[e] = h;
+            lo[e] = (_Float16)(v - (float)h);
+        }
+        half8* dst = reinterpret_cast<half8*>(p.out) + ((((size_t)j * p.nch + ch) * p.cotN + cot) * 2) * 64;
+        dst[lane] = hi;
+        dst[64 + lane] = lo;
+    }
+}
+
+template <int MI, int NJ, int TMAX>
+static int launch_fold_t(const ConvArgs& a, hipStream_t s) {
+    constexpr int NT = 4 * NJ * 32;
+    dim3 grid((unsigned)ceil_div((long)a.fold_S * a.fold_B, NT), (unsigned)(a.CoutP / (32 * MI)), 1u);
+    const size_t lds = (size_t)a.span_pad * 4 * 16 + (size_t)a.ntaps * MI * 2 * 64 * 16;
+    TTSC_REQUIRE(lds <= 160 * 1024, "ttsc_conv_train: LDS footprint %zu", lds);
+    if (int rc = ensure_full_lds((const void*)conv_f16x3_kernel<MI, NJ, TMAX, true>)) return rc;
+    hipLaunchKernelGGL((conv_f16x3_kernel<MI, NJ, TMAX, true>), grid, dim3(256), lds, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("conv_f16x3_kernel (folded) launch failed: %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    return TTSC_OK;
+}
+template <int MI, int NJ>
+static int launch_fold(const ConvArgs& a, hipStream_t s) {
+    if (a.ntaps <= 3) return launch_fold_t<MI, NJ, 3>(a, s);
+    if (a.ntaps <= 7) return launch_fold_t<MI, NJ, 7>(a, s);
+    if (a.ntaps <= 11) return launch_fold_t<MI, NJ, 11>(a, s);
+    return launch_fold_t<MI, NJ, 16>(a, s);
+}
+
+}  // namespace ttsc
+
+using namespace ttsc;
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+extern "C" int32_t ttsc_conv_train_supported(int32_t Cin, int32_t Cout, int32_t K, int32_t dilation) {
+    // (thin layers — the discriminators' first and last convolutions — would be mostly channel padding: they stay on the fp32 kernel)
+    return Cin >= 16 && Cout >= 32 && K >= 1 && K <= 16 && dilation >= 1 && (K - 1) * dilation <= 64;
+}
+
+extern "C" size_t ttsc_conv_train_workspace_bytes(int32_t Cin, int32_t Cout, int32_t K) {
+    const int mt = Cout >= 64 ? 64 : 32;
+    return 256 + (size_t)K * round_up(Cin, 16) * round_up(Cout, mt) * 2 * sizeof(_Float16);
+}
+
+extern "C" int ttsc_conv_train(const float* x, const float* w, const float* bias, const float* resid, const float* gate, float* y, int32_t B,
+                               int32_t Cin, int32_t Cout, int32_t K, int64_t Lin, int32_t padding, int32_t dilation, int32_t flip,
+                               float in_scale, float in_slope, float out_scale, float gate_slope, void* ws, size_t ws_bytes, void* stream) {
+    TTSC_REQUIRE(x && w && y && ws, "ttsc_conv_train: null argument");
+    TTSC_REQUIRE(ttsc_conv_train_supported(Cin, Cout, K, dilation), "ttsc_conv_train: shape not supported (Cin %d, Cout %d, K %d, dilation %d)", Cin, Cout,
+                 K, dilation);
+    TTSC_REQUIRE(B > 0 && Lin > 0 && padding >= 0, "ttsc_conv_train: bad B / Lin / padding");
+    TTSC_REQUIRE(in_slope >= 0.f && in_slope <= 1.f && in_scale > 0.f, "ttsc_conv_train: in_slope must be in [0, 1], in_scale positive");
+    const int64_t Lout = Lin + 2 * (int64_t)padding - (int64_t)dilation * (K - 1);
+    TTSC_REQUIRE(Lout > 0, "ttsc_conv_train: output length %lld <= 0", (long long)Lout);
+    const int64_t S = std::max<int64_t>(Lin + padding, Lout);
+    TTSC_REQUIRE((int64_t)B * Cin * Lin < (1ll << 31) && (int64_t)B * Cout * Lout < (1ll << 31) && S * B < (1ll << 30), "ttsc_conv_train: tensor too large");
+    TTSC_REQUIRE(ws_bytes >= ttsc_conv_train_workspace_bytes(Cin, Cout, K), "ttsc_conv_train: workspace too small");
+    TTSC_REQUIRE(((uintptr_t)ws & 15) == 0, "ttsc_conv_train: workspace must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    float* amax = reinterpret_cast<float*>(ws);
+    _Float16* wph = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(ws) + 256);
+    const int MI = Cout >= 64 ? 2 : 1;
+    const int CinP = round_up(Cin, 16), CoutP = round_up(Cout, 32 * MI);
+
+    TTSC_HIP_CHECK(hipMemsetAsync(amax, 0, 16, s));
+    {
+        const long nx = (long)B * Cin * Lin, nw = (long)Cin * Cout * K;
+        const int bx = (int)std::min<long>((nx / 16 + 255) / 256 + 1, 256), bw = (int)std::min<long>((nw / 16 + 255) / 256 + 1, 128);
+        hipLaunchKernelGGL(amax2_kernel, dim3(bx + bw), dim3(256), 0, s, x, nx, bx, w, nw, reinterpret_cast<unsigned*>(amax));
+    }
+    {
+        PackHArgs p;
+        p.w = w;
+        p.out = wph;
+        p.amax = amax;
+        p.Cin = Cin;
+        p.Cout = Cout;
+        p.K = K;
+        p.nch = CinP / 16;
+        p.cotN = CoutP / 32;
+        p.flip = flip;
+        const long total = (long)K * p.nch * p.cotN * 64;
+        hipLaunchKernelGGL(pack_wh_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, p);
+    }
+    ConvArgs a{};
+    a.x = x;
+    a.y = y;
+    a.resid = resid;
+    a.wph = wph;
+    a.w_unscale = 1.f;
+    a.bias = bias;
+    a.Cin = Cin;
+    a.CinTot = Cin;
+    a.CinP = CinP;
+    a.Cout = Cout;
+    a.CoutP = CoutP;
+    a.groups = 1;
+    a.Lin = (int)Lin;
+    a.Lout = (int)Lout;
+    a.ntaps = K;
+    a.tap_base = -padding;
+    a.tap_step = dilation;
+    a.out_stride = 1;
+    a.min_shift = -padding;
+    a.in_scale = in_scale;
+    a.in_slope = in_slope;
+    a.out_scale = out_scale;
+    a.out_act = TTSC_ACT_NONE;
+    a.gate = gate;
+    a.gate_slope = gate_slope;
+    a.fold_S = (int)S;
+    a.fold_B = B;
+    a.amax = amax;
+    a.q_cnt = (int)(S * B);
+    // column tile: 256 wide when that still gives every CU two workgroups, else 128
+    const long cols = S * B;
+    const long wg256 = ceil_div(cols, 256) * (CoutP / (32 * MI));
+    static const int nt_env = getenv("TTSC_TRAIN_NT") ? atoi(getenv("TTSC_TRAIN_NT")) : 0;
+    const int nt = nt_env ? nt_env : (wg256 >= 512 ? 256 : 128);
+    a.span = nt + (K - 1) * dilation;
+    a.span_pad = a.span;
+    int rc;
+    if (MI == 2)
+        rc = nt == 256 ? launch_fold<2, 2>(a, s) : launch_fold<2, 1>(a, s);
+    else
+        rc = nt == 256 ? launch_fold<1, 2>(a, s) : launch_fold<1, 1>(a, s);
+    if (rc) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("ttsc_conv_train launch failed: %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    return TTSC_OK;
+}

@@ -14,8 +14,12 @@ Weights live in torch parameters (weight-norm g, v stay torch leaves so the four
 cubegan.py:275-311 see the usual gradients); `ttsc_conv1d_set_weight_device` re-packs the MFMA fragments from the live
 tensors on the stream every step.  ConvTranspose1d backward runs on the phase-de-interleaved output gradient
 dyP[b, r*Co+co, q] = dy[b, co, q*u + r], which turns both legs into stride-1 problems of the same kernels.
-Arithmetic: fp32 MFMA throughout (gradients span too many orders of magnitude for the fp16 split path)."""
+Arithmetic: dense stride-1 convolutions run forward and data gradient on the split-precision kernel (`ttsc_conv_train`, csrc/conv_train.hip:
+fp16 hi/lo x 3 products on MFMA with fp32 accumulation; the fp16 ranges are set per launch from device-side maxima of the tensor and of
+the weights, so gradients of any magnitude are safe; on one forward graph its data gradients agree with the exact kernel's to 4e-7).
+Weight gradients, grouped and transposed layers and the thin first / last layers stay on the exact-fp32 MFMA kernels."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -128,6 +132,31 @@ def _wgrad(P, Q, A, Bc, J, base, step, q_scale, q_slope, groups=1):
     return G
 
 
+# Dense stride-1 convolutions run forward and data gradient on the split-precision kernel (csrc/conv_train.hip: fp16 hi/lo x 3 on MFMA, ranges
+# measured on the device per launch, batch folded into the tile columns); TTSC_TRAIN_SPLIT=0 keeps everything on the exact-fp32 kernel.
+SPLIT_TRAIN = os.environ.get('TTSC_TRAIN_SPLIT', '1') != '0'
+
+
+def _split_ok(Cin, Cout, K, dilation):
+    return SPLIT_TRAIN and bool(_lib.lib().ttsc_conv_train_supported(Cin, Cout, K, dilation))
+
+
+def _conv_split(x, w, b, resid, gate, Cin, Cout, K, padding, dilation, flip, in_scale=1.0, in_slope=1.0, out_scale=1.0, gate_slope=1.0):
+    """one launch group of ttsc_conv_train (range words + weight split + convolution); x [B,Cin,Lin] -> [B,Cout,Lout]"""
+    L = _lib.lib()
+    B, _, Lin = x.shape
+    Lout = Lin + 2 * padding - dilation * (K - 1)
+    y = torch.empty((B, Cout, Lout), dtype=torch.float32, device=x.device)
+    nbytes = int(L.ttsc_conv_train_workspace_bytes(Cin, Cout, K))
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+    ptr = lambda t: _lib.dev_ptr(t) if t is not None else None
+    with torch.cuda.device(x.device):
+        _lib.check(L.ttsc_conv_train(ptr(x), ptr(w), ptr(b), ptr(resid), ptr(gate), ptr(y), B, Cin, Cout, K, Lin, padding, dilation, int(flip),
+                                     float(in_scale), float(in_slope), float(out_scale), float(gate_slope), ptr(ws), nbytes,
+                                     _lib.current_stream()), 'ttsc_conv_train')
+    return y
+
+
 class HipConvFn(torch.autograd.Function):
     """y = conv(leaky_relu(in_scale * x, in_slope); w) + b [+ resid]  with HIP forward / dgrad / wgrad."""
 
@@ -135,8 +164,12 @@ class HipConvFn(torch.autograd.Function):
     def forward(ctx, x, w, b, resid, tc, in_scale, in_slope):
         x = x.contiguous()
         wd = w.detach().contiguous()
-        tc.fwd.set_weight_device(wd, b.detach() if b is not None else None)
-        y = tc.fwd(x, resid=resid, in_scale=in_scale, in_slope=in_slope)
+        if not tc.transposed and tc.groups == 1 and tc.stride == 1 and _split_ok(tc.Cin, tc.Cout, tc.K, tc.dilation):
+            y = _conv_split(x, wd, b.detach().contiguous() if b is not None else None, resid.contiguous() if resid is not None else None, None,
+                            tc.Cin, tc.Cout, tc.K, tc.padding, tc.dilation, 0, in_scale=in_scale, in_slope=in_slope)
+        else:
+            tc.fwd.set_weight_device(wd, b.detach() if b is not None else None)
+            y = tc.fwd(x, resid=resid, in_scale=in_scale, in_slope=in_slope)
         ctx.save_for_backward(x, wd)
         ctx.tc, ctx.in_scale, ctx.in_slope = tc, in_scale, in_slope
         ctx.has_b, ctx.has_r = b is not None, resid is not None
@@ -151,9 +184,14 @@ class HipConvFn(torch.autograd.Function):
         dx = dw = db = None
         if not tc.transposed:
             if ctx.needs_input_grad[0]:
-                h = tc.dgrad_handle()
-                h.set_weight_device_dgrad(w)
-                dx = h(dy, out_scale=sc, gate=x if sl != 1.0 else None, gate_slope=sl)
+                pd = tc.dilation * (tc.K - 1) - tc.padding
+                if tc.groups == 1 and tc.stride == 1 and pd >= 0 and _split_ok(tc.Cout, tc.Cin, tc.K, tc.dilation):
+                    dx = _conv_split(dy, w, None, None, x if sl != 1.0 else None, tc.Cout, tc.Cin, tc.K, pd, tc.dilation, 1, out_scale=sc,
+                                     gate_slope=sl)
+                else:
+                    h = tc.dgrad_handle()
+                    h.set_weight_device_dgrad(w)
+                    dx = h(dy, out_scale=sc, gate=x if sl != 1.0 else None, gate_slope=sl)
             if ctx.needs_input_grad[1]:
                 dw = _wgrad(dy, x, tc.Cout, tc.Cin, tc.K, -tc.padding, tc.dilation, sc, sl, tc.groups)
         else:
