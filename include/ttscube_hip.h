@@ -178,6 +178,15 @@ int ttsc_conv_wgrad_grouped(const float* p_dev, const float* q_dev, float* g_dev
 int ttsc_conv_wgrad(const float* p_dev, const float* q_dev, float* g_dev, int32_t N, int32_t A, int32_t B, int64_t LP, int64_t LQ,
                     int32_t J, int32_t base, int32_t step, float q_scale, float q_slope, void* ws_dev, size_t ws_bytes, void* stream);
 
+/* Split-precision weight gradient (csrc/conv_wgrad.hip::wgrad_f16x3_kernel): same contract as ttsc_conv_wgrad for the dense layers of the
+ * training step (cubegan.py:137-170: every parameter gradient of MPD / MSD and of the generator), operands carried as fp16 hi + lo with
+ * device-side ranges per launch, 128 x 64 tiles on v_mfma_f32_32x32x16_f16; agrees with ttsc_conv_wgrad to ~1e-6 of the largest entry.
+ * `ttsc_conv_wgrad_split_supported` says whether a shape is taken (A >= 64 rows, Bc >= 32 columns, J <= 16 taps). */
+int32_t ttsc_conv_wgrad_split_supported(int32_t A, int32_t B, int32_t J, int32_t step);
+size_t ttsc_conv_wgrad_split_workspace_bytes(int32_t N, int32_t A, int32_t B, int64_t LP, int32_t J);
+int ttsc_conv_wgrad_split(const float* p_dev, const float* q_dev, float* g_dev, int32_t N, int32_t A, int32_t B, int64_t LP, int64_t LQ, int32_t J,
+                          int32_t base, int32_t step, float q_scale, float q_slope, void* ws_dev, size_t ws_bytes, void* stream);
+
 /* Split-precision convolution of the training step (csrc/conv_train.hip): forward and data gradient of a dense, stride-1, dilated Conv1d
  * of the generator [EXTERNAL hifigan/models.py; trained by cube/networks/cubegan.py:131-170] and of the MPD / MSD discriminators
  * (cubegan.py:144-149,160-167) on the fp16 hi/lo three-product MFMA path, stateless: weights come straight from the live torch parameter.

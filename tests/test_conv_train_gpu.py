@@ -93,3 +93,44 @@ def test_unsupported_shapes_are_refused():
     assert not _lib.lib().ttsc_conv_train_supported(64, 64, 41, 1)     # MSD's k = 41 layers (grouped, fp32 kernel)
     with pytest.raises(_lib.TTSCError):
         _run(torch.zeros(1, 1, 64).cuda(), torch.zeros(32, 1, 5).cuda(), None, None, None, 2, 1, 0)
+
+
+WG_CASES = [  # N, A, Bc, LP, LQ, J, base, step
+    (3, 128, 64, 100, 100, 5, -2, 1),
+    (4, 192, 96, 210, 210, 5, -14, 7),      # MPD period 7
+    (2, 64, 96, 331, 334, 2, 0, 3),         # de-interleaved strided layer (no padding: LP = LQ - step)
+    (2, 128, 128, 300, 300, 11, -25, 5),    # generator ResBlock k = 11, dilation 5: three launches of <= 5 taps
+    (2, 160, 64, 80, 77, 4, 0, -1),         # ConvTranspose1d on the de-interleaved output gradient: taps run backwards
+    (5, 100, 40, 65, 65, 3, -1, 1),         # ragged tile edges, one position into the second chunk
+    (6, 1024, 64, 22, 22, 5, -4, 2),        # deep discriminator layer
+]
+
+
+@pytest.mark.parametrize('N,A,Bc,LP,LQ,J,base,step', WG_CASES)
+@pytest.mark.parametrize('mag', [1.0, 1e-6])
+def test_split_weight_gradient_matches_float64(N, A, Bc, LP, LQ, J, base, step, mag):
+    from ttscube_amd import _lib
+    from ttscube_amd.hifigan import autograd as AG
+    g = torch.Generator().manual_seed(N * 100 + A + J)
+    P = (torch.randn(N, A, LP, generator=g) * mag).cuda()
+    Q = torch.randn(N, Bc, LQ, generator=g).cuda()
+    sc, sl = 0.6, 0.1
+    assert _lib.lib().ttsc_conv_wgrad_split_supported(A, Bc, J, step)
+    G = AG._wgrad(P, Q, A, Bc, J, base, step, sc, sl)
+    Qa = F.leaky_relu(Q.double() * sc, sl)
+    ref = torch.zeros(A, Bc, J, dtype=torch.float64, device='cuda')
+    for j in range(J):
+        off = base + j * step
+        Qs = torch.zeros(N, Bc, LP, dtype=torch.float64, device='cuda')
+        lo, hi = max(0, -off), min(LP, LQ - off)
+        if hi > lo:
+            Qs[:, :, lo:hi] = Qa[:, :, lo + off:hi + off]
+        ref[:, :, j] = torch.einsum('nat,nbt->ab', P.double(), Qs)
+    assert G.shape == ref.shape
+    assert float((G.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    try:   # and the exact-fp32 kernel on the same inputs, for the record of what the split path replaces
+        AG.SPLIT_TRAIN = False
+        G32 = AG._wgrad(P, Q, A, Bc, J, base, step, sc, sl)
+    finally:
+        AG.SPLIT_TRAIN = True
+    assert float((G32.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())

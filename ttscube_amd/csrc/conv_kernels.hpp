@@ -64,6 +64,7 @@ __device__ __forceinline__ float pow2_to(float m, int target) {
     s = s > 100 ? 100 : (s < -100 ? -100 : s);
     return __uint_as_float((unsigned)(127 + s) << 23);
 }
+int launch_amax2(const float* x, long nx, const float* w, long nw, float* amax, hipStream_t s);   // conv_train.hip: amax[0] = max |x|, amax[1] = max |w|
 static constexpr int SPLIT_X_TARGET = 15, SPLIT_W_TARGET = 10;   // |x| < 2^15 (fp16 max 65504), |w| < 2^10 (as the host-side packing)
 
 __device__ __forceinline__ float apply_act(float v, int act) {

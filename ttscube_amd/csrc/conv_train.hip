@@ -82,6 +82,18 @@ __global__ __launch_bounds__(256) void pack_wh_kernel(PackHArgs p) {
     }
 }
 
+// zero the two range words, then one launch over both tensors (also used by the split-precision weight gradient, conv_wgrad.hip)
+int launch_amax2(const float* x, long nx, const float* w, long nw, float* amax, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(amax, 0, 16, s);
+    if (e != hipSuccess) {
+        set_error("hipMemsetAsync: %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    const int bx = (int)std::min<long>((nx / 16 + 255) / 256 + 1, 256), bw = (int)std::min<long>((nw / 16 + 255) / 256 + 1, 128);
+    hipLaunchKernelGGL(amax2_kernel, dim3(bx + bw), dim3(256), 0, s, x, nx, bx, w, nw, reinterpret_cast<unsigned*>(amax));
+    return TTSC_OK;
+}
+
 template <int MI, int NJ, int TMAX>
 static int launch_fold_t(const ConvArgs& a, hipStream_t s) {
     constexpr int NT = 4 * NJ * 32;
@@ -141,12 +153,7 @@ extern "C" int ttsc_conv_train(const float* x, const float* w, const float* bias
     const int MI = Cout >= 64 ? 2 : 1;
     const int CinP = round_up(Cin, 16), CoutP = round_up(Cout, 32 * MI);
 
-    TTSC_HIP_CHECK(hipMemsetAsync(amax, 0, 16, s));
-    {
-        const long nx = (long)B * Cin * Lin, nw = (long)Cin * Cout * K;
-        const int bx = (int)std::min<long>((nx / 16 + 255) / 256 + 1, 256), bw = (int)std::min<long>((nw / 16 + 255) / 256 + 1, 128);
-        hipLaunchKernelGGL(amax2_kernel, dim3(bx + bw), dim3(256), 0, s, x, nx, bx, w, nw, reinterpret_cast<unsigned*>(amax));
-    }
+    if (int rc = launch_amax2(x, (long)B * Cin * Lin, w, (long)Cin * Cout * K, amax, s)) return rc;
     {
         PackHArgs p;
         p.w = w;

@@ -17,10 +17,9 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "conv_kernels.hpp"
 
 namespace ttsc {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct WgArgs {
     const float* P;
@@ -210,6 +209,170 @@ static int launch_wgrad(const WgArgs& a, hipStream_t s) {
     return TTSC_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Split-precision weight gradient (the dense layers of the training step: discriminator 512..1024-channel layers, generator ResBlocks).
+// Same correlation as above, but as a proper GEMM tile on v_mfma_f32_32x32x16_f16: a workgroup owns 128 rows (a) x 64 columns (b) with all
+// taps of the launch (2 x 2 waves, 64 x 32 each: 2 x JT accumulator tiles) and walks 64-position chunks of (batch item, time); both
+// operands are ACTIVATIONS here, so both are scaled by a device-side maximum (amax[0] = max |Q|, amax[1] = max |P|), split into fp16
+// hi + lo while they are staged, and multiplied as hi*hi + hi*lo + lo*hi.  LDS rows are [channel][position] in fp16: the P fragment of a lane
+// is 8 consecutive positions at a 16-byte aligned address; the Q fragment of tap j is the same 8 positions shifted by the tap offset — a
+// 2-byte aligned ds_read_b128 (gfx950 reads LDS unaligned).  The fp32 kernel gives every WAVE its own 32 x 32 tile, i.e. re-reads P and Q
+// from L2 32 times each for a 1024 x 1024 layer (467 us); here the operands are read 16 / 8 times and the products run at the fp16 rate.
+struct WgsArgs {
+    const float* P;
+    const float* Q;
+    float* part;         // [splits = gridDim.x][Jtot][A][Bc]
+    const float* amax;   // amax[0] = max |Q|, amax[1] = max |P|
+    int N, A, Bc, LP, LQ;
+    int Jtot, j0, base, step;
+    float q_scale, q_slope;
+    int chunks, CH, items;   // 64-position chunks per batch item; work items (batch item, chunk) per workgroup; N * chunks
+    int minoff, span;
+};
+constexpr int WS_PP = 72, WS_QP = 136;   // row pitches in halves: 144 / 272 bytes = 16 mod 128 (eight rows cover all banks), 16-byte multiples
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+struct __attribute__((packed, aligned(2))) half8_u {
+    half8 v;
+};
+
+template <int JT>
+__global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(WgsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smraw[];
+    _Float16* Ph = reinterpret_cast<_Float16*>(smraw);   // [128][WS_PP]
+    _Float16* Pl = Ph + 128 * WS_PP;
+    _Float16* Qh = Pl + 128 * WS_PP;                     // [64][WS_QP]
+    _Float16* Ql = Qh + 64 * WS_QP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    const int tb_n = (a.Bc + 63) >> 6;
+    const int a0 = (blockIdx.y / tb_n) * 128, b0 = (blockIdx.y % tb_n) * 64;
+    const int it_beg = blockIdx.x * a.CH, it_end = min(it_beg + a.CH, a.items);
+    // power-of-two ranges from the device-side maxima (same rule as the convolution: conv_kernels.hpp)
+    const float sq = pow2_to(a.amax[0] * a.q_scale, SPLIT_X_TARGET), sp = pow2_to(a.amax[1], SPLIT_X_TARGET);
+    const float qs = a.q_scale * sq;
+
+    f32x16 acc[2][JT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int it = it_beg; it < it_end; ++it) {
+        const int n = it / a.chunks, t0 = (it - n * a.chunks) * 64;
+        // (opaque copies of the row lengths: otherwise hipcc hoists the 48 clamped row offsets out of this loop and keeps them in VGPRs
+        // next to the 160 accumulator registers)
+        int lp = a.LP, lq = a.LQ, a0v = a0 + wave * 32, b0v = b0 + wave * 16;
+        asm volatile("" : "+s"(lp), "+s"(lq), "+v"(a0v), "+v"(b0v));
+        __syncthreads();   // the fragment reads of the previous chunk are done
+        // Staging: lane = position (coalesced 256-byte row segments).  Loads are ISSUED in batches of 16 into registers with clamped addresses and no
+        // use of the values (hipcc waits for a load right before its first use: load-convert-store per element is one L2 round trip each),
+        // then masked, scaled, split and written as fp16.
+        {   // P: wave w stages rows 32 w .. 32 w + 31
+            const float* Pn = a.P + (size_t)n * a.A * a.LP;
+            const int t = t0 + lane;
+            const bool tok = t < a.LP;
+            const unsigned tc = (unsigned)(tok ? t : a.LP - 1);
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                float pr[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ar = a0v + pb * 16 + r;
+                    pr[r] = Pn[(unsigned)((ar < a.A ? ar : a.A - 1) * lp) + tc];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wave * 32 + pb * 16 + r;
+                    const float v = (tok && a0 + row < a.A) ? pr[r] * sp : 0.f;
+                    const _Float16 h = (_Float16)v;
+                    Ph[row * WS_PP + lane] = h;
+                    Pl[row * WS_PP + lane] = (_Float16)(v - (float)h);
+                }
+            }
+        }
+        {   // Q: wave w stages rows 16 w .. 16 w + 15: columns 0..63 and, when the taps reach further, 64 .. 64 + span - 1
+            const float* Qn = a.Q + (size_t)n * a.Bc * a.LQ;
+            const int q1 = t0 + a.minoff + lane, q2 = q1 + 64;
+            const bool ok1 = q1 >= 0 && q1 < a.LQ, ok2 = lane < a.span && q2 >= 0 && q2 < a.LQ;
+            const unsigned c1 = (unsigned)min(max(q1, 0), a.LQ - 1), c2 = (unsigned)min(max(q2, 0), a.LQ - 1);
+            const bool two = a.span > 0;
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {   // columns 0..63, then 64..64+span-1 (16 staging registers live at a time)
+                if (ph == 1 && !two) break;
+                float qr[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int br = b0v + r;
+                    qr[r] = Qn[(unsigned)((br < a.Bc ? br : a.Bc - 1) * lq) + (ph ? c2 : c1)];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wave * 16 + r;
+                    float v = qr[r] * qs;
+                    v = fmaxf(v, v * a.q_slope);   // leaky-relu for slopes in [0, 1]
+                    v = ((ph ? ok2 : ok1) && b0 + row < a.Bc) ? v : 0.f;
+                    const _Float16 h = (_Float16)v;
+                    Qh[row * WS_QP + ph * 64 + lane] = h;
+                    Ql[row * WS_QP + ph * 64 + lane] = (_Float16)(v - (float)h);
+                }
+            }
+        }
+        __syncthreads();
+        const _Float16* pa = Ph + (wm * 64 + l31) * WS_PP + half * 8;
+        const _Float16* qb = Qh + (wn * 32 + l31) * WS_QP + half * 8 + (a.base + a.j0 * a.step - a.minoff);
+#pragma unroll 1
+        for (int ks = 0; ks < 4; ++ks) {
+            half8 ah[2], al[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const half8*>(pa + i * 32 * WS_PP + ks * 16);
+                al[i] = *reinterpret_cast<const half8*>(pa + 128 * WS_PP + i * 32 * WS_PP + ks * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                const half8 bh = reinterpret_cast<const half8_u*>(qb + ks * 16 + j * a.step)->v;
+                const half8 bl = reinterpret_cast<const half8_u*>(qb + 64 * WS_QP + ks * 16 + j * a.step)->v;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // partial tile -> workspace (C/D layout: column b = lane & 31, row a = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)); 128-byte runs per row
+    const float un = 1.f / (sp * sq);
+    const int bcol = b0 + wn * 32 + l31;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+        float* dst = a.part + ((size_t)blockIdx.x * a.Jtot + a.j0 + j) * a.A * a.Bc;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int arow = a0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (arow < a.A && bcol < a.Bc) dst[(size_t)arow * a.Bc + bcol] = acc[i][j][r] * un;
+            }
+    }
+}
+
+template <int JT>
+static int launch_wgrad_split(const WgsArgs& a, int splits, hipStream_t s) {
+    const int tiles = ((a.A + 127) / 128) * ((a.Bc + 63) / 64);
+    const size_t lds = (size_t)(2 * 128 * WS_PP + 2 * 64 * WS_QP) * sizeof(_Float16);
+    if (int rc = ensure_full_lds(reinterpret_cast<const void*>(wgrad_f16x3_kernel<JT>))) return rc;
+    hipLaunchKernelGGL(wgrad_f16x3_kernel<JT>, dim3(splits, tiles), dim3(256), lds, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("wgrad_f16x3_kernel launch failed: %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    return TTSC_OK;
+}
+
 }  // namespace ttsc
 
 using namespace ttsc;
@@ -298,6 +461,90 @@ extern "C" int ttsc_conv_wgrad_grouped(const float* p_dev, const float* q_dev, f
     const long blocks = (AB * J + 31) / 32;
     TTSC_REQUIRE(blocks < (1l << 31), "ttsc_conv_wgrad: weight tensor too large");
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)ws_dev, g_dev, splits, (int)J, AB);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("wgrad_reduce_kernel launch failed: %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    return TTSC_OK;
+}
+
+
+// ---- split-precision variant (wgrad_f16x3_kernel) ---------------------------------------------------------------------------------
+static void wgrad_split_plan(int N, int A, int Bc, int64_t LP, int* chunks, int* CH, int* items, int* splits) {
+    *chunks = (int)ceil_div(LP, 64);
+    *items = N * *chunks;
+    const int tiles = ((A + 127) / 128) * ((Bc + 63) / 64);
+    long want = (512 + tiles - 1) / tiles;   // ~two workgroups per CU
+    if (want < 1) want = 1;
+    if (want > *items) want = *items;
+    *CH = (int)ceil_div(*items, want);
+    *splits = (int)ceil_div(*items, *CH);    // every split owns at least one item
+}
+
+extern "C" int32_t ttsc_conv_wgrad_split_supported(int32_t A, int32_t Bc, int32_t J, int32_t step) {
+    const int st = step < 0 ? -step : step;
+    return A >= 64 && Bc >= 32 && J >= 1 && J <= 16 && st >= 1 && st <= 64;
+}
+
+extern "C" size_t ttsc_conv_wgrad_split_workspace_bytes(int32_t N, int32_t A, int32_t Bc, int64_t LP, int32_t J) {
+    if (N <= 0 || A <= 0 || Bc <= 0 || LP <= 0 || J <= 0) return 0;
+    int chunks, CH, items, splits;
+    wgrad_split_plan(N, A, Bc, LP, &chunks, &CH, &items, &splits);
+    return 256 + (size_t)splits * J * A * Bc * sizeof(float);
+}
+
+extern "C" int ttsc_conv_wgrad_split(const float* p_dev, const float* q_dev, float* g_dev, int32_t N, int32_t A, int32_t Bc, int64_t LP, int64_t LQ,
+                                     int32_t J, int32_t base, int32_t step, float q_scale, float q_slope, void* ws_dev, size_t ws_bytes, void* stream) {
+    TTSC_REQUIRE(p_dev && q_dev && g_dev && ws_dev, "ttsc_conv_wgrad_split: null argument");
+    TTSC_REQUIRE(N > 0 && LP > 0 && LQ > 0 && ttsc_conv_wgrad_split_supported(A, Bc, J, step), "ttsc_conv_wgrad_split: shape not supported (N=%d A=%d B=%d J=%d step=%d)",
+                 N, A, Bc, J, step);
+    TTSC_REQUIRE((int64_t)N * A * LP < (1ll << 31) && (int64_t)N * Bc * LQ < (1ll << 31), "ttsc_conv_wgrad_split: tensor too large");
+    TTSC_REQUIRE(q_slope >= 0.f && q_slope <= 1.f && q_scale > 0.f, "ttsc_conv_wgrad_split: q_slope must be in [0,1], q_scale positive");
+    TTSC_REQUIRE(ws_bytes >= ttsc_conv_wgrad_split_workspace_bytes(N, A, Bc, LP, J) && ((uintptr_t)ws_dev & 15) == 0, "ttsc_conv_wgrad_split: workspace too small or misaligned");
+    hipStream_t s = (hipStream_t)stream;
+    float* amax = reinterpret_cast<float*>(ws_dev);
+    if (int rc = launch_amax2(q_dev, (long)N * Bc * LQ, p_dev, (long)N * A * LP, amax, s)) return rc;
+    WgsArgs a;
+    a.P = p_dev;
+    a.Q = q_dev;
+    a.part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws_dev) + 256);
+    a.amax = amax;
+    a.N = N;
+    a.A = A;
+    a.Bc = Bc;
+    a.LP = (int)LP;
+    a.LQ = (int)LQ;
+    a.Jtot = J;
+    a.base = base;
+    a.step = step;
+    a.q_scale = q_scale;
+    a.q_slope = q_slope;
+    int splits;
+    wgrad_split_plan(N, A, Bc, LP, &a.chunks, &a.CH, &a.items, &splits);
+    const int st = step < 0 ? -step : step;
+    const int jt_max = std::min(5, 64 / st + 1);   // taps per launch: five accumulator pairs, and a Q window of at most 64 extra positions
+    for (int j0 = 0; j0 < J;) {
+        const int jt = std::min(jt_max, J - j0);
+        a.j0 = j0;
+        const int off_first = base + j0 * step, off_last = base + (j0 + jt - 1) * step;
+        a.minoff = std::min(off_first, off_last);
+        a.span = std::max(off_first, off_last) - a.minoff;
+        int rc;
+        switch (jt) {
+            case 1: rc = launch_wgrad_split<1>(a, splits, s); break;
+            case 2: rc = launch_wgrad_split<2>(a, splits, s); break;
+            case 3: rc = launch_wgrad_split<3>(a, splits, s); break;
+            case 4: rc = launch_wgrad_split<4>(a, splits, s); break;
+            default: rc = launch_wgrad_split<5>(a, splits, s); break;
+        }
+        if (rc) return rc;
+        j0 += jt;
+    }
+    const long AB = (long)A * Bc;
+    const long blocks = (AB * J + 31) / 32;
+    TTSC_REQUIRE(blocks < (1l << 31), "ttsc_conv_wgrad_split: weight tensor too large");
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)a.part, g_dev, splits, (int)J, AB);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("wgrad_reduce_kernel launch failed: %s", hipGetErrorString(e));

@@ -124,6 +124,13 @@ def _wgrad(P, Q, A, Bc, J, base, step, q_scale, q_slope, groups=1):
     N, _, LP = P.shape
     LQ = Q.shape[2]
     L = _lib.lib()
+    if SPLIT_TRAIN and groups == 1 and L.ttsc_conv_wgrad_split_supported(A, Bc, J, step):   # dense layer: fp16 hi/lo x 3 on MFMA, 128 x 64 tiles
+        nbytes = int(L.ttsc_conv_wgrad_split_workspace_bytes(N, A, Bc, LP, J))
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=P.device)
+        with torch.cuda.device(P.device):
+            _lib.check(L.ttsc_conv_wgrad_split(_lib.dev_ptr(P), _lib.dev_ptr(Q), _lib.dev_ptr(G), N, A, Bc, LP, LQ, J, base, step, q_scale, q_slope,
+                                               _lib.dev_ptr(ws), nbytes, _lib.current_stream()), 'ttsc_conv_wgrad_split')
+        return G
     nbytes = int(L.ttsc_conv_wgrad_workspace_bytes(N, A, Bg, LP, J))
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=P.device)
     with torch.cuda.device(P.device):
