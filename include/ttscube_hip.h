@@ -194,13 +194,14 @@ int ttsc_conv_wgrad_split(const float* p_dev, const float* q_dev, float* g_dev, 
  *   g = 1 without `gate_dev`, else (gate[b,co,t] > 0 ? 1 : gate_slope)    (the leaky-relu derivative of a data-gradient launch),
  *   W = w_dev [Cout][Cin][K] (flip = 0), or W[co,ci,k] = w_dev[ci][co][K-1-k] with w_dev [Cin][Cout][K] (flip = 1: `w_dev` is the forward
  *   weight of the layer being differentiated).  x [B,Cin,Lin], y / resid / gate [B,Cout,Lout], Lout = Lin + 2 padding - dilation (K-1).
+ *   groups > 1 (MSD's grouped k = 41 layers): torch Conv1d `groups`; w_dev [Cout][Cin/groups][K] (flip = 1: [Cin][Cout/groups][K]).
  * Both fp16 ranges are set per launch from device-side maxima of x and w (no host synchronisation, no calibration state); results agree
  * with the fp32 kernel to ~1e-6 relative.  `ttsc_conv_train_supported` says whether a shape is taken (thin layers stay on
  * ttsc_conv1d_forward); the workspace holds the two range words and the packed weight fragments. */
-int32_t ttsc_conv_train_supported(int32_t Cin, int32_t Cout, int32_t K, int32_t dilation);
-size_t ttsc_conv_train_workspace_bytes(int32_t Cin, int32_t Cout, int32_t K);
+int32_t ttsc_conv_train_supported(int32_t Cin, int32_t Cout, int32_t K, int32_t dilation, int32_t groups);
+size_t ttsc_conv_train_workspace_bytes(int32_t Cin, int32_t Cout, int32_t K, int32_t groups);
 int ttsc_conv_train(const float* x_dev, const float* w_dev, const float* bias_dev, const float* resid_dev, const float* gate_dev, float* y_dev,
-                    int32_t B, int32_t Cin, int32_t Cout, int32_t K, int64_t Lin, int32_t padding, int32_t dilation, int32_t flip, float in_scale,
+                    int32_t B, int32_t Cin, int32_t Cout, int32_t K, int64_t Lin, int32_t padding, int32_t dilation, int32_t groups, int32_t flip, float in_scale,
                     float in_slope, float out_scale, float gate_slope, void* ws_dev, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

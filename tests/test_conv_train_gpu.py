@@ -9,13 +9,13 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-def _run(x, w, b, resid, gate, padding, dilation, flip, **kw):
+def _run(x, w, b, resid, gate, padding, dilation, flip, groups=1, **kw):
     from ttscube_amd.hifigan.autograd import _conv_split
     if flip:
-        Cin, Cout, K = w.shape[0], w.shape[1], w.shape[2]
+        Cin, Cout, K = w.shape[0], w.shape[1] * groups, w.shape[2]
     else:
-        Cout, Cin, K = w.shape
-    return _conv_split(x, w, b, resid, gate, Cin, Cout, K, padding, dilation, flip, **kw)
+        Cout, Cin, K = w.shape[0], w.shape[1] * groups, w.shape[2]
+    return _conv_split(x, w, b, resid, gate, Cin, Cout, K, padding, dilation, flip, groups=groups, **kw)
 
 
 def _ref(x, w, b, resid, gate, padding, dilation, flip, in_scale=1.0, in_slope=1.0, out_scale=1.0, gate_slope=1.0):
@@ -88,9 +88,10 @@ def test_zero_and_non_finite_inputs_are_visible():
 
 def test_unsupported_shapes_are_refused():
     from ttscube_amd import _lib
-    assert not _lib.lib().ttsc_conv_train_supported(1, 32, 5, 1)       # discriminator input layer
-    assert not _lib.lib().ttsc_conv_train_supported(1024, 1, 3, 1)     # conv_post
-    assert not _lib.lib().ttsc_conv_train_supported(64, 64, 41, 1)     # MSD's k = 41 layers (grouped, fp32 kernel)
+    assert not _lib.lib().ttsc_conv_train_supported(1, 32, 5, 1, 1)       # discriminator input layer
+    assert not _lib.lib().ttsc_conv_train_supported(1024, 1, 3, 1, 1)     # conv_post
+    assert not _lib.lib().ttsc_conv_train_supported(64, 64, 41, 2, 1)     # receptive field beyond the staged window
+    assert not _lib.lib().ttsc_conv_train_supported(64, 96, 7, 1, 2)      # 48 output channels per group do not tile into 32-row blocks
     with pytest.raises(_lib.TTSCError):
         _run(torch.zeros(1, 1, 64).cuda(), torch.zeros(32, 1, 5).cuda(), None, None, None, 2, 1, 0)
 
@@ -134,3 +135,32 @@ def test_split_weight_gradient_matches_float64(N, A, Bc, LP, LQ, J, base, step, 
     finally:
         AG.SPLIT_TRAIN = True
     assert float((G32.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+GROUPED = [  # B, Cin, Cout, K, L, padding, groups   (MSD after the stride de-interleave: k = 41 -> 21 / 11 taps; and its stride-1 layer)
+    (3, 256, 128, 21, 150, 0, 4),      # 64 -> 32 channels per group: one group per 32-row tile
+    (2, 256, 256, 21, 97, 0, 16),      # 16 -> 16: two groups per tile, block-diagonal weights
+    (2, 1024, 512, 11, 60, 0, 16),     # 64 -> 32
+    (2, 2048, 1024, 11, 31, 0, 16),    # 128 -> 64: 64-row tiles
+    (3, 1024, 1024, 41, 47, 20, 16),   # k = 41 at stride 1: 41 taps
+    (2, 128, 256, 21, 140, 20, 4),     # the data-gradient shape of the first case (32 -> 64)
+]
+
+
+@pytest.mark.parametrize('B,Cin,Cout,K,L,pad,G', GROUPED)
+def test_grouped_forward_and_data_gradient_match_float64(B, Cin, Cout, K, L, pad, G):
+    g = torch.Generator().manual_seed(Cin + Cout + K)
+    x = torch.randn(B, Cin, L, generator=g, dtype=torch.float64).cuda().requires_grad_(True)
+    w = (torch.randn(Cout, Cin // G, K, generator=g, dtype=torch.float64) / (Cin // G * K) ** 0.5).cuda()
+    b = torch.randn(Cout, generator=g, dtype=torch.float64).cuda()
+    sc, sl = 0.8, 0.1
+    ref = F.conv1d(F.leaky_relu(x * sc, sl), w, b, padding=pad, groups=G)
+    y = _run(x.detach().float(), w.float().contiguous(), b.float(), None, None, pad, 1, 0, groups=G, in_scale=sc, in_slope=sl)
+    assert y.shape == ref.shape
+    assert float((y.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    dy = torch.randn(ref.shape, generator=g, dtype=torch.float64).cuda() * 1e-4
+    (dx_ref,) = torch.autograd.grad(ref, x, dy)
+    pd = (K - 1) - pad
+    dx = _run(dy.float(), w.float().contiguous(), None, None, x.detach().float(), pd, 1, 1, groups=G, out_scale=sc, gate_slope=sl)
+    assert dx.shape == dx_ref.shape
+    assert float((dx.double() - dx_ref).abs().max()) <= 2e-6 * float(dx_ref.abs().max())

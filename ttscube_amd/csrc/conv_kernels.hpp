@@ -206,6 +206,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_mfma_kernel(ConvArgs a) {
     // grouped convolution: this workgroup's rows only meet the input channels of their own group(s)
     const int cin0 = a.groups > 1 ? ((blockIdx.y * (WM * MI * 32)) / a.cout_g) * a.cin_g : 0;
     const float* xb = a.x + ((size_t)b * a.CinTot + cin0) * a.Lin;
+    const int cin_n = a.groups > 1 ? min(a.Cin, a.CinTot - cin0) : a.Cin;   // (the last row tile of a grouped layer may hold fewer groups than a full one)
     const int lo = q0 + a.min_shift;  // x position of LDS column 0
     const int cipN = a.CinP >> 1;
     const int nchunks = a.CinP / KC;
@@ -230,13 +231,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_mfma_kernel(ConvArgs a) {
         for (int i = 0; i < SMAIN; ++i) {
             const int e = tid + i * NTHREADS;
             const int c = e / NT, p = e % NT;
-            const int ci = min(cc + c, a.Cin - 1), pos = min(max(lo + p, 0), a.Lin - 1);
+            const int ci = min(cc + c, cin_n - 1), pos = min(max(lo + p, 0), a.Lin - 1);
             sreg[i] = xb[(unsigned)(ci * a.Lin + pos)];
         }
 #pragma unroll
         for (int i = 0; i < SHALO; ++i) {
             const int c = wave + i * NWAVES, p = NT + lane;
-            const int ci = min(cc + c, a.Cin - 1), pos = min(max(lo + p, 0), a.Lin - 1);
+            const int ci = min(cc + c, cin_n - 1), pos = min(max(lo + p, 0), a.Lin - 1);
             sreg[SMAIN + i] = xb[(unsigned)(ci * a.Lin + pos)];
         }
     };
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_mfma_kernel(ConvArgs a) {
             const int ci = cc + c, pos = lo + p;
             float v = sreg[i] * a.in_scale;
             v = v > 0.f ? v : v * a.in_slope;
-            if (p < a.span) buf[c * a.span_pad + p] = (ci < a.Cin && pos >= 0 && pos < lin) ? v : 0.f;
+            if (p < a.span) buf[c * a.span_pad + p] = (ci < cin_n && pos >= 0 && pos < lin) ? v : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < SHALO; ++i) {
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_mfma_kernel(ConvArgs a) {
             const int ci = cc + c, pos = lo + p;
             float v = sreg[SMAIN + i] * a.in_scale;
             v = v > 0.f ? v : v * a.in_slope;
-            if (p < a.span) buf[c * a.span_pad + p] = (ci < a.Cin && pos >= 0 && pos < lin) ? v : 0.f;
+            if (p < a.span) buf[c * a.span_pad + p] = (ci < cin_n && pos >= 0 && pos < lin) ? v : 0.f;
         }
         if (wide) {
             for (int c = wave; c < KC; c += NWAVES) {
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_mfma_kernel(ConvArgs a) {
                 for (int p = SPC + lane; p < a.span; p += 64) {
                     const int pos = lo + p;
                     float v = 0.f;
-                    if (ci < a.Cin && pos >= 0 && pos < lin) {
+                    if (ci < cin_n && pos >= 0 && pos < lin) {
                         v = xb[(size_t)ci * a.Lin + pos] * a.in_scale;
                         v = v > 0.f ? v : v * a.in_slope;
                     }
@@ -404,7 +405,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const float* xb = a.x + (size_t)b * a.Cin * a.Lin;
+    // FOLD (training) launches also take grouped layers: a row tile only meets the input channels of its own group(s), a.Cin of them
+    const int cin0 = (FOLD && a.groups > 1) ? ((blockIdx.y * (MI * 32)) / a.cout_g) * a.cin_g : 0;
+    const float* xb = a.x + (FOLD ? (size_t)cin0 * a.Lin : (size_t)b * a.Cin * a.Lin);
+    const int cin_n = (FOLD && a.groups > 1) ? min(a.Cin, a.CinTot - cin0) : a.Cin;   // (the last row tile may hold fewer groups than a full one)
     const int lo = q0 + a.min_shift;
     const half8* wsrc = reinterpret_cast<const half8*>(a.wph);
 
@@ -451,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
             const int sq = pos >= 0 ? pos / a.fold_S : 0;
             const int pp = pos - sq * a.fold_S;
             xok[e] = pos >= 0 && sq < a.fold_B && pp < lin;
-            xoff[e] = xok[e] ? (unsigned)sq * (unsigned)(a.Cin * a.Lin) + (unsigned)pp : 0u;
+            xoff[e] = xok[e] ? (unsigned)sq * (unsigned)(a.CinTot * a.Lin) + (unsigned)pp : 0u;
         } else {
             xok[e] = pos >= 0 && pos < lin;
             int pc = pos > lin - 1 ? lin - 1 : pos;
@@ -466,8 +470,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
         for (int ch = 0; ch < 8; ++ch) {
             // the two channel rows (h = 0 / 1) of this step are wave-uniform scalars: sgpr base + vgpr offset
             const int c0 = c * 16 + ch, c1 = c * 16 + 8 + ch;
-            const float* r0 = xb + (size_t)(c0 < a.Cin ? c0 : a.Cin - 1) * a.Lin;
-            const float* r1 = xb + (size_t)(c1 < a.Cin ? c1 : a.Cin - 1) * a.Lin;
+            const float* r0 = xb + (size_t)(c0 < cin_n ? c0 : cin_n - 1) * a.Lin;
+            const float* r1 = xb + (size_t)(c1 < cin_n ? c1 : cin_n - 1) * a.Lin;
 #pragma unroll
             for (int e = 0; e < XIT; ++e) xr[e][ch] = (xh[e] ? r1 : r0)[xoff[e]];
         }
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
                 half8 vh, vl;
 #pragma unroll
                 for (int ch = 0; ch < 8; ++ch) {
-                    float v = (xok[e] && cb + ch < a.Cin) ? xr[e][ch] * in_scale : 0.f;
+                    float v = (xok[e] && cb + ch < cin_n) ? xr[e][ch] * in_scale : 0.f;
                     v = fmaxf(v, v * a.in_slope);   // leaky-relu for slopes in [0,1] (1 = identity)
                     const _Float16 hh = (_Float16)v;
                     vh[ch] = hh;

@@ -52,6 +52,7 @@ struct PackHArgs {
     _Float16* out;       // [K][CinP/16][CoutP/32][2 (hi, lo)][64 lanes][8 half]
     const float* amax;   // amax[1] = max |w|
     int Cin, Cout, K, nch, cotN, flip;
+    int groups, cin_g, cout_g, cin_tile, MT;   // grouped layer (torch `groups`): a row tile of MT rows meets the cin_tile input channels of its group(s)
 };
 __global__ __launch_bounds__(256) void pack_wh_kernel(PackHArgs p) {
     const float scale = pow2_to(p.amax[1], SPLIT_W_TARGET);
@@ -69,7 +70,14 @@ __global__ __launch_bounds__(256) void pack_wh_kernel(PackHArgs p) {
         for (int e = 0; e < 8; ++e) {
             const int ci = ch * 16 + 8 * (lane >> 5) + e;
             float v = 0.f;
-            if (co < p.Cout && ci < p.Cin)
+            if (p.groups > 1) {
+                // ci counts from the first input channel of the row tile's group(s) (block-diagonal when a tile holds several groups).  Forward
+                // weight [Cout][cin_g][K]; as a data gradient the source is the differentiated layer's weight [Cin(this)][cout_g(this)][K]
+                const int gco = co / p.cout_g, cig = ((co / p.MT) * p.MT / p.cout_g) * p.cin_g + ci;
+                if (co < p.Cout && ci < p.cin_tile && cig / p.cin_g == gco)
+                    v = p.flip ? p.w[((size_t)cig * p.cout_g + (co - gco * p.cout_g)) * p.K + (p.K - 1 - j)]
+                               : p.w[((size_t)co * p.cin_g + (cig - gco * p.cin_g)) * p.K + j];
+            } else if (co < p.Cout && ci < p.Cin)
                 v = p.flip ? p.w[((size_t)ci * p.Cout + co) * p.K + (p.K - 1 - j)] : p.w[((size_t)co * p.Cin + ci) * p.K + j];
             v *= scale;
             const _Float16 h = (_Float16)v;
@@ -114,7 +122,8 @@ static int launch_fold(const ConvArgs& a, hipStream_t s) {
     if (a.ntaps <= 3) return launch_fold_t<MI, NJ, 3>(a, s);
     if (a.ntaps <= 7) return launch_fold_t<MI, NJ, 7>(a, s);
     if (a.ntaps <= 11) return launch_fold_t<MI, NJ, 11>(a, s);
-    return launch_fold_t<MI, NJ, 16>(a, s);
+    if (a.ntaps <= 16) return launch_fold_t<MI, NJ, 16>(a, s);
+    return launch_fold_t<MI, NJ, 21>(a, s);   // MSD's k = 41, stride 2 layers: 21 taps after the de-interleave
 }
 
 }  // namespace ttsc
@@ -123,37 +132,55 @@ using namespace ttsc;
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-extern "C" int32_t ttsc_conv_train_supported(int32_t Cin, int32_t Cout, int32_t K, int32_t dilation) {
-    // (thin layers — the discriminators' first and last convolutions — would be mostly channel padding: they stay on the fp32 kernel)
-    return Cin >= 16 && Cout >= 32 && K >= 1 && K <= 16 && dilation >= 1 && (K - 1) * dilation <= 64;
+// row tile of a (grouped) layer: 64 rows when they stay inside one group or hold whole groups, else 32; 0 = does not tile
+static int train_mt(int Cout, int groups, int K) {
+    if (K > 21) return 32;                       // k = 41 at stride 1: all taps of a chunk must fit the LDS beside the window
+    const int cout_g = Cout / groups;
+    int mt = Cout >= 64 ? 64 : 32;
+    if (groups > 1) {
+        mt = cout_g % 64 == 0 ? 64 : 32;
+        if (!(cout_g % mt == 0 || mt % cout_g == 0)) return 0;
+    }
+    return mt;
 }
 
-extern "C" size_t ttsc_conv_train_workspace_bytes(int32_t Cin, int32_t Cout, int32_t K) {
-    const int mt = Cout >= 64 ? 64 : 32;
-    return 256 + (size_t)K * round_up(Cin, 16) * round_up(Cout, mt) * 2 * sizeof(_Float16);
+extern "C" int32_t ttsc_conv_train_supported(int32_t Cin, int32_t Cout, int32_t K, int32_t dilation, int32_t groups) {
+    // (thin layers — the discriminators' first and last convolutions — would be mostly channel padding: they stay on the fp32 kernel)
+    if (groups < 1 || Cin % groups || Cout % groups) return 0;
+    const int cin_g = Cin / groups;
+    return cin_g >= 8 && Cin >= 16 && Cout >= 32 && K >= 1 && K <= 41 && dilation >= 1 && (K - 1) * dilation <= 64 && train_mt(Cout, groups, K) != 0;
+}
+
+extern "C" size_t ttsc_conv_train_workspace_bytes(int32_t Cin, int32_t Cout, int32_t K, int32_t groups) {
+    if (groups < 1) groups = 1;
+    const int mt = std::max(train_mt(Cout, groups, K), 32), cout_g = Cout / groups, cin_g = Cin / groups;
+    const int cin_tile = groups > 1 ? (mt > cout_g ? mt / cout_g : 1) * cin_g : Cin;
+    return 256 + (size_t)K * round_up(cin_tile, 16) * round_up(Cout, mt) * 2 * sizeof(_Float16);
 }
 
 extern "C" int ttsc_conv_train(const float* x, const float* w, const float* bias, const float* resid, const float* gate, float* y, int32_t B,
-                               int32_t Cin, int32_t Cout, int32_t K, int64_t Lin, int32_t padding, int32_t dilation, int32_t flip,
+                               int32_t Cin, int32_t Cout, int32_t K, int64_t Lin, int32_t padding, int32_t dilation, int32_t groups, int32_t flip,
                                float in_scale, float in_slope, float out_scale, float gate_slope, void* ws, size_t ws_bytes, void* stream) {
     TTSC_REQUIRE(x && w && y && ws, "ttsc_conv_train: null argument");
-    TTSC_REQUIRE(ttsc_conv_train_supported(Cin, Cout, K, dilation), "ttsc_conv_train: shape not supported (Cin %d, Cout %d, K %d, dilation %d)", Cin, Cout,
-                 K, dilation);
+    TTSC_REQUIRE(ttsc_conv_train_supported(Cin, Cout, K, dilation, groups), "ttsc_conv_train: shape not supported (Cin %d, Cout %d, K %d, dilation %d, groups %d)",
+                 Cin, Cout, K, dilation, groups);
     TTSC_REQUIRE(B > 0 && Lin > 0 && padding >= 0, "ttsc_conv_train: bad B / Lin / padding");
     TTSC_REQUIRE(in_slope >= 0.f && in_slope <= 1.f && in_scale > 0.f, "ttsc_conv_train: in_slope must be in [0, 1], in_scale positive");
     const int64_t Lout = Lin + 2 * (int64_t)padding - (int64_t)dilation * (K - 1);
     TTSC_REQUIRE(Lout > 0, "ttsc_conv_train: output length %lld <= 0", (long long)Lout);
     const int64_t S = std::max<int64_t>(Lin + padding, Lout);
     TTSC_REQUIRE((int64_t)B * Cin * Lin < (1ll << 31) && (int64_t)B * Cout * Lout < (1ll << 31) && S * B < (1ll << 30), "ttsc_conv_train: tensor too large");
-    TTSC_REQUIRE(ws_bytes >= ttsc_conv_train_workspace_bytes(Cin, Cout, K), "ttsc_conv_train: workspace too small");
+    TTSC_REQUIRE(ws_bytes >= ttsc_conv_train_workspace_bytes(Cin, Cout, K, groups), "ttsc_conv_train: workspace too small");
     TTSC_REQUIRE(((uintptr_t)ws & 15) == 0, "ttsc_conv_train: workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     float* amax = reinterpret_cast<float*>(ws);
     _Float16* wph = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(ws) + 256);
-    const int MI = Cout >= 64 ? 2 : 1;
-    const int CinP = round_up(Cin, 16), CoutP = round_up(Cout, 32 * MI);
+    const int MT = train_mt(Cout, groups, K), MI = MT / 32;
+    const int cin_g = Cin / groups, cout_g = Cout / groups;
+    const int cin_tile = groups > 1 ? (MT > cout_g ? MT / cout_g : 1) * cin_g : Cin;
+    const int CinP = round_up(cin_tile, 16), CoutP = round_up(Cout, MT);
 
-    if (int rc = launch_amax2(x, (long)B * Cin * Lin, w, (long)Cin * Cout * K, amax, s)) return rc;
+    if (int rc = launch_amax2(x, (long)B * Cin * Lin, w, (long)cin_g * Cout * K, amax, s)) return rc;
     {
         PackHArgs p;
         p.w = w;
@@ -165,6 +192,11 @@ extern "C" int ttsc_conv_train(const float* x, const float* w, const float* bias
         p.nch = CinP / 16;
         p.cotN = CoutP / 32;
         p.flip = flip;
+        p.groups = groups;
+        p.cin_g = cin_g;
+        p.cout_g = cout_g;
+        p.cin_tile = cin_tile;
+        p.MT = MT;
         const long total = (long)K * p.nch * p.cotN * 64;
         hipLaunchKernelGGL(pack_wh_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, p);
     }
@@ -175,12 +207,14 @@ extern "C" int ttsc_conv_train(const float* x, const float* w, const float* bias
     a.wph = wph;
     a.w_unscale = 1.f;
     a.bias = bias;
-    a.Cin = Cin;
+    a.Cin = cin_tile;
     a.CinTot = Cin;
     a.CinP = CinP;
     a.Cout = Cout;
     a.CoutP = CoutP;
-    a.groups = 1;
+    a.groups = groups;
+    a.cin_g = cin_g;
+    a.cout_g = cout_g;
     a.Lin = (int)Lin;
     a.Lout = (int)Lout;
     a.ntaps = K;
@@ -198,15 +232,17 @@ extern "C" int ttsc_conv_train(const float* x, const float* w, const float* bias
     a.fold_B = B;
     a.amax = amax;
     a.q_cnt = (int)(S * B);
-    // column tile: 256 wide when that still gives every CU two workgroups, else 128
+    // column tile: 256 wide when that still gives every CU two workgroups, else 128 (and 128 when 21+ taps of weights share the LDS)
     const long cols = S * B;
-    const long wg256 = ceil_div(cols, 256) * (CoutP / (32 * MI));
+    const long wg256 = ceil_div(cols, 256) * (CoutP / MT);
     static const int nt_env = getenv("TTSC_TRAIN_NT") ? atoi(getenv("TTSC_TRAIN_NT")) : 0;
-    const int nt = nt_env ? nt_env : (wg256 >= 512 ? 256 : 128);
+    const int nt = K > 16 ? 128 : (nt_env ? nt_env : (wg256 >= 512 ? 256 : 128));
     a.span = nt + (K - 1) * dilation;
     a.span_pad = a.span;
     int rc;
-    if (MI == 2)
+    if (K > 21)
+        rc = launch_fold_t<1, 1, 41>(a, s);
+    else if (MI == 2)
         rc = nt == 256 ? launch_fold<2, 2>(a, s) : launch_fold<2, 1>(a, s);
     else
         rc = nt == 256 ? launch_fold<1, 2>(a, s) : launch_fold<1, 1>(a, s);

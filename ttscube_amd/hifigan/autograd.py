@@ -144,21 +144,21 @@ def _wgrad(P, Q, A, Bc, J, base, step, q_scale, q_slope, groups=1):
 SPLIT_TRAIN = os.environ.get('TTSC_TRAIN_SPLIT', '1') != '0'
 
 
-def _split_ok(Cin, Cout, K, dilation):
-    return SPLIT_TRAIN and bool(_lib.lib().ttsc_conv_train_supported(Cin, Cout, K, dilation))
+def _split_ok(Cin, Cout, K, dilation, groups=1):
+    return SPLIT_TRAIN and bool(_lib.lib().ttsc_conv_train_supported(Cin, Cout, K, dilation, groups))
 
 
-def _conv_split(x, w, b, resid, gate, Cin, Cout, K, padding, dilation, flip, in_scale=1.0, in_slope=1.0, out_scale=1.0, gate_slope=1.0):
+def _conv_split(x, w, b, resid, gate, Cin, Cout, K, padding, dilation, flip, in_scale=1.0, in_slope=1.0, out_scale=1.0, gate_slope=1.0, groups=1):
     """one launch group of ttsc_conv_train (range words + weight split + convolution); x [B,Cin,Lin] -> [B,Cout,Lout]"""
     L = _lib.lib()
     B, _, Lin = x.shape
     Lout = Lin + 2 * padding - dilation * (K - 1)
     y = torch.empty((B, Cout, Lout), dtype=torch.float32, device=x.device)
-    nbytes = int(L.ttsc_conv_train_workspace_bytes(Cin, Cout, K))
+    nbytes = int(L.ttsc_conv_train_workspace_bytes(Cin, Cout, K, groups))
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
     ptr = lambda t: _lib.dev_ptr(t) if t is not None else None
     with torch.cuda.device(x.device):
-        _lib.check(L.ttsc_conv_train(ptr(x), ptr(w), ptr(b), ptr(resid), ptr(gate), ptr(y), B, Cin, Cout, K, Lin, padding, dilation, int(flip),
+        _lib.check(L.ttsc_conv_train(ptr(x), ptr(w), ptr(b), ptr(resid), ptr(gate), ptr(y), B, Cin, Cout, K, Lin, padding, dilation, groups, int(flip),
                                      float(in_scale), float(in_slope), float(out_scale), float(gate_slope), ptr(ws), nbytes,
                                      _lib.current_stream()), 'ttsc_conv_train')
     return y
@@ -171,9 +171,9 @@ class HipConvFn(torch.autograd.Function):
     def forward(ctx, x, w, b, resid, tc, in_scale, in_slope):
         x = x.contiguous()
         wd = w.detach().contiguous()
-        if not tc.transposed and tc.groups == 1 and tc.stride == 1 and _split_ok(tc.Cin, tc.Cout, tc.K, tc.dilation):
+        if not tc.transposed and tc.stride == 1 and _split_ok(tc.Cin, tc.Cout, tc.K, tc.dilation, tc.groups):
             y = _conv_split(x, wd, b.detach().contiguous() if b is not None else None, resid.contiguous() if resid is not None else None, None,
-                            tc.Cin, tc.Cout, tc.K, tc.padding, tc.dilation, 0, in_scale=in_scale, in_slope=in_slope)
+                            tc.Cin, tc.Cout, tc.K, tc.padding, tc.dilation, 0, in_scale=in_scale, in_slope=in_slope, groups=tc.groups)
         else:
             tc.fwd.set_weight_device(wd, b.detach() if b is not None else None)
             y = tc.fwd(x, resid=resid, in_scale=in_scale, in_slope=in_slope)
@@ -192,9 +192,9 @@ class HipConvFn(torch.autograd.Function):
         if not tc.transposed:
             if ctx.needs_input_grad[0]:
                 pd = tc.dilation * (tc.K - 1) - tc.padding
-                if tc.groups == 1 and tc.stride == 1 and pd >= 0 and _split_ok(tc.Cout, tc.Cin, tc.K, tc.dilation):
+                if tc.stride == 1 and pd >= 0 and _split_ok(tc.Cout, tc.Cin, tc.K, tc.dilation, tc.groups):
                     dx = _conv_split(dy, w, None, None, x if sl != 1.0 else None, tc.Cout, tc.Cin, tc.K, pd, tc.dilation, 1, out_scale=sc,
-                                     gate_slope=sl)
+                                     gate_slope=sl, groups=tc.groups)
                 else:
                     h = tc.dgrad_handle()
                     h.set_weight_device_dgrad(w)
