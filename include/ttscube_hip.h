@@ -181,11 +181,13 @@ int ttsc_conv_wgrad(const float* p_dev, const float* q_dev, float* g_dev, int32_
 /* Split-precision weight gradient (csrc/conv_wgrad.hip::wgrad_f16x3_kernel): same contract as ttsc_conv_wgrad for the dense layers of the
  * training step (cubegan.py:137-170: every parameter gradient of MPD / MSD and of the generator), operands carried as fp16 hi + lo with
  * device-side ranges per launch, 128 x 64 tiles on v_mfma_f32_32x32x16_f16; agrees with ttsc_conv_wgrad to ~1e-6 of the largest entry.
- * `ttsc_conv_wgrad_split_supported` says whether a shape is taken (A >= 64 rows, Bc >= 32 columns, J <= 16 taps). */
+ * `ttsc_conv_wgrad_split_supported` says whether a shape is taken (A >= 64 rows, Bc >= 32 columns, J <= 16 taps).  Range words as for
+ * ttsc_conv_train: `measure` bit 0 = reduce max |Q| now, bit 1 = max |P| now; null pointers = workspace words measured by this call. */
 int32_t ttsc_conv_wgrad_split_supported(int32_t A, int32_t B, int32_t J, int32_t step);
 size_t ttsc_conv_wgrad_split_workspace_bytes(int32_t N, int32_t A, int32_t B, int64_t LP, int32_t J);
 int ttsc_conv_wgrad_split(const float* p_dev, const float* q_dev, float* g_dev, int32_t N, int32_t A, int32_t B, int64_t LP, int64_t LQ, int32_t J,
-                          int32_t base, int32_t step, float q_scale, float q_slope, void* ws_dev, size_t ws_bytes, void* stream);
+                          int32_t base, int32_t step, float q_scale, float q_slope, float* amax_q_dev, float* amax_p_dev, int32_t measure, void* ws_dev,
+                          size_t ws_bytes, void* stream);
 
 /* Split-precision convolution of the training step (csrc/conv_train.hip): forward and data gradient of a dense, stride-1, dilated Conv1d
  * of the generator [EXTERNAL hifigan/models.py; trained by cube/networks/cubegan.py:131-170] and of the MPD / MSD discriminators
@@ -196,13 +198,17 @@ int ttsc_conv_wgrad_split(const float* p_dev, const float* q_dev, float* g_dev, 
  *   weight of the layer being differentiated).  x [B,Cin,Lin], y / resid / gate [B,Cout,Lout], Lout = Lin + 2 padding - dilation (K-1).
  *   groups > 1 (MSD's grouped k = 41 layers): torch Conv1d `groups`; w_dev [Cout][Cin/groups][K] (flip = 1: [Cin][Cout/groups][K]).
  * Both fp16 ranges are set per launch from device-side maxima of x and w (no host synchronisation, no calibration state); results agree
- * with the fp32 kernel to ~1e-6 relative.  `ttsc_conv_train_supported` says whether a shape is taken (thin layers stay on
+ * with the fp32 kernel to ~1e-6 relative.  The two range words (one float each, device) can be shared by the launches of one layer so that every
+ * tensor is reduced once per step: forward measures max |x| and max |w| (`measure` = 3), the data gradient re-uses the weight word and measures
+ * max |dy| (`measure` = 1), the weight gradient re-uses both; null pointers = measured into the workspace by this call.
+ * `ttsc_conv_train_supported` says whether a shape is taken (thin layers stay on
  * ttsc_conv1d_forward); the workspace holds the two range words and the packed weight fragments. */
 int32_t ttsc_conv_train_supported(int32_t Cin, int32_t Cout, int32_t K, int32_t dilation, int32_t groups);
 size_t ttsc_conv_train_workspace_bytes(int32_t Cin, int32_t Cout, int32_t K, int32_t groups);
 int ttsc_conv_train(const float* x_dev, const float* w_dev, const float* bias_dev, const float* resid_dev, const float* gate_dev, float* y_dev,
                     int32_t B, int32_t Cin, int32_t Cout, int32_t K, int64_t Lin, int32_t padding, int32_t dilation, int32_t groups, int32_t flip, float in_scale,
-                    float in_slope, float out_scale, float gate_slope, void* ws_dev, size_t ws_bytes, void* stream);
+                    float in_slope, float out_scale, float gate_slope, float* amax_x_dev, float* amax_w_dev, int32_t measure, void* ws_dev, size_t ws_bytes,
+                    void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * HiFi-GAN generator.  Replaces `hifigan.models.Generator(h)` [EXTERNAL submodule]:

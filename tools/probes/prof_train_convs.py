@@ -39,11 +39,11 @@ hip_layers.Conv1dHip.__call__ = lambda self, x, *a, **kw: timed(
      int(self.cfg.transposed), tuple(x.shape)), _call, self, x, *a, **kw)
 _split = AG._conv_split
 AG._conv_split = lambda x, w, b, resid, gate, Cin, Cout, K, padding, dilation, flip, **kw: timed(
-    ('split conv', Cin, Cout, K, 1, dilation, 1, flip, tuple(x.shape)), _split, x, w, b, resid, gate, Cin, Cout, K, padding, dilation, flip, **kw)
+    ('split conv', Cin, Cout, K, 1, dilation, kw.get('groups', 1), flip, tuple(x.shape)), _split, x, w, b, resid, gate, Cin, Cout, K, padding, dilation, flip, **kw)
 _wg = AG._wgrad
-AG._wgrad = lambda P, Q, A, Bc, J, base, step, qs, ql, groups=1: timed(
+AG._wgrad = lambda P, Q, A, Bc, J, base, step, qs, ql, groups=1, **kw: timed(
     ('wgrad' + (' split' if AG.SPLIT_TRAIN and groups == 1 and AG._lib.lib().ttsc_conv_wgrad_split_supported(A, Bc, J, step) else ' fp32'), A, Bc, J,
-     step, groups, tuple(P.shape)), _wg, P, Q, A, Bc, J, base, step, qs, ql, groups)
+     step, groups, tuple(P.shape)), _wg, P, Q, A, Bc, J, base, step, qs, ql, groups, **kw)
 
 dev = torch.device('cuda', 0)
 enc = synthetic_encodings()

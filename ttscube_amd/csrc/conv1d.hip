@@ -1259,7 +1259,7 @@ extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, 
         a.dbg = 0;
         a.skew = 0;
         a.fold_S = a.fold_B = 0;
-        a.amax = nullptr;
+        a.amax_x = a.amax_w = nullptr;
 #ifdef TTSC_ABLATE
         if (const char* ev = getenv("TTSC_CONV_DBG")) a.dbg = atoi(ev);
 #endif

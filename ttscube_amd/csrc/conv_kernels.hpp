@@ -49,10 +49,11 @@ struct ConvArgs {
     //   * the batch is folded into the GEMM's column dimension: column v of the launch is position v % fold_S of sequence v / fold_S,
     //     fold_S >= Lin + padding so that a tap that leaves a sequence lands in the (zero) gap before the next one — training crops and
     //     the deep discriminator layers are 50 .. 1 200 positions long, far below a useful tile width;
-    //   * both power-of-two scales are derived IN the kernel from device-side maxima (amax[0] = max |x|, amax[1] = max |w|, written by
+    //   * both power-of-two scales are derived IN the kernel from device-side maxima (*amax_x = max |x|, *amax_w = max |w|, written by
     //     the launches before this one): activations and gradients move every step, no host round trip decides their range.
     int fold_S, fold_B;
-    const float* amax;
+    const float* amax_x;
+    const float* amax_w;
 };
 
 // power of two that moves a magnitude m = f * 2^e (f in [0.5, 1)) to [2^(target-1), 2^target); 1 for zero, subnormal and non-finite m
@@ -64,7 +65,8 @@ __device__ __forceinline__ float pow2_to(float m, int target) {
     s = s > 100 ? 100 : (s < -100 ? -100 : s);
     return __uint_as_float((unsigned)(127 + s) << 23);
 }
-int launch_amax2(const float* x, long nx, const float* w, long nw, float* amax, hipStream_t s);   // conv_train.hip: amax[0] = max |x|, amax[1] = max |w|
+// conv_train.hip: *out_x = max |x|, *out_w = max |w| in one launch; a null tensor is skipped (its word was measured by an earlier launch of the layer)
+int launch_amax2(const float* x, long nx, float* out_x, const float* w, long nw, float* out_w, hipStream_t s);
 static constexpr int SPLIT_X_TARGET = 15, SPLIT_W_TARGET = 10;   // |x| < 2^15 (fp16 max 65504), |w| < 2^10 (as the host-side packing)
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -391,8 +393,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
     const int cotN = a.CoutP >> 5;
     const int nchunks = a.CinP >> 4;
     float in_scale = a.in_scale, w_unscale = a.w_unscale;
-    if (FOLD) {   // device-side range: see ConvArgs::amax
-        const float sx = pow2_to(a.amax[0] * a.in_scale, SPLIT_X_TARGET), sw = pow2_to(a.amax[1], SPLIT_W_TARGET);
+    if (FOLD) {   // device-side range: see ConvArgs::amax_x
+        const float sx = pow2_to(*a.amax_x * a.in_scale, SPLIT_X_TARGET), sw = pow2_to(*a.amax_w, SPLIT_W_TARGET);
         in_scale *= sx;
         w_unscale = 1.f / (sx * sw);
     }

@@ -18,9 +18,10 @@
 
 namespace ttsc {
 
-// amax[0] = max |x|, amax[1] = max |w| (caller zeroes both words first; non-negative floats order like their bit patterns)
-__global__ __launch_bounds__(256) void amax2_kernel(const float* __restrict__ x, long nx, int bx, const float* __restrict__ w, long nw,
-                                                    unsigned* __restrict__ out) {
+// *out_x = max |x|, *out_w = max |w| (the words are zeroed first; non-negative floats order like their bit patterns).  Blocks [0, bx) reduce x,
+// the rest w; either tensor may be absent (bx == 0 / bx == gridDim.x).
+__global__ __launch_bounds__(256) void amax2_kernel(const float* __restrict__ x, long nx, int bx, unsigned* __restrict__ out_x, const float* __restrict__ w,
+                                                    long nw, unsigned* __restrict__ out_w) {
     const bool is_w = (int)blockIdx.x >= bx;
     const float* src = is_w ? w : x;
     const long n = is_w ? nw : nx;
@@ -43,19 +44,19 @@ __global__ __launch_bounds__(256) void amax2_kernel(const float* __restrict__ x,
     __syncthreads();
     if (threadIdx.x == 0) {
         m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-        if (m > 0.f) atomicMax(out + (is_w ? 1 : 0), __float_as_uint(m));
+        if (m > 0.f) atomicMax(is_w ? out_w : out_x, __float_as_uint(m));
     }
 }
 
 struct PackHArgs {
     const float* w;      // flip == 0: [Cout][Cin][K];  flip == 1: the forward weight [Cin][Cout][K] of the layer being differentiated
     _Float16* out;       // [K][CinP/16][CoutP/32][2 (hi, lo)][64 lanes][8 half]
-    const float* amax;   // amax[1] = max |w|
+    const float* amax_w;   // *amax_w = max |w|
     int Cin, Cout, K, nch, cotN, flip;
     int groups, cin_g, cout_g, cin_tile, MT;   // grouped layer (torch `groups`): a row tile of MT rows meets the cin_tile input channels of its group(s)
 };
 __global__ __launch_bounds__(256) void pack_wh_kernel(PackHArgs p) {
-    const float scale = pow2_to(p.amax[1], SPLIT_W_TARGET);
+    const float scale = pow2_to(*p.amax_w, SPLIT_W_TARGET);
     const long total = (long)p.K * p.nch * p.cotN * 64;   // one thread per (tap, chunk, row tile, lane): 8 channels
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int lane = (int)(i & 63);
@@ -90,15 +91,22 @@ __global__ __launch_bounds__(256) void pack_wh_kernel(PackHArgs p) {
     }
 }
 
-// zero the two range words, then one launch over both tensors (also used by the split-precision weight gradient, conv_wgrad.hip)
-int launch_amax2(const float* x, long nx, const float* w, long nw, float* amax, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(amax, 0, 16, s);
+// zero the range words to be measured, then one launch over the tensors (also used by the split-precision weight gradient, conv_wgrad.hip)
+int launch_amax2(const float* x, long nx, float* out_x, const float* w, long nw, float* out_w, hipStream_t s) {
+    if (!x && !w) return TTSC_OK;
+    hipError_t e = hipSuccess;
+    if (x && w && out_w == out_x + 1)
+        e = hipMemsetAsync(out_x, 0, 8, s);
+    else {
+        if (x) e = hipMemsetAsync(out_x, 0, 4, s);
+        if (w && e == hipSuccess) e = hipMemsetAsync(out_w, 0, 4, s);
+    }
     if (e != hipSuccess) {
         set_error("hipMemsetAsync: %s", hipGetErrorString(e));
         return TTSC_EHIP;
     }
-    const int bx = (int)std::min<long>((nx / 16 + 255) / 256 + 1, 256), bw = (int)std::min<long>((nw / 16 + 255) / 256 + 1, 128);
-    hipLaunchKernelGGL(amax2_kernel, dim3(bx + bw), dim3(256), 0, s, x, nx, bx, w, nw, reinterpret_cast<unsigned*>(amax));
+    const int bx = x ? (int)std::min<long>((nx / 16 + 255) / 256 + 1, 256) : 0, bw = w ? (int)std::min<long>((nw / 16 + 255) / 256 + 1, 128) : 0;
+    hipLaunchKernelGGL(amax2_kernel, dim3(bx + bw), dim3(256), 0, s, x, nx, bx, reinterpret_cast<unsigned*>(out_x), w, nw, reinterpret_cast<unsigned*>(out_w));
     return TTSC_OK;
 }
 
@@ -160,7 +168,8 @@ extern "C" size_t ttsc_conv_train_workspace_bytes(int32_t Cin, int32_t Cout, int
 
 extern "C" int ttsc_conv_train(const float* x, const float* w, const float* bias, const float* resid, const float* gate, float* y, int32_t B,
                                int32_t Cin, int32_t Cout, int32_t K, int64_t Lin, int32_t padding, int32_t dilation, int32_t groups, int32_t flip,
-                               float in_scale, float in_slope, float out_scale, float gate_slope, void* ws, size_t ws_bytes, void* stream) {
+                               float in_scale, float in_slope, float out_scale, float gate_slope, float* amax_x, float* amax_w, int32_t measure, void* ws,
+                               size_t ws_bytes, void* stream) {
     TTSC_REQUIRE(x && w && y && ws, "ttsc_conv_train: null argument");
     TTSC_REQUIRE(ttsc_conv_train_supported(Cin, Cout, K, dilation, groups), "ttsc_conv_train: shape not supported (Cin %d, Cout %d, K %d, dilation %d, groups %d)",
                  Cin, Cout, K, dilation, groups);
@@ -173,19 +182,23 @@ extern "C" int ttsc_conv_train(const float* x, const float* w, const float* bias
     TTSC_REQUIRE(ws_bytes >= ttsc_conv_train_workspace_bytes(Cin, Cout, K, groups), "ttsc_conv_train: workspace too small");
     TTSC_REQUIRE(((uintptr_t)ws & 15) == 0, "ttsc_conv_train: workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    float* amax = reinterpret_cast<float*>(ws);
+    // range words: the caller's (shared between the launches of one layer: `measure` bit 0 = write max |x| now, bit 1 = write max |w| now; a clear
+    // bit means an earlier launch of the layer measured that tensor) or, with null pointers, two words of the workspace measured here
+    float* ws_words = reinterpret_cast<float*>(ws);
+    if (!amax_x) { amax_x = ws_words; measure |= 1; }
+    if (!amax_w) { amax_w = ws_words + 1; measure |= 2; }
     _Float16* wph = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(ws) + 256);
     const int MT = train_mt(Cout, groups, K), MI = MT / 32;
     const int cin_g = Cin / groups, cout_g = Cout / groups;
     const int cin_tile = groups > 1 ? (MT > cout_g ? MT / cout_g : 1) * cin_g : Cin;
     const int CinP = round_up(cin_tile, 16), CoutP = round_up(Cout, MT);
 
-    if (int rc = launch_amax2(x, (long)B * Cin * Lin, w, (long)cin_g * Cout * K, amax, s)) return rc;
+    if (int rc = launch_amax2((measure & 1) ? x : nullptr, (long)B * Cin * Lin, amax_x, (measure & 2) ? w : nullptr, (long)cin_g * Cout * K, amax_w, s)) return rc;
     {
         PackHArgs p;
         p.w = w;
         p.out = wph;
-        p.amax = amax;
+        p.amax_w = amax_w;
         p.Cin = Cin;
         p.Cout = Cout;
         p.K = K;
@@ -230,7 +243,8 @@ extern "C" int ttsc_conv_train(const float* x, const float* w, const float* bias
     a.gate_slope = gate_slope;
     a.fold_S = (int)S;
     a.fold_B = B;
-    a.amax = amax;
+    a.amax_x = amax_x;
+    a.amax_w = amax_w;
     a.q_cnt = (int)(S * B);
     // column tile: 256 wide when that still gives every CU two workgroups, else 128 (and 128 when 21+ taps of weights share the LDS)
     const long cols = S * B;

@@ -223,7 +223,8 @@ struct WgsArgs {
     const float* P;
     const float* Q;
     float* part;         // [splits = gridDim.x][Jtot][A][Bc]
-    const float* amax;   // amax[0] = max |Q|, amax[1] = max |P|
+    const float* amax_q;   // *amax_q = max |Q|, *amax_p = max |P|
+    const float* amax_p;
     int N, A, Bc, LP, LQ;
     int Jtot, j0, base, step;
     float q_scale, q_slope;
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(WgsArgs a) {
     const int a0 = (blockIdx.y / tb_n) * 128, b0 = (blockIdx.y % tb_n) * 64;
     const int it_beg = blockIdx.x * a.CH, it_end = min(it_beg + a.CH, a.items);
     // power-of-two ranges from the device-side maxima (same rule as the convolution: conv_kernels.hpp)
-    const float sq = pow2_to(a.amax[0] * a.q_scale, SPLIT_X_TARGET), sp = pow2_to(a.amax[1], SPLIT_X_TARGET);
+    const float sq = pow2_to(*a.amax_q * a.q_scale, SPLIT_X_TARGET), sp = pow2_to(*a.amax_p, SPLIT_X_TARGET);
     const float qs = a.q_scale * sq;
 
     f32x16 acc[2][JT];
@@ -495,7 +496,8 @@ extern "C" size_t ttsc_conv_wgrad_split_workspace_bytes(int32_t N, int32_t A, in
 }
 
 extern "C" int ttsc_conv_wgrad_split(const float* p_dev, const float* q_dev, float* g_dev, int32_t N, int32_t A, int32_t Bc, int64_t LP, int64_t LQ,
-                                     int32_t J, int32_t base, int32_t step, float q_scale, float q_slope, void* ws_dev, size_t ws_bytes, void* stream) {
+                                     int32_t J, int32_t base, int32_t step, float q_scale, float q_slope, float* amax_q, float* amax_p, int32_t measure, void* ws_dev,
+                                     size_t ws_bytes, void* stream) {
     TTSC_REQUIRE(p_dev && q_dev && g_dev && ws_dev, "ttsc_conv_wgrad_split: null argument");
     TTSC_REQUIRE(N > 0 && LP > 0 && LQ > 0 && ttsc_conv_wgrad_split_supported(A, Bc, J, step), "ttsc_conv_wgrad_split: shape not supported (N=%d A=%d B=%d J=%d step=%d)",
                  N, A, Bc, J, step);
@@ -503,13 +505,17 @@ extern "C" int ttsc_conv_wgrad_split(const float* p_dev, const float* q_dev, flo
     TTSC_REQUIRE(q_slope >= 0.f && q_slope <= 1.f && q_scale > 0.f, "ttsc_conv_wgrad_split: q_slope must be in [0,1], q_scale positive");
     TTSC_REQUIRE(ws_bytes >= ttsc_conv_wgrad_split_workspace_bytes(N, A, Bc, LP, J) && ((uintptr_t)ws_dev & 15) == 0, "ttsc_conv_wgrad_split: workspace too small or misaligned");
     hipStream_t s = (hipStream_t)stream;
-    float* amax = reinterpret_cast<float*>(ws_dev);
-    if (int rc = launch_amax2(q_dev, (long)N * Bc * LQ, p_dev, (long)N * A * LP, amax, s)) return rc;
+    // range words as in ttsc_conv_train: measure bit 0 = max |Q| now, bit 1 = max |P| now; null pointers = workspace words, measured here
+    float* ws_words = reinterpret_cast<float*>(ws_dev);
+    if (!amax_q) { amax_q = ws_words; measure |= 1; }
+    if (!amax_p) { amax_p = ws_words + 1; measure |= 2; }
+    if (int rc = launch_amax2((measure & 1) ? q_dev : nullptr, (long)N * Bc * LQ, amax_q, (measure & 2) ? p_dev : nullptr, (long)N * A * LP, amax_p, s)) return rc;
     WgsArgs a;
     a.P = p_dev;
     a.Q = q_dev;
     a.part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws_dev) + 256);
-    a.amax = amax;
+    a.amax_q = amax_q;
+    a.amax_p = amax_p;
     a.N = N;
     a.A = A;
     a.Bc = Bc;

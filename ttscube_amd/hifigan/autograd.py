@@ -117,8 +117,9 @@ def _bias_grad(tc, dy):
     return db
 
 
-def _wgrad(P, Q, A, Bc, J, base, step, q_scale, q_slope, groups=1):
-    """G [A, Bc / groups, J]: weight gradient of a (grouped) Conv1d, torch layout"""
+def _wgrad(P, Q, A, Bc, J, base, step, q_scale, q_slope, groups=1, amax=None, p_measured=False):
+    """G [A, Bc / groups, J]: weight gradient of a (grouped) Conv1d, torch layout.  amax: the layer's range words [max |Q|, max |w|, max |P|] from
+    the forward launch (max |Q| valid; max |P| valid when `p_measured`), None = measured here"""
     Bg = Bc // groups
     G = torch.empty((A, Bg, J), dtype=torch.float32, device=P.device)
     N, _, LP = P.shape
@@ -128,8 +129,11 @@ def _wgrad(P, Q, A, Bc, J, base, step, q_scale, q_slope, groups=1):
         nbytes = int(L.ttsc_conv_wgrad_split_workspace_bytes(N, A, Bc, LP, J))
         ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=P.device)
         with torch.cuda.device(P.device):
+            aq = _lib.dev_ptr(amax[0:1]) if amax is not None else None
+            ap = _lib.dev_ptr(amax[2:3]) if amax is not None else None
             _lib.check(L.ttsc_conv_wgrad_split(_lib.dev_ptr(P), _lib.dev_ptr(Q), _lib.dev_ptr(G), N, A, Bc, LP, LQ, J, base, step, q_scale, q_slope,
-                                               _lib.dev_ptr(ws), nbytes, _lib.current_stream()), 'ttsc_conv_wgrad_split')
+                                               aq, ap, 0 if amax is None else (0 if p_measured else 2), _lib.dev_ptr(ws), nbytes,
+                                               _lib.current_stream()), 'ttsc_conv_wgrad_split')
         return G
     nbytes = int(L.ttsc_conv_wgrad_workspace_bytes(N, A, Bg, LP, J))
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=P.device)
@@ -148,8 +152,10 @@ def _split_ok(Cin, Cout, K, dilation, groups=1):
     return SPLIT_TRAIN and bool(_lib.lib().ttsc_conv_train_supported(Cin, Cout, K, dilation, groups))
 
 
-def _conv_split(x, w, b, resid, gate, Cin, Cout, K, padding, dilation, flip, in_scale=1.0, in_slope=1.0, out_scale=1.0, gate_slope=1.0, groups=1):
-    """one launch group of ttsc_conv_train (range words + weight split + convolution); x [B,Cin,Lin] -> [B,Cout,Lout]"""
+def _conv_split(x, w, b, resid, gate, Cin, Cout, K, padding, dilation, flip, in_scale=1.0, in_slope=1.0, out_scale=1.0, gate_slope=1.0, groups=1,
+                amax_x=None, amax_w=None, measure=3):
+    """one launch group of ttsc_conv_train (range words + weight split + convolution); x [B,Cin,Lin] -> [B,Cout,Lout].
+    amax_x / amax_w: one-element fp32 device tensors holding (or, per `measure` bit 0 / 1, receiving) max |x| / max |w|; None = internal"""
     L = _lib.lib()
     B, _, Lin = x.shape
     Lout = Lin + 2 * padding - dilation * (K - 1)
@@ -159,8 +165,8 @@ def _conv_split(x, w, b, resid, gate, Cin, Cout, K, padding, dilation, flip, in_
     ptr = lambda t: _lib.dev_ptr(t) if t is not None else None
     with torch.cuda.device(x.device):
         _lib.check(L.ttsc_conv_train(ptr(x), ptr(w), ptr(b), ptr(resid), ptr(gate), ptr(y), B, Cin, Cout, K, Lin, padding, dilation, groups, int(flip),
-                                     float(in_scale), float(in_slope), float(out_scale), float(gate_slope), ptr(ws), nbytes,
-                                     _lib.current_stream()), 'ttsc_conv_train')
+                                     float(in_scale), float(in_slope), float(out_scale), float(gate_slope), ptr(amax_x), ptr(amax_w), int(measure),
+                                     ptr(ws), nbytes, _lib.current_stream()), 'ttsc_conv_train')
     return y
 
 
@@ -172,12 +178,17 @@ class HipConvFn(torch.autograd.Function):
         x = x.contiguous()
         wd = w.detach().contiguous()
         if not tc.transposed and tc.stride == 1 and _split_ok(tc.Cin, tc.Cout, tc.K, tc.dilation, tc.groups):
+            # range words of this layer for this step: [max |x|, max |w|, max |dy|] — each tensor is reduced once, by the first launch that needs it
+            ctx.amax = torch.empty(3, dtype=torch.float32, device=x.device)
             y = _conv_split(x, wd, b.detach().contiguous() if b is not None else None, resid.contiguous() if resid is not None else None, None,
-                            tc.Cin, tc.Cout, tc.K, tc.padding, tc.dilation, 0, in_scale=in_scale, in_slope=in_slope, groups=tc.groups)
+                            tc.Cin, tc.Cout, tc.K, tc.padding, tc.dilation, 0, in_scale=in_scale, in_slope=in_slope, groups=tc.groups,
+                            amax_x=ctx.amax[0:1], amax_w=ctx.amax[1:2], measure=3)
         else:
             tc.fwd.set_weight_device(wd, b.detach() if b is not None else None)
             y = tc.fwd(x, resid=resid, in_scale=in_scale, in_slope=in_slope)
         ctx.save_for_backward(x, wd)
+        if not hasattr(ctx, 'amax'):
+            ctx.amax = None
         ctx.tc, ctx.in_scale, ctx.in_slope = tc, in_scale, in_slope
         ctx.has_b, ctx.has_r = b is not None, resid is not None
         return y
@@ -189,18 +200,22 @@ class HipConvFn(torch.autograd.Function):
         dy = dy.contiguous()
         B, _, Lin = x.shape
         dx = dw = db = None
+        dy_measured = False
         if not tc.transposed:
             if ctx.needs_input_grad[0]:
                 pd = tc.dilation * (tc.K - 1) - tc.padding
                 if tc.stride == 1 and pd >= 0 and _split_ok(tc.Cout, tc.Cin, tc.K, tc.dilation, tc.groups):
+                    am = ctx.amax
                     dx = _conv_split(dy, w, None, None, x if sl != 1.0 else None, tc.Cout, tc.Cin, tc.K, pd, tc.dilation, 1, out_scale=sc,
-                                     gate_slope=sl, groups=tc.groups)
+                                     gate_slope=sl, groups=tc.groups, amax_x=am[2:3] if am is not None else None,
+                                     amax_w=am[1:2] if am is not None else None, measure=1)
+                    dy_measured = am is not None
                 else:
                     h = tc.dgrad_handle()
                     h.set_weight_device_dgrad(w)
                     dx = h(dy, out_scale=sc, gate=x if sl != 1.0 else None, gate_slope=sl)
             if ctx.needs_input_grad[1]:
-                dw = _wgrad(dy, x, tc.Cout, tc.Cin, tc.K, -tc.padding, tc.dilation, sc, sl, tc.groups)
+                dw = _wgrad(dy, x, tc.Cout, tc.Cin, tc.K, -tc.padding, tc.dilation, sc, sl, tc.groups, amax=ctx.amax, p_measured=dy_measured)
         else:
             m_lo, _, M = tc.taps_t()
             dyp = tc.deinterleave(dy, Lin)
