@@ -574,6 +574,135 @@ __global__ __launch_bounds__(512) void lstm_bwd_split_kernel(LstmSplitArgs s) {
     }
 }
 
+// Backward-through-time with the member's slice of W_hh^T RESIDENT IN REGISTERS (KL = 4H / KS = 128 gate rows per thread: H = 256 over 4 members) —
+// the counterpart of lstm_seq_split_res_kernel.  lstm_bwd_split_kernel above streams 256 KB of W_hh^T per member and step from L2, hands the gate
+// gradients over through the output tensor plus a counter (two round trips) and loads the saved gates of a step only when it gets there: 2.9 us per
+// step against the forward's 0.85.  Here the weights are loaded once, the gate gradients travel as 8-byte {value, step tag} granules in a
+// two-slot ring that the consumers poll directly, and the owner threads fetch the saved gates / cell states / dy of step t-1 before they wait for
+// the exchange of step t.  Chain order = the streaming kernel's (k ascending per slice, slices added in order): results are bit-identical to it.
+template <int KL>
+__global__ __launch_bounds__(512) void lstm_bwd_split_res_kernel(LstmSplitArgs s, lstm_u64* ring) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // dg[4H] | part[KS][HU]
+    const LstmBwdArgs& a = s.bw;
+    const int H = a.H, H4 = 4 * H, HU = s.HU, KS = s.KS;
+    const int tid = threadIdx.x, u = tid % HU, ks = tid / HU;
+    const int m = blockIdx.x, b = blockIdx.y, dir = blockIdx.z;
+    const int j = m * HU + u;
+    float* dg = sm;
+    float* part = sm + H4;
+    lstm_u64* rg = ring + (size_t)(b * a.ndir + dir) * 2 * H4;
+    const bool owner = ks == 0;
+    const int len = a.lengths ? a.lengths[b] : a.T;
+    const size_t gstride = (size_t)a.ndir * H4, cstride = (size_t)a.ndir * H;
+    const float* gb = a.gates + (size_t)b * a.T * gstride + (size_t)dir * H4 + j;
+    const float* cb = a.cst + (size_t)b * a.T * cstride + (size_t)dir * H + j;
+    const float* dyb = a.dy + (size_t)b * a.T * a.ldy + a.yoff + dir * H + j;
+    float* dgrow = a.dgates + (size_t)b * a.T * gstride + (size_t)dir * H4;
+    float w[KL];
+    {
+        // transposed pack [4H/4][H][4]: k-block kb of this slice holds gate rows ks*KL + 4*kb .. + 3 of column j
+        const float4* w4 = reinterpret_cast<const float4*>(a.whhT + (size_t)dir * H * H4 + (size_t)(ks * (KL / 4)) * H * 4) + j;
+#pragma unroll
+        for (int kb = 0; kb < KL / 4; ++kb) {
+            const float4 v = w4[(size_t)kb * H];
+            w[4 * kb] = v.x;
+            w[4 * kb + 1] = v.y;
+            w[4 * kb + 2] = v.z;
+            w[4 * kb + 3] = v.w;
+        }
+    }
+    if (owner)
+        for (int t = len; t < a.T; ++t) {
+            float* p = dgrow + (size_t)t * gstride + j;
+            p[0] = 0.f;
+            p[H] = 0.f;
+            p[2 * H] = 0.f;
+            p[3 * H] = 0.f;
+        }
+    float dh_rec = 0.f, dc_next = 0.f;
+    float pg[4] = {0.f, 0.f, 0.f, 0.f}, pct = 0.f, pcp = 0.f, pdy = 0.f;   // saved state of the step about to be differentiated
+    auto fetch = [&](int st) __attribute__((always_inline)) {
+        const int tpos = dir == 0 ? st : (len - 1 - st);
+        const int tprev = dir == 0 ? tpos - 1 : tpos + 1;
+        const float* g = gb + (size_t)tpos * gstride;
+        pg[0] = g[0];
+        pg[1] = g[H];
+        pg[2] = g[2 * H];
+        pg[3] = g[3 * H];
+        pct = cb[(size_t)tpos * cstride];
+        pcp = st > 0 ? cb[(size_t)tprev * cstride] : 0.f;
+        pdy = dyb[(size_t)tpos * a.ldy];
+    };
+    if (owner && len > 0) fetch(len - 1);
+    for (int st = len - 1; st >= 0; --st) {
+        const int tpos = dir == 0 ? st : (len - 1 - st);
+        const unsigned tag = (unsigned)(len - st);
+        lstm_u64* slot = rg + (size_t)(st & 1) * H4;
+        if (owner) {
+            const float ig = pg[0], fg = pg[1], gg = pg[2], og = pg[3];
+            const float dh = pdy + dh_rec;
+            const float tc = ttsc_tanhf(pct);
+            const float d_o = dh * tc * og * (1.f - og);
+            const float dc = dc_next + dh * og * (1.f - tc * tc);
+            const float d_i = dc * gg * ig * (1.f - ig);
+            const float d_g = dc * ig * (1.f - gg * gg);
+            const float d_f = dc * pcp * fg * (1.f - fg);
+            dc_next = dc * fg;
+            if (st > 0) {   // hand-off first: the other members are waiting for these four values
+                const lstm_u64 tg = (lstm_u64)tag << 32;
+                __hip_atomic_store(slot + j, tg | (lstm_u64)__float_as_uint(d_i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(slot + H + j, tg | (lstm_u64)__float_as_uint(d_f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(slot + 2 * H + j, tg | (lstm_u64)__float_as_uint(d_g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(slot + 3 * H + j, tg | (lstm_u64)__float_as_uint(d_o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            float* p = dgrow + (size_t)tpos * gstride + j;   // (read by the weight-gradient GEMMs after this kernel)
+            p[0] = d_i;
+            p[H] = d_f;
+            p[2 * H] = d_g;
+            p[3 * H] = d_o;
+        }
+        if (st == 0) break;
+        if (owner) fetch(st - 1);   // in flight while the exchange completes
+        bool fail = false;
+        for (int i = tid; i < H4; i += 512) {
+            lstm_u64 gq;
+            unsigned spins = 0;
+            for (;;) {
+                gq = __hip_atomic_load(slot + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(gq >> 32) == tag) break;
+                if (++spins > GS_SPIN_LIMIT || ((spins & 63u) == 0u && __hip_atomic_load(s.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    __hip_atomic_store(s.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(s.abort_word + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sticky copy
+                    fail = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            dg[i] = __uint_as_float((unsigned)gq);
+        }
+        if (__syncthreads_or(fail)) return;
+        float x = 0.f;
+        {
+            const float4* d4 = reinterpret_cast<const float4*>(dg + ks * KL);
+#pragma unroll
+            for (int kb = 0; kb < KL / 4; ++kb) {
+                const float4 dv = d4[kb];
+                x = fmaf(w[4 * kb], dv.x, x);
+                x = fmaf(w[4 * kb + 1], dv.y, x);
+                x = fmaf(w[4 * kb + 2], dv.z, x);
+                x = fmaf(w[4 * kb + 3], dv.w, x);
+            }
+        }
+        part[ks * HU + u] = x;
+        __syncthreads();
+        if (owner) {
+            float v = 0.f;
+            for (int q = 0; q < KS; ++q) v += part[q * HU + u];
+            dh_rec = v;
+        }
+    }
+}
+
 // [ndir][4H][H] (torch weight_hh layout, device)  ->  forward pack [ndir][H/4][4H][4]  or  transposed pack [ndir][4H/4][H][4]
 __global__ void lstm_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int ndir, int H, int transpose) {
     const long per = (long)4 * H * H;
@@ -698,7 +827,18 @@ extern "C" int ttsc_lstm_seq_backward(const float* dy_dev, const float* gates_de
         sa.HU = H / G;
         sa.KS = 512 / sa.HU;
         const size_t lds = ((size_t)4 * H + (size_t)sa.KS * sa.HU) * sizeof(float);
-        hipLaunchKernelGGL(lstm_bwd_split_kernel, dim3((unsigned)G, (unsigned)B, (unsigned)ndir), dim3(512), lds, (hipStream_t)stream, sa);
+        static const bool bwd_resident = !(getenv("TTSC_LSTM_BWD_RESIDENT") && atoi(getenv("TTSC_LSTM_BWD_RESIDENT")) == 0);
+        if (bwd_resident && 4 * H / sa.KS == 128) {   // H = 256 over 4 members: 128 rows of W_hh^T per thread stay in registers, granule hand-off
+            const size_t ring_bytes = (size_t)B * ndir * 2 * 4 * H * sizeof(lstm_u64);
+            HandoffArea* ar2 = lstm_area((hipStream_t)stream, ring_bytes);
+            TTSC_REQUIRE(ar2, "ttsc_lstm_seq_backward: cannot allocate the hand-off ring");
+            sa.cnt = ar2->words;
+            sa.abort_word = ar2->abort_word();
+            lstm_u64* ring = reinterpret_cast<lstm_u64*>(ar2->buf);
+            TTSC_HIP_CHECK(hipMemsetAsync(ring, 0, ring_bytes, (hipStream_t)stream));
+            hipLaunchKernelGGL(lstm_bwd_split_res_kernel<128>, dim3((unsigned)G, (unsigned)B, (unsigned)ndir), dim3(512), lds, (hipStream_t)stream, sa, ring);
+        } else
+            hipLaunchKernelGGL(lstm_bwd_split_kernel, dim3((unsigned)G, (unsigned)B, (unsigned)ndir), dim3(512), lds, (hipStream_t)stream, sa);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             set_error("lstm_bwd_split_kernel launch failed: %s", hipGetErrorString(e));
