@@ -296,6 +296,98 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdArgs a) {
 }
 
 
+// H = 64 / 128 (Languasito2's frame-level `_cond_rnn`: 300-700 steps per sentence): lstm_bwd_kernel above runs ONE wave per H = 64 sequence, each
+// thread streaming all 4H rows of W_hh^T from L2 every step (3.2 us per step).  Here a workgroup is (unit j, k-slice) pairs — 4 slices of H gate rows
+// — with the slice's H weights of column j in registers for the whole sequence; the four partial sums meet in LDS.
+template <int H>
+__global__ __launch_bounds__(4 * H) void lstm_bwd_resident_kernel(LstmBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float dg[4 * H];
+    __shared__ float part[4][H];
+    constexpr int H4 = 4 * H;
+    const int u = threadIdx.x % H, ks = threadIdx.x / H;
+    const bool owner = ks == 0;
+    const int b = blockIdx.x, dir = blockIdx.y;
+    const int len = a.lengths ? a.lengths[b] : a.T;
+    const size_t gstride = (size_t)a.ndir * H4, cstride = (size_t)a.ndir * H;
+    const float* gb = a.gates + (size_t)b * a.T * gstride + (size_t)dir * H4 + u;
+    const float* cb = a.cst + (size_t)b * a.T * cstride + (size_t)dir * H + u;
+    const float* dyb = a.dy + (size_t)b * a.T * a.ldy + a.yoff + dir * H + u;
+    float* dgb = a.dgates + (size_t)b * a.T * gstride + (size_t)dir * H4 + u;
+    float w[H];
+    {
+        const float4* w4 = reinterpret_cast<const float4*>(a.whhT + (size_t)dir * H * H4 + (size_t)(ks * (H / 4)) * H * 4) + u;
+#pragma unroll
+        for (int kb = 0; kb < H / 4; ++kb) {
+            const float4 v = w4[(size_t)kb * H];
+            w[4 * kb] = v.x;
+            w[4 * kb + 1] = v.y;
+            w[4 * kb + 2] = v.z;
+            w[4 * kb + 3] = v.w;
+        }
+    }
+    if (owner)
+        for (int t = len; t < a.T; ++t) {
+            float* p = dgb + (size_t)t * gstride;
+            p[0] = 0.f;
+            p[H] = 0.f;
+            p[2 * H] = 0.f;
+            p[3 * H] = 0.f;
+        }
+    float dh_rec = 0.f, dc_next = 0.f;
+    float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, ct = 0.f, cp = 0.f, dyv = 0.f;
+    auto fetch = [&](int s) __attribute__((always_inline)) {
+        const int tpos = dir == 0 ? s : (len - 1 - s);
+        const int tprev = dir == 0 ? tpos - 1 : tpos + 1;
+        const float* g = gb + (size_t)tpos * gstride;
+        ig = g[0];
+        fg = g[H];
+        gg = g[2 * H];
+        og = g[3 * H];
+        ct = cb[(size_t)tpos * cstride];
+        cp = s > 0 ? cb[(size_t)tprev * cstride] : 0.f;
+        dyv = dyb[(size_t)tpos * a.ldy];
+    };
+    if (owner && len > 0) fetch(len - 1);
+    for (int s = len - 1; s >= 0; --s) {
+        if (owner) {
+            const int tpos = dir == 0 ? s : (len - 1 - s);
+            const float dh = dyv + dh_rec;
+            const float tc = ttsc_tanhf(ct);
+            const float d_o = dh * tc * og * (1.f - og);
+            const float dc = dc_next + dh * og * (1.f - tc * tc);
+            const float d_i = dc * gg * ig * (1.f - ig);
+            const float d_g = dc * ig * (1.f - gg * gg);
+            const float d_f = dc * cp * fg * (1.f - fg);
+            dc_next = dc * fg;
+            dg[u] = d_i;
+            dg[H + u] = d_f;
+            dg[2 * H + u] = d_g;
+            dg[3 * H + u] = d_o;
+            float* p = dgb + (size_t)tpos * gstride;
+            p[0] = d_i;
+            p[H] = d_f;
+            p[2 * H] = d_g;
+            p[3 * H] = d_o;
+        }
+        if (s == 0) break;
+        __syncthreads();
+        if (owner) fetch(s - 1);   // in flight during the chain
+        float x = 0.f;
+        const float4* d4 = reinterpret_cast<const float4*>(dg + ks * H);
+#pragma unroll
+        for (int kb = 0; kb < H / 4; ++kb) {
+            const float4 dv = d4[kb];
+            x = fmaf(w[4 * kb], dv.x, x);
+            x = fmaf(w[4 * kb + 1], dv.y, x);
+            x = fmaf(w[4 * kb + 2], dv.z, x);
+            x = fmaf(w[4 * kb + 3], dv.w, x);
+        }
+        part[ks][u] = x;
+        __syncthreads();
+        if (owner) dh_rec = ((part[0][u] + part[1][u]) + part[2][u]) + part[3][u];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Split recurrences (same scheme as gru.hip): when B * ndir is small the kernels above leave most CUs idle while each
 // workgroup is bound by ONE CU's L2 load path (W_hh: 1 MB for H = 256, 4 MB for H = 512, per step).  Here G workgroups share
@@ -842,6 +934,19 @@ extern "C" int ttsc_lstm_seq_backward(const float* dy_dev, const float* gates_de
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             set_error("lstm_bwd_split_kernel launch failed: %s", hipGetErrorString(e));
+            return TTSC_EHIP;
+        }
+        return TTSC_OK;
+    }
+    static const bool bwd_res1 = !(getenv("TTSC_LSTM_BWD_RESIDENT") && atoi(getenv("TTSC_LSTM_BWD_RESIDENT")) == 0);
+    if (bwd_res1 && (H == 64 || H == 128)) {   // the slice's column of W_hh^T in registers, four k-slices per unit
+        if (H == 64)
+            hipLaunchKernelGGL(lstm_bwd_resident_kernel<64>, dim3((unsigned)B, (unsigned)ndir), dim3(256), 0, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL(lstm_bwd_resident_kernel<128>, dim3((unsigned)B, (unsigned)ndir), dim3(512), 0, (hipStream_t)stream, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            set_error("lstm_bwd_resident_kernel launch failed: %s", hipGetErrorString(e));
             return TTSC_EHIP;
         }
         return TTSC_OK;
