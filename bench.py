@@ -322,7 +322,7 @@ def bench_train(args):
         res = {'metric': 'audio samples/sec (HiFi-GAN adversarial training step, Cubegan)', 'value': samples * args.steps / elapsed,
                'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': max(1, args.warmup),
                'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               'dtype': 'f32', 'data': 'synthetic',
+               'dtype': 'f32 (convolutions: split fp16 hi/lo x3 MFMA with per-launch device-side ranges; TTSC_TRAIN_SPLIT=0 = exact fp32 MFMA)', 'data': 'synthetic',
                'config': {'workload': 'Cubegan.training_step (D + G + text steps, 4 optimizers), %d utterances x 12000-sample crops per GPU, '
                                       'generator + Languasito2 + MPD + MSD = %.1f M parameters' % (b, nparam / 1e6),
                           'global_batch': world * b, 'parallelism': 'dp%d: replicated parameters, 3 flat-bucket RCCL exchanges per step '
