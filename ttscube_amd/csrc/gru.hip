@@ -291,6 +291,225 @@ __global__ __launch_bounds__(512) void gru_bwd_split_kernel(GruSplitArgs s) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same split with the member's weights RESIDENT IN REGISTERS and the state handed over as 8-byte {value, step tag} granules that the
+// consumers poll directly (the scheme of lstm_seq_split_res_kernel / lstm_bwd_split_res_kernel): H = 512 over 16 members (all 256 CUs for 16
+// utterances) or H = 256 over 4 — 3 x 32 forward weights / 96 backward weights per thread.  The kernels above stream 768 KB (G = 4) of W_hh per
+// member and step from L2 and pay counter + data round trips: 8 + 12 us per time step at H = 512, i.e. 0.48 s for the vocoder's 24 000-step
+// training sequences.
+typedef unsigned long long gru_u64;
+
+__device__ __forceinline__ bool gru_poll(const gru_u64* src, unsigned tag, unsigned* abort_word, float* out) {
+    gru_u64 gq;
+    unsigned spins = 0;
+    for (;;) {
+        gq = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(gq >> 32) == tag) break;
+        if (++spins > GS_SPIN_LIMIT || ((spins & 63u) == 0u && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+            __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(abort_word + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sticky copy
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    *out = __uint_as_float((unsigned)gq);
+    return true;
+}
+
+template <int KL>   // inputs per k-slice = H / KS
+__global__ __launch_bounds__(512) void gru_seq_split_res_kernel(GruSplitArgs s, gru_u64* ring) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // h[H] | part[KS][3][HU]
+    const GruArgs& a = s.f;
+    const int H = a.H, H3 = 3 * H, HU = s.HU, KS = s.KS;
+    const int tid = threadIdx.x, u = tid % HU, ks = tid / HU;
+    const int m = blockIdx.x, b = blockIdx.y;
+    const int j = m * HU + u;
+    float* hs = sm;
+    float* part = sm + H;
+    gru_u64* rg = ring + (size_t)b * 2 * H;
+    const bool owner = ks == 0;
+    float w[3][KL];
+    {
+        // packed [H/4][3H][4]: row g*H + j, k-block kb holds k = 4*kb .. 4*kb+3
+        const float4* w4 = reinterpret_cast<const float4*>(a.whh) + j;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int kb = 0; kb < KL / 4; ++kb) {
+                const float4 v = w4[(size_t)(ks * (KL / 4) + kb) * H3 + g * H];
+                w[g][4 * kb] = v.x;
+                w[g][4 * kb + 1] = v.y;
+                w[g][4 * kb + 2] = v.z;
+                w[g][4 * kb + 3] = v.w;
+            }
+    }
+    float br = 0.f, bz = 0.f, bn = 0.f;
+    if (owner) {
+        br = a.bhh[j];
+        bz = a.bhh[H + j];
+        bn = a.bhh[2 * H + j];
+    }
+    const float* xb = a.xg + (size_t)b * a.T * H3 + j;
+    float* yb = a.y + (size_t)b * a.T * H;
+    for (int t = 0; t < a.T; ++t) {
+        float xr = 0.f, xz = 0.f, xn = 0.f;
+        if (owner) {   // issued before the wait: in flight while the other members finish step t-1
+            const float* xp = xb + (size_t)t * H3;
+            xr = xp[0];
+            xz = xp[H];
+            xn = xp[2 * H];
+        }
+        bool fail = false;
+        if (t > 0) {
+            const gru_u64* src = rg + (size_t)((t - 1) & 1) * H;
+            for (int i = tid; i < H; i += 512) fail = !gru_poll(src + i, (unsigned)t, s.abort_word, &hs[i]) || fail;
+        } else {
+            for (int i = tid; i < H; i += 512) hs[i] = a.h_0 ? a.h_0[(size_t)b * H + i] : 0.f;
+        }
+        if (__syncthreads_or(fail)) return;
+        const float hprev = owner ? hs[j] : 0.f;   // (hs is rewritten by the next step's poll while the owners are still combining)
+        float acc[3] = {0.f, 0.f, 0.f};
+        {
+            const float4* h4 = reinterpret_cast<const float4*>(hs + ks * KL);
+#pragma unroll
+            for (int kb = 0; kb < KL / 4; ++kb) {
+                const float4 hv = h4[kb];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    float x = acc[g];
+                    x = fmaf(w[g][4 * kb], hv.x, x);
+                    x = fmaf(w[g][4 * kb + 1], hv.y, x);
+                    x = fmaf(w[g][4 * kb + 2], hv.z, x);
+                    x = fmaf(w[g][4 * kb + 3], hv.w, x);
+                    acc[g] = x;
+                }
+            }
+        }
+        part[(ks * 3 + 0) * HU + u] = acc[0];
+        part[(ks * 3 + 1) * HU + u] = acc[1];
+        part[(ks * 3 + 2) * HU + u] = acc[2];
+        __syncthreads();
+        if (owner) {
+            float hr = br, hz = bz, hl = bn;
+            for (int q = 0; q < KS; ++q) {
+                hr += part[(q * 3 + 0) * HU + u];
+                hz += part[(q * 3 + 1) * HU + u];
+                hl += part[(q * 3 + 2) * HU + u];
+            }
+            const float r = ttsc_sigmoidf(xr + hr);
+            const float z = ttsc_sigmoidf(xz + hz);
+            const float n = ttsc_tanhf(fmaf(r, hl, xn));
+            const float hv = fmaf(z, hprev - n, n);
+            __hip_atomic_store(rg + (size_t)(t & 1) * H + j, ((gru_u64)(unsigned)(t + 1) << 32) | (gru_u64)__float_as_uint(hv), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            yb[(size_t)t * H + j] = hv;
+            if (a.saved) {
+                float* sp = a.saved + ((size_t)b * a.T + t) * (4 * (size_t)H) + j;
+                sp[0] = r;
+                sp[H] = z;
+                sp[2 * H] = n;
+                sp[3 * H] = hl;
+            }
+        }
+    }
+}
+
+template <int KL>   // gate rows per k-slice = 3H / KS
+__global__ __launch_bounds__(512) void gru_bwd_split_res_kernel(GruSplitArgs s, gru_u64* ring) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // dGh[3H] | part[KS][HU]
+    const GruBwdArgs& a = s.bw;
+    const int H = a.H, H3 = 3 * H, HU = s.HU, KS = s.KS;
+    const int tid = threadIdx.x, u = tid % HU, ks = tid / HU;
+    const int m = blockIdx.x, b = blockIdx.y;
+    const int j = m * HU + u;
+    float* dg = sm;
+    float* part = sm + H3;
+    gru_u64* rg = ring + (size_t)b * 2 * H3;
+    const bool owner = ks == 0;
+    float w[KL];
+    {
+        // transposed pack [3H/4][H][4]: k-block kb of this slice holds gate rows ks*KL + 4*kb .. + 3 of column j
+        const float4* w4 = reinterpret_cast<const float4*>(a.whhT + (size_t)(ks * (KL / 4)) * H * 4) + j;
+#pragma unroll
+        for (int kb = 0; kb < KL / 4; ++kb) {
+            const float4 v = w4[(size_t)kb * H];
+            w[4 * kb] = v.x;
+            w[4 * kb + 1] = v.y;
+            w[4 * kb + 2] = v.z;
+            w[4 * kb + 3] = v.w;
+        }
+    }
+    const float* sb = a.saved + (size_t)b * a.T * (4 * (size_t)H) + j;
+    const float* yb = a.y + (size_t)b * a.T * H + j;
+    const float* dyb = a.dy + (size_t)b * a.T * H + j;
+    float* gib = a.dgi + (size_t)b * a.T * H3;
+    float* ghb = a.dgh + (size_t)b * a.T * H3;
+    const float h0 = (owner && a.h_0) ? a.h_0[(size_t)b * H + j] : 0.f;
+    float dh_rec = 0.f;
+    float pr = 0.f, pz = 0.f, pn = 0.f, phl = 0.f, php = 0.f, pdy = 0.f;   // saved state of the step about to be differentiated
+    auto fetch = [&](int t) __attribute__((always_inline)) {
+        const float* sv = sb + (size_t)t * (4 * (size_t)H);
+        pr = sv[0];
+        pz = sv[H];
+        pn = sv[2 * H];
+        phl = sv[3 * H];
+        php = t > 0 ? yb[(size_t)(t - 1) * H] : h0;
+        pdy = dyb[(size_t)t * H];
+    };
+    if (owner) fetch(a.T - 1);
+    for (int t = a.T - 1; t >= 0; --t) {
+        const unsigned tag = (unsigned)(a.T - t);
+        gru_u64* slot = rg + (size_t)(t & 1) * H3;
+        float dh_direct = 0.f;
+        if (owner) {
+            const float r = pr, z = pz, n = pn, hl = phl, hp = php;
+            const float dh = pdy + dh_rec;
+            const float dn_pre = dh * (1.f - z) * (1.f - n * n);
+            const float dz_pre = dh * (hp - n) * z * (1.f - z);
+            const float dr_pre = dn_pre * hl * r * (1.f - r);
+            dh_direct = dh * z;
+            if (t > 0) {   // hand-off first
+                const gru_u64 tg = (gru_u64)tag << 32;
+                __hip_atomic_store(slot + j, tg | (gru_u64)__float_as_uint(dr_pre), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(slot + H + j, tg | (gru_u64)__float_as_uint(dz_pre), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(slot + 2 * H + j, tg | (gru_u64)__float_as_uint(dn_pre * r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            float* gi = gib + (size_t)t * H3 + j;
+            gi[0] = dr_pre;
+            gi[H] = dz_pre;
+            gi[2 * H] = dn_pre;
+            float* gh = ghb + (size_t)t * H3 + j;
+            gh[0] = dr_pre;
+            gh[H] = dz_pre;
+            gh[2 * H] = dn_pre * r;
+        }
+        if (t == 0) break;   // dh_{-1} is not needed
+        if (owner) fetch(t - 1);   // in flight while the exchange completes
+        bool fail = false;
+        for (int i = tid; i < H3; i += 512) fail = !gru_poll(slot + i, tag, s.abort_word, &dg[i]) || fail;
+        if (__syncthreads_or(fail)) return;
+        float x = 0.f;
+        {
+            const float4* d4 = reinterpret_cast<const float4*>(dg + ks * KL);
+#pragma unroll
+            for (int kb = 0; kb < KL / 4; ++kb) {
+                const float4 dv = d4[kb];
+                x = fmaf(w[4 * kb], dv.x, x);
+                x = fmaf(w[4 * kb + 1], dv.y, x);
+                x = fmaf(w[4 * kb + 2], dv.z, x);
+                x = fmaf(w[4 * kb + 3], dv.w, x);
+            }
+        }
+        part[ks * HU + u] = x;
+        __syncthreads();
+        if (owner) {
+            float v = dh_direct;
+            for (int q = 0; q < KS; ++q) v += part[q * HU + u];
+            dh_rec = v;
+        }
+    }
+}
+
 // weight_hh [3H][H] (device) -> forward pack [H/4][3H][4] (transpose = 0) or transposed pack [3H/4][H][4] (transpose = 1)
 __global__ void gru_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int H, int transpose) {
     const long total = (long)3 * H * H;
@@ -345,6 +564,21 @@ static HandoffArea* gru_area(int B, hipStream_t s) {
     return ar;
 }
 
+// members per utterance of the register-resident kernels (0 = not applicable): every thread holds 3 x 32 forward / 96 backward weights, i.e.
+// H = 512 over 16 members or H = 256 over 4; all members of all utterances must be co-resident, one workgroup per CU
+static int gru_resident_members(int B, int H) {
+    static const bool on = !(getenv("TTSC_GRU_RESIDENT") && atoi(getenv("TTSC_GRU_RESIDENT")) == 0);
+    if (!on) return 0;
+    const int G = H == 512 ? 16 : (H == 256 ? 4 : 0);
+    if (!G || (long)G * B > device_cus() || B > 4096) return 0;
+    return G;
+}
+static HandoffArea* gru_ring_area(hipStream_t s, size_t ring_bytes) {
+    HandoffArea* ar = handoff_area("gru", s, 4096, ring_bytes);
+    if (!ar || ar->rearm(s) != hipSuccess) return nullptr;
+    return ar;
+}
+
 // 0 = every hand-off of the split GRU launches on this device since the last call completed; 1 = a bounded spin timed out (that
 // launch's results are invalid).  Synchronises the device; meant for tests and debugging.
 extern "C" int32_t ttsc_gru_split_status(void) { return handoff_status("gru"); }
@@ -363,6 +597,21 @@ extern "C" int ttsc_gru_seq_forward(const float* xg_dev, const float* whh_packed
     TTSC_REQUIRE(xg_dev && whh_packed_dev && bhh_dev && y_dev, "ttsc_gru_seq_forward: null argument");
     TTSC_REQUIRE(B > 0 && T > 0 && H >= 4 && H <= 512 && H % 4 == 0, "ttsc_gru_seq_forward: bad shape B=%d T=%d H=%d", B, T, H);
     GruArgs a{xg_dev, whh_packed_dev, bhh_dev, y_dev, saved_dev, h0_dev, B, T, H};
+    if (const int Gr = gru_resident_members(B, H)) {   // weights in registers, granule hand-off (H = 512: 16 members, H = 256: 4)
+        HandoffArea* ar = gru_ring_area((hipStream_t)stream, (size_t)B * 2 * H * sizeof(gru_u64));
+        TTSC_REQUIRE(ar, "ttsc_gru_seq_forward: cannot allocate the hand-off ring");
+        TTSC_HIP_CHECK(hipMemsetAsync(ar->buf, 0, (size_t)B * 2 * H * sizeof(gru_u64), (hipStream_t)stream));
+        GruSplitArgs sa{};
+        sa.f = a;
+        sa.cnt = ar->words;
+        sa.abort_word = ar->abort_word();
+        sa.G = Gr;
+        sa.HU = H / Gr;
+        sa.KS = 512 / sa.HU;
+        const size_t lds = ((size_t)H + (size_t)sa.KS * 3 * sa.HU) * sizeof(float);
+        hipLaunchKernelGGL(gru_seq_split_res_kernel<32>, dim3((unsigned)Gr, (unsigned)B), dim3(512), lds, (hipStream_t)stream, sa, reinterpret_cast<gru_u64*>(ar->buf));
+        return gru_check_launch("gru_seq_split_res_kernel");
+    }
     const int G = gru_split_members(B, H);
     if (G > 1) {
         HandoffArea* ar = gru_area(B, (hipStream_t)stream);
@@ -387,6 +636,21 @@ extern "C" int ttsc_gru_seq_backward(const float* dy_dev, const float* saved_dev
     TTSC_REQUIRE(dy_dev && saved_dev && y_dev && whhT_packed_dev && dgi_dev && dgh_dev, "ttsc_gru_seq_backward: null argument");
     TTSC_REQUIRE(B > 0 && T > 0 && H >= 4 && H <= 512 && H % 4 == 0, "ttsc_gru_seq_backward: bad shape B=%d T=%d H=%d", B, T, H);
     GruBwdArgs a{dy_dev, saved_dev, y_dev, h0_dev, whhT_packed_dev, dgi_dev, dgh_dev, B, T, H};
+    if (const int Gr = gru_resident_members(B, H)) {
+        HandoffArea* ar = gru_ring_area((hipStream_t)stream, (size_t)B * 2 * 3 * H * sizeof(gru_u64));
+        TTSC_REQUIRE(ar, "ttsc_gru_seq_backward: cannot allocate the hand-off ring");
+        TTSC_HIP_CHECK(hipMemsetAsync(ar->buf, 0, (size_t)B * 2 * 3 * H * sizeof(gru_u64), (hipStream_t)stream));
+        GruSplitArgs sa{};
+        sa.bw = a;
+        sa.cnt = ar->words;
+        sa.abort_word = ar->abort_word();
+        sa.G = Gr;
+        sa.HU = H / Gr;
+        sa.KS = 512 / sa.HU;
+        const size_t lds = ((size_t)3 * H + (size_t)sa.KS * sa.HU) * sizeof(float);
+        hipLaunchKernelGGL(gru_bwd_split_res_kernel<96>, dim3((unsigned)Gr, (unsigned)B), dim3(512), lds, (hipStream_t)stream, sa, reinterpret_cast<gru_u64*>(ar->buf));
+        return gru_check_launch("gru_bwd_split_res_kernel");
+    }
     const int G = gru_split_members(B, H);
     if (G > 1) {
         HandoffArea* ar = gru_area(B, (hipStream_t)stream);
