@@ -353,15 +353,27 @@ def cubegan_validation_step(model, batch, rng=None):
 
 def wavernn_logits_train(net, X):
     """Differentiable WaveRNN._train_forward (modules.py:505-539): the GRU(s) run on the persistent HIP forward / backward
-    kernels (gru_autograd.py); conditioning build and the two output Linears are torch-ROCm ops."""
+    kernels (gru_autograd.py), the low-resolution conditioning convolutions on the HIP convolution kernels; repeat / interpolate / concat and the
+    two output Linears are torch-ROCm ops."""
     mel, gs_x = X['mel'], X['x']
     up = mel.repeat_interleave(net._upsample, dim=1)
     if net._use_lowres:
         low_x = X['x_low']
         interp = F.interpolate(low_x.unsqueeze(1), net._upsample_low * low_x.shape[1], mode='linear').squeeze(1)
         hidden = low_x.unsqueeze(1)
-        for conv in net._lowres_conv:
-            hidden = torch.tanh(F.conv1d(hidden, conv.conv.weight, conv.conv.bias, padding=3))
+        if TORCH_REFERENCE or not hidden.is_cuda:
+            for conv in net._lowres_conv:
+                hidden = torch.tanh(F.conv1d(hidden, conv.conv.weight, conv.conv.bias, padding=3))
+        else:   # the three k = 7 ConvNorm layers on the HIP convolution / weight-gradient kernels (MIOpen picks naive kernels for these shapes:
+                # 38 ms of the 166 ms step)
+            from ..hifigan.autograd import TrainConv, hip_conv
+            cache = net.__dict__.setdefault('_train_lowres', {})
+            for i, conv in enumerate(net._lowres_conv):
+                c = conv.conv
+                tc = cache.get(i)
+                if tc is None:
+                    tc = cache[i] = TrainConv(c.in_channels, c.out_channels, c.kernel_size[0], padding=c.padding[0], dilation=c.dilation[0])
+                hidden = torch.tanh(hip_conv(tc, hidden.contiguous(), c.weight, c.bias))
         ux = hidden.repeat_interleave(net._upsample_low, dim=2).permute(0, 2, 1)
         m = min(up.shape[1], gs_x.shape[1], ux.shape[1], interp.shape[1])
         hidden = torch.cat([up[:, :m], ux[:, :m], interp[:, :m].unsqueeze(2), gs_x[:, :m].unsqueeze(2)], dim=-1)
