@@ -39,6 +39,10 @@ CASES = [  # B, Cin, Cout, K, L, padding, dilation
     (2, 128, 128, 11, 300, 25, 5),   # generator ResBlock, widest receptive field
     (1, 16, 33, 7, 1000, 3, 1),      # ragged channel counts
     (7, 1024, 64, 5, 22, 4, 2),      # deep discriminator layer: many channels, a sliver of positions
+    (3, 1, 32, 5, 500, 2, 1),        # discriminator input layer: one input channel
+    (2, 3, 32, 2, 400, 0, 7),        # ... after the stride de-interleave
+    (4, 1024, 1, 3, 150, 2, 2),      # conv_post: one output channel
+    (2, 1, 128, 15, 3000, 7, 1),     # MSD input layer
 ]
 
 
@@ -68,8 +72,6 @@ def test_data_gradient_matches_autograd(B, Cin, Cout, K, L, pad, d):
     dy = torch.randn(y.shape, generator=g, dtype=torch.float64).cuda() * 1e-5     # gradients are small numbers
     (dx_ref,) = torch.autograd.grad(y, x, dy)
     pd = d * (K - 1) - pad
-    if Cout < 16 or Cin < 32:
-        pytest.skip('the data gradient of this shape stays on the fp32 kernel')
     dx = _run(dy.float(), w.float().contiguous(), None, None, x.detach().float(), pd, d, 1, out_scale=sc, gate_slope=sl)
     assert dx.shape == dx_ref.shape
     assert float((dx.double() - dx_ref).abs().max()) <= 2e-6 * float(dx_ref.abs().max())
@@ -88,12 +90,12 @@ def test_zero_and_non_finite_inputs_are_visible():
 
 def test_unsupported_shapes_are_refused():
     from ttscube_amd import _lib
-    assert not _lib.lib().ttsc_conv_train_supported(1, 32, 5, 1, 1)       # discriminator input layer
-    assert not _lib.lib().ttsc_conv_train_supported(1024, 1, 3, 1, 1)     # conv_post
+    assert _lib.lib().ttsc_conv_train_supported(1, 32, 5, 1, 1)           # discriminator input layer: taken (one padded channel chunk)
+    assert _lib.lib().ttsc_conv_train_supported(1024, 1, 3, 1, 1)         # conv_post: taken (one padded row tile)
     assert not _lib.lib().ttsc_conv_train_supported(64, 64, 41, 2, 1)     # receptive field beyond the staged window
     assert not _lib.lib().ttsc_conv_train_supported(64, 96, 7, 1, 2)      # 48 output channels per group do not tile into 32-row blocks
     with pytest.raises(_lib.TTSCError):
-        _run(torch.zeros(1, 1, 64).cuda(), torch.zeros(32, 1, 5).cuda(), None, None, None, 2, 1, 0)
+        _run(torch.zeros(1, 64, 64).cuda(), torch.zeros(64, 64, 41).cuda(), None, None, None, 40, 2, 0)
 
 
 WG_CASES = [  # N, A, Bc, LP, LQ, J, base, step

@@ -153,10 +153,11 @@ static int train_mt(int Cout, int groups, int K) {
 }
 
 extern "C" int32_t ttsc_conv_train_supported(int32_t Cin, int32_t Cout, int32_t K, int32_t dilation, int32_t groups) {
-    // (thin layers — the discriminators' first and last convolutions — would be mostly channel padding: they stay on the fp32 kernel)
-    if (groups < 1 || Cin % groups || Cout % groups) return 0;
-    const int cin_g = Cin / groups;
-    return cin_g >= 8 && Cin >= 16 && Cout >= 32 && K >= 1 && K <= 41 && dilation >= 1 && (K - 1) * dilation <= 64 && train_mt(Cout, groups, K) != 0;
+    // (thin layers — the discriminators' first and last convolutions, 1 input or 1 output channel — are mostly channel padding on either kernel:
+    // one 16-channel chunk / one 32-row tile; they are taken too, the launches around them cost more than their MFMAs)
+    if (groups < 1 || Cin < 1 || Cout < 1 || Cin % groups || Cout % groups) return 0;
+    if (groups > 1 && Cin / groups < 8) return 0;
+    return K >= 1 && K <= 41 && dilation >= 1 && (K - 1) * dilation <= 64 && train_mt(Cout, groups, K) != 0;
 }
 
 extern "C" size_t ttsc_conv_train_workspace_bytes(int32_t Cin, int32_t Cout, int32_t K, int32_t groups) {
