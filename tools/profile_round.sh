@@ -32,5 +32,10 @@ timeout 300 python tools/bench_lstm.py > $O/lstm.log 2>&1
 fi
 timeout 300 python bench.py --mode e2e --steps 5 --warmup 2 2>/dev/null | grep '^{' > $O/bench_e2e.json
 (timeout 120 python tools/bench_wavernn.py --frames 20 --layers 2; TTSC_WR_TILE2=0 timeout 120 python tools/bench_wavernn.py --frames 4 --layers 2) > $O/wavernn_n2.log 2>&1
-timeout 600 python bench.py > $O/bench_final.json 2> $O/bench_final.err
+# per-layer probes of the training convolutions (exact-fp32 kernels vs the split-precision path) and the vocoder training step
+(echo "# tools/probes/prof_disc_layers.py, TTSC_TRAIN_SPLIT=0 (exact-fp32 MFMA kernels), batch 32 x 8192 samples"; TTSC_TRAIN_SPLIT=0 timeout 100 python tools/probes/prof_disc_layers.py 2>/dev/null < /dev/null) > $O/disc_layers_fp32.log
+(echo "# tools/probes/prof_disc_layers.py, split-precision training kernels (default), batch 32 x 8192 samples"; timeout 100 python tools/probes/prof_disc_layers.py 2>/dev/null < /dev/null) > $O/disc_layers_split.log
+(echo "# tools/probes/prof_train_convs.py: per-layer kernel time of one Cubegan step, b = 16 (synchronising timers)"; timeout 200 python tools/probes/prof_train_convs.py 2>/dev/null < /dev/null | grep -E "ms/step|per step") > $O/train_convs_by_layer.log
+timeout 200 python tools/bench_vocoder_step.py 2>/dev/null < /dev/null | tail -1 > $O/vocoder_step.log
+timeout 600 python bench.py > $O/bench_final.json 2> $O/bench_final.err < /dev/null
 du -sh $O; ls $O; tail -c 300 $O/bench_final.json
