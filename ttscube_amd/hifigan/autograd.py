@@ -308,6 +308,7 @@ def _train_convs(gen):
 def generator_forward_with_grad(gen, x):
     """Differentiable HiFi-GAN generator forward on the HIP kernels (same math as `ttsc_hifigan_forward`)."""
     from .models import ResBlock1
+    from .streams import fan_out
     if not x.is_cuda:
         raise _lib.TTSCError('generator training needs a HIP device; no CPU path')
     h = gen.h
@@ -316,8 +317,7 @@ def generator_forward_with_grad(gen, x):
     x = hip_conv(T['conv_pre'], x.float(), _wn(gen.conv_pre), gen.conv_pre.bias)
     for i in range(len(h['upsample_rates'])):
         x = hip_conv(T['ups.%d' % i], x, _wn(gen.ups[i]), gen.ups[i].bias, in_scale=(1.0 / nk) if i > 0 else 1.0, in_slope=0.1)
-        xs = None
-        for j in range(nk):
+        def branch(j, x=x, i=i):
             rb = gen.resblocks[i * nk + j]
             r = x
             if isinstance(rb, ResBlock1):
@@ -327,7 +327,13 @@ def generator_forward_with_grad(gen, x):
             else:
                 for m, c in enumerate(rb.convs):
                     r = hip_conv(T['rb.%d.c.%d' % (i * nk + j, m)], r, _wn(c), c.bias, resid=r, in_slope=0.1)
-            xs = r if xs is None else xs + r
+            return r
+
+        # the nk ResBlocks of a stage are independent branches: one stream each (training crops are small launches, see streams.py)
+        rs = fan_out([(lambda j=j: branch(j)) for j in range(nk)], x.device)
+        xs = rs[0]
+        for r in rs[1:]:
+            xs = xs + r
         x = xs
     x = hip_conv(T['conv_post'], x, _wn(gen.conv_post), gen.conv_post.bias, in_scale=1.0 / nk, in_slope=0.01)
     return torch.tanh(x)

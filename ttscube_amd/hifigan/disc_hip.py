@@ -12,13 +12,13 @@ How the discriminators' convolutions map onto the stride-1, 1-D kernels:
     p columns kept inside each block — so the batch stays B sequences of T / s^i samples (B p sequences of a few dozen frames would
     leave the kernel's 64..128-column tiles mostly empty), and the feature maps are the reference's [B, C, H, p] tensors as views;
   * MSD's grouped k = 41 layers use the kernels' group support (block-diagonal M tiles, `ttsc_conv_wgrad_grouped`)."""
-import os
 
 import torch
 import torch.nn.functional as F
 
 from .. import _lib
 from .autograd import HipWeightNormFn, TrainConv, hip_conv
+from .streams import fan_out
 
 LRELU_SLOPE = 0.1
 
@@ -111,45 +111,7 @@ def _pair(d, kind, y, y_hat, batch_ok, want_fmap):
     return out_r, fmap_r, out_g, fmap_g
 
 
-# The sub-discriminators (5 periods, 3 scales) are independent graphs of small launches — a 1024 x 1024 x 5 layer over 16 crops is ~320 workgroups
-# on 256 CUs — so each runs on its own stream: launches of different sub-discriminators fill each other's idle CUs, forward and (autograd replays
-# a node on its forward stream) backward.  TTSC_DISC_STREAMS=0 keeps one stream.
-DISC_STREAMS = os.environ.get('TTSC_DISC_STREAMS', '1') != '0'
-_SIDE = {}
-
-
-def _side_streams(dev, n):
-    key = (dev.index if dev.index is not None else torch.cuda.current_device())
-    ss = _SIDE.setdefault(key, [])
-    while len(ss) < n:
-        ss.append(torch.cuda.Stream(device=dev))
-    return ss[:n]
-
-
-def _fan_out(jobs, dev):
-    """run the thunks `jobs` (each returns a nest of tensors) on one side stream each; results are safe to use on the current stream afterwards"""
-    if not DISC_STREAMS or len(jobs) < 2:
-        return [j() for j in jobs]
-    main = torch.cuda.current_stream(dev)
-    outs = []
-    for st, job in zip(_side_streams(dev, len(jobs)), jobs):
-        st.wait_stream(main)
-        with torch.cuda.stream(st):
-            r = job()
-        for t in _tensors(r):
-            t.record_stream(main)      # allocated on the side stream, consumed (and freed) on the main one
-        outs.append((st, r))
-    for st, _ in outs:
-        main.wait_stream(st)
-    return [r for _, r in outs]
-
-
-def _tensors(nest):
-    if torch.is_tensor(nest):
-        yield nest
-    elif isinstance(nest, (list, tuple)):
-        for v in nest:
-            yield from _tensors(v)
+# The sub-discriminators (5 periods, 3 scales) are independent graphs of small launches: each runs on its own stream (streams.fan_out)
 
 
 def mpd_forward(mpd, y, y_hat, want_fmap=True):
@@ -158,7 +120,7 @@ def mpd_forward(mpd, y, y_hat, want_fmap=True):
         raise _lib.TTSCError('discriminators: inputs must live on a HIP device; no CPU path')
     res = ([], [], [], [])
     jobs = [(lambda d=d: _pair(d, 'p', _fold(y, d.period), _fold(y_hat, d.period), True, want_fmap)) for d in mpd.discriminators]
-    for r in _fan_out(jobs, y.device):
+    for r in fan_out(jobs, y.device):
         for acc, v in zip(res, (r[0], r[2], r[1], r[3])):
             acc.append(v)
     return res
@@ -177,7 +139,7 @@ def msd_forward(msd, y, y_hat, want_fmap=True):
         ins.append((y, y_hat))
     # discriminator 0 is spectrally normed: two calls, two power iterations
     jobs = [(lambda i=i, d=d: _pair(d, 's', ins[i][0], ins[i][1], i != 0, want_fmap)) for i, d in enumerate(msd.discriminators)]
-    for r in _fan_out(jobs, y.device):
+    for r in fan_out(jobs, y.device):
         for acc, v in zip(res, (r[0], r[2], r[1], r[3])):
             acc.append(v)
     return res

@@ -1,0 +1,44 @@
+"""Independent sub-graphs of the training step on separate HIP streams (hifigan/disc_hip.py: the 5 + 3 sub-discriminators; hifigan/autograd.py:
+the three ResBlock branches of a generator stage).  At the reference's batch of 16 crops a layer is a few hundred workgroups on 256 CUs (a
+1024 x 1024 x 5 discriminator layer: ~320): launches of different sub-graphs fill each other's idle CUs, in the forward pass and — autograd replays
+a node on the stream its forward ran on — in the backward pass.  TTSC_DISC_STREAMS=0 keeps everything on the current stream."""
+import os
+
+import torch
+
+DISC_STREAMS = os.environ.get('TTSC_DISC_STREAMS', '1') != '0'
+_SIDE = {}
+
+
+def _side_streams(dev, n):
+    key = (dev.index if dev.index is not None else torch.cuda.current_device())
+    ss = _SIDE.setdefault(key, [])
+    while len(ss) < n:
+        ss.append(torch.cuda.Stream(device=dev))
+    return ss[:n]
+
+
+def _tensors(nest):
+    if torch.is_tensor(nest):
+        yield nest
+    elif isinstance(nest, (list, tuple)):
+        for v in nest:
+            yield from _tensors(v)
+
+
+def fan_out(jobs, dev):
+    """run the thunks `jobs` (each returns a nest of tensors) on one side stream each; results are safe to use on the current stream afterwards"""
+    if not DISC_STREAMS or len(jobs) < 2:
+        return [j() for j in jobs]
+    main = torch.cuda.current_stream(dev)
+    outs = []
+    for st, job in zip(_side_streams(dev, len(jobs)), jobs):
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            r = job()
+        for t in _tensors(r):
+            t.record_stream(main)      # allocated on the side stream, consumed (and freed) on the main one
+        outs.append((st, r))
+    for st, _ in outs:
+        main.wait_stream(st)
+    return [r for _, r in outs]
