@@ -182,6 +182,11 @@ class ArenaReducer:
     def _launch(self, c):
         world = dist.get_world_size(self.group)
         g = self.opt.g
+        if g.is_cuda and self._armed:
+            # launched from a gradient hook, i.e. inside backward(): the parameters of this chunk may have received their gradients on different
+            # streams (hifigan/streams.py runs independent sub-graphs on side streams); wait for all of them before the chunk is read
+            from .hifigan.streams import join_side_streams
+            join_side_streams(g.device)
         if c['buf'] is None:   # ragged tail: stage into a padded buffer
             if 'stage' not in c:
                 c['stage'] = torch.zeros(c['pad'], dtype=torch.float32, device=g.device)

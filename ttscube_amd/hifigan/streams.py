@@ -42,3 +42,14 @@ def fan_out(jobs, dev):
     for st, _ in outs:
         main.wait_stream(st)
     return [r for _, r in outs]
+
+
+def join_side_streams(dev):
+    """make the CURRENT stream wait for everything queued so far on the side streams of `dev`.  For code that runs inside a backward pass and reads
+    results of several sub-graphs — the gradient-exchange hooks of distributed.ArenaReducer: the host-side order of autograd nodes says nothing about
+    the completion order of kernels on different streams."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    cur = torch.cuda.current_stream(dev)
+    for st in _SIDE.get(key, []):
+        if st != cur:
+            cur.wait_stream(st)
