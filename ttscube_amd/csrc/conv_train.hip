@@ -3,13 +3,13 @@
 // accumulation: 22 significant bits, see conv_kernels.hpp) instead of the exact-fp32 MFMA kernel (157 TF/s peak, 45-90 TF/s measured on
 // these shapes, profiles/r03_disc_layers_fp32.log).  What inference does with calibrated, sticky per-layer scales cannot work here:
 // activations AND gradients move every step and span many orders of magnitude between layers.  So
-//   * the range is measured on the device for every launch: one reduction launch writes max |x| and max |w| (amax_kernel), the weight
+//   * the range is measured on the device for every launch group: one reduction launch writes max |x| and max |w| (amax2_kernel), the weight
 //     packing and the convolution derive their power-of-two scales from those words in-kernel — no host round trip, no state;
 //   * the weights are split and laid out in fragment order from the live torch parameter by pack_wh_kernel (also for the data gradient:
 //     roles of the channel dimensions swapped, taps reversed);
 //   * the batch is folded into the GEMM's column dimension (ConvArgs::fold_S): the deep discriminator layers are 1024 x 1024 x 5 weights
 //     over 100 .. 1 200 positions per sequence; one tile per (sequence, 64 rows) re-streams 1.3 MB of weights for a sliver of columns.
-// The weight gradient stays on the exact-fp32 kernel (conv_wgrad.hip).
+// The weight gradient has its own split-precision kernel (conv_wgrad.hip::wgrad_f16x3_kernel) that shares these range words.
 #include <algorithm>
 #include <cstdlib>
 

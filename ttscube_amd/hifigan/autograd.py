@@ -17,7 +17,8 @@ dyP[b, r*Co+co, q] = dy[b, co, q*u + r], which turns both legs into stride-1 pro
 Arithmetic: dense stride-1 convolutions run forward and data gradient on the split-precision kernel (`ttsc_conv_train`, csrc/conv_train.hip:
 fp16 hi/lo x 3 products on MFMA with fp32 accumulation; the fp16 ranges are set per launch from device-side maxima of the tensor and of
 the weights, so gradients of any magnitude are safe; on one forward graph its data gradients agree with the exact kernel's to 4e-7).
-Weight gradients, grouped and transposed layers and the thin first / last layers stay on the exact-fp32 MFMA kernels."""
+Dense weight gradients run on the split-precision 128 x 64 tile kernel (`ttsc_conv_wgrad_split`), grouped layers and 1-channel layers on the split
+convolution too; ConvTranspose1d, grouped weight gradients and weight gradients with < 64 rows stay on the exact-fp32 MFMA kernels."""
 import ctypes as C
 import os
 
