@@ -222,10 +222,14 @@ class HipConvFn(torch.autograd.Function):
             dyp = tc.deinterleave(dy, Lin)
             w_map, g_map = tc.maps_t(dy.device)
             if ctx.needs_input_grad[0]:
-                h = tc.dgrad_handle()
                 wz = torch.cat([w.reshape(-1), w.new_zeros(1)])
-                h.set_weight_device(wz[w_map].contiguous())
-                dx = h(dyp, out_scale=sc, gate=x if sl != 1.0 else None, gate_slope=sl)
+                wd = wz[w_map].contiguous()                      # [Ci, u*Co, M]: the data gradient is a dense stride-1 convolution of dyP
+                if _split_ok(tc.stride * tc.Cout, tc.Cin, M, 1):
+                    dx = _conv_split(dyp, wd, None, None, x if sl != 1.0 else None, tc.stride * tc.Cout, tc.Cin, M, 0, 1, 0, out_scale=sc, gate_slope=sl)
+                else:
+                    h = tc.dgrad_handle()
+                    h.set_weight_device(wd)
+                    dx = h(dyp, out_scale=sc, gate=x if sl != 1.0 else None, gate_slope=sl)
             if ctx.needs_input_grad[1]:
                 G = _wgrad(dyp, x, tc.stride * tc.Cout, tc.Cin, M, 0, -1, sc, sl)
                 dw = G.reshape(-1)[g_map]
