@@ -166,6 +166,14 @@ int ttsc_adamw_step(float* p_dev, const float* g_dev, float* m_dev, float* v_dev
 int ttsc_rows_gather(const float* table_dev, const int32_t* idx_dev, float* out_dev, int64_t n, int32_t C, int32_t V, void* stream);
 int ttsc_rows_scatter_add(const float* gout_dev, const int32_t* idx_dev, float* gtable_dev, int64_t n, int32_t C, int32_t V, int32_t skip_row,
                           void* stream);
+/* Polyphase de-interleave of a strided Conv1d's operands (the discriminators' stride-2/3/4 layers [EXTERNAL hifigan/models.py DiscriminatorP /
+ * DiscriminatorS; call sites cube/networks/cubegan.py:144-149,160-167]): the layer runs as a stride-1 convolution over
+ *   xr[n, (g, r, ci), m P + w] = x[n, (g, ci), ((m s + r) - pad) P + w]   (zero outside; P = 1 or MPD's period, rows of P samples)
+ * with taps  wp[co, (r, ci), j] = w[co, ci, s j + r]  (zero beyond K).  backward = 1 maps a gradient of xr / wp back onto x / w.
+ * x [N, C, L P], xr [N, s C, M P]; w [Cout, Cg, K], wp [Cout, s Cg, ceil(K / s)]. */
+int ttsc_deinterleave_x(const float* src_dev, float* dst_dev, int32_t N, int32_t C, int64_t L, int32_t groups, int32_t stride, int32_t period, int32_t pad,
+                        int32_t M, int32_t backward, void* stream);
+int ttsc_deinterleave_w(const float* src_dev, float* dst_dev, int32_t Cout, int32_t Cg, int32_t K, int32_t stride, int32_t backward, void* stream);
 size_t ttsc_gan_loss_workspace_bytes(int32_t nseg);
 int ttsc_gan_loss(int32_t kind, int32_t nseg, const void* const* a_dev, const void* const* b_dev, void* const* ga_dev, void* const* gb_dev,
                   const int64_t* numel, const float* weight, float target, float* out_dev, void* ws_dev, size_t ws_bytes, void* stream);

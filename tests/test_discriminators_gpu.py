@@ -126,3 +126,28 @@ def test_native_discriminators_match_torch_modules(which):
     nat_d = fwd(m, y, y_hat.detach(), want_fmap=False)
     ld2 = D.discriminator_loss(nat_d[0], nat_d[1])[0]
     assert abs(float(ld2) - float(ld0)) < 1e-4 * abs(float(ld0)) and nat_d[2][0] == []
+
+
+@pytest.mark.parametrize('N,C,L,G,s,P,pad,K', [(3, 8, 100, 1, 3, 1, 2, 5), (2, 12, 61, 3, 2, 1, 20, 41), (2, 4, 37, 1, 3, 7, 2, 5), (1, 16, 50, 4, 4, 1, 20, 41),
+                                              (2, 1, 200, 1, 3, 11, 2, 5)])
+def test_fused_deinterleave_equals_the_torch_views(N, C, L, G, s, P, pad, K):
+    """`ttsc_deinterleave_x` / `_w` forward and backward == pad + view + permute + reshape and their autograd, exactly (pure data movement)"""
+    from ttscube_amd.hifigan.disc_hip import _DeintW, _DeintX
+    g = torch.Generator().manual_seed(N * 100 + C + s)
+    J = -(-K // s)
+    Lout = (L + 2 * pad - K) // s + 1
+    M = Lout + J - 1
+    x = torch.randn(N, C, L * P, generator=g).cuda().requires_grad_(True)
+    xp = F.pad(x, (pad * P, (s * M - L - pad) * P))
+    ref = xp.view(N, G, C // G, M, s, P).permute(0, 1, 4, 2, 3, 5).reshape(N, s * C, M * P)
+    out = _DeintX.apply(x, G, s, P, pad, M)
+    assert torch.equal(out, ref)
+    gy = torch.randn(ref.shape, generator=g).cuda()
+    assert torch.equal(torch.autograd.grad(out, x, gy)[0], torch.autograd.grad(ref, x, gy)[0])
+    Cout = 6
+    w = torch.randn(Cout, C // G, K, generator=g).cuda().requires_grad_(True)
+    wref = F.pad(w, (0, s * J - K)).view(Cout, C // G, J, s).permute(0, 3, 1, 2).reshape(Cout, s * (C // G), J)
+    wout = _DeintW.apply(w, s)
+    assert torch.equal(wout, wref)
+    gw = torch.randn(wref.shape, generator=g).cuda()
+    assert torch.equal(torch.autograd.grad(wout, w, gw)[0], torch.autograd.grad(wref, w, gw)[0])

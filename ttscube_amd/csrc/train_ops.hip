@@ -243,6 +243,76 @@ __global__ __launch_bounds__(256) void rows_scatter_add_kernel(const float* __re
     }
 }
 
+
+// ---- polyphase de-interleave of a strided convolution's operands (hifigan/disc_hip.py::HipStridedConv) ------------------------------------
+// A Conv1d with stride s runs as a stride-1 convolution over  xr[n, (g, r, ci), m P + w] = x[n, (g, ci), ((m s + r) - pad) P + w]  (zero outside the
+// sequence; P = 1, or MPD's period: rows of P samples) with the taps  wp[co, (r, ci), j] = w[co, ci, s j + r]  (zero beyond K).  torch builds both
+// with pad + view + permute + reshape: two copies and a fill forward, as many again in the backward pass, per operand — ~800 of the ~1500 element-wise
+// launches of a Cubegan step.  Each direction is ONE gather here (the maps are one-to-one onto the unpadded tensors, so the backward is a gather too).
+struct DeintArgs {
+    const float* src;
+    float* dst;
+    int N, C, G, s, P, pad, M;   // x [N, C, L P]  <->  xr [N, s C, M P]
+    long LP;                     // L * P
+};
+__global__ __launch_bounds__(256) void deinterleave_x_kernel(DeintArgs a, int backward) {
+    const int Cg = a.C / a.G;
+    const long MP = (long)a.M * a.P;
+    if (!backward) {
+        const long total = (long)a.N * a.s * a.C * MP;
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+            const long q = e % MP;
+            long t = e / MP;
+            const int cp = (int)(t % ((long)a.s * a.C));
+            const int n = (int)(t / ((long)a.s * a.C));
+            const int g = cp / (a.s * Cg), r = (cp / Cg) % a.s, ci = cp % Cg;
+            const long m = q / a.P, w = q - m * a.P;
+            const long row = m * a.s + r - a.pad;
+            const long src = row * a.P + w;
+            a.dst[e] = (row >= 0 && src < a.LP) ? a.src[((size_t)n * a.C + (size_t)g * Cg + ci) * a.LP + src] : 0.f;
+        }
+    } else {   // dx[n, c, t] = dxr[n, (g, r, ci), m P + w]  with (m s + r - pad) P + w = t; positions the window never reaches get zero
+        const long total = (long)a.N * a.C * a.LP;
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+            const long tq = e % a.LP;
+            long t = e / a.LP;
+            const int c = (int)(t % a.C);
+            const int n = (int)(t / a.C);
+            const int g = c / Cg, ci = c % Cg;
+            const long rowp = tq / a.P + a.pad, w = tq % a.P;
+            const long m = rowp / a.s;
+            const int r = (int)(rowp - m * a.s);
+            a.dst[e] = m < a.M ? a.src[((size_t)n * a.s * a.C + (size_t)g * a.s * Cg + (size_t)r * Cg + ci) * MP + m * a.P + w] : 0.f;
+        }
+    }
+}
+// w [Cout, Cg, K]  <->  wp [Cout, s Cg, J]
+__global__ __launch_bounds__(256) void deinterleave_w_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cg, int K, int s, int J,
+                                                            int backward) {
+    if (!backward) {
+        const long total = (long)Cout * s * Cg * J;
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+            const int j = (int)(e % J);
+            long t = e / J;
+            const int ci = (int)(t % Cg);
+            t /= Cg;
+            const int r = (int)(t % s);
+            const int co = (int)(t / s);
+            const int k = s * j + r;
+            dst[e] = k < K ? src[((size_t)co * Cg + ci) * K + k] : 0.f;
+        }
+    } else {
+        const long total = (long)Cout * Cg * K;
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+            const int k = (int)(e % K);
+            long t = e / K;
+            const int ci = (int)(t % Cg);
+            const int co = (int)(t / Cg);
+            dst[e] = src[(((size_t)co * s + (k % s)) * Cg + ci) * J + k / s];
+        }
+    }
+}
+
 }  // namespace ttsc
 
 using namespace ttsc;
@@ -364,4 +434,24 @@ extern "C" int ttsc_rows_scatter_add(const float* gout_dev, const int32_t* idx_d
     TTSC_REQUIRE(gout_dev && idx_dev && gtable_dev && n > 0 && C > 0 && V > 0, "ttsc_rows_scatter_add: bad argument");
     hipLaunchKernelGGL(rows_scatter_add_kernel, dim3((unsigned)V), dim3(256), 0, (hipStream_t)stream, gout_dev, idx_dev, gtable_dev, (long)n, C, skip_row);
     return check_launch("rows_scatter_add_kernel");
+}
+
+
+extern "C" int ttsc_deinterleave_x(const float* src_dev, float* dst_dev, int32_t N, int32_t C, int64_t L, int32_t groups, int32_t stride, int32_t period,
+                                   int32_t pad, int32_t M, int32_t backward, void* stream) {
+    TTSC_REQUIRE(src_dev && dst_dev && N > 0 && C > 0 && L > 0 && groups > 0 && C % groups == 0 && stride > 0 && period > 0 && pad >= 0 && M > 0,
+                 "ttsc_deinterleave_x: bad argument");
+    DeintArgs a{src_dev, dst_dev, N, C, groups, stride, period, pad, M, (long)L * period};
+    const long total = backward ? (long)N * C * a.LP : (long)N * stride * C * M * period;
+    hipLaunchKernelGGL(deinterleave_x_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, a, backward);
+    return check_launch("deinterleave_x_kernel");
+}
+
+extern "C" int ttsc_deinterleave_w(const float* src_dev, float* dst_dev, int32_t Cout, int32_t Cg, int32_t K, int32_t stride, int32_t backward, void* stream) {
+    TTSC_REQUIRE(src_dev && dst_dev && Cout > 0 && Cg > 0 && K > 0 && stride > 0, "ttsc_deinterleave_w: bad argument");
+    const int J = (K + stride - 1) / stride;
+    const long total = backward ? (long)Cout * Cg * K : (long)Cout * stride * Cg * J;
+    hipLaunchKernelGGL(deinterleave_w_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, src_dev, dst_dev,
+                       Cout, Cg, K, stride, J, backward);
+    return check_launch("deinterleave_w_kernel");
 }

@@ -13,6 +13,8 @@ How the discriminators' convolutions map onto the stride-1, 1-D kernels:
     leave the kernel's 64..128-column tiles mostly empty), and the feature maps are the reference's [B, C, H, p] tensors as views;
   * MSD's grouped k = 41 layers use the kernels' group support (block-diagonal M tiles, `ttsc_conv_wgrad_grouped`)."""
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -21,6 +23,57 @@ from .autograd import HipWeightNormFn, TrainConv, hip_conv
 from .streams import fan_out
 
 LRELU_SLOPE = 0.1
+FUSED_DEINTERLEAVE = os.environ.get('TTSC_FUSED_DEINTERLEAVE', '1') != '0'
+
+
+class _DeintX(torch.autograd.Function):
+    """xr[n, (g, r, ci), m P + w] = x[n, (g, ci), ((m s + r) - pad) P + w] (zero outside) — one gather forward, one backward (`ttsc_deinterleave_x`)
+    instead of pad + view + permute + reshape"""
+
+    @staticmethod
+    def forward(ctx, x, G, s, P, pad, M):
+        x = x.contiguous()
+        N, C, LP = x.shape
+        out = torch.empty((N, s * C, M * P), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ttsc_deinterleave_x(_lib.dev_ptr(x), _lib.dev_ptr(out), N, C, LP // P, G, s, P, pad, M, 0, _lib.current_stream()),
+                       'ttsc_deinterleave_x')
+        ctx.meta = (N, C, LP, G, s, P, pad, M)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, LP, G, s, P, pad, M = ctx.meta
+        g = g.contiguous()
+        dx = torch.empty((N, C, LP), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.lib().ttsc_deinterleave_x(_lib.dev_ptr(g), _lib.dev_ptr(dx), N, C, LP // P, G, s, P, pad, M, 1, _lib.current_stream()),
+                       'ttsc_deinterleave_x')
+        return dx, None, None, None, None, None
+
+
+class _DeintW(torch.autograd.Function):
+    """wp[co, (r, ci), j] = w[co, ci, s j + r] (zero beyond K) and its adjoint (`ttsc_deinterleave_w`)"""
+
+    @staticmethod
+    def forward(ctx, w, s):
+        w = w.contiguous()
+        Cout, Cg, K = w.shape
+        J = -(-K // s)
+        out = torch.empty((Cout, s * Cg, J), dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            _lib.check(_lib.lib().ttsc_deinterleave_w(_lib.dev_ptr(w), _lib.dev_ptr(out), Cout, Cg, K, s, 0, _lib.current_stream()), 'ttsc_deinterleave_w')
+        ctx.meta = (Cout, Cg, K, s)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        Cout, Cg, K, s = ctx.meta
+        g = g.contiguous()
+        dw = torch.empty((Cout, Cg, K), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.lib().ttsc_deinterleave_w(_lib.dev_ptr(g), _lib.dev_ptr(dw), Cout, Cg, K, s, 1, _lib.current_stream()), 'ttsc_deinterleave_w')
+        return dw, None
 
 
 class HipStridedConv:
@@ -44,11 +97,15 @@ class HipStridedConv:
         L = LP // P                                                     # rows of P samples
         Lout = (L + 2 * self.p - K) // s + 1
         M = Lout + J - 1
-        xp = F.pad(x, (self.p * P, (s * M - L - self.p) * P))           # (a negative right pad crops)
-        xr = xp.view(N, G, Cin // G, M, s, P).permute(0, 1, 4, 2, 3, 5).reshape(N, s * Cin, M * P)
-        wp = F.pad(w, (0, s * J - K)).view(self.Cout, Cin // G, J, s).permute(0, 3, 1, 2).reshape(self.Cout, s * (Cin // G), J)
+        if FUSED_DEINTERLEAVE:   # one gather per operand and direction (csrc/train_ops.hip)
+            xr = _DeintX.apply(x, G, s, P, self.p, M)
+            wp = _DeintW.apply(w, s)
+        else:                    # the same maps as torch views + copies (kept as the formulation the kernels are tested against)
+            xp = F.pad(x, (self.p * P, (s * M - L - self.p) * P))           # (a negative right pad crops)
+            xr = xp.view(N, G, Cin // G, M, s, P).permute(0, 1, 4, 2, 3, 5).reshape(N, s * Cin, M * P)
+            wp = F.pad(w, (0, s * J - K)).view(self.Cout, Cin // G, J, s).permute(0, 3, 1, 2).reshape(self.Cout, s * (Cin // G), J).contiguous()
         # leaky-relu commutes with the de-interleave (and lrelu(0) = 0 keeps the zero padding): it rides in the kernel's staging pass
-        return hip_conv(self.tc, xr, wp.contiguous(), b, in_slope=in_slope)
+        return hip_conv(self.tc, xr, wp, b, in_slope=in_slope)
 
 
 def _weight(l):
