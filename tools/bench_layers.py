@@ -92,6 +92,8 @@ def main():
             if L_.ttsc_rbchain_supported(a1, a2, 3):
                 res.append(('chain0', timed(lambda: chain(0), a.iters)))
                 res.append(('chain1', timed(lambda: chain(1), a.iters)))
+                for sh in [int(v) for v in os.environ.get('BENCH_CHAIN_SHAPES', '').split(',') if v]:
+                    res.append(('chain%d' % sh, timed(lambda: chain(sh), a.iters)))
             print('stage %d C=%3d L=%6d K=%2d  ' % (st, Cc, L, k) + '  '.join(
                 '%s %.3f ms %.0f TF/s (%.2f)' % (n, ms, flops / ms / 1e9, flops / ms / 1e9 / (2500.0 / 3)) for n, ms in res), flush=True)
 

@@ -77,8 +77,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
     constexpr int STEP_ITEMS = MI * 2 * 64;       // 16-byte items of the weight fragments of one (tap, chunk) step
     constexpr int GRP_ITEMS = GRP * STEP_ITEMS;
     constexpr int AHEAD = NSLOT - 1;              // weight groups in flight ahead of the one being multiplied
-    constexpr int NS = K * NCH, NGRP = NS / GRP;
-    static_assert(NS % GRP == 0, "weight groups");
+    constexpr int NS = K * NCH, NGRP = (NS + GRP - 1) / GRP;   // the last group may be short
     half8* P = reinterpret_cast<half8*>(smem_raw);   // plane (group g, pl) at P + (g*2 + pl) * PW, tile column c at + MARG + c
     half8* Aw = P + (size_t)NG * 2 * PW;             // weight fragments: [NSLOT slots][GRP_ITEMS]
 
@@ -99,10 +98,11 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
     // publishes the next one.  Every wave of the workgroup needs the same fragments: fetched per wave straight into registers
     // (the first version of this kernel) they cost a quarter to a third of the run time in the CU's vector-memory path.
     auto stage_group = [&](const half8* w, int g, int slot) __attribute__((always_inline)) {
-        constexpr int NI = GRP_ITEMS / 64;   // 1-KB wave instructions per group
+        constexpr int NIMAX = GRP_ITEMS / 64;   // 1-KB wave instructions per (full) group
+        const int NI = ((NS - g * GRP < GRP ? NS - g * GRP : GRP) * STEP_ITEMS) / 64;
         if (TTSC_DBG(a, 16)) return;
 #pragma unroll
-        for (int i = 0; i < (NI + NW - 1) / NW; ++i) {
+        for (int i = 0; i < (NIMAX + NW - 1) / NW; ++i) {
             const int blk = wv + i * NW;     // wave-uniform
             if (blk < NI)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w + (size_t)g * GRP_ITEMS + blk * 64 + lane),
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
                 if (q < 2 * CT + 2 * MIW) __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if ((s + 1) % GRP == 0 && !TTSC_DBG(a, 2)) __syncthreads();   // publishes the next weight group, retires this one
+            if (((s + 1) % GRP == 0 || s + 1 == NS) && !TTSC_DBG(a, 2)) __syncthreads();   // publishes the next weight group, retires this one
         }
     };
 
@@ -357,9 +357,17 @@ static int launch_chain_k(ChainArgs& a, int B, int shape, hipStream_t s) {
     if constexpr (MI == 4) {   // 128 channels: 2 x 4 waves of (64 channels x 64 columns), the whole LDS (image 136 KiB + three 8-KiB weight slots)
         return launch_chain<4, K, 2, 8, 2, 1, 3, 2>(a, B, s);
     }
-    if (MI == 1) {
+    // shapes >= 2: experiments with longer weight groups (fewer barriers per convolution) and 768-column tiles
+    constexpr int G768 = K == 3 ? 6 : (K == 7 ? 7 : 11), G768W = K == 3 ? 6 : (K == 7 ? 14 : 11);
+    if constexpr (MI == 1) {
+        if (shape == 4) return launch_chain<1, K, 3, 8, 2, G768W, 2>(a, B, s);
+        if (shape == 3) return launch_chain<1, K, 3, 8, 2, G768, 2>(a, B, s);
+        if (shape == 2) return launch_chain<1, K, 4, 8, 2, 6, 2>(a, B, s);
         if (shape == 1) return launch_chain<1, K, 4, 8, 2>(a, B, s);
         return launch_chain<1, K, 4, 4, 2>(a, B, s);
+    }
+    if constexpr (MI == 2 && K == 3) {
+        if (shape == 2) return launch_chain<2, K, 3, 8, 2, 6, 2, 2>(a, B, s);
     }
     if (shape == 1) return launch_chain<2, K, 2, 8, 2>(a, B, s);
     return launch_chain<2, K, 2, 4, 2>(a, B, s);
