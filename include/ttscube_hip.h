@@ -124,7 +124,10 @@ int ttsc_respair_forward(const ttsc_conv1d* conv1, const ttsc_conv1d* conv2, con
  * All layers C -> C with C in {32, 64}, one odd kernel size K in {3, 7, 11}, conv1 dilation <= 5, conv2 undilated, "same"
  * padding, TTSC_PREC_F16X3, host-set weights with bias.  `supported` returns 1 when the fused kernel applies.
  * tile_shape: -1 = pick by halo, 0 = small tile (512 columns at C=32 / 256 at C=64; two workgroups per CU), 1 = large tile
- * (1024 / 512 columns, one 8-wave workgroup per CU).  y must not alias x. */
+ * (1024 / 512 columns, one 8-wave workgroup per CU); 0 and 1 run with interleaved columns (a lane's column tiles are consecutive
+ * samples: the tile moves as dwordx4 / dwordx2 accesses; bit-identical results) when the dilations are in {1, 3, 5} unless the
+ * environment says TTSC_CHAIN_IL=0; 10 / 11 ask for the interleaved kernels explicitly, 12 = 11 with 6-step weight groups (C = 32),
+ * 2 .. 4 = measurement variants (longer weight groups, 768-column tiles).  y must not alias x. */
 int ttsc_rbchain_supported(const ttsc_conv1d* const* convs1, const ttsc_conv1d* const* convs2, int32_t npairs);
 int ttsc_rbchain_forward(const ttsc_conv1d* const* convs1, const ttsc_conv1d* const* convs2, int32_t npairs, const float* x_dev,
                          int32_t B, int64_t L, float* y_dev, int32_t accumulate, const int32_t* len_dev, int32_t tile_shape,

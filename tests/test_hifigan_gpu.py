@@ -150,7 +150,7 @@ def test_stage_launch_is_bit_identical_to_the_chain_launches(shape, monkeypatch)
     g0 = _gen(h, sd)
     with torch.no_grad():
         g0(warm)    # (the C handle reads the switches when the first forward creates it)
-    monkeypatch.setenv('TTSC_HIFIGAN_STAGE', '1')
+    monkeypatch.setenv('TTSC_HIFIGAN_STAGE', '1')   # (off by default: see hifigan.cpp)
     monkeypatch.setenv('TTSC_HIFIGAN_STAGE_SHAPE', shape)
     g1 = _gen(h, sd)
     with torch.no_grad():

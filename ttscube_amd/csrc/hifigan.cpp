@@ -45,7 +45,8 @@ struct ttsc_hifigan {
     bool use_chain = true;      // env TTSC_HIFIGAN_CHAIN=0 disables the whole-ResBlock fused chain kernel (resblock.hip)
     bool use_chain128 = true;   // env TTSC_HIFIGAN_CHAIN128=0: keep the 128-channel K=3 block on the layer-by-layer wide kernel (A/B)
     int chain_shape = -1;       // env TTSC_HIFIGAN_CHAIN_SHAPE: tile shape of the chain kernel (-1 = by halo)
-    bool use_stage = true;      // env TTSC_HIFIGAN_STAGE=0: keep the 32-channel stage as three chain launches (+ conv_post) instead of ONE stage launch (resstage.hip)
+    bool use_stage = false;     // env TTSC_HIFIGAN_STAGE=1: the 32-channel stage as ONE stage launch (resstage.hip) instead of three chain launches + conv_post
+                                // (bit-identical; measured 10.60 ms against 10.35 ms for the chain launches with interleaved columns at config[1]: off by default)
     int stage_shape = 0;        // env TTSC_HIFIGAN_STAGE_SHAPE: 0 = 8 waves x 96 columns, 1 = 4 waves x 192 columns (one wave per SIMD)
     int precision = TTSC_PREC_FP32;
     // Split precision keeps activations as fp16 (hi, lo) pairs, so every layer's input gets a power-of-two pre-scale that

@@ -64,15 +64,36 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 // WM = waves along the channel axis: a wave owns MI / WM row tiles of its CT column tiles (WM = 1: every wave owns all channels of its
 // columns).  At 128 channels 2 x 4 waves of (2 row tiles x 2 column tiles) read 8 fragments per 12 MFMAs instead of 10 and hold
 // half the weight fragments in registers.
-template <int MI, int K, int CT, int NW, int WPS, int GRP = 2, int NSLOT = 2, int WM = 1>
+//
+// IL ("interleaved columns"): MFMA column tile ct, lane l of a wave stand for tile column  colw + CT * l + ct  instead of
+// colw + 32 * ct + l.  A lane's CT accumulator registers of one channel are then CT CONSECUTIVE samples of a [B, C, L] row: the x
+// tile comes in and the y tile goes out (and comes in again when it is accumulated) as 16 dwordx4 (CT = 4) / dwordx2 (CT = 2)
+// accesses per lane and row tile instead of 64 / 32 dword accesses — the prologue and the read-modify-write epilogue of a workgroup
+// that owns its whole CU are exposed, issue-bound time (round-2 ablation: 15 % + 8 % of the K = 11 launch at 32 channels, 26 % + 23 %
+// of the K = 3 one).  The LDS image becomes phase-major: plane row = CT phase rows [q = column / CT], so that the B fragment of any
+// (tap, tile) is still one conflict-free ds_read_b128 over 32 consecutive q; which phase row and which q shift a tap needs depends on
+// the dilation, so the IL convolutions take the dilation as a compile-time constant (1, 3 or 5) and every offset is an immediate.
+template <int K, int CT>
+struct ChainGeo {
+    static constexpr int OMAX = (CT - 1) + 5 * ((K - 1) / 2);       // largest |column offset| a B fragment is read at (dilation <= 5)
+    static constexpr int MARGQ = (OMAX + CT - 1) / CT + 1;          // margin of a phase row, in q
+    static constexpr int MARG = (K == 3) ? 8 : (K == 7 ? 16 : 26);  // margin of a plain row, in columns
+};
+template <int V> struct IntTag { static constexpr int value = V; };
+
+template <int MI, int K, int CT, int NW, int WPS, int GRP = 2, int NSLOT = 2, int WM = 1, bool IL = false>
 __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int C = 32 * MI, NCH = 2 * MI, NG = 4 * MI;
     constexpr int WN = NW / WM, MIW = MI / WM;    // waves along time; row tiles per wave
     static_assert(NW % WM == 0 && MI % WM == 0, "wave grid");
     constexpr int NCOL = WN * CT * 32;
-    constexpr int MARG = (K == 3) ? 8 : (K == 7 ? 16 : 26);   // >= the largest tap offset (dilation 5: 5*(K-1)/2)
-    constexpr int PW = NCOL + 2 * MARG;
+    constexpr int MARG = ChainGeo<K, CT>::MARG;   // >= the largest tap offset (dilation 5: 5*(K-1)/2)
+    constexpr int NQ = NCOL / CT, MARGQ = ChainGeo<K, CT>::MARGQ, PQ = NQ + 2 * MARGQ;   // IL: phase row = MARGQ | NQ | MARGQ items
+    constexpr int PW = IL ? CT * PQ : NCOL + 2 * MARG;
+    constexpr int H = (K - 1) / 2;
+    typedef float fvecT __attribute__((ext_vector_type(CT == 3 ? 4 : CT)));
+    static_assert(!IL || CT == 2 || CT == 4, "interleaved columns: 2 or 4 column tiles per wave");
     constexpr int NTHR = 64 * NW;
     constexpr int STEP_ITEMS = MI * 2 * 64;       // 16-byte items of the weight fragments of one (tap, chunk) step
     constexpr int GRP_ITEMS = GRP * STEP_ITEMS;
@@ -90,8 +111,14 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
     const int wm = wv / WN;                          // this wave's row-tile group
     const int mi0 = wm * MIW;                        // its first row tile
     const int colw = (wv % WN) * (CT * 32);          // first tile column of this wave
-    const int pos_w = q0 - a.halo + colw + l31;      // sequence position of this lane's column in column tile 0
+    const int pos_w = q0 - a.halo + colw + (IL ? CT * l31 : l31);   // sequence position of this lane's column in column tile 0
+    constexpr int CSTEP = IL ? 1 : 32;               // column distance between the lane's columns of consecutive column tiles
+    const int qw = (wv % WN) * 32;                   // IL: first q of this wave
     const float* xb = a.x + (size_t)b * C * a.L;
+    // IL: a lane's CT columns move as ONE vector when every group of CT columns is wholly inside or wholly outside the sequence and
+    // the rows are vector-aligned (workgroup-uniform); otherwise column by column like the plain layout
+    const bool vec = IL && (lin % CT == 0) && (a.L % CT == 0) && ((q0 - a.halo) % CT == 0) && (a.nto % CT == 0) &&
+                     ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.y)) % (4 * CT) == 0);
 
     // Weight fragments reach the MFMAs through LDS: one group (GRP steps, 4*MI KB) is copied global -> LDS by the LDS-DMA
     // path (no VGPRs, one 1-KB instruction per wave) while the previous group is multiplied; the barrier that ends a group
@@ -118,12 +145,22 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
     stage_first(a.w1[0]);
 
     // the margins only feed columns that are never stored, but they must hold finite numbers
-    for (int i = tid; i < NG * 2 * 2 * MARG; i += NTHR) {
-        const int pl = i / (2 * MARG), m = i - pl * (2 * MARG);
-        half8 z;
+    if constexpr (IL) {
+        for (int i = tid; i < NG * 2 * CT * 2 * MARGQ; i += NTHR) {
+            const int row = i / (2 * MARGQ), m = i - row * (2 * MARGQ);   // row = (plane, phase)
+            half8 z;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.f;
-        P[(size_t)pl * PW + (m < MARG ? m : NCOL + m)] = z;
+            for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.f;
+            P[(size_t)row * PQ + (m < MARGQ ? m : NQ + m)] = z;
+        }
+    } else {
+        for (int i = tid; i < NG * 2 * 2 * MARG; i += NTHR) {
+            const int pl = i / (2 * MARG), m = i - pl * (2 * MARG);
+            half8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.f;
+            P[(size_t)pl * PW + (m < MARG ? m : NCOL + m)] = z;
+        }
     }
 
     // residual stream of the tile: C/D layout, channel = 32*mi + (r & 3) + 8*(r >> 2) + 4*half, column = lane & 31
@@ -131,17 +168,36 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
     bool pok[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-        const int pos = pos_w + ct * 32;
+        const int pos = pos_w + ct * CSTEP;
         pok[ct] = pos >= 0 && pos < lin;
-        int pc = pos < lin - 1 ? pos : lin - 1;
-        pc = pc < 0 ? 0 : pc;
+    }
+    if (IL && vec) {
+        int p0 = pos_w < lin - CT ? pos_w : lin - CT;
+        p0 = p0 < 0 ? 0 : p0;
+        const unsigned voff = (unsigned)(4 * half * a.L + p0);
 #pragma unroll
         for (int mi = 0; mi < MIW; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ch = 32 * (mi0 + mi) + (r & 3) + 8 * (r >> 2) + 4 * half;
-                xres[mi][ct][r] = TTSC_DBG(a, 8) ? (float)(ch + pc) * 1e-3f : xb[(size_t)ch * a.L + pc];
+                const float* row = xb + (size_t)(32 * (mi0 + mi) + (r & 3) + 8 * (r >> 2)) * a.L;
+                const fvecT v = TTSC_DBG(a, 8) ? fvecT(1e-3f) : *reinterpret_cast<const fvecT*>(row + voff);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) xres[mi][ct][r] = v[ct];
             }
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int pos = pos_w + ct * CSTEP;
+            int pc = pos < lin - 1 ? pos : lin - 1;
+            pc = pc < 0 ? 0 : pc;
+#pragma unroll
+            for (int mi = 0; mi < MIW; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = 32 * (mi0 + mi) + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    xres[mi][ct][r] = TTSC_DBG(a, 8) ? (float)(ch + pc) * 1e-3f : xb[(size_t)ch * a.L + pc];
+                }
+        }
     }
 
     // four channels (one lane's share of 8-channel group 4*mi + gi) of one column -> (hi, lo) halves in the image.
@@ -153,7 +209,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
         const half2v l0 = __builtin_convertvector(p0 - __builtin_convertvector(h0, float2v), half2v);
         const half2v l1 = __builtin_convertvector(p1 - __builtin_convertvector(h1, float2v), half2v);
         const half4 vh = {h0[0], h0[1], h1[0], h1[1]}, vl = {l0[0], l0[1], l1[0], l1[1]};
-        _Float16* ph = reinterpret_cast<_Float16*>(P + (size_t)(((mi0 + mi) * 4 + gi) * 2) * PW + MARG + colw + ct * 32 + l31) + 4 * half;
+        _Float16* ph = reinterpret_cast<_Float16*>(P + (size_t)(((mi0 + mi) * 4 + gi) * 2) * PW + (IL ? ct * PQ + MARGQ + qw + l31 : MARG + colw + ct * 32 + l31)) + 4 * half;
         *reinterpret_cast<half4*>(ph) = vh;
         *reinterpret_cast<half4*>(ph + (size_t)PW * 8) = vl;
     };
@@ -178,14 +234,26 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
     // acc = sum over taps j and 16-channel chunks c of  W[j][c] x image[c][column + (j - (K-1)/2) * d]   (three split products).
     // Precondition: weight group 0 of `w` sits in slot 0, published by a barrier.  Ends with a barrier (every wave has
     // finished reading the image and the weight slots).
-    auto conv = [&](const half8* w, int d, f32x16 (&acc)[MIW][CT]) __attribute__((always_inline)) {
+    auto conv = [&](const half8* w, auto dtag, int d, f32x16 (&acc)[MIW][CT]) __attribute__((always_inline)) {
+        constexpr int D = decltype(dtag)::value;   // IL: the dilation (compile time); plain layout: unused (d is a run-time value)
 #pragma unroll
         for (int mi = 0; mi < MIW; ++mi)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ct][r] = 0.f;
-        const half8* base = P + (size_t)(half * 2) * PW + MARG + colw + l31 - d * ((K - 1) / 2);
+        const half8* base = IL ? P + (size_t)(half * 2) * PW + MARGQ + qw + l31 : P + (size_t)(half * 2) * PW + MARG + colw + l31 - d * ((K - 1) / 2);
+        // B fragment of step s (tap s / NCH, chunk s % NCH), plane pl (0 hi, 1 lo), column tile ct
+        auto bfrag = [&](int s, int pl, int ct) __attribute__((always_inline)) -> const half8* {
+            const int j = s / NCH, cn = s % NCH;
+            if constexpr (IL) {
+                const int o = ct + (j - H) * D;                   // column offset of the lane's tile-ct column
+                const int ph = ((o % CT) + CT) % CT, qs = (o - ph) / CT;
+                return base + (size_t)(cn * 4 + pl) * PW + ph * PQ + qs;
+            } else {
+                return base + (size_t)(cn * 4 + pl) * PW + j * d + ct * 32;
+            }
+        };
         // Software pipeline, written out and pinned with scheduling barriers because hipcc will not build it (it sinks
         // every LDS read to just before its first use): the activation fragments of step s+1 are read between the MFMAs
         // of step s; the weight fragments of the group's second step are read during its first.
@@ -199,13 +267,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
                 Aq[mi][1] = ap[(mi * 2 + 1) * 64];
             }
         };
-        {
-            const half8* bp = base;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                Bf[0][0][ct] = bp[ct * 32];
-                Bf[0][1][ct] = bp[PW + ct * 32];
-            }
+        for (int ct = 0; ct < CT; ++ct) {
+            Bf[0][0][ct] = *bfrag(0, 0, ct);
+            Bf[0][1][ct] = *bfrag(0, 1, ct);
         }
         constexpr int NM = 3 * MIW * CT;   // MFMAs per step (and wave)
 #pragma unroll
@@ -215,8 +280,6 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
                 if (s / GRP + AHEAD < NGRP) stage_group(w, s / GRP + AHEAD, (s / GRP + AHEAD) % NSLOT);
                 if (s == 0 || NSLOT < 3) readA(Af[s & 1], s);   // (with three slots the next group was read ahead during the previous step)
             }
-            const int jn = (s + 1) / NCH, cn = (s + 1) % NCH;
-            const half8* bpn = base + (size_t)(cn * 4) * PW + jn * d;
             __builtin_amdgcn_sched_barrier(0);
             // issue order of a step, pinned: (MFMA, one LDS read for the next step) pairs, then the rest of the MFMAs.
             // Term order lo_w*hi_x, hi_w*lo_x, hi_w*hi_x; consecutive MFMAs go to different accumulators.
@@ -225,7 +288,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
                 const int term = q / (MIW * CT), mi = (q / CT) % MIW, ct = q % CT;
                 acc[mi][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[s & 1][mi][term == 0 ? 1 : 0], Bf[s & 1][term == 1 ? 1 : 0][ct],
                                                                    acc[mi][ct], 0, 0, 0);
-                if (q < 2 * CT && s + 1 < NS) Bf[(s + 1) & 1][q / CT][q % CT] = bpn[(q / CT) * PW + (q % CT) * 32];
+                if (q < 2 * CT && s + 1 < NS) Bf[(s + 1) & 1][q / CT][q % CT] = *bfrag(s + 1, q / CT, q % CT);
                 // weights of the next step: same group, or (three slots) the next group, published one barrier ago
                 if (q >= 2 * CT && q < 2 * CT + 2 * MIW && s + 1 < NS && ((s + 1) % GRP != 0 || NSLOT >= 3)) {
                     const int i = q - 2 * CT;
@@ -242,7 +305,13 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
     if (!TTSC_DBG(a, 2)) __syncthreads();
     for (int p = 0; p < a.npairs; ++p) {
         f32x16 acc[MIW][CT];
-        conv(a.w1[p], a.d1[p], acc);           // (ends with a barrier: the image may be overwritten in place)
+        if constexpr (IL) {                    // (ends with a barrier: the image may be overwritten in place)
+            if (a.d1[p] == 1) conv(a.w1[p], IntTag<1>(), 1, acc);
+            else if (a.d1[p] == 3) conv(a.w1[p], IntTag<3>(), 3, acc);
+            else conv(a.w1[p], IntTag<5>(), 5, acc);
+        } else {
+            conv(a.w1[p], IntTag<0>(), a.d1[p], acc);
+        }
         stage_first(a.w2[p]);                  // conv2's first weight group(s) travel while the epilogue runs
         {
             const float us = a.us1[p];
@@ -266,7 +335,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
                 }
         }
         if (!TTSC_DBG(a, 2)) __syncthreads();
-        conv(a.w2[p], 1, acc);
+        conv(a.w2[p], IntTag<1>(), 1, acc);
         if (p + 1 < a.npairs) stage_first(a.w1[p + 1]);
         {
             const float us = a.us2[p];
@@ -299,9 +368,34 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
         return;
     }
     float* yb = a.y + (size_t)b * C * a.L;
+    if (IL && vec) {
+        // the lane's CT columns of a channel are CT consecutive samples of the row: one vector access per channel
+        const int col0 = colw + CT * l31;
+        const bool ok = col0 >= a.halo && col0 + CT <= a.halo + a.nto && pos_w + CT <= lin;
+        const unsigned voff = (unsigned)(4 * half * a.L + (ok ? pos_w : 0));
+#pragma unroll
+        for (int mi = 0; mi < MIW; ++mi) {
+            fvecT yv[16];
+            if (a.accumulate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yv[r] = *reinterpret_cast<const fvecT*>(yb + (size_t)(32 * (mi0 + mi) + (r & 3) + 8 * (r >> 2)) * a.L + voff);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yv[r] = fvecT(0.f);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                fvecT o;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) o[ct] = xres[mi][ct][r] + yv[r][ct];
+                if (ok) *reinterpret_cast<fvecT*>(yb + (size_t)(32 * (mi0 + mi) + (r & 3) + 8 * (r >> 2)) * a.L + voff) = o;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-        const int col = colw + ct * 32 + l31;
+        const int col = colw + (IL ? CT * l31 + ct : ct * 32 + l31);
         const int pos = q0 - a.halo + col;
         const bool ok = col >= a.halo && col < a.halo + a.nto && pos < lin;
         const int pc = ok ? pos : 0;
@@ -331,17 +425,18 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
 template __global__ void rbchain_f16x3_kernel<TTSC_RB_PROBE>(ChainArgs);
 }  // namespace ttsc
 #else
-template <int MI, int K, int CT, int NW, int WPS, int GRP = 2, int NSLOT = 2, int WM = 1>
+template <int MI, int K, int CT, int NW, int WPS, int GRP = 2, int NSLOT = 2, int WM = 1, bool IL = false>
 static int launch_chain(ChainArgs& a, int B, hipStream_t s) {
     constexpr int NCOL = (NW / WM) * CT * 32;
-    constexpr int MARG = (K == 3) ? 8 : (K == 7 ? 16 : 26);
-    constexpr size_t lds = (size_t)(4 * MI) * 2 * (NCOL + 2 * MARG) * 16 + (size_t)NSLOT * GRP * (MI * 2 * 64) * 16;   // image + weight ring
+    constexpr int PW = IL ? CT * (NCOL / CT + 2 * ChainGeo<K, CT>::MARGQ) : NCOL + 2 * ChainGeo<K, CT>::MARG;
+    constexpr size_t lds = (size_t)(4 * MI) * 2 * PW * 16 + (size_t)NSLOT * GRP * (MI * 2 * 64) * 16;   // image + weight ring
     static_assert(lds <= 160 * 1024, "activation image exceeds the LDS");
     a.nto = NCOL - 2 * a.halo;
+    if (IL && a.nto > 256) a.nto &= ~31;   // tile stores start on 128-byte boundaries of the row
     TTSC_REQUIRE(a.nto >= 64, "rbchain: halo %d leaves no output columns in a %d-column tile", a.halo, NCOL);
-    if (int rc = ensure_full_lds((const void*)rbchain_f16x3_kernel<MI, K, CT, NW, WPS, GRP, NSLOT, WM>)) return rc;   // once per (device, kernel)
+    if (int rc = ensure_full_lds((const void*)rbchain_f16x3_kernel<MI, K, CT, NW, WPS, GRP, NSLOT, WM, IL>)) return rc;   // once per (device, kernel)
     dim3 grid((unsigned)ceil_div(a.L, a.nto), (unsigned)B);
-    hipLaunchKernelGGL((rbchain_f16x3_kernel<MI, K, CT, NW, WPS, GRP, NSLOT, WM>), grid, dim3(64 * NW), lds, s, a);
+    hipLaunchKernelGGL((rbchain_f16x3_kernel<MI, K, CT, NW, WPS, GRP, NSLOT, WM, IL>), grid, dim3(64 * NW), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("rbchain_f16x3_kernel launch failed: %s", hipGetErrorString(e));
@@ -355,11 +450,16 @@ static int launch_chain(ChainArgs& a, int B, hipStream_t s) {
 template <int MI, int K>
 static int launch_chain_k(ChainArgs& a, int B, int shape, hipStream_t s) {
     if constexpr (MI == 4) {   // 128 channels: 2 x 4 waves of (64 channels x 64 columns), the whole LDS (image 136 KiB + three 8-KiB weight slots)
+        if (shape >= 10) return launch_chain<4, K, 2, 8, 2, 1, 3, 2, true>(a, B, s);
         return launch_chain<4, K, 2, 8, 2, 1, 3, 2>(a, B, s);
     }
-    // shapes >= 2: experiments with longer weight groups (fewer barriers per convolution) and 768-column tiles
+    // shapes 2 .. 4: experiments with longer weight groups (fewer barriers per convolution) and 768-column tiles;
+    // shapes 10 / 11: the small / large tile with interleaved columns (vector loads and stores of the tile); 12: 11 with 6-step groups
     constexpr int G768 = K == 3 ? 6 : (K == 7 ? 7 : 11), G768W = K == 3 ? 6 : (K == 7 ? 14 : 11);
     if constexpr (MI == 1) {
+        if (shape == 12) return launch_chain<1, K, 4, 8, 2, 6, 2, 1, true>(a, B, s);
+        if (shape == 11) return launch_chain<1, K, 4, 8, 2, 2, 2, 1, true>(a, B, s);
+        if (shape == 10) return launch_chain<1, K, 4, 4, 2, 2, 2, 1, true>(a, B, s);
         if (shape == 4) return launch_chain<1, K, 3, 8, 2, G768W, 2>(a, B, s);
         if (shape == 3) return launch_chain<1, K, 3, 8, 2, G768, 2>(a, B, s);
         if (shape == 2) return launch_chain<1, K, 4, 8, 2, 6, 2>(a, B, s);
@@ -369,6 +469,8 @@ static int launch_chain_k(ChainArgs& a, int B, int shape, hipStream_t s) {
     if constexpr (MI == 2 && K == 3) {
         if (shape == 2) return launch_chain<2, K, 3, 8, 2, 6, 2, 2>(a, B, s);
     }
+    if (shape == 11 || shape == 12) return launch_chain<2, K, 2, 8, 2, 2, 2, 1, true>(a, B, s);
+    if (shape == 10) return launch_chain<2, K, 2, 4, 2, 2, 2, 1, true>(a, B, s);
     if (shape == 1) return launch_chain<2, K, 2, 8, 2>(a, B, s);
     return launch_chain<2, K, 2, 4, 2>(a, B, s);
 }
@@ -441,13 +543,24 @@ extern "C" int ttsc_rbchain_forward(const ttsc_conv1d* const* convs1, const ttsc
         a.halo += (a.d1[p] + 1) * (k - 1) / 2;
     }
     hipStream_t s = (hipStream_t)stream;
+    bool auto_shape = false;
     if (shape < 0) {
         // default: the big tile once the halo would eat more than ~1/6 of the small one; at 64 channels the big tile also wins
         // for K = 3 (measured 1.54 vs 1.81 ms per ResBlock at config[1]) as long as it still fills the chip
         const int small = C == 32 ? 512 : 256;
-        shape = (2 * a.halo * 6 > small) ? 1 : 0;
+        shape = (2 * a.halo * 8 > small) ? 1 : 0;   // (round 4: K = 7 at 32 channels moved to the large tile: 3.26 vs 3.42 ms with interleaved columns)
         if (C == 64 && (int64_t)B * ceil_div(L, 2 * small - 2 * a.halo) >= 256) shape = 1;
+        auto_shape = true;
     }
+    // interleaved columns (vector loads / stores of the tile) for the two standard shapes unless TTSC_CHAIN_IL=0; needs dilations 1 / 3 / 5
+    const char* il_ev = getenv("TTSC_CHAIN_IL");
+    const int il_env = il_ev ? atoi(il_ev) : 1;
+    bool il_ok = true;
+    for (int p = 0; p < npairs; ++p) il_ok = il_ok && (a.d1[p] == 1 || a.d1[p] == 3 || a.d1[p] == 5);
+    if (shape >= 10 && !il_ok) shape -= 10;
+    if (shape >= 0 && shape <= 1 && il_env && il_ok) shape += 10;
+    if (auto_shape && shape == 11 && C == 32) shape = 12;   // large tile at 32 channels: 6-step weight groups fit beside the image (one barrier per 6 k-steps)
+    if (shape == 12 && !(C == 32)) shape = 11;
     if (C == 128) return launch_chain_k<4, 3>(a, B, shape, s);
     if (C == 32) {
         if (k == 3) return launch_chain_k<1, 3>(a, B, shape, s);
