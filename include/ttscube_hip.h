@@ -366,6 +366,21 @@ void ttsc_wavernn_destroy(ttsc_wavernn* w);
 int ttsc_linear_forward(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int64_t M, int32_t N,
                         int32_t K, int64_t ldx, int64_t ldy, int32_t act, int32_t accumulate, void* stream);
 
+/* General fp32-MFMA GEMM for the backward passes of the Linears and of the hoisted recurrent projections (training, row a9; the
+ * reference leaves these to autograd over torch.nn.Linear / nn.GRU / nn.LSTM: cube/networks/modules.py:505-563, cubegan.py:85-189):
+ *     C[M, :N] (+)= opA(A) . opB(B)     transA = 0: A is [M,K] (lda), 1: A is [K,M];   transB = 0: B is [K,N] (ldb), 1: B is [N,K]
+ *   dx = dG . W (NN), dW = dG^T . x (TN), dW_hh = dG^T . h_prev (TN with b_row_shift = -1 / +1 and b_period = T: row r of the
+ *   contraction reads B row r + shift when 0 <= r % period + shift < period and zero otherwise, so h_prev is never materialised).
+ * When M x N tiles alone cannot fill the device the contraction is split over K; partial tiles go through ws_dev
+ * (>= ttsc_gemm_workspace_bytes(M, N, K); may be NULL when that is 0) and are added in a fixed order (deterministic).
+ * ttsc_colsum: out[c] (+)= sum_r x[r, c] (bias gradients), two fixed-order stages through ws_dev (>= ttsc_colsum_workspace_bytes). */
+size_t ttsc_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int ttsc_gemm(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, const float* a_dev, int64_t lda, const float* b_dev, int64_t ldb,
+              float* c_dev, int64_t ldc, int32_t accumulate, int64_t b_row_shift, int64_t b_period, void* ws_dev, size_t ws_bytes, void* stream);
+size_t ttsc_colsum_workspace_bytes(int64_t R, int64_t C);
+int ttsc_colsum(const float* x_dev, int64_t R, int64_t C, int64_t ld, float* out_dev, int32_t accumulate, void* ws_dev, size_t ws_bytes,
+                void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * LSTM / BiLSTM recurrence.  Replaces the sequential part of torch.nn.LSTM (gate order i,f,g,o, `_reverse`
  * direction) for Languasito2 (modules.py:873-905) and CubenetTextcoder (textcoder.py:55-92).

@@ -125,3 +125,76 @@ def test_zero_frame_guard_and_single_phoneme(tmp_path):
         m._languasito._dur_output.linear_layer.bias.copy_(b)
     wav = m.inference({'x_char': torch.tensor([[5]]), 'x_speaker': torch.tensor([[2]])})
     assert wav.shape == (1, 1, 240 * 2 + 64)
+
+
+def test_two_stage_path_textcoder_to_generator_checkpoint(golden_dir, tmp_path):
+    """io_utils/runtime.py::synthesize_devset + load_generator_checkpoint (cube/io_utils/runtime.py:41-80): CubenetTextcoder.inference
+    (PreNet masks injected) -> log(10 ** mel) -> Generator loaded from a `{'generator': ...}` checkpoint with config.json beside it,
+    weight norm removed -> int16 wav on disk, against the oracle chain meldecoder_ref.textcoder_inference -> hifigan_ref."""
+    import json
+    import os
+
+    import scipy.io.wavfile
+    from oracle import hifigan_ref as R
+    from oracle import meldecoder_ref as M
+    from ttscube_amd.io_utils.runtime import load_generator_checkpoint, synthesize_devset
+    from ttscube_amd.networks.textcoder import CubenetTextcoder
+    z = np.load(os.path.join(golden_dir, 'textcoder_a.npz'))
+    shapes = [(k, tuple(s)) for k, s in json.loads(str(z['shapes']))]
+    tsd = M.fill_state_dict(shapes, int(z['seed']))
+
+    class Enc:
+        phon2int = {str(i): i for i in range(40)}
+        speaker2int = {str(i): i for i in range(2)}
+        max_pitch = 200
+        max_duration = int(z['max_duration'])
+
+    net = CubenetTextcoder(Enc())
+    net.load_state_dict(tsd, strict=True)
+    net = net.cuda().eval()
+    # the vocoder checkpoint in the external trainer's layout: weight-normed state under 'generator', config.json in the same directory
+    h = dict(R.CONFIG_V1)
+    gsd = R.synthetic_state_dict(h, seed=55)
+    vdir = tmp_path / 'vocoder'
+    vdir.mkdir()
+    torch.save({'generator': gsd}, str(vdir / 'g_00000001'))
+    (vdir / 'config.json').write_text(json.dumps(h))
+    voc = load_generator_checkpoint(str(vdir / 'g_00000001')).cuda()
+    assert not any(k.endswith('weight_g') for k in voc.state_dict())          # remove_weight_norm() happened
+
+    class OneItem:
+        def __len__(self):
+            return 1
+
+        def __getitem__(self, i):
+            return {'meta': {'id': 'utt0'}}
+
+    class Collate:
+        def collate_fn(self, exs):
+            return {'x_char': torch.from_numpy(z['x_char']), 'x_speaker': torch.from_numpy(z['x_speaker'])}
+
+    masks = torch.from_numpy(z['masks']).unsqueeze(2)
+    out_dir = str(tmp_path / 'wavs')
+    n = synthesize_devset(net, Collate(), OneItem(), voc, output_path=out_dir, forced_synthesis=False, dropout_masks=[masks])
+    assert n == 1
+    rate, wav = scipy.io.wavfile.read(os.path.join(out_dir, 'utt0.wav'))
+    assert rate == 24000 and wav.dtype == np.int16
+    # oracle chain
+    with torch.no_grad():
+        mel_ref, _ = M.textcoder_inference(tsd, torch.from_numpy(z['x_char']), torch.from_numpy(z['x_speaker']), torch.from_numpy(z['masks']).unsqueeze(2))
+    assert float((mel_ref - torch.from_numpy(z['mel'])).abs().max()) < 1e-4          # (the oracle itself is pinned to the reference's golden)
+    w = R.fold_state_dict(gsd)
+    with torch.no_grad():
+        ref = R.generator_forward(w, h, torch.log(10 ** mel_ref).permute(0, 2, 1).contiguous())
+    ref16 = np.asarray(ref.numpy().squeeze() * 32767, dtype=np.int16)
+    assert wav.shape == ref16.shape == (240 * mel_ref.shape[1] + 64,)
+    d_chain = np.abs(wav.astype(np.int32) - ref16.astype(np.int32))
+    # second stage alone: the oracle generator fed with the DEVICE textcoder's mel (isolates the log(10 ** mel) glue + checkpoint path)
+    with torch.no_grad():
+        mel_dev = net.inference({'x_char': torch.from_numpy(z['x_char']), 'x_speaker': torch.from_numpy(z['x_speaker'])}, dropout_masks=masks).cpu()
+    with torch.no_grad():
+        ref2 = R.generator_forward(w, h, torch.log(10 ** mel_dev).permute(0, 2, 1).contiguous())
+    d_stage2 = np.abs(wav.astype(np.int32) - np.asarray(ref2.numpy().squeeze() * 32767, dtype=np.int16).astype(np.int32))
+    print('two-stage path: max LSB vs oracle chain %d, vs oracle generator on the device mel %d' % (d_chain.max(), d_stage2.max()))
+    assert d_stage2.max() <= 4, int(d_stage2.max())          # 1e-4 of full scale = 3.3 LSB
+    assert d_chain.max() <= 8, int(d_chain.max())            # + the textcoder's own <= 1e-4 RMS through the generator's gain

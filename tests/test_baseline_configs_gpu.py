@@ -105,8 +105,6 @@ def test_c5_64_ragged_sentences_match_oracle_chain_and_solo_runs():
 
 
 def test_c4_b16_training_step_losses_match_torch_formulation(monkeypatch):
-    from ttscube_amd.hifigan import discriminators as D
-    from ttscube_amd.io_utils import melspec as MS
     from ttscube_amd.io_utils.io_cubegan import CubeganCollate
     from ttscube_amd.io_utils.synthetic import synthetic_encodings, synthetic_examples
     from ttscube_amd.networks import training as T
@@ -122,11 +120,8 @@ def test_c4_b16_training_step_losses_match_torch_formulation(monkeypatch):
     assert batch['x_char'].shape[0] == 16
     out = T.cubegan_training_step(model, batch, T.cubegan_configure_optimizers(model), rng=random.Random(99))
     # the same step with every native piece swapped for its torch-op formulation, same weights, same crops
-    monkeypatch.setattr(T, 'lstm_forward_train', lambda rnn, x: rnn(x)[0])
-    monkeypatch.setattr(T, 'generator_forward_with_grad', T.generator_forward_train)
-    monkeypatch.setattr(MS, 'mel_spectrogram', D.mel_spectrogram)
-    if hasattr(T, 'TORCH_REFERENCE'):
-        monkeypatch.setattr(T, 'TORCH_REFERENCE', True)   # discriminators / losses / optimizer as torch ops as well
+    from tests import torch_reference
+    torch_reference.install(monkeypatch)   # generator, discriminators, LSTMs, text stacks, mel loss, GAN losses, AdamW: all torch ops
     ref = T.cubegan_training_step(twin, batch, T.cubegan_configure_optimizers(twin), rng=random.Random(99))
     for k in ('loss_d', 'loss_g', 'loss_t', 'loss_mel'):
         assert abs(out[k] - ref[k]) <= 1e-4 * abs(ref[k]), (k, out[k], ref[k])

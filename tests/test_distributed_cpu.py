@@ -104,17 +104,27 @@ def _arena_worker(rank, world, port, q, overlap):
     x = torch.randn(8, 7, generator=g)
     y = torch.randn(8, 3, generator=g)
     xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
-    opt = FlatAdamW(list(net.parameters()) + list(frozen.parameters()), lr=1e-3, betas=(0.8, 0.99))
+    # `partial`: differentiated on rank 0 ONLY, and placed in the MIDDLE of the arena: live everywhere (liveness is decided with a MAX over the
+    # ranks), but on rank 1 its chunk never completes during backward().  Ranks that launched chunks "when ready" would pair different chunks
+    # in RCCL / gloo; with the agreed issue order the averages stay right.
+    partial = torch.nn.Linear(3, 1)
+    broadcast_parameters(partial)
+    ps = list(net.parameters())
+    opt = FlatAdamW(ps[:2] + list(partial.parameters()) + ps[2:] + list(frozen.parameters()), lr=1e-3, betas=(0.8, 0.99))
     red = ArenaReducer(opt, bucket_mb=0.0008, overlap=overlap)   # ~200-element chunks: several per layer, parameters straddle them
     early = []
     grads = None
-    for step in range(3):
+    for step in range(4):
         opt.zero_grad()
         red.arm()
-        ((net(xs) - ys) ** 2).mean().backward()
-        red.reduce()                                      # step 0 lays the arenas out (no hooks yet), later steps overlap
+        loss = ((net(xs) - ys) ** 2).mean()
+        if rank == 0:
+            loss = loss + partial(torch.ones(1, 3)).sum()
+        loss.backward()
+        red.reduce()                                      # step 0 lays the arenas out (no hooks yet), step 1 records the issue order, later steps overlap
         early.append(red.launched_early)
         grads = [p.grad.clone() for p in net.parameters()]
+        assert torch.allclose(partial.weight.grad, torch.full((1, 3), 0.5)), (rank, step, partial.weight.grad)   # mean of (ones, nothing)
     assert all(p.grad is None for p in frozen.parameters())
     assert all(p.grad.data_ptr() >= opt.g.data_ptr() for p in net.parameters())     # gradients live in the arena, parameters too
     assert all(p.data_ptr() >= opt.p.data_ptr() and p.data_ptr() < opt.p.data_ptr() + opt.p.numel() * 4 for p in net.parameters())
@@ -162,8 +172,8 @@ def test_arena_reducer_with_bucket_ready_hooks_matches_single_process_gradient(o
     for r in range(world):
         early, late, nbytes = res[r][2], res[r][3], res[r][4]
         assert late and nbytes > 0
-        assert early[0] == 0                           # first step: layout, exchange after backward
-        assert (early[1] > 0 and early[2] > 0) if overlap else (early[1] == 0 and early[2] == 0)
+        assert early[0] == 0 and early[1] == 0         # first step: layout; second: the issue order is recorded; both exchange after backward
+        assert (early[2] > 0 and early[3] > 0) if overlap else (early[2] == 0 and early[3] == 0)
 
 
 def test_utterance_sharding_is_a_partition():

@@ -47,3 +47,104 @@ def test_rccl_reduce_scatter_all_gather_world1(use_rs):
         assert len(red._buckets) > 1 and red.bytes_exchanged > 0
     finally:
         dist.destroy_process_group()
+
+
+def _cubegan_setup(seed, nitems=4):
+    import random
+
+    import numpy as np
+    from ttscube_amd.io_utils.io_cubegan import CubeganCollate
+    from ttscube_amd.io_utils.synthetic import synthetic_encodings, synthetic_examples
+    from ttscube_amd.networks.cubegan import Cubegan
+    enc = synthetic_encodings()
+    torch.manual_seed(1234)
+    model = Cubegan(enc, conditioning=None, train=True).cuda()
+    model.train()
+    batch = CubeganCollate(enc).collate_fn(list(synthetic_examples(nitems, seed, min_ph=30, max_ph=50)))
+    return model, batch, random
+
+
+def _run_steps(model, batch, random, nsteps, with_exchange):
+    """`nsteps` Cubegan steps; returns the gradient arenas' checksums per step and the final parameters"""
+    from ttscube_amd.networks import training as T
+    opts = T.cubegan_configure_optimizers(model)
+    reds = T.cubegan_reducers(model, opts, force=True, overlap=True, bucket_mb=4) if with_exchange else None
+    rng = random.Random(7)
+    early = []
+    for _ in range(nsteps):
+        out = T.cubegan_training_step(model, batch, opts, reducers=reds, rng=rng)
+        assert all(v == v for v in out.values())
+        if reds:
+            early.append(tuple(r.launched_early for r in reds))
+    torch.cuda.synchronize()
+    return [p.detach().clone() for p in model.parameters()], early
+
+
+def test_arena_reducer_hooks_and_side_streams_under_rccl_world1():
+    """The exchange that SHIPS: ArenaReducer over the FlatAdamW arenas, reduce_scatters launched from bucket-ready
+    hooks inside backward(), sub-graphs on side streams (hifigan/streams.py), backend nccl = RCCL.  At a world of one the averaged
+    gradient is the local gradient, so five steps with the exchange must leave exactly the parameters of five steps without it: a
+    chunk sent before all of its gradients were written (the stream-ordering race commit 188d005 fixed) shows up as a difference."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(_free_port())
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    model, batch, random = _cubegan_setup(777)
+    ref, _ = _run_steps(model, batch, random, 5, with_exchange=False)
+    model2, batch2, _ = _cubegan_setup(777)
+    twice, _ = _run_steps(model2, batch2, random, 5, with_exchange=False)
+    deterministic = all(torch.equal(a, b) for a, b in zip(ref, twice))
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        model3, batch3, _ = _cubegan_setup(777)
+        got, early = _run_steps(model3, batch3, random, 5, with_exchange=True)
+    finally:
+        dist.destroy_process_group()
+    assert early[0] == (0, 0, 0) and early[1] == (0, 0, 0)          # layout step, order-recording step
+    assert all(sum(e) > 0 for e in early[2:]), early                # then chunks leave while backward() is still running
+    worst = max(float((a - b).abs().max() / (b.abs().max() + 1e-12)) for a, b in zip(got, ref))
+    if deterministic:
+        assert all(torch.equal(a, b) for a, b in zip(got, ref)), worst
+    else:   # (the step itself is not bit-reproducible on this build: hold the exchange to the run-to-run spread instead)
+        spread = max(float((a - b).abs().max() / (b.abs().max() + 1e-12)) for a, b in zip(twice, ref))
+        assert worst <= 4 * spread + 1e-6, (worst, spread)
+
+
+def _world2_worker(rank, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dev = torch.device('cuda', rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group('nccl', rank=rank, world_size=2, device_id=dev)
+    try:
+        from ttscube_amd.distributed import broadcast_parameters
+        model, batch, random = _cubegan_setup(100 + rank)          # rank-distinct data, replicated parameters
+        broadcast_parameters(model)
+        params, early = _run_steps(model, batch, random, 4, with_exchange=True)
+        chk = torch.stack([p.double().sum() for p in params]).cpu()
+        q.put((rank, chk, early))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs (the driver\'s 8-GPU node); world 1 is covered above')
+def test_arena_reducer_world2_replicas_stay_identical():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_world2_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict()
+    for _ in range(2):
+        r, chk, early = q.get(timeout=600)
+        res[r] = (chk, early)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert torch.equal(res[0][0], res[1][0])          # replicas identical after four exchanged steps
+    assert all(sum(e) > 0 for e in res[0][1][2:])

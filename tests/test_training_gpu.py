@@ -37,7 +37,7 @@ def _batch(B, nph, rng):
 def test_training_forward_matches_hip_inference_kernels():
     from ttscube_amd.hifigan.env import AttrDict
     from ttscube_amd.hifigan.models import Generator
-    from ttscube_amd.networks.training import generator_forward_train
+    from tests.torch_reference import generator_forward_train
     h = dict(R.CONFIG_V1, upsample_initial_channel=128)
     g = Generator(AttrDict(h))
     g.load_state_dict(R.synthetic_state_dict(h, seed=2))
@@ -109,7 +109,7 @@ def test_hip_conv_autograd_matches_torch(cfg):
 def test_native_generator_gradients_match_torch_autograd():
     from ttscube_amd.hifigan.env import AttrDict
     from ttscube_amd.hifigan.models import Generator
-    from ttscube_amd.networks.training import generator_forward_train
+    from tests.torch_reference import generator_forward_train
     from ttscube_amd.hifigan.autograd import generator_forward_with_grad
     h = dict(R.CONFIG_V1, upsample_initial_channel=128)
     g = Generator(AttrDict(h))
@@ -150,7 +150,7 @@ def test_cubegan_training_step_runs_and_updates_all_groups(tmp_path):
     torch.save({**{str(i): o.state_dict() for i, o in enumerate(opts)}, 'global_step': model._global_step}, base + '.opt.last')
     sd = torch.load(base + '.last', map_location='cpu')
     assert {k.split('.')[0] for k in sd} == {'_generator', '_mpd', '_msd', '_languasito', '_dummy'}
-    m2 = Cubegan(enc, conditioning=None, train=True)
+    m2 = Cubegan(enc, conditioning=None, train=True).cuda()   # (the optimizers refuse CPU parameters: no CPU path)
     m2.load(base + '.last')
     m2._loaded_optimizer_states = torch.load(base + '.opt.last', map_location='cpu')
     o2 = T.cubegan_configure_optimizers(m2)

@@ -22,7 +22,7 @@ def main():
     from ttscube_amd.hifigan.env import AttrDict
     from ttscube_amd.hifigan.models import Generator
     from ttscube_amd.hifigan.autograd import generator_forward_with_grad
-    from ttscube_amd.networks.training import generator_forward_train
+    from tests.torch_reference import generator_forward_train   # the torch-op formulation (test infrastructure)
     h = dict(R.CONFIG_V1)
     g = Generator(AttrDict(h))
     g.load_state_dict(R.synthetic_state_dict(h, seed=1))

@@ -136,6 +136,11 @@ SIGNATURES = {
     'ttsc_wavernn_destroy': (None, [C.c_void_p]),
     'ttsc_linear_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                       C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    'ttsc_gemm_workspace_bytes': (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
+    'ttsc_gemm': (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                            C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'ttsc_colsum_workspace_bytes': (C.c_size_t, [C.c_int64, C.c_int64]),
+    'ttsc_colsum': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     'ttsc_lstm_split_status': (C.c_int32, []),
     'ttsc_melar_split_status': (C.c_int32, []),
     'ttsc_lstm_pack_whh_device': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

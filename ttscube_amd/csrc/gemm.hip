@@ -112,6 +112,175 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// General fp32-MFMA GEMM for the BACKWARD passes of the Linears and of the hoisted recurrent projections (training, row a9):
+//     C[M,N] (+)= opA(A) . opB(B)         opA(A) = A [M,K] or A^T with A stored [K,M];   opB(B) = B [K,N] or B^T with B stored [N,K]
+//   dx  = dG . W        (NN)      cube/networks/modules.py:505-563 (WaveRNN._train_forward differentiated by autograd in the reference)
+//   dW  = dG^T . x      (TN: the contraction runs over all B x T rows — split over K across workgroups, partial tiles through a
+//                        workspace, added in a fixed order by gemm_splitk_reduce_kernel: deterministic)
+//   dW_hh = dG^T . h_prev   (TN with the B operand's rows shifted by one time step inside every sequence: row r reads B row r + shift
+//                        when 0 <= r % period + shift < period, zero otherwise — h_prev is never materialised)
+// Same 128 x 128 x 16 tile and fragment reads as gemm_nt_kernel; an operand whose global rows run along K is staged with 16-byte
+// loads along K, one whose rows run along M / N with 16-byte loads along M / N and transposed on its way into LDS.
+struct GemmGArgs {
+    const float* A;
+    const float* B;
+    float* C;        // [M, ldc] or the split-K workspace [splits][M][N]
+    int M, N, K, lda, ldb, ldc;
+    int accumulate;
+    int kchunk;      // K range of one split (multiple of GK); gridDim.z splits
+    int splitk;      // 1: write partial tiles to C as [z][M][N]
+    int b_shift, period;
+};
+
+template <bool AT, bool BT>   // AT: A stored [K, M];  BT: B stored [N, K]
+__global__ __launch_bounds__(256) void gemm_general_kernel(GemmGArgs a) {
+    __shared__ float As[GM * GLD];
+    __shared__ float Bs[GN * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int kbeg = blockIdx.z * a.kchunk;
+    const int kend = kbeg + a.kchunk < a.K ? kbeg + a.kchunk : a.K;
+    const bool veca = (a.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0);
+    const bool vecb = (a.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // stage one 128 x 16 operand tile into LDS as [row (m or n)][k]: `kmajor` = the global rows run along K (transposed operand)
+    auto stage = [&](const float* __restrict__ src, int ld, int rows, int r0, int k0, bool kmajor, bool vec, float* dst, bool shifted) {
+        if (!kmajor) {
+            // global [rows, K]: thread -> (row, 4 consecutive k)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int idx = tid + it * 256;
+                const int row = idx >> 2, k4 = (idx & 3) * 4;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (r0 + row < rows) {
+                    const float* p = src + (size_t)(r0 + row) * ld + k0 + k4;
+                    if (vec && k0 + k4 + 3 < kend) {
+                        const float4 t = *reinterpret_cast<const float4*>(p);
+                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (k0 + k4 + e < kend) v[e] = p[e];
+                    }
+                }
+                float* d = dst + row * GLD + k4;
+                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+            }
+        } else {
+            // global [K, rows]: thread -> (k, 4 consecutive rows); 16 k x 32 row-quads = 512 items
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int idx = tid + it * 256;
+                const int k = idx >> 5, r4 = (idx & 31) * 4;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                int kr = k0 + k;
+                bool ok = kr < kend;
+                if (shifted && ok) {
+                    const int t = kr % a.period + a.b_shift;
+                    ok = t >= 0 && t < a.period;
+                    kr += a.b_shift;
+                }
+                if (ok) {
+                    const float* p = src + (size_t)kr * ld + r0 + r4;
+                    if (vec && r0 + r4 + 3 < rows) {
+                        const float4 t = *reinterpret_cast<const float4*>(p);
+                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (r0 + r4 + e < rows) v[e] = p[e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[(r4 + e) * GLD + k] = v[e];
+            }
+        }
+    };
+
+    for (int k0 = kbeg; k0 < kend; k0 += GK) {
+        __syncthreads();
+        stage(a.A, a.lda, a.M, m0, k0, AT, veca, As, false);
+        stage(a.B, a.ldb, a.N, n0, k0, !BT, vecb, Bs, a.b_shift != 0);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GK / 2; ++kk) {
+            float af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = As[(wm * 64 + i * 32 + l31) * GLD + kk * 2 + half];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = Bs[(wn * 64 + j * 32 + l31) * GLD + kk * 2 + half];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* Cb = a.splitk ? a.C + (size_t)blockIdx.z * a.M * a.N : a.C;
+    const int ldc = a.splitk ? a.N : a.ldc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + l31;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < a.M) {
+                    float* y = Cb + (size_t)m * ldc + n;
+                    float v = acc[i][j][r];
+                    if (a.accumulate && !a.splitk) v += *y;
+                    *y = v;
+                }
+            }
+        }
+}
+
+// C[m, n] (+)= sum_z ws[z][m][n], z ascending (fixed order)
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N, int ldc, int splits,
+                                                                 int accumulate) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)M * N) return;
+    const int m = (int)(i / N), n = (int)(i % N);
+    float s = accumulate ? C[(size_t)m * ldc + n] : 0.f;
+    for (int z = 0; z < splits; ++z) s += ws[(size_t)z * M * N + i];
+    C[(size_t)m * ldc + n] = s;
+}
+
+// out[c] (+)= sum_r x[r, c]: bias gradients of the Linears / recurrent projections.  Two fixed-order stages: partial sums of row
+// ranges into ws [parts][C], then the parts in ascending order.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int R, int Cn, int ld, int rows_per_part, float* __restrict__ ws) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_part;
+    const int r1 = r0 + rows_per_part < R ? r0 + rows_per_part : R;
+    float s = 0.f;
+    if (c < Cn)
+        for (int r = r0 + q; r < r1; r += 4) s += x[(size_t)r * ld + c];
+    red[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && c < Cn) ws[(size_t)blockIdx.y * Cn + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ ws, int parts, int Cn, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= Cn) return;
+    float s = accumulate ? out[c] : 0.f;
+    for (int p = 0; p < parts; ++p) s += ws[(size_t)p * Cn + c];
+    out[c] = s;
+}
+
 }  // namespace ttsc
 
 using namespace ttsc;
@@ -135,6 +304,85 @@ extern "C" int ttsc_linear_forward(const float* x_dev, const float* w_dev, const
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("gemm_nt_kernel launch failed: %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    return TTSC_OK;
+}
+
+static int gemm_splits(int64_t M, int64_t N, int64_t K) {
+    const int64_t tiles = ceil_div(M, GM) * ceil_div(N, GN);
+    if (tiles >= 256 || K < 4096) return 1;
+    int64_t s = ceil_div(768, tiles);                       // ~3 workgroups per CU
+    const int64_t smax = ceil_div(K, 512);                  // at least 512 rows of K per split
+    s = s < smax ? s : smax;
+    return (int)(s < 1 ? 1 : (s > 512 ? 512 : s));
+}
+
+extern "C" size_t ttsc_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int s = gemm_splits(M, N, K);
+    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
+extern "C" int ttsc_gemm(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                         float* C, int64_t ldc, int32_t accumulate, int64_t b_row_shift, int64_t b_period, void* ws_dev, size_t ws_bytes, void* stream) {
+    TTSC_REQUIRE(A && B && C, "ttsc_gemm: null argument");
+    TTSC_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "ttsc_gemm: bad shape M=%lld N=%lld K=%lld",
+                 (long long)M, (long long)N, (long long)K);
+    TTSC_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N && lda < (1ll << 31) && ldb < (1ll << 31) && ldc < (1ll << 31),
+                 "ttsc_gemm: leading dimensions too small (lda=%lld ldb=%lld ldc=%lld)", (long long)lda, (long long)ldb, (long long)ldc);
+    TTSC_REQUIRE(b_row_shift == 0 || (!transB && b_period > 0 && b_row_shift > -b_period && b_row_shift < b_period),
+                 "ttsc_gemm: the row shift applies to an untransposed B ([K, N]) with a positive period");
+    const int splits = gemm_splits(M, N, K);
+    TTSC_REQUIRE(splits == 1 || (ws_dev && ws_bytes >= (size_t)splits * M * N * sizeof(float)), "ttsc_gemm: workspace too small (need %zu bytes)",
+                 (size_t)splits * M * N * sizeof(float));
+    GemmGArgs a;
+    a.A = A; a.B = B;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.lda = (int)lda; a.ldb = (int)ldb; a.ldc = (int)ldc;
+    a.accumulate = accumulate;
+    a.splitk = splits > 1;
+    a.C = a.splitk ? (float*)ws_dev : C;
+    a.kchunk = (int)round_up(ceil_div(K, splits), GK);
+    a.b_shift = (int)b_row_shift;
+    a.period = b_period > 0 ? (int)b_period : 1;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)ceil_div(N, GN), (unsigned)ceil_div(M, GM), (unsigned)ceil_div(K, a.kchunk));
+    const int nz = (int)grid.z;
+    if (transA && transB) hipLaunchKernelGGL((gemm_general_kernel<true, true>), grid, dim3(256), 0, s, a);
+    else if (transA) hipLaunchKernelGGL((gemm_general_kernel<true, false>), grid, dim3(256), 0, s, a);
+    else if (transB) hipLaunchKernelGGL((gemm_general_kernel<false, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_general_kernel<false, false>), grid, dim3(256), 0, s, a);
+    if (a.splitk)
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)ceil_div(M * N, 256)), dim3(256), 0, s, (const float*)ws_dev, C, (int)M, (int)N,
+                           (int)ldc, nz, accumulate);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("gemm_general_kernel launch failed: %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    return TTSC_OK;
+}
+
+static int colsum_parts(int64_t R) { return (int)(R >= 4096 ? (ceil_div(R, 1024) > 256 ? 256 : ceil_div(R, 1024)) : 1); }
+
+extern "C" size_t ttsc_colsum_workspace_bytes(int64_t R, int64_t Cn) { return R > 0 && Cn > 0 ? (size_t)colsum_parts(R) * Cn * sizeof(float) : 0; }
+
+extern "C" int ttsc_colsum(const float* x_dev, int64_t R, int64_t Cn, int64_t ld, float* out_dev, int32_t accumulate, void* ws_dev, size_t ws_bytes,
+                           void* stream) {
+    TTSC_REQUIRE(x_dev && out_dev && ws_dev, "ttsc_colsum: null argument");
+    TTSC_REQUIRE(R > 0 && Cn > 0 && ld >= Cn && R < (1ll << 31) && ld < (1ll << 31), "ttsc_colsum: bad shape R=%lld C=%lld ld=%lld", (long long)R,
+                 (long long)Cn, (long long)ld);
+    const int parts = colsum_parts(R);
+    TTSC_REQUIRE(ws_bytes >= (size_t)parts * Cn * sizeof(float), "ttsc_colsum: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int rpp = (int)ceil_div(R, parts);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)ceil_div(Cn, 64), (unsigned)parts), dim3(256), 0, s, x_dev, (int)R, (int)Cn, (int)ld, rpp,
+                       (float*)ws_dev);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div(Cn, 256)), dim3(256), 0, s, (const float*)ws_dev, parts, (int)Cn, out_dev, accumulate);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("colsum kernels launch failed: %s", hipGetErrorString(e));
         return TTSC_EHIP;
     }
     return TTSC_OK;

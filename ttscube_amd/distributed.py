@@ -119,9 +119,16 @@ class ArenaReducer:
     post-accumulate-grad hook, and the moment the last parameter of a chunk has its gradient, that chunk's reduce_scatter is
     launched (async, on RCCL's stream) while autograd keeps differentiating the layers in front of it — what Lightning's DDP does
     per backward for the reference (scripts/train_cubegan.py:138-145), here with reduce_scatter + all_gather so that every GPU
-    drives all 7 of its xGMI links.  `reduce()` after backward() launches whatever is still pending, then all_gathers.  All ranks
-    run the same graph, so chunks complete — and collectives are issued — in the same order everywhere.
-    The first step has no arenas yet (liveness is decided from its gradients): `reduce()` builds them and exchanges un-overlapped."""
+    drives all 7 of its xGMI links.  `reduce()` after backward() launches whatever is still pending, then all_gathers.
+
+    Issue order: every rank issues the chunks' collectives in ONE agreed order, whatever its own gradients do.  A parameter is
+    live when ANY rank has a gradient for it, so a rank without that gradient never sees the chunk complete during backward(); if each rank
+    launched chunks "when ready", RCCL would pair chunk k of one rank with chunk j of another (all chunks but the tail have the same size): wrong
+    averages, no error.  So the order is fixed once — the order in which rank 0 saw the chunks complete during the first overlapped backward
+    pass, broadcast to everybody — and a chunk leaves from a hook only when it is ready AND every chunk before it in that order has left; what is
+    still pending leaves from `reduce()` in the same order.  A rank whose chunk never completes just launches the tail late.
+    The first step has no arenas yet (liveness is decided from its gradients): `reduce()` builds them and exchanges un-overlapped; the second
+    step records the order (un-overlapped as well); overlap starts with the third."""
 
     def __init__(self, opt, bucket_mb=64, group=None, use_reduce_scatter=True, force=False, overlap=True):
         self.opt, self.group, self.use_rs, self.force, self.overlap = opt, group, use_reduce_scatter, force, overlap
@@ -129,6 +136,9 @@ class ArenaReducer:
         self.bytes_exchanged = 0
         self.launched_early = 0      # chunks whose reduce_scatter left from a gradient hook during the last backward pass
         self._chunks = None
+        self._order = None           # agreed issue order of the chunks (list of chunk indices), None until recorded
+        self._seen = []              # recording pass: chunks in the order they completed on this rank
+        self._next = 0               # position in _order of the next chunk to issue
         opt.on_build(self._on_build)
 
     def _active(self):
@@ -165,10 +175,33 @@ class ArenaReducer:
             for k in cs:
                 c = self._chunks[k]
                 c['left'] -= 1
-                if c['left'] == 0 and c['work'] is None:
-                    self._launch(c)
-                    self.launched_early += 1
+                if c['left'] == 0:
+                    if self._order is None:
+                        self._seen.append(k)     # recording pass: nothing leaves early
+                    else:
+                        self._issue_ready()
         return hook
+
+    def _issue_ready(self):
+        """launch, in the agreed order, every chunk that is complete and whose predecessors have all left"""
+        while self._next < len(self._order):
+            c = self._chunks[self._order[self._next]]
+            if c['left'] != 0 or c['work'] is not None:
+                break
+            self._launch(c)
+            self.launched_early += 1
+            self._next += 1
+
+    def _agree_on_order(self):
+        """rank 0's completion order of the recording pass (chunks it never saw complete appended by index) becomes everybody's issue order"""
+        seen = list(dict.fromkeys(self._seen))
+        order = seen + [k for k in range(len(self._chunks)) if k not in set(seen)]
+        t = torch.tensor(order, dtype=torch.int64, device=self.opt.g.device)
+        dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        order = [int(v) for v in t.tolist()]
+        if sorted(order) != list(range(len(self._chunks))):
+            raise RuntimeError('ArenaReducer: the broadcast issue order is not a permutation of the chunks (ranks built different arenas?)')
+        self._order = order
 
     def arm(self):
         """call before a backward pass (right after zero_grad): chunk counters restart"""
@@ -177,6 +210,8 @@ class ArenaReducer:
             for c in self._chunks:
                 c['left'], c['work'] = c['need'], None
         self.launched_early = 0
+        self._next = 0
+        self._seen = []
 
     @torch.no_grad()
     def _launch(self, c):
@@ -186,7 +221,7 @@ class ArenaReducer:
             # launched from a gradient hook, i.e. inside backward(): the parameters of this chunk may have received their gradients on different
             # streams (hifigan/streams.py runs independent sub-graphs on side streams); wait for all of them before the chunk is read
             from .hifigan.streams import join_side_streams
-            join_side_streams(g.device)
+            join_side_streams(g.device, include_default=True)
         if c['buf'] is None:   # ragged tail: stage into a padded buffer
             if 'stage' not in c:
                 c['stage'] = torch.zeros(c['pad'], dtype=torch.float32, device=g.device)
@@ -205,10 +240,14 @@ class ArenaReducer:
     def reduce(self):
         if not self._active():
             return
+        recording = self._armed and self._order is None   # (decided before the arenas are built: the building step has recorded nothing)
         self.opt.ensure_built()
         self._armed = False
         self.bytes_exchanged = 0
-        for c in self._chunks:
+        if recording:
+            self._agree_on_order()
+        for k in (self._order if self._order is not None else range(len(self._chunks))):   # pending chunks, in the agreed order
+            c = self._chunks[k]
             if c['work'] is None:
                 self._launch(c)
         gathers = []

@@ -44,12 +44,18 @@ def fan_out(jobs, dev):
     return [r for _, r in outs]
 
 
-def join_side_streams(dev):
+def join_side_streams(dev, include_default=False):
     """make the CURRENT stream wait for everything queued so far on the side streams of `dev`.  For code that runs inside a backward pass and reads
     results of several sub-graphs — the gradient-exchange hooks of distributed.ArenaReducer: the host-side order of autograd nodes says nothing about
-    the completion order of kernels on different streams."""
+    the completion order of kernels on different streams.  include_default: also wait for the device's default stream — a hook can fire while the
+    current stream IS a side stream (an AccumulateGrad node runs on the stream of the parameter's first use), and gradients of the same chunk may
+    have been written on the main stream."""
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     cur = torch.cuda.current_stream(dev)
     for st in _SIDE.get(key, []):
         if st != cur:
             cur.wait_stream(st)
+    if include_default:
+        main = torch.cuda.default_stream(dev)
+        if main != cur:
+            cur.wait_stream(main)

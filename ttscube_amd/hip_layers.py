@@ -136,6 +136,49 @@ def linear_hip(x, weight, bias=None, act=None, out=None, accumulate=False):
     return out
 
 
+def gemm_hip(a, b, trans_a=False, trans_b=False, out=None, accumulate=False, b_row_shift=0, b_period=0):
+    """out[M, N] (+)= op(a) @ op(b) on the fp32 MFMA GEMM (ttsc_gemm): a is [M, K] ([K, M] when trans_a), b is [K, N] ([N, K] when
+    trans_b); 2-D device tensors whose last dimension is contiguous (row strides are passed as leading dimensions, so column slices
+    of a wider tensor work without a copy).  b_row_shift / b_period: see include/ttscube_hip.h (h_prev of a recurrence without
+    materialising it).  Deterministic (split-K partials are added in a fixed order)."""
+    for t in (a, b):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
+            raise _lib.TTSCError('gemm_hip: operands must be 2-D fp32 device tensors with a contiguous last dimension')
+    M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    N, Kb = (b.shape[0], b.shape[1]) if trans_b else (b.shape[1], b.shape[0])
+    if Kb != K:
+        raise _lib.TTSCError('gemm_hip: contraction lengths differ (%d vs %d)' % (K, Kb))
+    if out is None:
+        if accumulate:
+            raise _lib.TTSCError('gemm_hip: accumulate=True needs an `out` tensor')
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    assert out.is_cuda and out.dtype == torch.float32 and tuple(out.shape) == (M, N) and out.stride(1) == 1
+    L = _lib.lib()
+    wsb = int(L.ttsc_gemm_workspace_bytes(M, N, K))
+    ws = torch.empty((wsb // 4,), dtype=torch.float32, device=a.device) if wsb else None
+    with torch.cuda.device(a.device):
+        _lib.check(L.ttsc_gemm(int(trans_a), int(trans_b), M, N, K, C.c_void_p(a.data_ptr()), a.stride(0), C.c_void_p(b.data_ptr()), b.stride(0),
+                               C.c_void_p(out.data_ptr()), out.stride(0), int(accumulate), int(b_row_shift), int(b_period),
+                               C.c_void_p(ws.data_ptr()) if ws is not None else None, wsb, _lib.current_stream()), 'ttsc_gemm')
+    return out
+
+
+def colsum_hip(x, out=None, accumulate=False):
+    """out[c] (+)= sum_r x[r, c] for a 2-D fp32 device tensor with a contiguous last dimension (ttsc_colsum; fixed summation order)"""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
+        raise _lib.TTSCError('colsum_hip: need a 2-D fp32 device tensor with a contiguous last dimension')
+    R, Cn = x.shape
+    if out is None:
+        out = torch.empty((Cn,), dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    wsb = int(L.ttsc_colsum_workspace_bytes(R, Cn))
+    ws = torch.empty((max(wsb // 4, 1),), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(L.ttsc_colsum(C.c_void_p(x.data_ptr()), R, Cn, x.stride(0), C.c_void_p(out.data_ptr()), int(accumulate),
+                                 C.c_void_p(ws.data_ptr()), wsb, _lib.current_stream()), 'ttsc_colsum')
+    return out
+
+
 class LSTMHip:
     """Device-side handle for a (stacked, optionally bidirectional) torch.nn.LSTM parameter set (batch_first).
     Input projections of all time steps run as one MFMA GEMM per layer; the recurrence runs in the persistent

@@ -44,17 +44,20 @@ def load_generator_checkpoint(vocoder_path):
     return vocoder.eval()
 
 
-def synthesize_devset(textcoder, collate, dataset, vocoder, output_path='generated_files/', forced_synthesis=True, limit=-1):
+def synthesize_devset(textcoder, collate, dataset, vocoder, output_path='generated_files/', forced_synthesis=True, limit=-1, dropout_masks=None):
     """runtime.py:41-80 with the loaded objects passed in (textcoder: CubenetTextcoder on a HIP device; collate / dataset: whatever
     produces its batch dicts — the reference's TextcoderDataset / TextcoderCollate are corpus tooling; vocoder: from
-    load_generator_checkpoint, on the same device)."""
+    load_generator_checkpoint, on the same device).  dropout_masks (optional, one tensor per item): PreNet dropout masks to inject instead of
+    the in-kernel Philox draw — the PreNet's dropout is always on (modules.py:159-164), so reproducible synthesis (tests, A/B listening)
+    needs them."""
     os.makedirs(output_path, exist_ok=True)
     m_gen = len(dataset) if limit == -1 or limit >= len(dataset) else limit
     with torch.no_grad():
         for ii in range(m_gen):
             ex = dataset[ii]
             X = collate.collate_fn([ex])
-            mel = textcoder(X)[3] if forced_synthesis else textcoder.inference(X)
+            mk = dropout_masks[ii] if dropout_masks is not None else None
+            mel = textcoder(X, dropout_masks=mk)[3] if forced_synthesis else textcoder.inference(X, dropout_masks=mk)
             mel = torch.log(10 ** mel)                       # log10-mel -> natural-log mel (runtime.py:77)
             audio = vocoder(mel.permute(0, 2, 1).contiguous()).detach().cpu().numpy().squeeze()
             save_wav('{0}/{1}.wav'.format(output_path, ex['meta']['id']), np.array(audio * 32767, dtype=np.int16), 24000)

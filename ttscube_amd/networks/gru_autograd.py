@@ -6,11 +6,12 @@ back; on ROCm that is MIOpen's per-time-step chain.  Here one GRU layer is one `
   forward   ttsc_linear_forward      W_ih x + b_ih for all steps (fp32 MFMA GEMM)
             ttsc_gru_seq_forward     persistent recurrence kernel, saves r, z, n and W_hn h + b_hn
   backward  ttsc_gru_seq_backward    persistent backward-through-time kernel -> per-step gate gradients
-            three library GEMMs      dx = dGi W_ih,  dW_ih = dGi^T x,  dW_hh = dGh^T h_prev   (+ column sums for the biases)"""
+            ttsc_gemm x3             dx = dGi W_ih (NN),  dW_ih = dGi^T x,  dW_hh = dGh^T h_prev (TN, split-K, h_prev by row shift)
+            ttsc_colsum x2           bias gradients"""
 import torch
 
 from .. import _lib
-from ..hip_layers import linear_hip
+from ..hip_layers import colsum_hip, gemm_hip, linear_hip
 
 
 def _pack(whh, transpose):
@@ -54,12 +55,11 @@ class HipGRUFn(torch.autograd.Function):
                                                         _lib.dev_ptr(dgi), _lib.dev_ptr(dgh), B, T, H, _lib.current_stream()),
                        'ttsc_gru_seq_backward')
         gi2, gh2 = dgi.reshape(B * T, 3 * H), dgh.reshape(B * T, 3 * H)
-        dx = (gi2 @ wih).reshape(x.shape) if ctx.needs_input_grad[0] else None
-        dwih = gi2.t() @ x.reshape(B * T, -1)
-        hprev = torch.zeros_like(y)
-        hprev[:, 1:] = y[:, :-1]
-        dwhh = gh2.t() @ hprev.reshape(B * T, H)
-        return dx, dwih, dwhh, gi2.sum(dim=0), gh2.sum(dim=0)
+        dx = gemm_hip(gi2, wih).reshape(x.shape) if ctx.needs_input_grad[0] else None       # dGi . W_ih                       (NN)
+        dwih = gemm_hip(gi2, x.reshape(B * T, -1), trans_a=True)                             # dGi^T . x, split over the B*T rows (TN)
+        # dGh^T . h_prev with h_prev[b, t] = y[b, t-1] (0 at t = 0): the GEMM reads y one row up inside every sequence
+        dwhh = gemm_hip(gh2, y.reshape(B * T, H), trans_a=True, b_row_shift=-1, b_period=T)
+        return dx, dwih, dwhh, colsum_hip(gi2), colsum_hip(gh2)
 
 
 def gru_forward_train(m, x):

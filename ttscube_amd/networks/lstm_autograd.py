@@ -7,13 +7,13 @@ crop sizes.  Here one layer (both directions) is one `torch.autograd.Function`:
   forward   ttsc_linear_forward            x W_ih^T + (b_ih + b_hh) for all steps (fp32 MFMA GEMM)
             ttsc_lstm_seq_forward_train    persistent recurrence kernel, saves gates + cell states
   backward  ttsc_lstm_seq_backward         persistent backward-through-time kernel -> gate gradients of all steps
-            three library GEMMs            dx = dG W_ih,  dW_ih = dG^T x,  dW_hh = dG^T h_prev   (+ column sums for the biases)
+            ttsc_gemm (NN, TN split-K)     dx = dG W_ih,  dW_ih = dG^T x,  dW_hh = dG^T h_prev (h_prev by row shift);  ttsc_colsum: biases
 
 W_hh is re-packed on the device every step (`ttsc_lstm_pack_whh_device`, forward and transposed layouts)."""
 import torch
 
 from .. import _lib
-from ..hip_layers import linear_hip
+from ..hip_layers import colsum_hip, gemm_hip, linear_hip
 
 
 def _pack(whh, transpose):
@@ -63,19 +63,16 @@ class HipLSTMLayerFn(torch.autograd.Function):
                                                          _lib.dev_ptr(_pack(whh, True)), _lib.dev_ptr(dG), None, B, T, H, nd, nd * H, 0,
                                                          _lib.current_stream()), 'ttsc_lstm_seq_backward')
         dG2 = dG.reshape(B * T, nd * 4 * H)
-        dx = (dG2 @ wih).reshape(x.shape) if ctx.needs_input_grad[0] else None
-        dwih = dG2.t() @ x.reshape(B * T, -1)                          # [nd*4H, in]
-        db = dG2.sum(dim=0)
+        dx = gemm_hip(dG2, wih).reshape(x.shape) if ctx.needs_input_grad[0] else None   # dG . W_ih                          (NN)
+        dwih = gemm_hip(dG2, x.reshape(B * T, -1), trans_a=True)                         # dG^T . x, split over the B*T rows   (TN) [nd*4H, in]
+        db = colsum_hip(dG2)
+        y2 = y.reshape(B * T, nd * H)
         grads = []
         for d in range(nd):
             sl = slice(d * 4 * H, (d + 1) * 4 * H)
-            hy = y[:, :, d * H:(d + 1) * H]
-            hprev = torch.zeros_like(hy)
-            if d == 0:
-                hprev[:, 1:] = hy[:, :-1]          # forward direction: h_{t-1}
-            else:
-                hprev[:, :-1] = hy[:, 1:]          # reverse direction: the previous step is t+1
-            dwhh = dG2[:, sl].t() @ hprev.reshape(B * T, H)
+            # dG_d^T . h_prev: the forward direction's previous step is t - 1, the reverse direction's t + 1 — a row shift of the
+            # direction's column slice of y inside every sequence (zero at the sequence's first step), nothing is materialised
+            dwhh = gemm_hip(dG2[:, sl], y2[:, d * H:(d + 1) * H], trans_a=True, b_row_shift=-1 if d == 0 else 1, b_period=T)
             grads += [dwih[sl], dwhh, db[sl], db[sl]]
         return (dx, None) + tuple(grads)
 

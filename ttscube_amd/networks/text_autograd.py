@@ -6,11 +6,12 @@ import torch
 
 from .. import _lib
 from ..hifigan.autograd import TrainConv, hip_conv
-from ..hip_layers import linear_hip
+from ..hip_layers import colsum_hip, gemm_hip, linear_hip
 
 
 class HipLinearFn(torch.autograd.Function):
-    """y = x W^T + b on gemm_nt_kernel; backward dx = dy W, dW = dy^T x (both the same NT GEMM on transposed views), db = column sums"""
+    """y = x W^T + b on gemm_nt_kernel; backward dx = dy W (NN) and dW = dy^T x (TN, split-K) on gemm_general_kernel — no transposed
+    copies —, db = fixed-order column sums (colsum kernels)"""
 
     @staticmethod
     def forward(ctx, x, w, b):
@@ -27,11 +28,11 @@ class HipLinearFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = linear_hip(dy2, w.detach().t().contiguous()).view(ctx.shp)
+            dx = gemm_hip(dy2, w.detach()).view(ctx.shp)                   # dy [M, N] . W [N, K]                      (NN)
         if ctx.needs_input_grad[1]:
-            dw = linear_hip(dy2.t().contiguous(), x2.t().contiguous())
+            dw = gemm_hip(dy2, x2, trans_a=True)                           # dy^T [N, M] . x [M, K], split over the M rows (TN)
         if ctx.has_b and ctx.needs_input_grad[2]:
-            db = dy2.sum(dim=0)
+            db = colsum_hip(dy2)
         return dx, dw, db
 
 

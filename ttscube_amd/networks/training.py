@@ -49,66 +49,79 @@ def wavernn_loss(net, X):
 
 
 # =====================================================================================================================
-# Training steps (torch-ROCm autograd + explicit RCCL gradient exchange).
+# Training steps (autograd graph of hand-written HIP kernels + explicit RCCL gradient exchange).
 #
-# Status (round 1): the GENERATOR trains on the hand-written HIP kernels (hifigan/autograd.py: forward, data gradient
-# and weight gradient of every convolution behind `torch.autograd.Function`); `generator_forward_train` below is the
-# torch-op formulation of the same network, kept as the gradient reference for tests/test_training_gpu.py.  The
-# discriminators, the mel decoder stacks and the teacher-forced WaveRNN still differentiate through torch-ROCm ops on
-# the SAME parameter tensors the HIP inference kernels read.  The explicit flat-bucket RCCL exchange
-# (ttscube_amd/distributed.py) replaces Lightning's implicit DDP.
+# Every parametrised layer of the two steps runs forward AND backward on `ttsc::` kernels behind `torch.autograd.Function`s:
+# generator / discriminator convolutions (hifigan/autograd.py, hifigan/disc_hip.py), LSTM / GRU recurrences with their weight and
+# input gradient GEMMs (lstm_autograd.py, gru_autograd.py), embeddings / char-CNN / Linears (text_autograd.py), the STFT-mel loss
+# (io_utils/melspec.py), the GAN losses (hifigan/losses_hip.py) and AdamW over flat arenas (optim.py).  There is no CPU path and
+# no torch-op formulation in this package: the all-torch formulation of the same steps that the native steps are held to lives
+# under tests/ (tests/torch_reference.py) and is swapped in through the module-level hooks below (`_text_ops`, `_make_adamw`,
+# `_gan_loss_fns`, `_discriminator_fns`, `_lowres_features`, `_output_linears`, `lstm_forward_train`, `gru_forward_train`,
+# `generator_forward_with_grad`).  The explicit flat-arena RCCL exchange (ttscube_amd/distributed.py) replaces Lightning's
+# implicit DDP.
 # =====================================================================================================================
 import itertools
 import random
 
-# True: every piece of the training steps that has a native counterpart runs as its torch-op formulation instead (torch.optim.AdamW,
-# per-tensor GAN loss expressions): the reference the native step is held to by tests/test_baseline_configs_gpu.py.  Never set in production.
-TORCH_REFERENCE = False
-# None / True: MPD and MSD run on the HIP convolution kernels (hifigan/disc_hip.py); False: the torch-op modules (A/B measurements)
-NATIVE_DISCRIMINATORS = None if __import__('os').environ.get('TTSC_NATIVE_DISC', '1') != '0' else False
-
 import torch.nn.functional as F
 
-from ..hifigan.models import ResBlock1
 from ..hifigan.autograd import generator_forward_with_grad
 from .lstm_autograd import lstm_forward_train
 from .gru_autograd import gru_forward_train
 
 
-def _wn(l):
-    """live weight-norm: w = g * v / ||v|| (so that gradients reach weight_g and weight_v)."""
-    if hasattr(l, 'weight'):
-        return l.weight
-    v, g = l.weight_v, l.weight_g
-    return g * v / v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, 1, 1)
+def _require_device(t, what):
+    if not t.is_cuda:
+        raise _lib.TTSCError('%s: tensors must live on a HIP device (got %s); the training steps have no CPU path' % (what, t.device))
 
 
-def generator_forward_train(gen, x):
-    """HiFi-GAN generator forward as torch ops: the autograd REFERENCE the native path (hifigan/autograd.py) is tested against."""
-    h = gen.h
-    x = F.conv1d(x, _wn(gen.conv_pre), gen.conv_pre.bias, padding=3)
-    nk = gen.num_kernels
-    for i, (u, k) in enumerate(zip(h['upsample_rates'], h['upsample_kernel_sizes'])):
-        x = F.leaky_relu(x, 0.1)
-        x = F.conv_transpose1d(x, _wn(gen.ups[i]), gen.ups[i].bias, stride=u, padding=(k - u) // 2)
-        xs = None
-        for j in range(nk):
-            rb = gen.resblocks[i * nk + j]
-            kr, ds = h['resblock_kernel_sizes'][j], h['resblock_dilation_sizes'][j]
-            r = x
-            if isinstance(rb, ResBlock1):
-                for c1, c2, d in zip(rb.convs1, rb.convs2, ds):
-                    xt = F.conv1d(F.leaky_relu(r, 0.1), _wn(c1), c1.bias, dilation=d, padding=d * (kr - 1) // 2)
-                    xt = F.conv1d(F.leaky_relu(xt, 0.1), _wn(c2), c2.bias, padding=(kr - 1) // 2)
-                    r = xt + r
-            else:
-                for c, d in zip(rb.convs, ds):
-                    r = F.conv1d(F.leaky_relu(r, 0.1), _wn(c), c.bias, dilation=d, padding=d * (kr - 1) // 2) + r
-            xs = r if xs is None else xs + r
-        x = xs / nk
-    x = F.leaky_relu(x)
-    x = F.conv1d(x, _wn(gen.conv_post), gen.conv_post.bias, padding=3)
-    return torch.tanh(x)
+# ---- hooks: the native building blocks of the steps (tests substitute torch formulations here, never the product) ---------
+def _text_ops(lang):
+    """(embedding, linear, char_cnn(name, h)) of the text stacks on the HIP kernels (networks/text_autograd.py)"""
+    from .text_autograd import char_cnn_train, hip_embedding, hip_linear
+    return hip_embedding, hip_linear, (lambda name, h: char_cnn_train(lang, name, h))
+
+
+def _make_adamw(params, lr):
+    """one HIP kernel per group and step over flat parameter / gradient / moment arenas (ttscube_amd/optim.py); the gradient arena
+    doubles as the RCCL exchange buffer (distributed.ArenaReducer).  state_dict layout == torch.optim.AdamW's."""
+    from ..optim import FlatAdamW
+    return FlatAdamW(params, lr, betas=(0.8, 0.99))
+
+
+def _gan_loss_fns():
+    """(discriminator_loss, feature_loss, generator_loss): value + gradient of a whole list of tensors in one launch"""
+    from ..hifigan.losses_hip import discriminator_loss, feature_loss, generator_loss
+    return discriminator_loss, feature_loss, generator_loss
+
+
+def _discriminator_fns(model):
+    """(mpd(y, y_hat, want_fmap), msd(...)): every convolution of MPD / MSD on the HIP kernels (hifigan/disc_hip.py)"""
+    from ..hifigan.disc_hip import mpd_forward, msd_forward
+    return (lambda a_, b_, fm=True: mpd_forward(model._mpd, a_, b_, want_fmap=fm),
+            lambda a_, b_, fm=True: msd_forward(model._msd, a_, b_, want_fmap=fm))
+
+
+def _lowres_features(net, hidden):
+    """WaveRNN's three k = 7 ConvNorm + tanh layers over the low-resolution signal (modules.py:416-420,459-461) on the HIP
+    convolution / weight-gradient kernels"""
+    from ..hifigan.autograd import TrainConv, hip_conv
+    cache = net.__dict__.setdefault('_train_lowres', {})
+    for i, conv in enumerate(net._lowres_conv):
+        c = conv.conv
+        tc = cache.get(i)
+        if tc is None:
+            tc = cache[i] = TrainConv(c.in_channels, c.out_channels, c.kernel_size[0], padding=c.padding[0], dilation=c.dilation[0])
+        hidden = torch.tanh(hip_conv(tc, hidden.contiguous(), c.weight, c.bias))
+    return hidden
+
+
+def _output_linears(net, hidden):
+    """tanh(Linear H -> 256) -> Linear 256 -> S over all B x L rows (modules.py:535-537) on the MFMA GEMM, forward and backward"""
+    from .text_autograd import hip_linear
+    pre = torch.tanh(hip_linear(hidden, net._preoutput.linear_layer.weight, net._preoutput.linear_layer.bias))
+    return hip_linear(pre, net._output.linear_layer.weight, net._output.linear_layer.bias)
 
 
 def languasito_forward_train(lang, X):
@@ -119,19 +132,8 @@ def languasito_forward_train(lang, X):
     dev = lang._get_device()
     x_char, x_speaker = X['x_char'].to(dev), X['x_speaker'].to(dev)
 
-    if TORCH_REFERENCE:
-        embed = lambda emb, idx: emb(idx)
-        linear = F.linear
-
-        def cnn(name, h):
-            for layer in getattr(lang, name):
-                if hasattr(layer, 'conv'):
-                    h = torch.tanh(F.conv1d(h, layer.conv.weight, layer.conv.bias, padding=1))
-            return h
-    else:   # embeddings, char-CNN and output Linears on the HIP kernels too (networks/text_autograd.py)
-        from .text_autograd import char_cnn_train, hip_embedding, hip_linear
-        embed, linear = hip_embedding, hip_linear
-        cnn = lambda name, h: char_cnn_train(lang, name, h)
+    _require_device(x_char, 'languasito_forward_train')
+    embed, linear, cnn = _text_ops(lang)
 
     def stack(which):
         h = embed(getattr(lang, '_phon_emb_' + which), x_char).permute(0, 2, 1)
@@ -178,15 +180,9 @@ def cubegan_configure_optimizers(model):
     """cubegan.py:275-311: AdamW(0.8,0.99) x3 + Adam(1e-6) on the dummy; restores `.opt.last` states when present
     (the reference sets `_loaded_optimizer_state` but reads `_loaded_optimizer_states`, so its resume silently skips this)."""
     g, d, t = cubegan_param_groups(model)
-    on_gpu = all(p.is_cuda for p in itertools.chain(g, d, t))
-    if on_gpu and not TORCH_REFERENCE:
-        # one HIP kernel per group and step over flat parameter / gradient / moment arenas (ttscube_amd/optim.py); the gradient arena
-        # doubles as the RCCL exchange buffer (distributed.ArenaReducer).  state_dict layout == torch.optim.AdamW's.
-        from ..optim import FlatAdamW
-        mk = lambda ps: FlatAdamW(ps, model._current_lr, betas=(0.8, 0.99))
-    else:
-        # fused=True: one multi-tensor kernel per optimizer step instead of ~10 element-wise launches per state update
-        mk = lambda ps: torch.optim.AdamW(ps, model._current_lr, betas=[0.8, 0.99], fused=on_gpu)
+    for p_ in itertools.chain(g, d, t):
+        _require_device(p_, 'cubegan_configure_optimizers')
+    mk = lambda ps: _make_adamw(ps, model._current_lr)
     opt_g, opt_d, opt_t = mk(g), mk(d), mk(t)
     opt_b = torch.optim.Adam(model._dummy.parameters(), lr=1e-6)
     if model._loaded_optimizer_states is not None:
@@ -216,19 +212,11 @@ def cubegan_reducers(model, optimizers, force=False, overlap=True, bucket_mb=64)
 def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
     """Cubegan.training_step (cubegan.py:85-189): discriminator step, generator step (adv + feature + 45 x mel-L1),
     text step (duration CE + pitch/vuv L1); one gradient exchange per backward pass (reducers = (g, d, t))."""
-    if TORCH_REFERENCE:
-        from ..hifigan.discriminators import discriminator_loss, feature_loss, generator_loss
-    else:   # value + gradient of a whole list of discriminator outputs / feature maps in one launch (hifigan/losses_hip.py)
-        from ..hifigan.losses_hip import discriminator_loss, feature_loss, generator_loss
-    from ..io_utils.melspec import mel_spectrogram   # DFT / mel GEMMs + element-wise kernels on HIP, forward and backward
+    discriminator_loss, feature_loss, generator_loss = _gan_loss_fns()
+    from ..io_utils import melspec as _melspec   # DFT / mel GEMMs + element-wise kernels on HIP, forward and backward
+    mel_spectrogram = _melspec.mel_spectrogram
     arm = lambda i: reducers and hasattr(reducers[i], 'arm') and reducers[i].arm()   # bucket-ready hooks restart with every backward pass
-    if TORCH_REFERENCE or NATIVE_DISCRIMINATORS is False:
-        mpd = lambda a_, b_, fm=True: model._mpd(a_, b_)
-        msd = lambda a_, b_, fm=True: model._msd(a_, b_)
-    else:   # every convolution of MPD / MSD (forward, data gradient, weight gradient) on the HIP kernels (hifigan/disc_hip.py)
-        from ..hifigan.disc_hip import mpd_forward, msd_forward
-        mpd = lambda a_, b_, fm=True: mpd_forward(model._mpd, a_, b_, want_fmap=fm)
-        msd = lambda a_, b_, fm=True: msd_forward(model._msd, a_, b_, want_fmap=fm)
+    mpd, msd = _discriminator_fns(model)
     opt_g, opt_d, opt_t, opt_b = optimizers
     rng = rng or random
     dev = model.get_device()
@@ -353,27 +341,17 @@ def cubegan_validation_step(model, batch, rng=None):
 
 def wavernn_logits_train(net, X):
     """Differentiable WaveRNN._train_forward (modules.py:505-539): the GRU(s) run on the persistent HIP forward / backward
-    kernels (gru_autograd.py), the low-resolution conditioning convolutions on the HIP convolution kernels; repeat / interpolate / concat and the
-    two output Linears are torch-ROCm ops."""
+    kernels with their weight / input gradients on the MFMA GEMMs (gru_autograd.py), the low-resolution conditioning convolutions on
+    the HIP convolution kernels, the two output Linears on the MFMA GEMM (text_autograd.hip_linear); repeat / interpolate / concat
+    are data movement."""
     mel, gs_x = X['mel'], X['x']
+    _require_device(mel, 'wavernn_logits_train')
     up = mel.repeat_interleave(net._upsample, dim=1)
     if net._use_lowres:
         low_x = X['x_low']
         interp = F.interpolate(low_x.unsqueeze(1), net._upsample_low * low_x.shape[1], mode='linear').squeeze(1)
         hidden = low_x.unsqueeze(1)
-        if TORCH_REFERENCE or not hidden.is_cuda:
-            for conv in net._lowres_conv:
-                hidden = torch.tanh(F.conv1d(hidden, conv.conv.weight, conv.conv.bias, padding=3))
-        else:   # the three k = 7 ConvNorm layers on the HIP convolution / weight-gradient kernels (MIOpen picks naive kernels for these shapes:
-                # 38 ms of the 166 ms step)
-            from ..hifigan.autograd import TrainConv, hip_conv
-            cache = net.__dict__.setdefault('_train_lowres', {})
-            for i, conv in enumerate(net._lowres_conv):
-                c = conv.conv
-                tc = cache.get(i)
-                if tc is None:
-                    tc = cache[i] = TrainConv(c.in_channels, c.out_channels, c.kernel_size[0], padding=c.padding[0], dilation=c.dilation[0])
-                hidden = torch.tanh(hip_conv(tc, hidden.contiguous(), c.weight, c.bias))
+        hidden = _lowres_features(net, hidden)
         ux = hidden.repeat_interleave(net._upsample_low, dim=2).permute(0, 2, 1)
         m = min(up.shape[1], gs_x.shape[1], ux.shape[1], interp.shape[1])
         hidden = torch.cat([up[:, :m], ux[:, :m], interp[:, :m].unsqueeze(2), gs_x[:, :m].unsqueeze(2)], dim=-1)
@@ -382,8 +360,7 @@ def wavernn_logits_train(net, X):
         hidden = torch.cat([up[:, :m], gs_x[:, :m].unsqueeze(2)], dim=-1)
     for rnn in net._rnns:
         hidden = gru_forward_train(rnn, hidden)
-    pre = torch.tanh(F.linear(hidden, net._preoutput.linear_layer.weight, net._preoutput.linear_layer.bias))
-    return F.linear(pre, net._output.linear_layer.weight, net._output.linear_layer.bias)
+    return _output_linears(net, hidden)
 
 
 def wavernn_train_loss(net, batch):
