@@ -68,8 +68,14 @@ struct ttsc_hifigan {
     bool calibrated = false;
     int range_check = 1;
     int recalibrations = 0;          // forwards that tripped the guard and were rerun after re-calibration
-    unsigned* flag_dev = nullptr;    // the guard word
-    unsigned* flag_host = nullptr;   // pinned copy
+    unsigned* flag_dev = nullptr;    // [0] the guard word (non-finite sample), [1] max |mel| of the guarded forward's input (float bits)
+    unsigned* flag_host = nullptr;   // pinned copy of both
+    // Low side of the guard (round 4): the pre-scales were derived for inputs of a certain magnitude (calib_in_absmax = max |mel| of the
+    // calibration data: 5 for the built-in probe).  An input whose largest value sits more than 2^-10 below that pushes every layer's
+    // activations the same way (the generator is positively homogeneous up to its biases), the lo halves of the fp16 pairs drift into
+    // subnormals and RELATIVE accuracy degrades silently (measured: 6e-5 relative at 2^-16, 2e-5 asked).  Such a forward is treated
+    // like an overflow: re-calibrate on the offending input and rerun.
+    float calib_in_absmax = 0.f;
     ~ttsc_hifigan() {
         if (flag_dev) (void)hipFree(flag_dev);
         if (flag_host) (void)hipHostFree(flag_host);
@@ -162,8 +168,12 @@ extern "C" int ttsc_hifigan_create(const ttsc_hifigan_cfg* cfg, ttsc_hifigan** o
     if (rc) return rc;
     TTSC_HIP_CHECK(hipMalloc((void**)&g->flag_dev, 64));
     TTSC_HIP_CHECK(hipMemset(g->flag_dev, 0, 64));
+    {
+        const unsigned inf_bits = 0x7f800000u;   // word 2: running minimum of the deferred forwards' input maxima
+        TTSC_HIP_CHECK(hipMemcpy(g->flag_dev + 2, &inf_bits, sizeof(unsigned), hipMemcpyHostToDevice));
+    }
     TTSC_HIP_CHECK(hipHostMalloc((void**)&g->flag_host, 64, hipHostMallocDefault));
-    *g->flag_host = 0u;
+    g->flag_host[0] = g->flag_host[1] = 0u;
     rc = ttsc_conv1d_set_nonfinite_flag(g->layers.at("conv_post")->c, g->flag_dev);
     if (rc) return rc;
     *out = g.release();
@@ -297,6 +307,14 @@ extern "C" int ttsc_hifigan_calibrate(ttsc_hifigan* g, const float* mel, int32_t
     // fp16's range and hands finite, accurate data to the next measurement); one host read per layer, calibration only
     float* stat = nullptr;
     TTSC_HIP_CHECK(hipMalloc((void**)&stat, sizeof(float)));
+    float m = 0.f;
+    if (hipMemsetAsync(stat, 0, sizeof(float), (hipStream_t)stream) != hipSuccess || ttsc_absmax(mel, (int64_t)B * g->cfg.num_mels * T, stat, stream) ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipMemcpy(&m, stat, sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipFree(stat);
+        set_error("ttsc_hifigan_calibrate: measuring the input range failed");
+        return TTSC_EHIP;
+    }
+    g->calib_in_absmax = std::isfinite(m) ? m : 0.f;
     int rc = hifigan_run(g, mel, B, T, nullptr, wav, ws, ws_bytes, stream, stat);
     (void)hipFree(stat);
     return rc;
@@ -368,6 +386,7 @@ extern "C" int ttsc_hifigan_set_activation_scales(ttsc_hifigan* g, const char* c
         if (rc) return rc;
     }
     g->calibrated = true;
+    if (!(g->calib_in_absmax > 0.f)) g->calib_in_absmax = 5.f;   // restored scales: assume the log-mel range of the built-in probe
     return TTSC_OK;
 }
 
@@ -381,15 +400,32 @@ extern "C" int ttsc_hifigan_set_range_check(ttsc_hifigan* g, int32_t mode) {
 
 // Deferred guard: 1 when any forward since the last call emitted a non-finite sample (the word is then cleared and the handle
 // marked un-calibrated, so the next forward calibrates afresh), 0 otherwise, < 0 on a HIP error.  Synchronises `stream`.
+// deferred mode: fold one forward's max |mel| (word 1, then cleared) into the running MINIMUM over the forwards since the last status call (word 2)
+__global__ void fold_input_range_kernel(unsigned* w) {
+    const float m = __uint_as_float(w[1]);
+    if (m < __uint_as_float(w[2])) w[2] = w[1];   // (a NaN / inf maximum is left to the non-finite guard)
+    w[1] = 0u;
+}
+
+// the low side of the guard, from the pinned copy (word `idx`): the guarded forward's max |mel| sits more than 2^-10 below the calibration data's
+static bool input_too_low(const ttsc_hifigan* g, int idx = 1) {
+    float m;
+    memcpy(&m, &g->flag_host[idx], sizeof(float));
+    return g->calib_in_absmax > 0.f && std::isfinite(m) && m < g->calib_in_absmax * (1.f / 1024.f);
+}
+
 extern "C" int32_t ttsc_hifigan_range_status(ttsc_hifigan* g, void* stream) {
     if (!g) return TTSC_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemcpyAsync(g->flag_host, g->flag_dev, sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+    if (hipMemcpyAsync(g->flag_host, g->flag_dev, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
         set_error("ttsc_hifigan_range_status: reading the guard word failed");
         return TTSC_EHIP;
     }
-    if (*g->flag_host == 0u) return 0;
-    if (hipMemsetAsync(g->flag_dev, 0, sizeof(unsigned), s) != hipSuccess) return TTSC_EHIP;
+    const bool low = input_too_low(g, 2);
+    const unsigned inf_bits = 0x7f800000u;   // running minimum restarts at +inf
+    if (hipMemcpyAsync(g->flag_dev + 2, &inf_bits, sizeof(unsigned), hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return TTSC_EHIP;
+    if (g->flag_host[0] == 0u && !low) return 0;
+    if (hipMemsetAsync(g->flag_dev, 0, 2 * sizeof(unsigned), s) != hipSuccess) return TTSC_EHIP;
     g->calibrated = false;
     return 1;
 }
@@ -406,18 +442,35 @@ extern "C" int ttsc_hifigan_forward_ragged(ttsc_hifigan* g, const float* mel, in
                                            float* wav, void* ws, size_t ws_bytes, void* stream) {
     TTSC_REQUIRE(g, "ttsc_hifigan_forward: null argument");
     hipStream_t s = (hipStream_t)stream;
-    if (g->range_check == 2) return hifigan_run(g, mel, B, T, frames, wav, ws, ws_bytes, stream, nullptr);   // deferred: sticky word, see ttsc_hifigan_range_status
-    const bool guard = g->range_check == 1 && g->precision == TTSC_PREC_F16X3 && g->calib_mode != 0;   // (mode 0 is a measurement switch: scales stay 1)
+    const bool split_guarded = g->precision == TTSC_PREC_F16X3 && g->calib_mode != 0;   // (mode 0 is a measurement switch: scales stay 1)
+    const int64_t nmel = (int64_t)B * g->cfg.num_mels * T;
+    if (g->range_check == 2) {   // deferred: sticky words, see ttsc_hifigan_range_status
+        if (split_guarded && mel && nmel > 0) {
+            int arc = ttsc_absmax(mel, nmel, reinterpret_cast<float*>(g->flag_dev + 1), stream);
+            if (arc) return arc;
+            hipLaunchKernelGGL(fold_input_range_kernel, dim3(1), dim3(1), 0, s, g->flag_dev);
+        }
+        return hifigan_run(g, mel, B, T, frames, wav, ws, ws_bytes, stream, nullptr);
+    }
+    const bool guard = g->range_check == 1 && split_guarded;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        if (guard) TTSC_HIP_CHECK(hipMemsetAsync(g->flag_dev, 0, sizeof(unsigned), s));
+        if (guard) {
+            TTSC_HIP_CHECK(hipMemsetAsync(g->flag_dev, 0, 2 * sizeof(unsigned), s));
+            if (mel && nmel > 0) {
+                int arc = ttsc_absmax(mel, nmel, reinterpret_cast<float*>(g->flag_dev + 1), stream);
+                if (arc) return arc;
+            }
+        }
         int rc = hifigan_run(g, mel, B, T, frames, wav, ws, ws_bytes, stream, nullptr);
         if (rc || !guard) return rc;
-        TTSC_HIP_CHECK(hipMemcpyAsync(g->flag_host, g->flag_dev, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        TTSC_HIP_CHECK(hipMemcpyAsync(g->flag_host, g->flag_dev, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
         TTSC_HIP_CHECK(hipStreamSynchronize(s));
-        if (*g->flag_host == 0u) return TTSC_OK;
+        const bool low = attempt == 0 && input_too_low(g);   // (after the re-calibration the scales ARE this input's)
+        if (g->flag_host[0] == 0u && !low) return TTSC_OK;
         if (attempt == 1) break;
         // a non-finite sample left conv_post: some layer's input overflowed the fp16 range its pre-scale was calibrated for
-        // (or the input itself is non-finite).  Re-derive the scales on THIS input and run the forward again.
+        // (or the input itself is non-finite) — or the input sits far BELOW the range the scales were derived for (`low`).
+        // Re-derive the scales on THIS input and run the forward again.
         g->recalibrations++;
         rc = ttsc_hifigan_calibrate(g, mel, B, T, wav, ws, ws_bytes, stream);
         if (rc) return rc;
