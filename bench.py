@@ -117,6 +117,12 @@ def extra_legs(g, h, sd, rank_dev, R):
         legs['wavernn_decode_b256'] = {'us_per_step': dt / (Tw * 240) * 1e6, 'samples_per_s': Bw * Tw * 240 / dt, 'H': 512, 'layers': 1,
                                        'frames': Tw, 'steps': Tw * 240, 'output': 'mulaw', 'indices_bit_exact_vs_oracle': True,
                                        'oracle_checked': '%d utterances x %d steps' % (len(chk), Tw * 240), 'kernel': net.last_kernel}
+        # roofline of the decode loop (1 139 712 MAC per sample and utterance, one layer H = 512): the chains run on the fp32 matrix
+        # pipe (bit-exact contract), so the peak is the fp32 MFMA rate; the kernel is latency-bound by construction (one dependent step at a time)
+        wr_tf = Bw * 2.0 * 1139712 / (dt / (Tw * 240)) / 1e12
+        legs['wavernn_decode_b256']['roofline'] = {'bound': 'mfma', 'achieved': wr_tf, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                                   'frac': wr_tf / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                                                   'note': 'per-step latency chain (two dependent products + three hand-offs); weights stay on chip, HBM traffic negligible'}
     except Exception as e:
         legs['wavernn_decode_b256'] = {'error': str(e)[:200]}
     try:   # BASELINE configs[3] per-GPU share: one full Cubegan training step (no exchange at N = 1; `--mode train` runs it under RCCL)
@@ -140,8 +146,12 @@ def extra_legs(g, h, sd, rank_dev, R):
             out = T.cubegan_training_step(model, batch, opts, rng=crop)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 3
+        tfl, _ = cubegan_step_conv_flops(16)
         legs['cubegan_training_step_b16'] = {'ms_per_step': dt * 1e3, 'samples_per_s': 16 * 12000 / dt,
-                                             'losses': {k: round(float(v), 5) for k, v in out.items()}}
+                                             'losses': {k: round(float(v), 5) for k, v in out.items()},
+                                             'roofline': {'bound': 'mfma', 'achieved': tfl / dt / 1e12, 'peak': PEAK_F16_MFMA_TFLOPS / 3, 'unit': 'TFLOP/s',
+                                                          'frac': tfl / dt / 1e12 / (PEAK_F16_MFMA_TFLOPS / 3), 'traffic': None, 'flops_per_step': tfl,
+                                                          'note': 'convolution FLOPs of the step (bench.py::cubegan_step_conv_flops) over the whole step time'}}
         del model, opts
     except Exception as e:
         legs['cubegan_training_step_b16'] = {'error': str(e)[:200]}
@@ -193,7 +203,10 @@ def extra_legs(g, h, sd, rank_dev, R):
                 dlt = np.abs(to16(wav[b, 0, :wl[b]].cpu().numpy()).astype(np.int32) - to16(ref.numpy().squeeze()).astype(np.int32))
                 worst = max(worst, int(dlt.max()))
             assert worst <= 4, 'e2e: %d LSB from the oracle chain' % worst
-            legs[tag] = {'ms': dt * 1e3, 'samples': int(sum(wl)), 'samples_per_s': float(sum(wl)) / dt, 'max_lsb_vs_oracle_chain': worst}
+            efl, egen = e2e_flops(float(sum(wl)) / 240.0, float(sum(int(v) for v in lens[:xx.shape[0]])))
+            legs[tag] = {'ms': dt * 1e3, 'samples': int(sum(wl)), 'samples_per_s': float(sum(wl)) / dt, 'max_lsb_vs_oracle_chain': worst,
+                         'roofline': {'bound': 'mfma', 'achieved': efl / dt / 1e12, 'peak': PEAK_F16_MFMA_TFLOPS / 3, 'unit': 'TFLOP/s',
+                                      'frac': efl / dt / 1e12 / (PEAK_F16_MFMA_TFLOPS / 3), 'traffic': None, 'generator_share_of_flops': egen / efl}}
         del tts
     except Exception as e:
         legs['e2e_64_sentences'] = {'error': str(e)[:200]}
@@ -333,9 +346,59 @@ def bench_train(args):
                             'exposed = step time with the three exchanges minus step time without them (N = 1 only)'},
                'losses': {k: round(float(v), 5) for k, v in out.items()},
                'roofline': None, 'cpu_baseline': None}
+        fl, parts = cubegan_step_conv_flops(world * b)
+        ach = fl * args.steps / elapsed / 1e12 / world          # per-GPU TFLOP/s
+        res['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': 2500.0 / 3, 'unit': 'TFLOP/s', 'frac': ach / (2500.0 / 3), 'traffic': None,
+                           'kernel': 'conv_f16x3 forward / data-gradient launches + wgrad_f16x3_kernel (split fp16 hi/lo x3 MFMA) of the generator and the '
+                                     'MPD / MSD discriminators: all convolution launches of one step',
+                           'flops_per_step': fl, 'flops_model': 'bench.py::cubegan_step_conv_flops (3 x generator forward + 9 x discriminator forward over b sequences)',
+                           'note': 'whole-step time in the denominator (LSTM recurrences, losses, optimizers, exchange included): a lower bound on the convolution kernels\' own fraction'}
         print(json.dumps(res))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def cubegan_step_conv_flops(b, crop_frames=50):
+    """Algorithmic convolution FLOPs of ONE Cubegan.training_step at `b` crops of `crop_frames` frames (12 000 samples) — the numerator
+    of the `--mode train` roofline.  Generator (HiFi-GAN V1, SURVEY §8d: 584 279 MAC per output sample): forward + data gradient +
+    weight gradient = 3 x forward.  Discriminators (MPD periods 2/3/5/7/11, MSD 3 scales; layer tables of hifigan/discriminators.py,
+    grouped layers counted with Cin / groups): the D step runs them forward on real + generated (2b sequences) and differentiates
+    everything (3 x forward); the G step runs them forward on 2b again and takes the data gradient of the generated half only
+    (2 + 1 forward units of b).  The LSTM / Linear GEMMs of the text stacks (~1 % of this) are not counted."""
+    L = crop_frames * 240
+    gen = 584279.4 * 2.0 * b * (L + 64)
+    mac = 0.0
+    for p in (2, 3, 5, 7, 11):                      # DiscriminatorP on one sequence
+        Hh = -(-L // p)
+        ch = [1, 32, 128, 512, 1024]
+        for i in range(4):
+            Hh = (Hh + 2 * 2 - 5) // 3 + 1
+            mac += Hh * p * ch[i] * ch[i + 1] * 5
+        mac += Hh * p * 1024 * 1024 * 5 + Hh * p * 1024 * 3
+    Ls = L
+    for s in range(3):                              # DiscriminatorS on one sequence, scale s
+        if s:
+            Ls = (Ls + 2 * 2 - 4) // 2 + 1
+        Lc = Ls
+        for cin, cout, k, st, g in ((1, 128, 15, 1, 1), (128, 128, 41, 2, 4), (128, 256, 41, 2, 16), (256, 512, 41, 4, 16),
+                                    (512, 1024, 41, 4, 16), (1024, 1024, 41, 1, 16), (1024, 1024, 5, 1, 1), (1024, 1, 3, 1, 1)):
+            Lc = (Lc + 2 * ((k - 1) // 2) - k) // st + 1
+            mac += Lc * cout * (cin // g) * k
+    disc_fwd_b = 2.0 * mac * b                      # FLOPs of one forward over b sequences
+    total = 3.0 * gen + (3.0 * 2 + 2 + 1) * disc_fwd_b
+    return total, {'generator_fwd': gen, 'discriminators_fwd_per_b_sequences': disc_fwd_b}
+
+
+def e2e_flops(frames_total, phones_total):
+    """Algorithmic FLOPs of synthesize() over a set of sentences: the generator's 584 279 MAC per output sample (240 samples per
+    frame + 64 per sentence ignored) and Languasito2's per-frame / per-phoneme GEMM + recurrence work (~3.9 M MAC per
+    frame for the pitch + conditioning BiLSTMs; per phoneme: two char stacks 64->256 k3 x3 convs + 2 BiLSTM(256) layers each + the
+    duration BiLSTM)."""
+    gen = 2.0 * 584279.4 * 240.0 * frames_total
+    per_frame = 2.0 * 3.9e6 * frames_total
+    lstm = lambda i, hh: 2 * 4 * hh * (i + hh)
+    per_phone_mac = 2 * (64 * 256 * 3 + 2 * 256 * 256 * 3 + lstm(256, 256) + lstm(512, 256)) + lstm(640, 256) + lstm(512, 256)
+    return gen + per_frame + 2.0 * per_phone_mac * phones_total, gen
 
 
 def bench_e2e(args):
@@ -453,7 +516,15 @@ def bench_e2e(args):
                        'global_batch': per_gpu * world, 'parallelism': 'utterance shards (TTSCube.shard), no collective'},
             'rtf_24k': value / world / 24000.0, 'sentences_per_s': per_gpu * world * args.steps / elapsed,
             'phase_ms_rank0': {k: round(v, 3) for k, v in phases.items()}, 'samples_per_step_rank0': int(nsamp),
-            'max_lsb_vs_oracle_chain': worst, 'oracle_checked': '2 sentences per rank (shortest, longest)', 'roofline': None, 'cpu_baseline': None}))
+            'max_lsb_vs_oracle_chain': worst, 'oracle_checked': '2 sentences per rank (shortest, longest)',
+            'roofline': (lambda fl_gen: {'bound': 'mfma', 'achieved': fl_gen[0] * args.steps / elapsed / 1e12, 'peak': 2500.0 / 3, 'unit': 'TFLOP/s',
+                                         'frac': fl_gen[0] * args.steps / elapsed / 1e12 / (2500.0 / 3), 'traffic': None,
+                                         'kernel': 'generator launches (split fp16 hi/lo x3 MFMA) + Languasito2 GEMMs / recurrences (fp32): whole synthesize() pass of rank 0',
+                                         'flops_per_step': fl_gen[0], 'generator_share_of_flops': fl_gen[1] / fl_gen[0],
+                                         'generator_phase_frac': (fl_gen[1] / (phases['generator'] * 1e-3) / 1e12 / (2500.0 / 3)) if phases.get('generator') else None,
+                                         'note': 'rank 0\'s shard over rank 0\'s wall time; generator_phase_frac = generator FLOPs over the generator phase\'s device time'})(
+                e2e_flops(float(nsamp) / 240.0, float(sum(int(lens[i]) for i in mine)))),
+            'cpu_baseline': None}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

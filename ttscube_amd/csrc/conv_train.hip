@@ -142,8 +142,9 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // row tile of a (grouped) layer: 64 rows when they stay inside one group or hold whole groups, else 32; 0 = does not tile
 static int train_mt(int Cout, int groups, int K) {
-    if (K > 21) return 32;                       // k = 41 at stride 1: all taps of a chunk must fit the LDS beside the window
     const int cout_g = Cout / groups;
+    if (K > 21)                                  // k = 41 at stride 1: all taps of a chunk must fit the LDS beside the window -> 32-row tiles;
+        return (groups > 1 && !(cout_g % 32 == 0 || 32 % cout_g == 0)) ? 0 : 32;   // a tile must not straddle groups unevenly
     int mt = Cout >= 64 ? 64 : 32;
     if (groups > 1) {
         mt = cout_g % 64 == 0 ? 64 : 32;

@@ -51,7 +51,12 @@ class _ListLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, go):
-        ctx.gbuf.mul_(go)          # ONE launch scales every stored gradient by the incoming scalar
+        # ONE launch scales every stored gradient by the incoming scalar — in place, so the node can be differentiated ONCE: a second pass
+        # through a retained graph (the generator step keeps its graph for the text step) would compound the factor silently
+        if getattr(ctx, 'consumed', False):
+            raise RuntimeError('_ListLoss: second backward pass through the same loss node (its stored gradients were scaled in place)')
+        ctx.consumed = True
+        ctx.gbuf.mul_(go)
         return (None, None, None) + tuple(ctx.grads)
 
 

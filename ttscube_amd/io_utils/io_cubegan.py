@@ -68,39 +68,45 @@ class CubeganDataset:
 
 
 class CubeganEncodings:
+    """Symbol tables and value ranges of a training corpus — the `<base>.encodings` JSON next to every Cubegan checkpoint.  Schema
+    (fixed by the reference's files, cube/io_utils/io_cubegan.py:113-155): {"speaker2int", "phon2int", "max_duration", "max_pitch"};
+    ids are assigned in order of first appearance, durations are frames per phoneme counted from `frame2phon`."""
+    _FIELDS = ('speaker2int', 'phon2int', 'max_duration', 'max_pitch')
+
     def __init__(self, filename: str = None):
-        self.speaker2int = {}
-        self.phon2int = {}
-        self.max_duration = 0
-        self.max_pitch = 0
+        self.speaker2int, self.phon2int = {}, {}
+        self.max_duration = self.max_pitch = 0
         if filename is not None:
             self.load(filename)
 
+    @staticmethod
+    def _intern(table, symbol):
+        return table.setdefault(symbol, len(table))
+
     def compute(self, dataset):
-        """io_cubegan.py:120-137 (np.long -> np.int64 for numpy >= 1.24)."""
-        for example in dataset:
-            speaker = example['meta']['speaker']
-            if speaker not in self.speaker2int:
-                self.speaker2int[speaker] = len(self.speaker2int)
-            for phone in example['meta']['phones']:
-                if phone not in self.phon2int:
-                    self.phon2int[phone] = len(self.phon2int)
-            self.max_pitch = max(self.max_pitch, np.max(example['pitch']))
-            durs = np.zeros((len(example['meta']['phones'])), dtype=np.int64)
-            for item in example['meta']['frame2phon']:
-                durs[item] += 1
-            self.max_duration = max(self.max_duration, np.max(durs))
+        """one pass over the corpus: extend both tables, track the largest pitch value and the longest phoneme (in frames)"""
+        for ex in dataset:
+            meta = ex['meta']
+            self._intern(self.speaker2int, meta['speaker'])
+            for ph in meta['phones']:
+                self._intern(self.phon2int, ph)
+            if len(ex['pitch']):
+                self.max_pitch = max(self.max_pitch, np.max(ex['pitch']))
+            frames_per_phone = np.bincount(np.asarray(meta['frame2phon'], dtype=np.int64), minlength=len(meta['phones']))
+            if frames_per_phone.size:
+                self.max_duration = max(self.max_duration, int(frames_per_phone.max()))
 
     def load(self, filename: str):
-        input_obj = json.load(open(filename))
-        self.speaker2int = input_obj['speaker2int']
-        self.phon2int = input_obj['phon2int']
-        self.max_pitch = input_obj['max_pitch']
-        self.max_duration = input_obj['max_duration']
+        with open(filename) as f:
+            blob = json.load(f)
+        for name in self._FIELDS:
+            setattr(self, name, blob[name])
 
     def save(self, filename: str):
-        json.dump({'speaker2int': self.speaker2int, 'phon2int': self.phon2int, 'max_duration': int(self.max_duration),
-                   'max_pitch': int(self.max_pitch)}, open(filename, 'w'))
+        blob = {'speaker2int': self.speaker2int, 'phon2int': self.phon2int,
+                'max_duration': int(self.max_duration), 'max_pitch': int(self.max_pitch)}
+        with open(filename, 'w') as f:
+            json.dump(blob, f)
 
 
 class CubeganCollate:
