@@ -650,6 +650,25 @@ def main():
                          'hbm_frac_compulsory': alg_bytes * args.steps / (dev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
         }
         res['self_check_rms_vs_oracle'] = check_rms
+        if precision == 'f16x3':
+            # What the matrix pipe of THIS device sustains, measured now (csrc/probe.hip: register-only v_mfma_f32_32x32x16_f16 loop on every CU):
+            # MI355X clocks to its power budget, so operands with real bit patterns run well below the nominal peak that `peak` must quote.
+            # `frac` stays achieved / nominal; `frac_of_sustained` prices the same number against the split-mix loop measured in this run.
+            try:
+                import ctypes as C
+                from ttscube_amd import _lib
+                sus = {}
+                for mode, name in ((0, 'zeros'), (1, 'random_fp16'), (2, 'split_mix')):
+                    tf = C.c_double(0.0)
+                    _lib.check(_lib.lib().ttsc_probe_mfma_tflops(mode, 60.0, C.byref(tf), _lib.current_stream()), 'ttsc_probe_mfma_tflops')
+                    sus[name] = tf.value
+                res['roofline']['sustained_f16_mfma_tflops'] = sus
+                res['roofline']['frac_of_sustained'] = executed / sus['split_mix']
+                res['roofline']['sustained_note'] = ('register-only MFMA loop, all CUs, ~60 ms per operand pattern, measured in this run after the timed region; '
+                                                     'split_mix = the three products of the split-precision scheme on random data: the ceiling an MFMA-bound '
+                                                     'split-precision kernel has on this chip at its power budget')
+            except Exception as e:
+                res['roofline']['sustained_f16_mfma_tflops'] = {'error': str(e)[:200]}
         if world == 1 and not args.no_extra:
             res['extra'] = extra_legs(g, h, sd, dev, R)
             if precision == 'f16x3':   # the same workload on the exact fp32 MFMA (k-ordered fmaf chain), for the record

@@ -381,6 +381,12 @@ size_t ttsc_colsum_workspace_bytes(int64_t R, int64_t C);
 int ttsc_colsum(const float* x_dev, int64_t R, int64_t C, int64_t ld, float* out_dev, int32_t accumulate, void* ws_dev, size_t ws_bytes,
                 void* stream);
 
+/* Measurement helper (bench.py `roofline`): executed dense f16 MFMA TFLOP/s that a register-only v_mfma_f32_32x32x16_f16 loop sustains on every
+ * CU of the current device for ~ms_target milliseconds, by operand data — mode 0: all-zero operands, 1: random fp16 operands, 2: the
+ * split-precision mix (hi x hi, hi x lo, lo x hi with lo at 2^-11 scale).  The chip clocks to its power budget: real data sustains ~2/3 of the
+ * nominal peak (csrc/probe.hip).  Synchronises `stream`.  No counterpart in the reference (it has no kernels). */
+int ttsc_probe_mfma_tflops(int32_t mode, double ms_target, double* tflops_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * LSTM / BiLSTM recurrence.  Replaces the sequential part of torch.nn.LSTM (gate order i,f,g,o, `_reverse`
  * direction) for Languasito2 (modules.py:873-905) and CubenetTextcoder (textcoder.py:55-92).

@@ -388,9 +388,12 @@ def test_inputs_far_below_the_calibration_range_keep_relative_accuracy(shift):
     # (round 4: inputs more than 2^-10 below the calibration data's range trip the low side of the guard — re-calibrated on the offending input
     # and rerun; without it the 2^-16 case measured 6e-5)
     assert (nrecal > 0) == (shift < -10), (shift, nrecal)
-    # the next ordinary input overflows the scales derived for the tiny one, trips the HIGH side and is re-calibrated in turn: still correct
+    # the handle's own (probe) scales are back afterwards: an ordinary input is computed exactly as by a handle that never saw the quiet one
     mel2 = R.synthetic_mel(1, 20, seed=95)
+    fresh = _gen(h, sd)
     with torch.no_grad():
-        out2 = g(mel2.cuda()).cpu()
+        out2, want2 = g(mel2.cuda()), fresh(mel2.cuda())
+    assert torch.equal(out2, want2)
+    assert int(_lib.lib().ttsc_hifigan_recalibrations(g._handle)) == nrecal          # ... without another re-calibration
     ref2 = R.generator_forward(w, h, mel2)
-    assert float((out2 - ref2).pow(2).mean().sqrt()) < 2e-5
+    assert float((out2.cpu() - ref2).pow(2).mean().sqrt()) < 2e-5

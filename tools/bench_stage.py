@@ -39,11 +39,13 @@ def main():
     ap.add_argument('--C', type=int, default=32)
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--shapes', default='0,1,2,3,4')
+    ap.add_argument('--data', choices=('random', 'zeros'), default='random', help='zeros: all-zero input, weights and biases (how much of the time is the power budget)')
     a = ap.parse_args()
     L_ = _lib.lib()
     Cc, L, B = a.C, a.L, a.B
     torch.manual_seed(0)
-    x = torch.randn(B, Cc, L, device='cuda')
+    x = torch.randn(B, Cc, L, device='cuda') if a.data == 'random' else torch.zeros(B, Cc, L, device='cuda')
+    wscale = 1.0 if a.data == 'random' else 0.0
     y = torch.empty_like(x)
     wav = torch.empty(B, 1, L, device='cuda')
     wav2 = torch.empty(B, 1, L, device='cuda')
@@ -53,8 +55,8 @@ def main():
         for d in (1, 3, 5):
             c1 = Conv1dHip(Cc, Cc, k, padding=d * (k - 1) // 2, dilation=d).set_precision('f16x3')
             c2 = Conv1dHip(Cc, Cc, k, padding=(k - 1) // 2).set_precision('f16x3')
-            c1.set_weight(torch.randn(Cc, Cc, k) / (Cc * k) ** 0.5 * 0.5, torch.randn(Cc) * 0.1)
-            c2.set_weight(torch.randn(Cc, Cc, k) / (Cc * k) ** 0.5 * 0.5, torch.randn(Cc) * 0.1)
+            c1.set_weight(torch.randn(Cc, Cc, k) / (Cc * k) ** 0.5 * 0.5 * wscale, torch.randn(Cc) * 0.1 * wscale)
+            c2.set_weight(torch.randn(Cc, Cc, k) / (Cc * k) ** 0.5 * 0.5 * wscale, torch.randn(Cc) * 0.1 * wscale)
             c1s.append(c1)
             c2s.append(c2)
         blocks.append((k, c1s, c2s))

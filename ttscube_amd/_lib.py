@@ -136,6 +136,7 @@ SIGNATURES = {
     'ttsc_wavernn_destroy': (None, [C.c_void_p]),
     'ttsc_linear_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                       C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    'ttsc_probe_mfma_tflops': (C.c_int, [C.c_int32, C.c_double, C.POINTER(C.c_double), C.c_void_p]),
     'ttsc_gemm_workspace_bytes': (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
     'ttsc_gemm': (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                             C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),

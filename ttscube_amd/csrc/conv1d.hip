@@ -122,15 +122,21 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_wide_kernel(ConvArgs a) {
         for (int ch = 0; ch < 8; ++ch) xr[e][ch] = rc[(size_t)ch * a.Lin + xoff[e]];
     };
     auto x_commit_item = [&](int e, half8* buf) __attribute__((always_inline)) {
-        half8 vh, vl;
+        // (hi, lo) split of the 8 channels, pairwise: cvt_pk + two fma_mix + cvt_pk per pair (conv_internal.hpp::split2_f16; same bits as the
+        // scalar convert / convert back / subtract / convert sequence, two instructions fewer per pair)
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 uh, ul;
 #pragma unroll
-        for (int ch = 0; ch < 8; ++ch) {
-            float v = xok[e] ? xr[e][ch] * a.in_scale : 0.f;
-            v = fmaxf(v, v * a.in_slope);
-            const _Float16 hh = (_Float16)v;
-            vh[ch] = hh;
-            vl[ch] = (_Float16)(v - (float)hh);
+        for (int ch = 0; ch < 8; ch += 2) {
+            float v0 = xok[e] ? xr[e][ch] * a.in_scale : 0.f, v1 = xok[e] ? xr[e][ch + 1] * a.in_scale : 0.f;
+            v0 = fmaxf(v0, v0 * a.in_slope);
+            v1 = fmaxf(v1, v1 * a.in_slope);
+            unsigned h, l;
+            split2_f16(v0, v1, h, l);
+            uh[ch >> 1] = h;
+            ul[ch >> 1] = l;
         }
+        const half8 vh = __builtin_bit_cast(half8, uh), vl = __builtin_bit_cast(half8, ul);
         buf[xslot[e]] = vh;
         buf[xslot[e] + (xslot[e] < 4 * SPAN ? SPAN : 1)] = vl;   // (the dump slot's partner is the item right behind it)
     };
@@ -630,15 +636,21 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_tall_kernel(ConvArgs a) {
         for (int ch = 0; ch < 8; ++ch) xr[e][ch] = rc[(size_t)ch * a.Lin + xoff[e]];
     };
     auto x_commit_item = [&](int e, half8* buf) __attribute__((always_inline)) {
-        half8 vh, vl;
+        // (hi, lo) split of the 8 channels, pairwise: cvt_pk + two fma_mix + cvt_pk per pair (conv_internal.hpp::split2_f16; same bits as the
+        // scalar convert / convert back / subtract / convert sequence, two instructions fewer per pair)
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 uh, ul;
 #pragma unroll
-        for (int ch = 0; ch < 8; ++ch) {
-            float v = xok[e] ? xr[e][ch] * a.in_scale : 0.f;
-            v = fmaxf(v, v * a.in_slope);
-            const _Float16 hh = (_Float16)v;
-            vh[ch] = hh;
-            vl[ch] = (_Float16)(v - (float)hh);
+        for (int ch = 0; ch < 8; ch += 2) {
+            float v0 = xok[e] ? xr[e][ch] * a.in_scale : 0.f, v1 = xok[e] ? xr[e][ch + 1] * a.in_scale : 0.f;
+            v0 = fmaxf(v0, v0 * a.in_slope);
+            v1 = fmaxf(v1, v1 * a.in_slope);
+            unsigned h, l;
+            split2_f16(v0, v1, h, l);
+            uh[ch >> 1] = h;
+            ul[ch >> 1] = l;
         }
+        const half8 vh = __builtin_bit_cast(half8, uh), vl = __builtin_bit_cast(half8, ul);
         buf[xslot[e]] = vh;
         buf[xslot[e] + (xslot[e] < 4 * SPAN ? SPAN : 1)] = vl;
     };

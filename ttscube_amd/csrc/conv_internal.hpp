@@ -35,3 +35,21 @@ struct ttsc_conv1d {
     unsigned* nf_flag = nullptr;          // out_channels == 1: device word that conv_cout1_kernel ORs with 1 when it emits a non-finite sample
 };
 
+
+#ifdef __HIPCC__
+namespace ttsc {
+// (hi, lo) fp16 halves of two fp32 values, packed: hi = rn16(v), lo = rn16(v - hi).  v - hi as v_fma_mix_f32 (an f16 operand read as f32
+// inside the fma: exact, one rounding — the same bits as convert-back + subtract) saves the two back-conversions per pair.
+__device__ __forceinline__ void split2_f16(float v0, float v1, unsigned& hi, unsigned& lo) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const f2_t p = {v0, v1};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(p, h2_t));
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi), "v"(v0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi), "v"(v1));
+    const f2_t l = {l0, l1};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(l, h2_t));
+}
+}  // namespace ttsc
+#endif

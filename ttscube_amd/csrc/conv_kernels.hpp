@@ -3,6 +3,7 @@
 // split-precision kernel.
 #pragma once
 #include "common.hpp"
+#include "conv_internal.hpp"
 
 namespace ttsc {
 
@@ -483,15 +484,20 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
         for (int e = 0; e < XIT; ++e) {
             if (xslot[e] >= 0) {
                 const int cb = c * 16 + xh[e] * 8;
-                half8 vh, vl;
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 uh, ul;
 #pragma unroll
-                for (int ch = 0; ch < 8; ++ch) {
-                    float v = (xok[e] && cb + ch < cin_n) ? xr[e][ch] * in_scale : 0.f;
-                    v = fmaxf(v, v * a.in_slope);   // leaky-relu for slopes in [0,1] (1 = identity)
-                    const _Float16 hh = (_Float16)v;
-                    vh[ch] = hh;
-                    vl[ch] = (_Float16)(v - (float)hh);
+                for (int ch = 0; ch < 8; ch += 2) {
+                    float v0 = (xok[e] && cb + ch < cin_n) ? xr[e][ch] * in_scale : 0.f;
+                    float v1 = (xok[e] && cb + ch + 1 < cin_n) ? xr[e][ch + 1] * in_scale : 0.f;
+                    v0 = fmaxf(v0, v0 * a.in_slope);   // leaky-relu for slopes in [0,1] (1 = identity)
+                    v1 = fmaxf(v1, v1 * a.in_slope);
+                    unsigned h, l;
+                    split2_f16(v0, v1, h, l);   // (conv_internal.hpp: packed hi / lo split, same bits as the scalar sequence)
+                    uh[ch >> 1] = h;
+                    ul[ch >> 1] = l;
                 }
+                const half8 vh = __builtin_bit_cast(half8, uh), vl = __builtin_bit_cast(half8, ul);
                 Xp[xslot[e]] = vh;
                 Xp[xslot[e] + a.span_pad] = vl;
             }

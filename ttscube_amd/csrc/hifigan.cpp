@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <map>
 #include <memory>
+#include <utility>
 
 #include "common.hpp"
 
@@ -74,7 +75,7 @@ struct ttsc_hifigan {
     // calibration data: 5 for the built-in probe).  An input whose largest value sits more than 2^-10 below that pushes every layer's
     // activations the same way (the generator is positively homogeneous up to its biases), the lo halves of the fp16 pairs drift into
     // subnormals and RELATIVE accuracy degrades silently (measured: 6e-5 relative at 2^-16, 2e-5 asked).  Such a forward is treated
-    // like an overflow: re-calibrate on the offending input and rerun.
+    // like an overflow — rerun with scales derived from the offending input — except that the handle's own scales are restored afterwards.
     float calib_in_absmax = 0.f;
     ~ttsc_hifigan() {
         if (flag_dev) (void)hipFree(flag_dev);
@@ -411,7 +412,7 @@ __global__ void fold_input_range_kernel(unsigned* w) {
 static bool input_too_low(const ttsc_hifigan* g, int idx = 1) {
     float m;
     memcpy(&m, &g->flag_host[idx], sizeof(float));
-    return g->calib_in_absmax > 0.f && std::isfinite(m) && m < g->calib_in_absmax * (1.f / 1024.f);
+    return g->calib_in_absmax > 0.f && std::isfinite(m) && m > 0.f && m < g->calib_in_absmax * (1.f / 1024.f);   // (an all-zero input has nothing to lose)
 }
 
 extern "C" int32_t ttsc_hifigan_range_status(ttsc_hifigan* g, void* stream) {
@@ -465,13 +466,35 @@ extern "C" int ttsc_hifigan_forward_ragged(ttsc_hifigan* g, const float* mel, in
         if (rc || !guard) return rc;
         TTSC_HIP_CHECK(hipMemcpyAsync(g->flag_host, g->flag_dev, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
         TTSC_HIP_CHECK(hipStreamSynchronize(s));
-        const bool low = attempt == 0 && input_too_low(g);   // (after the re-calibration the scales ARE this input's)
-        if (g->flag_host[0] == 0u && !low) return TTSC_OK;
+        const bool bad = g->flag_host[0] != 0u;
+        const bool low = attempt == 0 && !bad && input_too_low(g);
+        if (!bad && !low) return TTSC_OK;
         if (attempt == 1) break;
-        // a non-finite sample left conv_post: some layer's input overflowed the fp16 range its pre-scale was calibrated for
-        // (or the input itself is non-finite) — or the input sits far BELOW the range the scales were derived for (`low`).
-        // Re-derive the scales on THIS input and run the forward again.
         g->recalibrations++;
+        if (low) {
+            // The input sits far BELOW the range the scales were derived for: this forward is rerun with scales derived from the input itself,
+            // and the handle's own scales (normally the weight-only probe calibration) are put back afterwards — a quiet batch must not change
+            // what the next ordinary batch computes (two handles with the same weights stay bit-identical whatever they saw before).
+            std::vector<std::pair<ttsc_conv1d*, float>> saved;
+            for (auto& kv : g->layers) saved.emplace_back(kv.second->c, ttsc_conv1d_get_activation_scale(kv.second->c));
+            const float saved_absmax = g->calib_in_absmax;
+            rc = ttsc_hifigan_calibrate(g, mel, B, T, wav, ws, ws_bytes, stream);
+            if (!rc) {
+                TTSC_HIP_CHECK(hipMemsetAsync(g->flag_dev, 0, 2 * sizeof(unsigned), s));
+                rc = hifigan_run(g, mel, B, T, frames, wav, ws, ws_bytes, stream, nullptr);
+            }
+            if (!rc) {
+                TTSC_HIP_CHECK(hipMemcpyAsync(g->flag_host, g->flag_dev, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+                TTSC_HIP_CHECK(hipStreamSynchronize(s));
+            }
+            for (auto& sv : saved) (void)ttsc_conv1d_set_activation_scale(sv.first, sv.second);
+            g->calib_in_absmax = saved_absmax;
+            if (rc) return rc;
+            if (g->flag_host[0] == 0u) return TTSC_OK;
+            break;
+        }
+        // a non-finite sample left conv_post: some layer's input overflowed the fp16 range its pre-scale was calibrated for
+        // (or the input itself is non-finite).  Re-derive the scales on THIS input and run the forward again.
         rc = ttsc_hifigan_calibrate(g, mel, B, T, wav, ws, ws_bytes, stream);
         if (rc) return rc;
     }

@@ -40,6 +40,11 @@ struct MelArArgs {
 template <int NG, int UN>
 __device__ __forceinline__ void ar_chain(float (&acc)[NG], const float* __restrict__ wp, int rows, int gstride, int row,
                                          const float* v, int K) {
+    // The lane's row index is made opaque at every call: the persistent kernels call this inside their time-step loop with the same
+    // weights every step, so all UN x NG load addresses are loop-invariant — hoisted out of the step loop they are 64-bit per-lane
+    // values that do not fit the register file (round-3 review: up to 225 VGPRs in scratch, each reload a dependent
+    // scratch_load -> global_load pair inside the step).  Recomputing them per call is two VALU instructions per load.
+    asm volatile("" : "+v"(row));
     const float4* w4 = reinterpret_cast<const float4*>(wp) + row;
     const int KB = K >> 2;
     auto load = [&](float4 (&w)[UN][NG], int kb0) {
@@ -192,6 +197,13 @@ __global__ __launch_bounds__(512) void melar_split_kernel(MelArSplitArgs s) {
     for (int i = tid; i < M; i += 512) lm[i] = a.init_mel;
     float c1 = 0.f, c2 = 0.f;
     __syncthreads();
+    // this thread's slice of a weight matrix: k-slice ks (Kslice inputs) of gate rows j, j + H, ...; uniform base + one 32-bit lane offset
+    auto chain = [&](float (&acc)[1][4], const float* w, int Kslice, const float* v, int vstride) __attribute__((always_inline)) {
+        if ((Kslice >> 2) % 2 == 0)
+            lstm_chain_u<1, 4, 2>(acc, w, (unsigned)((ks * Kslice / 4) * H4 + j), H4, H, v, vstride, Kslice);
+        else
+            lstm_chain<1, 4, 2>(acc, w + (size_t)(ks * Kslice / 4) * H4 * 4, H4, H, j, v, vstride, Kslice);
+    };
     for (int t = 0; t < nsteps; ++t) {
         const int par = t & 1;
         auto mask = [&](int layer, int unit) -> float {
@@ -222,8 +234,8 @@ __global__ __launch_bounds__(512) void melar_split_kernel(MelArSplitArgs s) {
         // ---- LSTM layer 1, this member's units: partial sums over the k-slices of p2 and h1_{t-1} ----
         {
             float acc[1][4] = {{0.f, 0.f, 0.f, 0.f}};
-            lstm_chain<1, 4, 2>(acc, a.w_p2l + (size_t)(ks * KP / 4) * H4 * 4, H4, H, j, p2 + ks * KP, P, KP);
-            lstm_chain<1, 4, 2>(acc, a.w_hh1 + (size_t)(ks * KH / 4) * H4 * 4, H4, H, j, h1 + ks * KH, H, KH);
+            chain(acc, a.w_p2l, KP, p2 + ks * KP, P);
+            chain(acc, a.w_hh1, KH, h1 + ks * KH, H);
 #pragma unroll
             for (int g = 0; g < 4; ++g) part[(ks * 4 + g) * HU + u] = acc[0][g];
         }
@@ -244,8 +256,8 @@ __global__ __launch_bounds__(512) void melar_split_kernel(MelArSplitArgs s) {
         // ---- LSTM layer 2 ----
         {
             float acc[1][4] = {{0.f, 0.f, 0.f, 0.f}};
-            lstm_chain<1, 4, 2>(acc, a.w_ih2 + (size_t)(ks * KH / 4) * H4 * 4, H4, H, j, h1 + ks * KH, H, KH);
-            lstm_chain<1, 4, 2>(acc, a.w_hh2 + (size_t)(ks * KH / 4) * H4 * 4, H4, H, j, h2 + ks * KH, H, KH);
+            chain(acc, a.w_ih2, KH, h1 + ks * KH, H);
+            chain(acc, a.w_hh2, KH, h2 + ks * KH, H);
 #pragma unroll
             for (int g = 0; g < 4; ++g) part[(ks * 4 + g) * HU + u] = acc[0][g];
         }

@@ -202,17 +202,37 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
 
     // four channels (one lane's share of 8-channel group 4*mi + gi) of one column -> (hi, lo) halves in the image.
     // Written pairwise so that the conversions are packed: cvt_pk (hi), two cvt back, two subtractions, cvt_pk (lo).
+    // The image columns outside the sequence hold zeros (the convolutions pad with zeros): they are zeroed ONCE below and never written
+    // again — every later store is predicated on the lane's column being inside (an exec-masked ds_write instead of one v_cndmask per value).
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    auto image_ptr = [&](int mi, int ct, int gi) __attribute__((always_inline)) {
+        return reinterpret_cast<_Float16*>(P + (size_t)(((mi0 + mi) * 4 + gi) * 2) * PW + (IL ? ct * PQ + MARGQ + qw + l31 : MARG + colw + ct * 32 + l31)) + 4 * half;
+    };
     auto store_split = [&](int mi, int ct, int gi, float v0, float v1, float v2, float v3) __attribute__((always_inline)) {
         if (TTSC_DBG(a, 1)) return;
-        const float2v p0 = {v0, v1}, p1 = {v2, v3};
-        const half2v h0 = __builtin_convertvector(p0, half2v), h1 = __builtin_convertvector(p1, half2v);
-        const half2v l0 = __builtin_convertvector(p0 - __builtin_convertvector(h0, float2v), half2v);
-        const half2v l1 = __builtin_convertvector(p1 - __builtin_convertvector(h1, float2v), half2v);
-        const half4 vh = {h0[0], h0[1], h1[0], h1[1]}, vl = {l0[0], l0[1], l1[0], l1[1]};
-        _Float16* ph = reinterpret_cast<_Float16*>(P + (size_t)(((mi0 + mi) * 4 + gi) * 2) * PW + (IL ? ct * PQ + MARGQ + qw + l31 : MARG + colw + ct * 32 + l31)) + 4 * half;
-        *reinterpret_cast<half4*>(ph) = vh;
-        *reinterpret_cast<half4*>(ph + (size_t)PW * 8) = vl;
+        unsigned h0, l0, h1, l1;
+        split2_f16(v0, v1, h0, l0);
+        split2_f16(v2, v3, h1, l1);
+        const u32x2 vh = {h0, h1}, vl = {l0, l1};
+        _Float16* ph = image_ptr(mi, ct, gi);
+        if (pok[ct]) {
+            *reinterpret_cast<u32x2*>(ph) = vh;
+            *reinterpret_cast<u32x2*>(ph + (size_t)PW * 8) = vl;
+        }
     };
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+        if (!pok[ct]) {
+#pragma unroll
+            for (int mi = 0; mi < MIW; ++mi)
+#pragma unroll
+                for (int gi = 0; gi < 4; ++gi) {
+                    _Float16* ph = image_ptr(mi, ct, gi);
+                    const u32x2 z = {0u, 0u};
+                    *reinterpret_cast<u32x2*>(ph) = z;
+                    *reinterpret_cast<u32x2*>(ph + (size_t)PW * 8) = z;
+                }
+        }
     // image <- split(s * lrelu(x)), zero outside the sequence (the convolutions pad with zeros); s = power-of-two pre-scale
     auto xres_to_image = [&](float s) __attribute__((always_inline)) {
 #pragma unroll
@@ -224,9 +244,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float t = xres[mi][ct][4 * gi + e] * s;
-                        t = fmaxf(t, t * 0.1f);
-                        v[e] = pok[ct] ? t : 0.f;
+                        const float t = xres[mi][ct][4 * gi + e] * s;
+                        v[e] = fmaxf(t, t * 0.1f);
                     }
                     store_split(mi, ct, gi, v[0], v[1], v[2], v[3]);
                 }
@@ -234,14 +253,18 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
     // acc = sum over taps j and 16-channel chunks c of  W[j][c] x image[c][column + (j - (K-1)/2) * d]   (three split products).
     // Precondition: weight group 0 of `w` sits in slot 0, published by a barrier.  Ends with a barrier (every wave has
     // finished reading the image and the weight slots).
-    auto conv = [&](const half8* w, auto dtag, int d, f32x16 (&acc)[MIW][CT]) __attribute__((always_inline)) {
+    // c0 (or null = zeros): initial value of every accumulator tile of row tile mi — the first MFMA of a tile reads it as its C operand, so a
+    // per-channel constant (conv2's bias, pre-divided by the epilogue factor) joins the sum without a single extra instruction
+    auto conv = [&](const half8* w, auto dtag, int d, f32x16 (&acc)[MIW][CT], const f32x16* c0) __attribute__((always_inline)) {
         constexpr int D = decltype(dtag)::value;   // IL: the dilation (compile time); plain layout: unused (d is a run-time value)
+        if (!c0) {
 #pragma unroll
-        for (int mi = 0; mi < MIW; ++mi)
+            for (int mi = 0; mi < MIW; ++mi)
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
+                for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ct][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) acc[mi][ct][r] = 0.f;
+        }
         const half8* base = IL ? P + (size_t)(half * 2) * PW + MARGQ + qw + l31 : P + (size_t)(half * 2) * PW + MARG + colw + l31 - d * ((K - 1) / 2);
         // B fragment of step s (tap s / NCH, chunk s % NCH), plane pl (0 hi, 1 lo), column tile ct
         auto bfrag = [&](int s, int pl, int ct) __attribute__((always_inline)) -> const half8* {
@@ -287,7 +310,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
             for (int q = 0; q < NM; ++q) {
                 const int term = q / (MIW * CT), mi = (q / CT) % MIW, ct = q % CT;
                 acc[mi][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[s & 1][mi][term == 0 ? 1 : 0], Bf[s & 1][term == 1 ? 1 : 0][ct],
-                                                                   acc[mi][ct], 0, 0, 0);
+                                                                   (s == 0 && term == 0 && c0) ? c0[mi] : acc[mi][ct], 0, 0, 0);
                 if (q < 2 * CT && s + 1 < NS) Bf[(s + 1) & 1][q / CT][q % CT] = *bfrag(s + 1, q / CT, q % CT);
                 // weights of the next step: same group, or (three slots) the next group, published one barrier ago
                 if (q >= 2 * CT && q < 2 * CT + 2 * MIW && s + 1 < NS && ((s + 1) % GRP != 0 || NSLOT >= 3)) {
@@ -306,11 +329,11 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
     for (int p = 0; p < a.npairs; ++p) {
         f32x16 acc[MIW][CT];
         if constexpr (IL) {                    // (ends with a barrier: the image may be overwritten in place)
-            if (a.d1[p] == 1) conv(a.w1[p], IntTag<1>(), 1, acc);
-            else if (a.d1[p] == 3) conv(a.w1[p], IntTag<3>(), 3, acc);
-            else conv(a.w1[p], IntTag<5>(), 5, acc);
+            if (a.d1[p] == 1) conv(a.w1[p], IntTag<1>(), 1, acc, nullptr);
+            else if (a.d1[p] == 3) conv(a.w1[p], IntTag<3>(), 3, acc, nullptr);
+            else conv(a.w1[p], IntTag<5>(), 5, acc, nullptr);
         } else {
-            conv(a.w1[p], IntTag<0>(), a.d1[p], acc);
+            conv(a.w1[p], IntTag<0>(), a.d1[p], acc, nullptr);
         }
         stage_first(a.w2[p]);                  // conv2's first weight group(s) travel while the epilogue runs
         {
@@ -326,19 +349,18 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
                         float v[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float t = __builtin_fmaf(acc[mi][ct][4 * gi + e], us, bv[e]);
-                            t = fmaxf(t, t * 0.1f);
-                            v[e] = pok[ct] ? t : 0.f;
+                            const float t = __builtin_fmaf(acc[mi][ct][4 * gi + e], us, bv[e]);
+                            v[e] = fmaxf(t, t * 0.1f);
                         }
                         store_split(mi, ct, gi, v[0], v[1], v[2], v[3]);
                     }
                 }
         }
         if (!TTSC_DBG(a, 2)) __syncthreads();
-        conv(a.w2[p], IntTag<1>(), 1, acc);
-        if (p + 1 < a.npairs) stage_first(a.w1[p + 1]);
         {
-            const float us = a.us2[p];
+            // conv2's bias rides in the accumulators (divided by the epilogue factor, a power of two: exact), the residual add is the epilogue's fma
+            f32x16 bias_c[MIW];
+            const float inv_us = 1.f / a.us2[p];
             const float* bias = a.b2[p];
 #pragma unroll
             for (int mi = 0; mi < MIW; ++mi)
@@ -346,10 +368,19 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
                 for (int gi = 0; gi < 4; ++gi) {
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 32 * (mi0 + mi) + 8 * gi + 4 * half);
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) xres[mi][ct][4 * gi + e] += __builtin_fmaf(acc[mi][ct][4 * gi + e], us, bv[e]);
+                    for (int e = 0; e < 4; ++e) bias_c[mi][4 * gi + e] = bv[e] * inv_us;
                 }
+            conv(a.w2[p], IntTag<1>(), 1, acc, bias_c);
+        }
+        if (p + 1 < a.npairs) stage_first(a.w1[p + 1]);
+        {
+            const float us = a.us2[p];
+#pragma unroll
+            for (int mi = 0; mi < MIW; ++mi)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xres[mi][ct][r] = __builtin_fmaf(acc[mi][ct][r], us, xres[mi][ct][r]);
         }
         if (p + 1 < a.npairs) {
             xres_to_image(a.xs[p + 1]);

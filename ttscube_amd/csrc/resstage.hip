@@ -96,17 +96,24 @@ __device__ __forceinline__ void rs_stage_group(const StageCtx& c, const half8* w
     }
 }
 
-// four channels (one lane's share of 8-channel group 4*mi + gi) of one column -> (hi, lo) halves in the image
+// four channels (one lane's share of 8-channel group 4*mi + gi) of one column -> (hi, lo) halves in the image; `inside`: the lane's column
+// lies inside the sequence — columns outside are zeroed once by the kernel and never written again (same scheme as rbchain_f16x3_kernel)
 template <class G>
-__device__ __forceinline__ void rs_store_split(const StageCtx& c, int mi, int ct, int gi, float v0, float v1, float v2, float v3) {
-    const float2v p0 = {v0, v1}, p1 = {v2, v3};
-    const half2v h0 = __builtin_convertvector(p0, half2v), h1 = __builtin_convertvector(p1, half2v);
-    const half2v l0 = __builtin_convertvector(p0 - __builtin_convertvector(h0, float2v), half2v);
-    const half2v l1 = __builtin_convertvector(p1 - __builtin_convertvector(h1, float2v), half2v);
-    const half4 vh = {h0[0], h0[1], h1[0], h1[1]}, vl = {l0[0], l0[1], l1[0], l1[1]};
-    _Float16* ph = reinterpret_cast<_Float16*>(c.P + (size_t)((mi * 4 + gi) * 2) * G::PW + G::MARG + c.colw + ct * 32 + c.l31) + 4 * c.half;
-    *reinterpret_cast<half4*>(ph) = vh;
-    *reinterpret_cast<half4*>(ph + (size_t)G::PW * 8) = vl;
+__device__ __forceinline__ _Float16* rs_image_ptr(const StageCtx& c, int mi, int ct, int gi) {
+    return reinterpret_cast<_Float16*>(c.P + (size_t)((mi * 4 + gi) * 2) * G::PW + G::MARG + c.colw + ct * 32 + c.l31) + 4 * c.half;
+}
+template <class G>
+__device__ __forceinline__ void rs_store_split(const StageCtx& c, int mi, int ct, int gi, bool inside, float v0, float v1, float v2, float v3) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    unsigned h0, l0, h1, l1;
+    split2_f16(v0, v1, h0, l0);
+    split2_f16(v2, v3, h1, l1);
+    const u32x2 vh = {h0, h1}, vl = {l0, l1};
+    _Float16* ph = rs_image_ptr<G>(c, mi, ct, gi);
+    if (inside) {
+        *reinterpret_cast<u32x2*>(ph) = vh;
+        *reinterpret_cast<u32x2*>(ph + (size_t)G::PW * 8) = vl;
+    }
 }
 
 // image <- split(s * lrelu(x)), zero outside the sequence
@@ -121,11 +128,10 @@ __device__ __forceinline__ void rs_xres_to_image(const StageCtx& c, const f32x16
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float t = xres[mi][ct][4 * gi + e] * s;
-                    t = fmaxf(t, t * 0.1f);
-                    v[e] = pok[ct] ? t : 0.f;
+                    const float t = xres[mi][ct][4 * gi + e] * s;
+                    v[e] = fmaxf(t, t * 0.1f);
                 }
-                rs_store_split<G>(c, mi, ct, gi, v[0], v[1], v[2], v[3]);
+                rs_store_split<G>(c, mi, ct, gi, pok[ct], v[0], v[1], v[2], v[3]);
             }
 }
 
@@ -134,15 +140,17 @@ __device__ __forceinline__ void rs_xres_to_image(const StageCtx& c, const f32x16
 // barrier.  `wnext` (or null): the convolution that follows in the same chain — its group 0 leaves for slot (SLOT0 + NGRP) & 1 when this
 // convolution's last group starts.  Ends with a barrier (every wave has finished reading the image and the weight slots).
 template <class G, int K, int SLOT0>
-__device__ __forceinline__ void rs_conv(const StageCtx& c, const half8* w, const half8* wnext, int d, f32x16 (&acc)[G::MI][G::CT]) {
+__device__ __forceinline__ void rs_conv(const StageCtx& c, const half8* w, const half8* wnext, int d, f32x16 (&acc)[G::MI][G::CT], const f32x16* c0) {
     constexpr int MI = G::MI, CT = G::CT, NCH = G::NCH, PW = G::PW;
     constexpr int GRP = rs_grp(MI, K), NS = K * NCH, NGRP = (NS + GRP - 1) / GRP, GRP_ITEMS = GRP * G::STEP_ITEMS;
+    if (!c0) {   // (c0: initial accumulator value per row tile, read by the first MFMA of every tile as its C operand — conv2's bias)
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+            for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ct][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[mi][ct][r] = 0.f;
+    }
     const half8* base = c.P + (size_t)(c.half * 2) * PW + G::MARG + c.colw + c.l31 - d * ((K - 1) / 2);
     half8 Af[2][MI][2];
     half8 Bh[2][CT];   // B fragments, hi plane: used by the first and the last product of a step -> double-buffered
@@ -176,7 +184,8 @@ __device__ __forceinline__ void rs_conv(const StageCtx& c, const half8* w, const
 #pragma unroll
         for (int q = 0; q < NM; ++q) {
             const int term = q / CT, ct = q % CT;
-            acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[s & 1][0][term == 0 ? 1 : 0], term == 1 ? Bl[ct] : Bh[s & 1][ct], acc[0][ct], 0, 0, 0);
+            acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[s & 1][0][term == 0 ? 1 : 0], term == 1 ? Bl[ct] : Bh[s & 1][ct],
+                                                              (s == 0 && term == 0 && c0) ? c0[0] : acc[0][ct], 0, 0, 0);
             if (s + 1 < NS) {
                 if (term == 0) Bh[(s + 1) & 1][ct] = bpn[ct * 32];
                 if (term == 1) Bl[ct] = bpn[PW + ct * 32];
@@ -199,7 +208,7 @@ __device__ __forceinline__ void rs_block(const StageCtx& c, const StageBlock& bk
     __syncthreads();    // (also publishes group 0 of w1[0], sent by the caller)
     for (int p = 0; p < RS_NP; ++p) {
         f32x16 acc[MI][CT];
-        rs_conv<G, K, 0>(c, bk.w1[p], bk.w2[p], bk.d1[p], acc);
+        rs_conv<G, K, 0>(c, bk.w1[p], bk.w2[p], bk.d1[p], acc, nullptr);
         {
             const float us = bk.us1[p];
             const float* bias = bk.b1[p];
@@ -213,18 +222,17 @@ __device__ __forceinline__ void rs_block(const StageCtx& c, const StageBlock& bk
                         float v[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float t = __builtin_fmaf(acc[mi][ct][4 * gi + e], us, bv[e]);
-                            t = fmaxf(t, t * 0.1f);
-                            v[e] = pok[ct] ? t : 0.f;
+                            const float t = __builtin_fmaf(acc[mi][ct][4 * gi + e], us, bv[e]);
+                            v[e] = fmaxf(t, t * 0.1f);
                         }
-                        rs_store_split<G>(c, mi, ct, gi, v[0], v[1], v[2], v[3]);
+                        rs_store_split<G>(c, mi, ct, gi, pok[ct], v[0], v[1], v[2], v[3]);
                     }
                 }
         }
         __syncthreads();
-        rs_conv<G, K, SLOT1>(c, bk.w2[p], p + 1 < RS_NP ? bk.w1[p + 1] : nullptr, 1, acc);
         {
-            const float us = bk.us2[p];
+            f32x16 bias_c[MI];
+            const float inv_us = 1.f / bk.us2[p];
             const float* bias = bk.b2[p];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
@@ -232,10 +240,18 @@ __device__ __forceinline__ void rs_block(const StageCtx& c, const StageBlock& bk
                 for (int gi = 0; gi < 4; ++gi) {
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 32 * mi + 8 * gi + 4 * c.half);
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) xres[mi][ct][4 * gi + e] += __builtin_fmaf(acc[mi][ct][4 * gi + e], us, bv[e]);
+                    for (int e = 0; e < 4; ++e) bias_c[mi][4 * gi + e] = bv[e] * inv_us;
                 }
+            rs_conv<G, K, SLOT1>(c, bk.w2[p], p + 1 < RS_NP ? bk.w1[p + 1] : nullptr, 1, acc, bias_c);
+        }
+        {
+            const float us = bk.us2[p];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xres[mi][ct][r] = __builtin_fmaf(acc[mi][ct][r], us, xres[mi][ct][r]);
         }
         if (p + 1 < RS_NP) {
             rs_xres_to_image<G>(c, xres, pok, bk.xs[p + 1]);
@@ -301,6 +317,20 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rbstage_f16x3_kernel(StageArg
         const int pos = pos_w + ct * 32;
         pok[ct] = pos >= 0 && pos < lin;
     }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+        if (!pok[ct]) {   // columns outside the sequence: zero, once (every later image store is predicated on the column being inside)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int gi = 0; gi < 4; ++gi) {
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    _Float16* ph = rs_image_ptr<G>(c, mi, ct, gi);
+                    const u32x2 z = {0u, 0u};
+                    *reinterpret_cast<u32x2*>(ph) = z;
+                    *reinterpret_cast<u32x2*>(ph + (size_t)G::PW * 8) = z;
+                }
+        }
     f32x16 xres[MI][CT], ysum[MI][CT];
     rs_load_x<G>(xb, a.L, lin, pos_w, c.half, xres);
     rs_block<G, K0>(c, a.blk[0], xres, pok);

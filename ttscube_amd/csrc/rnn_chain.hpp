@@ -12,6 +12,11 @@ __device__ __forceinline__ void lstm_chain(float (&acc)[BT][NG], const float* __
     // issued back to back into one register set while the fmaf chain consumes the other set.  Left to itself hipcc
     // places each load right before its use and waits vmcnt(0) per load, i.e. one L2 round trip per 16 bytes.
     // The chain order (k ascending, one fmaf per term) is unchanged.
+    // The lane's row index is made opaque at every call: the persistent kernels call this inside their time-step loop with the same
+    // weights every step, so all UN x NG load addresses are loop-invariant — hoisted out of the step loop they are 64-bit per-lane
+    // values that do not fit the register file (round-3 review: up to 225 VGPRs in scratch, each reload a dependent
+    // scratch_load -> global_load pair inside the step).  Recomputing them per call is two VALU instructions per load.
+    asm volatile("" : "+v"(row));
     const float4* w4 = reinterpret_cast<const float4*>(wp) + row;
     const int KB = K >> 2;
     auto load = [&](float4 (&w)[UN][NG], int kb0) {
@@ -67,6 +72,54 @@ __device__ __forceinline__ void lstm_chain(float (&acc)[BT][NG], const float* __
                 }
             }
         }
+    }
+}
+
+// The same chain with the weight address split into a WAVE-UNIFORM base (a kernel-argument pointer) and ONE 32-bit lane offset (in
+// float4 units: the lane's row plus whatever k-slice offset it owns).  Every load is then `global_load_dwordx4 v, v_off, s[base]` with
+// the k-block / gate part of the address folded into the scalar base: one address register for the whole chain instead of UN x NG
+// running 64-bit per-lane pointers (which is what the persistent kernels spilled: see lstm_chain).
+template <int BT, int NG, int UN>
+__device__ __forceinline__ void lstm_chain_u(float (&acc)[BT][NG], const float* __restrict__ wbase, unsigned lane_off4, int rows, int gstride,
+                                               const float* v, int vstride, int K) {
+    asm volatile("" : "+v"(lane_off4));
+    const int KB = K >> 2;
+    const float4* wu = reinterpret_cast<const float4*>(wbase);
+    auto load = [&](float4 (&w)[UN][NG], int kb0) {
+#pragma unroll
+        for (int q = 0; q < UN; ++q)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const float4* ub = wu + ((size_t)(kb0 + q) * rows + (size_t)g * gstride);   // uniform
+                w[q][g] = ub[lane_off4];
+            }
+    };
+    auto fma_batch = [&](const float4 (&w)[UN][NG], int kb0) {
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+#pragma unroll
+            for (int u = 0; u < BT; ++u) {
+                const float4 hv = *reinterpret_cast<const float4*>(v + u * vstride + 4 * (kb0 + q));
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    float x = acc[u][g];
+                    x = fmaf(w[q][g].x, hv.x, x);
+                    x = fmaf(w[q][g].y, hv.y, x);
+                    x = fmaf(w[q][g].z, hv.z, x);
+                    x = fmaf(w[q][g].w, hv.w, x);
+                    acc[u][g] = x;
+                }
+            }
+        }
+    };
+    float4 wa[UN][NG], wb[UN][NG];
+    const int NB = KB / UN;   // caller guarantees KB % UN == 0
+    load(wa, 0);
+    for (int bi = 0; bi < NB; bi += 2) {
+        if (bi + 1 < NB) load(wb, (bi + 1) * UN);
+        fma_batch(wa, bi * UN);
+        if (bi + 2 < NB) load(wa, (bi + 2) * UN);
+        if (bi + 1 < NB) fma_batch(wb, (bi + 1) * UN);
     }
 }
 

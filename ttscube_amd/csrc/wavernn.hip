@@ -111,6 +111,7 @@ __device__ __forceinline__ void chain_matvec(float (&acc)[BT][NG], const float* 
     // issued back to back into one register set while the fmaf chain consumes the other set.  Left to itself hipcc
     // places each load right before its use and waits vmcnt(0) per load, i.e. one L2 round trip per 16 bytes.
     // The chain order (k ascending, one fmaf per term) is unchanged.
+    asm volatile("" : "+v"(row));   // (keeps the UN x NG load addresses from being hoisted out of the caller's step loop as 64-bit per-lane values: see rnn_chain.hpp)
     const float4* w4 = reinterpret_cast<const float4*>(wp) + row;
     const int KB = K >> 2;
     auto load = [&](float4 (&w)[UN][NG], int kb0) {

@@ -251,12 +251,22 @@ __device__ __forceinline__ float fma_chain_lds(const float4* w4, int wstride, co
 // (L2 latency), while the h words (LDS latency) are read only two k-blocks ahead — which keeps the register count of the
 // two-accumulator recurrent blocks at ~100 instead of ~200.
 template <int NB, int UN>
-__device__ __forceinline__ void mfma_chain_g(f32x4_t (&acc)[NB], const float4* w4, int wstride, const float* hb, int vstride, int K) {
+// Wu = WAVE-UNIFORM base of the weight block, lrow = this lane's row: every load is (scalar base of k-block kb0 + q) + (one 32-bit lane
+// offset) — written as w4 + lane and stepped by a run-time stride the compiler kept UN running 64-bit per-lane pointers (16 VGPRs),
+// five of which lived in scratch and were reloaded, one dependent scratch_load -> global_load pair after the other, in every step.
+__device__ __forceinline__ void mfma_chain_g(f32x4_t (&acc)[NB], const float4* Wu, int lrow_, int wstride, const float* hb, int vstride, int K) {
     static_assert(UN % 4 == 0, "UN is consumed in pairs of pairs");
     const int KB = K >> 2;
+    // the lane offset is made opaque HERE, inside the caller's step loop: the first batch's addresses are loop-invariant, and hoisted out of the
+    // step loop they are 64-bit per-lane values again (that is what was spilled); recomputed per step they are scalar base + this one register
+    unsigned lrow = (unsigned)lrow_;
+    asm volatile("" : "+v"(lrow));
     auto loadw = [&](float4 (&w)[UN], int kb0) {
 #pragma unroll
-        for (int q = 0; q < UN; ++q) w[q] = w4[(size_t)(kb0 + q) * wstride];
+        for (int q = 0; q < UN; ++q) {
+            const float4* rb = Wu + (size_t)(kb0 + q) * wstride;   // uniform
+            w[q] = rb[lrow];
+        }
     };
     auto readh = [&](float4 (&hv)[2][NB], int kb) {
 #pragma unroll
@@ -319,7 +329,7 @@ __device__ __forceinline__ void mfma_chain_g(f32x4_t (&acc)[NB], const float4* w
             fma_batch(wa, bi * UN);
         }
     } else {
-        mfma_chain<NB, 1>(acc, w4, wstride, hb, vstride, K);
+        mfma_chain<NB, 1>(acc, Wu + lrow, wstride, hb, vstride, K);
     }
 }
 
@@ -345,7 +355,12 @@ __device__ __noinline__ void wt_row_block(const glb_float* W_g, const lds_float*
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[nb][i] = bias[min(r0 + mrow + i, R3 - 1)];
-    mfma_chain_g<2, WT_STREAM_UN>(acc, reinterpret_cast<const float4*>(W) + min(r0 + lane, R3 - 1), R3, v + mutt * VH, VH, H);
+    // (an out-of-line function receives its arguments in vector registers: tell the compiler which of them are wave-uniform)
+    const unsigned long long wu = (unsigned long long)reinterpret_cast<uintptr_t>(W);
+    const unsigned w_lo = __builtin_amdgcn_readfirstlane((unsigned)wu), w_hi = __builtin_amdgcn_readfirstlane((unsigned)(wu >> 32));
+    const float4* Wu = reinterpret_cast<const float4*>((uintptr_t)(((unsigned long long)w_hi << 32) | w_lo));
+    const int R3u = __builtin_amdgcn_readfirstlane(R3), Hu = __builtin_amdgcn_readfirstlane(H);
+    mfma_chain_g<2, WT_STREAM_UN>(acc, Wu, min(r0 + lane, R3 - 1), R3u, v + mutt * VH, VH, Hu);
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -658,7 +673,7 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
                 for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[nb][i] = bhh_m[min(r0 + mrow + i, R3 - 1)];
-                mfma_chain_g<2, WT_STREAM_UN>(acc, reinterpret_cast<const float4*>(Whh) + min(r0 + lane, R3 - 1), R3, hvec + mutt * VH, VH, H);
+                mfma_chain_g<2, WT_STREAM_UN>(acc, reinterpret_cast<const float4*>(Whh), min(r0 + lane, R3 - 1), R3, hvec + mutt * VH, VH, H);
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
