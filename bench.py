@@ -23,7 +23,7 @@ if ROOT not in sys.path:
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (no sparsity)
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_CSV = os.path.join(ROOT, 'profiles', 'r03_bench_hbm_pmc.csv')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this workload
+TRAFFIC_CSV = os.path.join(ROOT, 'profiles', 'r04_bench_hbm_pmc.csv')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this workload
 
 
 def measured_traffic(precision, B, T):

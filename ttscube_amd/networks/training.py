@@ -384,6 +384,9 @@ def vocoder_training_step(voc, batch, optimizers, reducers=None):
     loss_lr = wavernn_train_loss(voc._wavernn_lr, {'x': batch['x_low'], 'mel': batch['mel']})
     loss_lr.backward()
     loss_hr.backward()
+    # a split recurrence that timed out on a hand-off has produced garbage gradients: find out BEFORE they are exchanged with the other ranks and
+    # applied — the step already synchronises here for the gradient norms, so the check costs nothing extra
+    _lib.check_split_status('vocoder_training_step (before the update)')
     if reducers:
         reducers[0].reduce()
         reducers[1].reduce()
