@@ -39,6 +39,7 @@ def main():
     ap.add_argument('--C', type=int, default=32)
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--shapes', default='0,1,2,3,4')
+    ap.add_argument('--acc', type=int, default=0, help='1: time the chain launches as y += chain(x) (how the second and third block of a stage run)')
     ap.add_argument('--data', choices=('random', 'zeros'), default='random', help='zeros: all-zero input, weights and biases (how much of the time is the power budget)')
     a = ap.parse_args()
     L_ = _lib.lib()
@@ -85,7 +86,7 @@ def main():
         row = []
         for j, (k, _, _) in enumerate(blocks):
             try:
-                ms = timed(lambda: chain(j, sh, 0), a.iters)
+                ms = timed(lambda: chain(j, sh, a.acc), a.iters)
                 row.append('K=%2d %.3f ms (%.3f)' % (k, ms, flops_k[k] / ms / 1e9 / ceiling))
             except _lib.TTSCError as e:
                 row.append('K=%2d n/a' % k)

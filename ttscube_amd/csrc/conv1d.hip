@@ -1219,11 +1219,27 @@ extern "C" int ttsc_conv1d_set_nonfinite_flag(ttsc_conv1d* c, uint32_t* flag_dev
 
 namespace ttsc {
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+    __shared__ float red[4];
     float m = 0.f;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {   // 16-byte loads over the aligned body, the tail element-wise
+        const long n4 = n >> 2;
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        for (long i = i0; i < n4; i += stride) {
+            const float4 v = x4[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+        for (long i = (n4 << 2) + i0; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
+    } else {
+        for (long i = i0; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));   // non-negative floats order like their bit patterns
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    // ONE atomic per workgroup (the first version sent one per wave from up to 4096 workgroups to the same word: 0.19 ms for a 16 MB tensor)
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));   // non-negative floats order like their bit patterns
 }
 }  // namespace ttsc
 
@@ -1231,7 +1247,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
 // bit pattern, which compares above every finite value: the caller sees it.
 extern "C" int ttsc_absmax(const float* x_dev, int64_t n, float* out_dev, void* stream) {
     TTSC_REQUIRE(x_dev && out_dev && n > 0, "ttsc_absmax: bad argument");
-    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    const int blocks = (int)std::min<int64_t>((n / 4 + 255) / 256 + 1, 1024);
     hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x_dev, (long)n, reinterpret_cast<unsigned*>(out_dev));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -398,18 +398,28 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
         if (t == 12345.678f) a.y[0] = 1.f;
         return;
     }
+    // The lane geometry of the final store is derived AFRESH from the thread index (made opaque so that it is not merged with the copies at the
+    // top of the kernel): kept live across the whole chain these values were the last registers in scratch (one store before the pair loop, one
+    // reload after it) of the 8-wave variants.
+    int tid_f = threadIdx.x;
+    asm volatile("" : "+v"(tid_f));
+    const int lane_f = tid_f & 63, wv_f = tid_f >> 6;
+    const int half_f = lane_f >> 5, l31_f = lane_f & 31;
+    const int mi0_f = (wv_f / WN) * MIW;
+    const int colw_f = (wv_f % WN) * (CT * 32);
+    const int pos_w_f = q0 - a.halo + colw_f + (IL ? CT * l31_f : l31_f);
     float* yb = a.y + (size_t)b * C * a.L;
     if (IL && vec) {
         // the lane's CT columns of a channel are CT consecutive samples of the row: one vector access per channel
-        const int col0 = colw + CT * l31;
-        const bool ok = col0 >= a.halo && col0 + CT <= a.halo + a.nto && pos_w + CT <= lin;
-        const unsigned voff = (unsigned)(4 * half * a.L + (ok ? pos_w : 0));
+        const int col0 = colw_f + CT * l31_f;
+        const bool ok = col0 >= a.halo && col0 + CT <= a.halo + a.nto && pos_w_f + CT <= lin;
+        const unsigned voff = (unsigned)(4 * half_f * a.L + (ok ? pos_w_f : 0));
 #pragma unroll
         for (int mi = 0; mi < MIW; ++mi) {
             fvecT yv[16];
             if (a.accumulate) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) yv[r] = *reinterpret_cast<const fvecT*>(yb + (size_t)(32 * (mi0 + mi) + (r & 3) + 8 * (r >> 2)) * a.L + voff);
+                for (int r = 0; r < 16; ++r) yv[r] = *reinterpret_cast<const fvecT*>(yb + (size_t)(32 * (mi0_f + mi) + (r & 3) + 8 * (r >> 2)) * a.L + voff);
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) yv[r] = fvecT(0.f);
@@ -419,14 +429,14 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
                 fvecT o;
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) o[ct] = xres[mi][ct][r] + yv[r][ct];
-                if (ok) *reinterpret_cast<fvecT*>(yb + (size_t)(32 * (mi0 + mi) + (r & 3) + 8 * (r >> 2)) * a.L + voff) = o;
+                if (ok) *reinterpret_cast<fvecT*>(yb + (size_t)(32 * (mi0_f + mi) + (r & 3) + 8 * (r >> 2)) * a.L + voff) = o;
             }
         }
         return;
     }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-        const int col = colw + (IL ? CT * l31 + ct : ct * 32 + l31);
+        const int col = colw_f + (IL ? CT * l31_f + ct : ct * 32 + l31_f);
         const int pos = q0 - a.halo + col;
         const bool ok = col >= a.halo && col < a.halo + a.nto && pos < lin;
         const int pc = ok ? pos : 0;
@@ -436,7 +446,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
             if (a.accumulate) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int ch = 32 * (mi0 + mi) + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int ch = 32 * (mi0_f + mi) + (r & 3) + 8 * (r >> 2) + 4 * half_f;
                     yv[r] = yb[(size_t)ch * a.L + pc];
                 }
             } else {
@@ -445,7 +455,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ch = 32 * (mi0 + mi) + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int ch = 32 * (mi0_f + mi) + (r & 3) + 8 * (r >> 2) + 4 * half_f;
                 if (ok) yb[(size_t)ch * a.L + pc] = xres[mi][ct][r] + yv[r];
             }
         }
@@ -579,7 +589,7 @@ extern "C" int ttsc_rbchain_forward(const ttsc_conv1d* const* convs1, const ttsc
         // default: the big tile once the halo would eat more than ~1/6 of the small one; at 64 channels the big tile also wins
         // for K = 3 (measured 1.54 vs 1.81 ms per ResBlock at config[1]) as long as it still fills the chip
         const int small = C == 32 ? 512 : 256;
-        shape = (2 * a.halo * 8 > small) ? 1 : 0;   // (round 4: K = 7 at 32 channels moved to the large tile: 3.26 vs 3.42 ms with interleaved columns)
+        shape = (2 * a.halo * 6 > small) ? 1 : 0;
         if (C == 64 && (int64_t)B * ceil_div(L, 2 * small - 2 * a.halo) >= 256) shape = 1;
         auto_shape = true;
     }
@@ -589,6 +599,10 @@ extern "C" int ttsc_rbchain_forward(const ttsc_conv1d* const* convs1, const ttsc
     bool il_ok = true;
     for (int p = 0; p < npairs; ++p) il_ok = il_ok && (a.d1[p] == 1 || a.d1[p] == 3 || a.d1[p] == 5);
     if (shape >= 10 && !il_ok) shape -= 10;
+    // (measured at config[1], round 4, y += chain(x): K = 3 small tile 1.84 ms interleaved vs 1.92 plain; K = 7 small tile 3.43 plain vs 3.50
+    // interleaved vs 3.49 large interleaved; K = 11 large tile 4.90 interleaved with 6-step weight groups vs 5.12 plain — the K = 7 block at
+    // 32 channels keeps the plain small tile)
+    if (auto_shape && C == 32 && k == 7 && shape == 0) il_ok = false;
     if (shape >= 0 && shape <= 1 && il_env && il_ok) shape += 10;
     if (auto_shape && shape == 11 && C == 32) shape = 12;   // large tile at 32 channels: 6-step weight groups fit beside the image (one barrier per 6 k-steps)
     if (shape == 12 && !(C == 32)) shape = 11;
