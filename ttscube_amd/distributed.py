@@ -139,6 +139,7 @@ class ArenaReducer:
         self._order = None           # agreed issue order of the chunks (list of chunk indices), None until recorded
         self._seen = []              # recording pass: chunks in the order they completed on this rank
         self._next = 0               # position in _order of the next chunk to issue
+        self._ex_stream = None       # the stream early chunks are prepared and sent from (see _launch)
         opt.on_build(self._on_build)
 
     def _active(self):
@@ -217,24 +218,40 @@ class ArenaReducer:
     def _launch(self, c):
         world = dist.get_world_size(self.group)
         g = self.opt.g
+        ctx = None
         if g.is_cuda and self._armed:
-            # launched from a gradient hook, i.e. inside backward(): the parameters of this chunk may have received their gradients on different
-            # streams (hifigan/streams.py runs independent sub-graphs on side streams); wait for all of them before the chunk is read
-            from .hifigan.streams import join_side_streams
-            join_side_streams(g.device, include_default=True)
-        if c['buf'] is None:   # ragged tail: stage into a padded buffer
-            if 'stage' not in c:
-                c['stage'] = torch.zeros(c['pad'], dtype=torch.float32, device=g.device)
-            c['stage'][:c['e'] - c['s']].copy_(g[c['s']:c['e']])
-            flat = c['stage']
-        else:
-            flat = c['buf']
-        flat.div_(world)
-        c['flat'] = flat
-        if self.use_rs:
-            c['work'] = dist.reduce_scatter_tensor(c['shard'], flat, group=self.group, async_op=True)
-        else:
-            c['work'] = dist.all_reduce(flat, group=self.group, async_op=True)
+            # Launched from a gradient hook, i.e. inside backward(): the parameters of this chunk may have received their gradients on different
+            # streams (hifigan/streams.py runs independent sub-graphs on side streams; an AccumulateGrad node runs on the stream of the parameter's
+            # first use, which may be the default stream or a side stream).  The chunk is therefore prepared and sent from a stream of its OWN
+            # that waits for the current stream, the default stream and every side stream — none of THEM waits for anything, so the backward
+            # pass keeps its multi-stream overlap (round 4: making the hook's current stream do the waiting cost 3.6 ms per step).
+            from .hifigan.streams import side_streams_of
+            if self._ex_stream is None:
+                self._ex_stream = torch.cuda.Stream(device=g.device)
+            ex = self._ex_stream
+            ex.wait_stream(torch.cuda.current_stream(g.device))
+            ex.wait_stream(torch.cuda.default_stream(g.device))
+            for st in side_streams_of(g.device):
+                ex.wait_stream(st)
+            ctx = torch.cuda.stream(ex)
+            ctx.__enter__()
+        try:
+            if c['buf'] is None:   # ragged tail: stage into a padded buffer
+                if 'stage' not in c:
+                    c['stage'] = torch.zeros(c['pad'], dtype=torch.float32, device=g.device)
+                c['stage'][:c['e'] - c['s']].copy_(g[c['s']:c['e']])
+                flat = c['stage']
+            else:
+                flat = c['buf']
+            flat.div_(world)
+            c['flat'] = flat
+            if self.use_rs:
+                c['work'] = dist.reduce_scatter_tensor(c['shard'], flat, group=self.group, async_op=True)
+            else:
+                c['work'] = dist.all_reduce(flat, group=self.group, async_op=True)
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
 
     @torch.no_grad()
     def reduce(self):

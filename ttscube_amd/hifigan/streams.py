@@ -44,6 +44,12 @@ def fan_out(jobs, dev):
     return [r for _, r in outs]
 
 
+def side_streams_of(dev):
+    """the side streams created so far on `dev` (for code that must order its own stream behind all of them)"""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    return list(_SIDE.get(key, []))
+
+
 def join_side_streams(dev, include_default=False):
     """make the CURRENT stream wait for everything queued so far on the side streams of `dev`.  For code that runs inside a backward pass and reads
     results of several sub-graphs — the gradient-exchange hooks of distributed.ArenaReducer: the host-side order of autograd nodes says nothing about
