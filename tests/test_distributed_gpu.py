@@ -103,12 +103,11 @@ def test_arena_reducer_hooks_and_side_streams_under_rccl_world1():
         dist.destroy_process_group()
     assert early[0] == (0, 0, 0) and early[1] == (0, 0, 0)          # layout step, order-recording step
     assert all(sum(e) > 0 for e in early[2:]), early                # then chunks leave while backward() is still running
+    # the step itself is bit-reproducible (since round 4: the phoneme -> frame expansion no longer differentiates through torch.gather's
+    # float-atomic scatter), so "the exchange changes nothing" can be asked for bit by bit
+    assert deterministic, 'two identical 5-step runs without exchange differ: the training step lost its reproducibility'
     worst = max(float((a - b).abs().max() / (b.abs().max() + 1e-12)) for a, b in zip(got, ref))
-    if deterministic:
-        assert all(torch.equal(a, b) for a, b in zip(got, ref)), worst
-    else:   # (the step itself is not bit-reproducible on this build: hold the exchange to the run-to-run spread instead)
-        spread = max(float((a - b).abs().max() / (b.abs().max() + 1e-12)) for a, b in zip(twice, ref))
-        assert worst <= 4 * spread + 1e-6, (worst, spread)
+    assert all(torch.equal(a, b) for a, b in zip(got, ref)), worst
 
 
 def _world2_worker(rank, port, q):

@@ -143,12 +143,19 @@ def languasito_forward_train(lang, X):
         return torch.cat([h, spk.repeat(1, h.shape[1], 1)], dim=-1)
 
     def expand(x, alignments):
+        """phoneme rows -> frame rows (modules.py:1043-1053).  A row gather whose backward adds the frames of a phoneme in a FIXED order
+        (text_autograd.HipEmbeddingFn: ttsc_rows_gather / ttsc_rows_scatter_add) — torch.gather's backward is a scatter of float atomics, and its
+        run-to-run rounding noise, amplified by AdamW's normalisation, made the whole step irreproducible (round 4: ~440 of 900 parameter
+        tensors differed between two identical 5-step runs)."""
+        from .text_autograd import HipEmbeddingFn
+        B_, N_, C_ = x.shape
         m = max(len(a) for a in alignments)
         idx = torch.zeros((len(alignments), m), dtype=torch.long)
         for b, a in enumerate(alignments):
             idx[b, :len(a)] = torch.as_tensor(a)
             idx[b, len(a):] = a[-1]
-        return torch.gather(x, 1, idx.to(x.device)[:, :, None].expand(-1, -1, x.shape[2]))
+        flat = (idx + torch.arange(B_, dtype=torch.long)[:, None] * N_).to(x.device)
+        return HipEmbeddingFn.apply(x.reshape(B_ * N_, C_), flat, None)
 
     hcs = stack('t')
     hd = lstm_forward_train(lang._dur_rnn, hcs)
