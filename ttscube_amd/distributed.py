@@ -112,6 +112,12 @@ class FlatBucketReducer:
                 p.grad = v
 
 
+# measurement switches (tools/probes/train_hook_overhead.py): which stream prepares and sends an early chunk ('own' = a dedicated stream that waits for
+# the default stream and all side streams; 'current' = round 3's behaviour), and whether anything leaves before reduce() at all
+_EX_STREAM_MODE = __import__('os').environ.get('TTSC_EXCHANGE_STREAM', 'own')
+_EARLY_OFF = __import__('os').environ.get('TTSC_EXCHANGE_EARLY', '1') == '0'
+
+
 class ArenaReducer:
     """Gradient exchange of a `ttscube_amd.optim.FlatAdamW` group, overlapped with the backward pass that produces the gradients.
 
@@ -185,6 +191,8 @@ class ArenaReducer:
 
     def _issue_ready(self):
         """launch, in the agreed order, every chunk that is complete and whose predecessors have all left"""
+        if _EARLY_OFF:   # (measurement switch TTSC_EXCHANGE_EARLY=0: the hooks count, nothing leaves before reduce())
+            return
         while self._next < len(self._order):
             c = self._chunks[self._order[self._next]]
             if c['left'] != 0 or c['work'] is not None:
@@ -225,16 +233,22 @@ class ArenaReducer:
             # first use, which may be the default stream or a side stream).  The chunk is therefore prepared and sent from a stream of its OWN
             # that waits for the current stream, the default stream and every side stream — none of THEM waits for anything, so the backward
             # pass keeps its multi-stream overlap (round 4: making the hook's current stream do the waiting cost 3.6 ms per step).
-            from .hifigan.streams import side_streams_of
-            if self._ex_stream is None:
-                self._ex_stream = torch.cuda.Stream(device=g.device)
-            ex = self._ex_stream
-            ex.wait_stream(torch.cuda.current_stream(g.device))
-            ex.wait_stream(torch.cuda.default_stream(g.device))
-            for st in side_streams_of(g.device):
-                ex.wait_stream(st)
-            ctx = torch.cuda.stream(ex)
-            ctx.__enter__()
+            from .hifigan.streams import join_side_streams, side_streams_of
+            _mode = _EX_STREAM_MODE
+            if _mode == 'own':
+                if self._ex_stream is None:
+                    self._ex_stream = torch.cuda.Stream(device=g.device)
+                ex = self._ex_stream
+                ex.wait_stream(torch.cuda.current_stream(g.device))
+                ex.wait_stream(torch.cuda.default_stream(g.device))
+                for st in side_streams_of(g.device):
+                    ex.wait_stream(st)
+                ctx = torch.cuda.stream(ex)
+                ctx.__enter__()
+            elif _mode == 'current':      # (measurement: round 3's behaviour — the hook's own stream waits for the side streams)
+                join_side_streams(g.device)
+            elif _mode == 'current+default':
+                join_side_streams(g.device, include_default=True)
         try:
             if c['buf'] is None:   # ragged tail: stage into a padded buffer
                 if 'stage' not in c:
