@@ -132,6 +132,17 @@ int ttsc_rbchain_supported(const ttsc_conv1d* const* convs1, const ttsc_conv1d* 
 int ttsc_rbchain_forward(const ttsc_conv1d* const* convs1, const ttsc_conv1d* const* convs2, int32_t npairs, const float* x_dev,
                          int32_t B, int64_t L, float* y_dev, int32_t accumulate, const int32_t* len_dev, int32_t tile_shape,
                          void* stream);
+/* The last ResBlock1 chain of the generator with conv_post + activation in its epilogue:
+ *     wav = act((conv_post(lrelu((ysum + chain(x)) * in_scale, in_slope)) + bias) * out_scale)         (scales / activation of post_ep)
+ * — `xs += resblocks[-1](x); x = xs / nk; x = conv_post(lrelu(x)); tanh` of hifigan.models.Generator.forward [EXTERNAL; call sites
+ * cube/networks/cubegan.py:72,83,131, cube/io_utils/runtime.py:78] in one launch: ysum_dev [B,32,L] (the sum of the blocks before this one, or NULL)
+ * is only read, wav_dev [B,1,L] is the only tensor written, conv_post's range-guard word is honoured; bit-identical to
+ * ttsc_rbchain_forward(accumulate) + ttsc_conv1d_forward.  32 channels, dilations in {1, 3, 5}, conv_post 32 -> 1 with k = 7 and padding 3;
+ * L and every entry of len_dev multiples of 4, x / ysum 16-byte aligned.  ttsc_hifigan_forward uses it unless TTSC_HIFIGAN_FUSE_POST=0. */
+int ttsc_rbchain_post_supported(const ttsc_conv1d* const* convs1, const ttsc_conv1d* const* convs2, int32_t npairs, const ttsc_conv1d* post);
+int ttsc_rbchain_post_forward(const ttsc_conv1d* const* convs1, const ttsc_conv1d* const* convs2, int32_t npairs, const float* x_dev, int32_t B,
+                              int64_t L, const float* ysum_dev, const ttsc_conv1d* post, const ttsc_conv1d_epilogue* post_ep, float* wav_dev,
+                              const int32_t* len_dev, void* stream);
 /* One launch per generator STAGE of the 32-channel part: the three ResBlock1 chains (kernel sizes 3, 7, 11; three (conv1, conv2)
  * pairs each) of a time tile back to back, `xs = sum_j resblock_j(x)` kept in registers — hifigan.models.Generator.forward
  * [EXTERNAL; call sites cube/networks/cubegan.py:72,83,131, cube/io_utils/runtime.py:78]: `xs += self.resblocks[i*nk+j](x)`.

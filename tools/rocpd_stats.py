@@ -31,9 +31,12 @@ def main(db, out_csv, n_last=0, last_csv=None):
         # one forward = the run of launches that ends with the LAST launch of its final kernel (conv_cout1_kernel = conv_post) and
         # starts right after the previous launch of that kernel; only kernels whose name contains the prefix count (torch's own
         # launches between two forwards — the bench's isfinite / copies — are skipped), so the file holds exactly one forward
-        pref, final = n_last.split(':', 1)[1], 'conv_cout1_kernel'
+        # the forward's final kernel: conv_post (conv_cout1_kernel), or — when conv_post rides in the epilogue of the last chain launch (round 4) —
+        # the chain instantiation with the POST flag (last template argument true after the interleave flag)
+        pref = n_last.split(':', 1)[1]
+        is_final = lambda name: 'conv_cout1_kernel' in name or ('rbchain_f16x3_kernel' in name and name.split('>')[0].rstrip().endswith('true, true'))
         mine = [r for r in rows if pref in r[0]]
-        ends = [i for i, r in enumerate(mine) if final in r[0]]
+        ends = [i for i, r in enumerate(mine) if is_final(r[0])]
         assert len(ends) >= 2, 'need at least two forwards in the trace'
         fwd = mine[ends[-2] + 1:ends[-1] + 1]
         with open(last_csv, 'w') as f:

@@ -48,6 +48,7 @@ struct ttsc_hifigan {
     int chain_shape = -1;       // env TTSC_HIFIGAN_CHAIN_SHAPE: tile shape of the chain kernel (-1 = by halo)
     bool use_stage = false;     // env TTSC_HIFIGAN_STAGE=1: the 32-channel stage as ONE stage launch (resstage.hip) instead of three chain launches + conv_post
                                 // (bit-identical; measured 10.60 ms against 10.35 ms for the chain launches with interleaved columns at config[1]: off by default)
+    bool fuse_post = true;      // env TTSC_HIFIGAN_FUSE_POST=0: conv_post + tanh as their own launch instead of the epilogue of the last chain launch
     int stage_shape = 0;        // env TTSC_HIFIGAN_STAGE_SHAPE: 0 = 8 waves x 96 columns, 1 = 4 waves x 192 columns (one wave per SIMD)
     int precision = TTSC_PREC_FP32;
     // Split precision keeps activations as fp16 (hi, lo) pairs, so every layer's input gets a power-of-two pre-scale that
@@ -130,6 +131,7 @@ extern "C" int ttsc_hifigan_create(const ttsc_hifigan_cfg* cfg, ttsc_hifigan** o
     if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN_SHAPE")) g->chain_shape = atoi(ev);
     if (const char* ev = getenv("TTSC_HIFIGAN_STAGE")) g->use_stage = atoi(ev) != 0;
     if (const char* ev = getenv("TTSC_HIFIGAN_STAGE_SHAPE")) g->stage_shape = atoi(ev);
+    if (const char* ev = getenv("TTSC_HIFIGAN_FUSE_POST")) g->fuse_post = atoi(ev) != 0;
     if (const char* ev = getenv("TTSC_HIFIGAN_CALIBRATE")) {
         const std::string v(ev);
         g->calib_mode = (v == "0" || v == "off") ? 0 : (v == "input" || v == "2") ? 2 : 1;
@@ -535,6 +537,7 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
     float* S = R + be;
     // per-stage valid lengths of every utterance: row 0 = mel frames, row i+1 = samples after upsample i
     const int32_t* lens[TTSC_HIFIGAN_MAX_UPS + 1] = {nullptr};
+    bool last_lens_mult4 = true;   // (the fused conv_post epilogue moves the tile as 4-sample vectors)
     if (frames) {
         std::vector<int32_t> tab((size_t)(c.num_upsamples + 1) * B);
         for (int b = 0; b < B; ++b) {
@@ -547,6 +550,7 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
                 tab[(size_t)(i + 1) * B + b] = (int32_t)Lb;
             }
         }
+        for (int b = 0; b < B; ++b) last_lens_mult4 = last_lens_mult4 && (tab[(size_t)c.num_upsamples * B + b] % 4 == 0);
         int32_t* dtab = (int32_t*)(S + be);   // behind the fourth buffer
         TTSC_HIP_CHECK(hipMemcpyAsync(dtab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, (hipStream_t)stream));
         TTSC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));  // `tab` is pageable host memory going out of scope
@@ -646,6 +650,13 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
                 for (int m = 0; m < nd; ++m) {
                     c1[m] = layer(rb + ".convs1." + std::to_string(m));
                     c2[m] = layer(rb + ".convs2." + std::to_string(m));
+                }
+                if (g->fuse_post && i == c.num_upsamples - 1 && j == c.num_kernels - 1 && L % 4 == 0 && last_lens_mult4 &&
+                    ((uintptr_t)X % 16 == 0) && ((uintptr_t)S % 16 == 0) && ttsc_rbchain_post_supported(c1, c2, nd, layer("conv_post"))) {
+                    // the LAST block of the LAST stage: the block sum meets conv_post + tanh in the epilogue of this launch — S is read, never
+                    // written, and the waveform is the only thing that leaves (one launch and two passes over the widest tensor less)
+                    ttsc_conv1d_epilogue epost{inv_nk, 0.01f, 1.f, TTSC_ACT_TANH, 0};
+                    return ttsc_rbchain_post_forward(c1, c2, nd, X, B, L, j > 0 ? S : nullptr, layer("conv_post"), &epost, wav, ln, stream);
                 }
                 rc = ttsc_rbchain_forward(c1, c2, nd, X, B, L, S, j > 0 ? 1 : 0, ln, g->chain_shape, stream);
                 if (rc) return rc;

@@ -20,6 +20,7 @@
 // HBM traffic per chain: read x once (+ halo), write y once (read-modify-write when accumulating the block sum) —
 // 2-3 tensor passes instead of 15 for three unfused pairs.
 #include "conv_internal.hpp"
+#include "conv_kernels.hpp"
 
 namespace ttsc {
 
@@ -50,6 +51,15 @@ struct ChainArgs {
     const int* len;       // [B] valid length or null
     int L, npairs, accumulate;
     int halo, nto;        // columns of halo per side, output columns per tile (NCOL - 2*halo)
+    // POST instantiations (last block of the last stage): y is only READ (the sum of the blocks before this one, when `accumulate`), and
+    //     wav = act((conv_post(lrelu((y + chain(x)) * post_in_scale, post_slope)) + bias) * post_out_scale)
+    // leaves the kernel instead of the block sum — the same ci-major, tap-minor fmaf chain as conv_cout1_kernel (conv1d.hip): bit-identical
+    float* wav;           // [B, 1, L]
+    const float* wpost;   // conv_post weights, torch layout [1][C][7]
+    const float* bpost;   // [1] or null
+    float post_in_scale, post_slope, post_out_scale;
+    int post_act;
+    unsigned* nf_flag;    // range-guard word (conv_cout1_kernel) or null
     int dbg;              // -DTTSC_ABLATE builds: 1 skip the epilogue -> image conversions, 2 skip barriers, 4 skip the final store, 8 skip the x load, 16 skip weight loads in the loop
 };
 
@@ -81,8 +91,9 @@ struct ChainGeo {
 };
 template <int V> struct IntTag { static constexpr int value = V; };
 
-template <int MI, int K, int CT, int NW, int WPS, int GRP = 2, int NSLOT = 2, int WM = 1, bool IL = false>
+template <int MI, int K, int CT, int NW, int WPS, int GRP = 2, int NSLOT = 2, int WM = 1, bool IL = false, bool POST = false>
 __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a) {
+    static_assert(!POST || (IL && MI == 1 && WM == 1 && CT == 4), "conv_post epilogue: 32 channels, interleaved columns");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int C = 32 * MI, NCH = 2 * MI, NG = 4 * MI;
     constexpr int WN = NW / WM, MIW = MI / WM;    // waves along time; row tiles per wave
@@ -409,6 +420,71 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
     const int colw_f = (wv_f % WN) * (CT * 32);
     const int pos_w_f = q0 - a.halo + colw_f + (IL ? CT * l31_f : l31_f);
     float* yb = a.y + (size_t)b * C * a.L;
+    if constexpr (POST) {
+        // ---- conv_post + activation on the tile (host guarantees the vector path: L and all lengths multiples of CT) ----
+        // block sum of the lane's four columns (one group further out than the stored range on each side: conv_post's taps reach 3 columns)
+        constexpr int FOFF = 3, PWF = NCOL + 8;   // fp32 staging [C][PWF] in the (now idle) image area, tile column c at index c + FOFF
+        static_assert((size_t)C * PWF * 4 <= (size_t)NG * 2 * PW * 16, "conv_post staging exceeds the image area");
+        float* F = reinterpret_cast<float*>(smem_raw);
+        const int col0 = colw_f + CT * l31_f;
+        const bool need = col0 >= a.halo - CT && col0 + CT <= a.halo + a.nto + CT;
+        const bool inside = pos_w_f >= 0 && pos_w_f + CT <= lin;
+        const unsigned voff = (unsigned)(4 * half_f * a.L + (inside ? pos_w_f : 0));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch0 = (r & 3) + 8 * (r >> 2);
+            fvecT yv = fvecT(0.f);
+            if (a.accumulate && need && inside) yv = *reinterpret_cast<const fvecT*>(yb + (size_t)ch0 * a.L + voff);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                float t = (xres[0][ct][r] + yv[ct]) * a.post_in_scale;
+                t = fmaxf(t, t * a.post_slope);
+                F[(size_t)(ch0 + 4 * half_f) * PWF + FOFF + col0 + ct] = inside ? t : 0.f;
+            }
+        }
+        __syncthreads();
+        if (4 * tid_f < a.nto) {
+            const float* win = F + FOFF + a.halo - 3 + 4 * tid_f;   // 16-byte aligned: halo % 4 == 0
+            float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+            for (int ci = 0; ci < C; ++ci) {
+                float w[12];
+#pragma unroll
+                for (int v4 = 0; v4 < 3; ++v4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(win + (size_t)ci * PWF + 4 * v4);
+                    w[4 * v4] = t[0]; w[4 * v4 + 1] = t[1]; w[4 * v4 + 2] = t[2]; w[4 * v4 + 3] = t[3];
+                }
+                const float* wk = a.wpost + ci * 7;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    const float wj = wk[j];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc4[e] = fmaf(wj, w[e + j], acc4[e]);
+                }
+            }
+            const float bv = a.bpost ? a.bpost[0] : 0.f;
+            float* wb = a.wav + (size_t)b * a.L;
+            const int q = q0 + 4 * tid_f;
+            float res[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) res[e] = apply_act((acc4[e] + bv + 0.f) * a.post_out_scale, a.post_act) + 0.f;
+            if (a.nf_flag) {
+                bool bad = false;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bad = bad || (q + e < a.L && !(fabsf(res[e]) <= 3.0e38f));
+                if (bad) atomicOr(a.nf_flag, 1u);
+            }
+            if (q + 3 < a.L && (((uintptr_t)(wb + q)) & 15) == 0) {
+                const f32x4 o = {res[0], res[1], res[2], res[3]};
+                *reinterpret_cast<f32x4*>(wb + q) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (q + e < a.L) wb[q + e] = res[e];
+            }
+        }
+        return;
+    }
     if (IL && vec) {
         // the lane's CT columns of a channel are CT consecutive samples of the row: one vector access per channel
         const int col0 = colw_f + CT * l31_f;
@@ -466,18 +542,19 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
 template __global__ void rbchain_f16x3_kernel<TTSC_RB_PROBE>(ChainArgs);
 }  // namespace ttsc
 #else
-template <int MI, int K, int CT, int NW, int WPS, int GRP = 2, int NSLOT = 2, int WM = 1, bool IL = false>
+template <int MI, int K, int CT, int NW, int WPS, int GRP = 2, int NSLOT = 2, int WM = 1, bool IL = false, bool POST = false>
 static int launch_chain(ChainArgs& a, int B, hipStream_t s) {
     constexpr int NCOL = (NW / WM) * CT * 32;
     constexpr int PW = IL ? CT * (NCOL / CT + 2 * ChainGeo<K, CT>::MARGQ) : NCOL + 2 * ChainGeo<K, CT>::MARG;
     constexpr size_t lds = (size_t)(4 * MI) * 2 * PW * 16 + (size_t)NSLOT * GRP * (MI * 2 * 64) * 16;   // image + weight ring
     static_assert(lds <= 160 * 1024, "activation image exceeds the LDS");
+    if (POST) a.halo = (a.halo + 3 + CT - 1) / CT * CT;   // + conv_post's three columns, kept a multiple of the vector width
     a.nto = NCOL - 2 * a.halo;
     if (IL && a.nto > 256) a.nto &= ~31;   // tile stores start on 128-byte boundaries of the row
     TTSC_REQUIRE(a.nto >= 64, "rbchain: halo %d leaves no output columns in a %d-column tile", a.halo, NCOL);
-    if (int rc = ensure_full_lds((const void*)rbchain_f16x3_kernel<MI, K, CT, NW, WPS, GRP, NSLOT, WM, IL>)) return rc;   // once per (device, kernel)
+    if (int rc = ensure_full_lds((const void*)rbchain_f16x3_kernel<MI, K, CT, NW, WPS, GRP, NSLOT, WM, IL, POST>)) return rc;   // once per (device, kernel)
     dim3 grid((unsigned)ceil_div(a.L, a.nto), (unsigned)B);
-    hipLaunchKernelGGL((rbchain_f16x3_kernel<MI, K, CT, NW, WPS, GRP, NSLOT, WM, IL>), grid, dim3(64 * NW), lds, s, a);
+    hipLaunchKernelGGL((rbchain_f16x3_kernel<MI, K, CT, NW, WPS, GRP, NSLOT, WM, IL, POST>), grid, dim3(64 * NW), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("rbchain_f16x3_kernel launch failed: %s", hipGetErrorString(e));
@@ -498,6 +575,7 @@ static int launch_chain_k(ChainArgs& a, int B, int shape, hipStream_t s) {
     // shapes 10 / 11: the small / large tile with interleaved columns (vector loads and stores of the tile); 12: 11 with 6-step groups
     constexpr int G768 = K == 3 ? 6 : (K == 7 ? 7 : 11), G768W = K == 3 ? 6 : (K == 7 ? 14 : 11);
     if constexpr (MI == 1) {
+        if (shape == 22) return launch_chain<1, K, 4, 8, 2, 6, 2, 1, true, true>(a, B, s);   // (internal) + conv_post epilogue
         if (shape == 12) return launch_chain<1, K, 4, 8, 2, 6, 2, 1, true>(a, B, s);
         if (shape == 11) return launch_chain<1, K, 4, 8, 2, 2, 2, 1, true>(a, B, s);
         if (shape == 10) return launch_chain<1, K, 4, 4, 2, 2, 2, 1, true>(a, B, s);
@@ -549,15 +627,60 @@ extern "C" int ttsc_rbchain_supported(const ttsc_conv1d* const* convs1, const tt
     return ncol - 2 * halo >= ncol / 2 ? 1 : 0;
 }
 
+static int chain_forward(const ttsc_conv1d* const* convs1, const ttsc_conv1d* const* convs2, int32_t npairs, const float* x, int32_t B, int64_t L, float* y,
+                         int32_t accumulate, const int32_t* len_dev, int32_t shape, void* stream, const ttsc_conv1d* post, const ttsc_conv1d_epilogue* post_ep,
+                         float* wav);
+
 extern "C" int ttsc_rbchain_forward(const ttsc_conv1d* const* convs1, const ttsc_conv1d* const* convs2, int32_t npairs, const float* x,
                                     int32_t B, int64_t L, float* y, int32_t accumulate, const int32_t* len_dev, int32_t shape,
                                     void* stream) {
     TTSC_REQUIRE(convs1 && convs2 && x && y, "ttsc_rbchain_forward: null argument");
+    return chain_forward(convs1, convs2, npairs, x, B, L, y, accumulate, len_dev, shape, stream, nullptr, nullptr, nullptr);
+}
+
+// 1 when ttsc_rbchain_post_forward takes these layers: a 32-channel chain with dilations in {1, 3, 5} followed by conv_post (32 -> 1, k = 7, padding 3,
+// host-set weights); L must be a multiple of 4 (checked by the forward)
+extern "C" int ttsc_rbchain_post_supported(const ttsc_conv1d* const* convs1, const ttsc_conv1d* const* convs2, int32_t npairs, const ttsc_conv1d* post) {
+    if (!post || !ttsc_rbchain_supported(convs1, convs2, npairs)) return 0;
+    if (convs1[0]->cfg.in_channels != 32) return 0;
+    for (int p = 0; p < npairs; ++p) {
+        const int d = convs1[p]->cfg.dilation;
+        if (!(d == 1 || d == 3 || d == 5)) return 0;
+    }
+    const auto& g = post->cfg;
+    return !g.transposed && post->groups == 1 && g.in_channels == 32 && g.out_channels == 1 && g.kernel_size == 7 && g.dilation == 1 && g.padding == 3 &&
+           g.stride == 1 && post->w_plain_dev && !post->dev_weights;
+}
+
+extern "C" int ttsc_rbchain_post_forward(const ttsc_conv1d* const* convs1, const ttsc_conv1d* const* convs2, int32_t npairs, const float* x, int32_t B,
+                                         int64_t L, const float* ysum, const ttsc_conv1d* post, const ttsc_conv1d_epilogue* post_ep, float* wav,
+                                         const int32_t* len_dev, void* stream) {
+    TTSC_REQUIRE(convs1 && convs2 && x && post && wav, "ttsc_rbchain_post_forward: null argument");
+    TTSC_REQUIRE(ttsc_rbchain_post_supported(convs1, convs2, npairs, post), "ttsc_rbchain_post_forward: these layers are not eligible");
+    TTSC_REQUIRE(L % 4 == 0 && ((uintptr_t)x % 16 == 0) && (!ysum || (uintptr_t)ysum % 16 == 0),
+                 "ttsc_rbchain_post_forward: L must be a multiple of 4 and x / ysum 16-byte aligned (got L = %lld)", (long long)L);
+    TTSC_REQUIRE(!(post_ep && (post_ep->accumulate || post_ep->gate_dev)), "ttsc_rbchain_post_forward: conv_post epilogue options not available when fused");
+    return chain_forward(convs1, convs2, npairs, x, B, L, const_cast<float*>(ysum), ysum ? 1 : 0, len_dev, 22, stream, post, post_ep, wav);
+}
+
+static int chain_forward(const ttsc_conv1d* const* convs1, const ttsc_conv1d* const* convs2, int32_t npairs, const float* x, int32_t B, int64_t L, float* y,
+                         int32_t accumulate, const int32_t* len_dev, int32_t shape, void* stream, const ttsc_conv1d* post, const ttsc_conv1d_epilogue* post_ep,
+                         float* wav) {
     TTSC_REQUIRE(ttsc_rbchain_supported(convs1, convs2, npairs), "ttsc_rbchain_forward: these layers are not eligible for the fused chain");
     TTSC_REQUIRE(x != y, "ttsc_rbchain_forward: y must not alias x");
     TTSC_REQUIRE(B > 0 && L > 0 && L < (1ll << 30), "ttsc_rbchain_forward: bad B/L");
     ChainArgs a;
     memset(&a, 0, sizeof(a));
+    if (post) {
+        a.wav = wav;
+        a.wpost = post->w_plain_dev;
+        a.bpost = post->bias_dev;
+        a.post_in_scale = post_ep ? post_ep->in_scale : 1.f;
+        a.post_slope = post_ep ? post_ep->in_slope : 1.f;
+        a.post_out_scale = post_ep ? post_ep->out_scale : 1.f;
+        a.post_act = post_ep ? post_ep->out_act : TTSC_ACT_NONE;
+        a.nf_flag = post->nf_flag;
+    }
     a.x = x;
     a.y = y;
     a.len = len_dev;
@@ -598,7 +721,7 @@ extern "C" int ttsc_rbchain_forward(const ttsc_conv1d* const* convs1, const ttsc
     const int il_env = il_ev ? atoi(il_ev) : 1;
     bool il_ok = true;
     for (int p = 0; p < npairs; ++p) il_ok = il_ok && (a.d1[p] == 1 || a.d1[p] == 3 || a.d1[p] == 5);
-    if (shape >= 10 && !il_ok) shape -= 10;
+    if (shape >= 10 && shape < 20 && !il_ok) shape -= 10;
     // (measured at config[1], round 4, y += chain(x): K = 3 small tile 1.84 ms interleaved vs 1.92 plain; K = 7 small tile 3.43 plain vs 3.50
     // interleaved vs 3.49 large interleaved; K = 11 large tile 4.90 interleaved with 6-step weight groups vs 5.12 plain — the K = 7 block at
     // 32 channels keeps the plain small tile)
