@@ -468,6 +468,23 @@ def bench_e2e(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    def run_pipelined(nsteps):
+        """`nsteps` passes over this rank's shard as ONE stream of batches through Cubegan.inference_pipelined: the text / frame stacks of
+        the next batch run under the generator of the current one (two streams); returns the last pass's outputs"""
+        import itertools
+        def feed():
+            for _ in range(nsteps):
+                for b in batches:
+                    L = int(max(lens[i] for i in b))
+                    yield {'x_char': torch.from_numpy(xc[b][:, :L]), 'x_speaker': torch.ones((len(b), 1), dtype=torch.long)}
+        outs, n = {}, 0
+        for k, (wav, wl) in enumerate(tts.inference_pipelined(feed(), check='deferred')):
+            if k >= (nsteps - 1) * len(batches):
+                b = batches[k % len(batches)]
+                n += int(sum(wl))
+                outs.update({i: (wav[j, 0, :wl[j]], wl[j]) for j, i in enumerate(b)})
+        return outs, n
+
     for _ in range(max(1, args.warmup)):
         outs, nsamp = run()
     barrier()
@@ -475,7 +492,18 @@ def bench_e2e(args):
     for _ in range(args.steps):
         outs, nsamp = run()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_seq = time.perf_counter() - t0
+    elapsed = elapsed_seq
+    pipelined = not getattr(args, 'no_pipeline', False)
+    if pipelined:
+        run_pipelined(max(1, args.warmup))
+        barrier()
+        t0 = time.perf_counter()
+        outs_p, nsamp_p = run_pipelined(args.steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        assert nsamp_p == nsamp and all(bool(torch.equal(outs_p[i][0], outs[i][0])) for i in outs), 'pipelined synthesis differs from the sequential one'
+        outs = outs_p
     # per-phase device time of one more (untimed) pass
     tm = []
     run(tm)
@@ -516,6 +544,8 @@ def bench_e2e(args):
                        'global_batch': per_gpu * world, 'parallelism': 'utterance shards (TTSCube.shard), no collective'},
             'rtf_24k': value / world / 24000.0, 'sentences_per_s': per_gpu * world * args.steps / elapsed,
             'phase_ms_rank0': {k: round(v, 3) for k, v in phases.items()}, 'samples_per_step_rank0': int(nsamp),
+            'pipelined': pipelined, 'ms_per_step_sequential_rank0': elapsed_seq / args.steps * 1e3,
+            'pipeline_note': 'value / ms_per_step: all steps as one stream of batches through Cubegan.inference_pipelined (text + frame stacks of batch k+1 on one stream under the generator of batch k on another; outputs bit-identical to the sequential pass, asserted); ms_per_step_sequential = one batch after the other on one stream; phase_ms from a sequential pass',
             'max_lsb_vs_oracle_chain': worst, 'oracle_checked': '2 sentences per rank (shortest, longest)',
             'roofline': (lambda fl_gen: {'bound': 'mfma', 'achieved': fl_gen[0] * args.steps / elapsed / 1e12, 'peak': 2500.0 / 3, 'unit': 'TFLOP/s',
                                          'frac': fl_gen[0] * args.steps / elapsed / 1e12 / (2500.0 / 3), 'traffic': None,
@@ -536,6 +566,7 @@ def main():
                     help="'train': the Cubegan adversarial training step (BASELINE configs[3]); 'e2e': text -> audio, sentences sharded over the GPUs (configs[4])")
     ap.add_argument('--sentences-per-gpu', type=int, default=64, help='--mode e2e: sentences in every rank\'s shard')
     ap.add_argument('--e2e-batch', type=int, default=64, help='--mode e2e: sentences per padded batch')
+    ap.add_argument('--no-pipeline', action='store_true', help='--mode e2e: time the sequential pass only (no two-stream pipelining across batches)')
     ap.add_argument('--train-batch', type=int, default=16, help='utterances per GPU in --mode train')
     ap.add_argument('--miopen-find', action='store_true', help="--mode train: let MIOpen search its convolution algorithms exhaustively "
                     "(torch.backends.cudnn.benchmark): ~12 minutes once per process on a fresh box, then 108 instead of 145 ms per step; "

@@ -87,6 +87,37 @@ def test_batched_synthesis_equals_per_sentence_and_sharding(tmp_path):
     assert shards[0] + shards[1] == texts
 
 
+def test_pipelined_inference_equals_batch_by_batch(tmp_path):
+    """Cubegan.inference_pipelined (text / frame stacks of batch k + 1 on a high-priority stream under the generator of batch k) hands
+    out, per batch, exactly the bits `inference` gives; a consumer that stops early leaves the model usable."""
+    from ttscube_amd.io_utils.io_cubegan import CubeganEncodings
+    from ttscube_amd.io_utils.synthetic import synthetic_sentences
+    from ttscube_amd.networks.cubegan import Cubegan
+    base, _, _ = _make_model_dir(tmp_path)
+    m = Cubegan(CubeganEncodings(base + '.encodings'), conditioning=None, train=False)
+    m.load(base + '.model')
+    m = m.cuda().eval()
+    batches = []
+    for seed, n in ((1, 5), (2, 3), (3, 1), (4, 6)):
+        xc, _ = synthetic_sentences(n, seed=seed, nphones=16, min_ph=6, max_ph=24)     # zero-padded ragged sentences
+        batches.append({'x_char': torch.from_numpy(xc).cuda(), 'x_speaker': torch.full((n, 1), 1 + seed % 2, dtype=torch.long).cuda()})
+    with torch.no_grad():
+        want = [m.inference(X, return_lengths=True) for X in batches]
+        got = list(m.inference_pipelined(iter(batches)))
+        assert len(got) == len(want)
+        for (gw, gl), (ww, wl) in zip(got, want):
+            assert list(gl) == list(wl) and gw.shape == ww.shape
+            for b, n in enumerate(wl):                      # (samples past an utterance's own length are unspecified in a padded batch)
+                assert torch.equal(gw[b, 0, :n], ww[b, 0, :n])
+        it = m.inference_pipelined(iter(batches))
+        first = next(it)
+        it.close()                                         # early stop: nothing left pending on the side streams
+        torch.cuda.synchronize()
+        assert all(torch.equal(first[0][b, 0, :n], want[0][0][b, 0, :n]) for b, n in enumerate(want[0][1]))
+        again = m.inference(batches[1], return_lengths=True)
+        assert all(torch.equal(again[0][b, 0, :n], want[1][0][b, 0, :n]) for b, n in enumerate(want[1][1]))
+
+
 def test_cubegan_load_is_non_strict_and_device_checked(tmp_path):
     from ttscube_amd._lib import TTSCError
     from ttscube_amd.io_utils.io_cubegan import CubeganEncodings

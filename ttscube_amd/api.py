@@ -13,6 +13,7 @@ import numpy as np
 import torch
 import yaml
 
+from . import _lib
 from .io_utils.io_cubegan import CubeganCollate, CubeganEncodings
 from .networks.cubegan import Cubegan
 
@@ -80,17 +81,34 @@ class TTSCube:
         ex = [self._example(t, s) for t, s in zip(texts, speakers)]
         order = sorted(range(len(ex)), key=lambda i: len(ex[i]['meta']['phones']))
         out = [None] * len(ex)
-        with torch.no_grad():
-            for s in range(0, len(order), max_batch):
-                ids = order[s:s + max_batch]
+        groups = [order[s:s + max_batch] for s in range(0, len(order), max_batch)]
+
+        def feed():
+            for ids in groups:
                 X = self._collate.collate_fn([ex[i] for i in ids])
                 for key in X:
                     if isinstance(X[key], torch.Tensor):
                         X[key] = X[key].to(self._model.get_device())
-                wav, lens = self._model.inference(X, return_lengths=True)
+                yield X
+
+        def collect(results):
+            for ids, (wav, lens) in zip(groups, results):
                 wav = wav.detach().cpu().numpy()
                 for j, i in enumerate(ids):
                     out[i] = np.asarray(wav[j, 0, :lens[j]] * 32767, dtype=np.int16)
+
+        with torch.no_grad():
+            if len(groups) > 1:
+                # several padded batches: the text / frame stacks of batch k + 1 run under the generator of batch k (Cubegan.inference_pipelined);
+                # per-batch results are the ones `inference` gives.  The pipeline runs the range guard deferred; a batch that left the calibrated
+                # range raises there, and the whole list is then redone batch by batch with the self-repairing synchronous guard.
+                try:
+                    collect(self._model.inference_pipelined(feed()))
+                    return out
+                except _lib.TTSCError as e:
+                    if 'check="sync"' not in str(e):
+                        raise
+            collect(self._model.inference(X, return_lengths=True) for X in feed())
         return out
 
     @staticmethod

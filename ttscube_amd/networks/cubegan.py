@@ -71,6 +71,57 @@ class Cubegan(nn.Module):
             return wav, [self._generator.out_len(f) if f > 0 else 0 for f in flens]
         return wav
 
+    def inference_pipelined(self, batches, check='deferred'):
+        """`inference` over a SEQUENCE of padded batches as a two-stage pipeline on two streams: the text / frame stacks of batch k + 1
+        (latency-bound BiLSTM recurrences that occupy a few dozen CUs) run while the generator of batch k (which fills the chip) is still
+        running.  Yields (wav [B,1,L], sample counts) per batch, in order; a yielded waveform is complete (its stream has been waited for).
+        Same arithmetic as `inference` — per-batch results are bit-identical — only the overlap differs.  The reference is a B = 1 loop
+        (cube/api.py:45-66); batching and pipelining are this implementation's."""
+        dev = self.get_device()
+        # the recurrences' stream gets the higher priority: their workgroups are few and must all be resident to make progress, the generator's are
+        # thousands and short — the dispatcher should hand a freed CU to the recurrence first
+        s_txt, s_gen = torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        s_txt.wait_stream(main)
+        s_gen.wait_stream(main)
+        pending = None
+
+        def finish(p):
+            wav, lens, done = p
+            done.synchronize()
+            return wav, lens
+
+        try:                                          # (no_grad only around the compute: a `with` spanning a yield would leak into the consumer)
+            for X in batches:
+                with torch.cuda.stream(s_txt), torch.no_grad():
+                    cond, _, flens = self._languasito.inference(X, return_aux=True, check_status=False)   # (waits for ITS stream only: frame counts)
+                    if cond.shape[1] == 0:
+                        cond = torch.zeros((cond.shape[0], 1, cond.shape[2]), device=dev)
+                        flens = [1] * cond.shape[0]
+                    cond_t = cond.permute(0, 2, 1).contiguous()
+                    ready = torch.cuda.Event()
+                    ready.record(s_txt)
+                cond_t.record_stream(s_gen)
+                if pending is not None:               # hand the previous batch out while this one's generator is about to be queued
+                    out = finish(pending)
+                    pending = None
+                    yield out
+                with torch.cuda.stream(s_gen), torch.no_grad():
+                    s_gen.wait_event(ready)
+                    wav = self._generator(cond_t, frames=flens if cond_t.shape[0] > 1 else None, check=check)
+                    done = torch.cuda.Event()
+                    done.record(s_gen)
+                wav.record_stream(main)
+                pending = (wav, [self._generator.out_len(f) if f > 0 else 0 for f in flens], done)
+            if pending is not None:
+                yield finish(pending)
+            with torch.cuda.stream(s_gen):
+                self._generator.finish_range_check()
+        finally:                                      # also when the consumer stops early: whatever is still queued is ordered before the caller's stream
+            main.wait_stream(s_gen)
+            main.wait_stream(s_txt)
+        _lib.check_split_status('Cubegan.inference_pipelined')
+
     def forward(self, X):
         """cubegan.py:65-72: forced alignment path (X carries y_frame2phone / y_pitch)."""
         from .training import languasito_forward
