@@ -426,6 +426,12 @@ int ttsc_lstm_seq_forward(const float* xg_dev, const float* whh_packed_dev, floa
  * ttsc_lstm_split_status: 0 = every hand-off since the last call completed, 1 = a bounded spin timed out (sticky until read:
  * later split launches give up at once, so callers that care check it once per step / synthesis).  Synchronises the device. */
 int32_t ttsc_lstm_split_status(void);
+/* Utterances per member group of the register-resident split recurrence (H = 256 / 512: 4 / 16 workgroups per group hold W_hh in registers).
+ * 0 (default) = automatic: the smallest of 1 / 2 / 4 that takes the padded batch in one launch — the shortest step.  n = 1 / 2 / 4 / 8: n per
+ * group whenever the batch has that many — n times fewer CUs held for a somewhat longer step, for callers that run the recurrence beside a
+ * kernel that fills the chip (Cubegan.inference_pipelined).  Results do not depend on it (per utterance the arithmetic is the same).
+ * Process-wide; returns the previous value, -1 for a bad n.  Not in the reference (B = 1 there, cube/networks/modules.py:946-953). */
+int32_t ttsc_lstm_set_group_size(int32_t n);
 int ttsc_lstm_pack_whh_device(const float* whh_dev, int32_t ndir, int32_t H, int32_t transpose, float* out_dev, void* stream);
 int ttsc_lstm_seq_forward_train(const float* xg_dev, const float* whh_packed_dev, float* y_dev, const int32_t* lengths_dev,
                                 int32_t B, int32_t T, int32_t H, int32_t ndir, int64_t ldy, int32_t yoff, float* gates_dev,

@@ -79,11 +79,13 @@ def test_lstm_two_utterances_per_workgroup():
     assert float((y - ref).abs().max()) < 2e-5
 
 
-@pytest.mark.parametrize('H,B,T', [(256, 40, 23), (256, 3, 50), (512, 3, 21), (512, 10, 9), (64, 70, 33), (128, 5, 40)])
+@pytest.mark.parametrize('H,B,T', [(256, 40, 23), (256, 3, 50), (512, 3, 21), (512, 10, 9), (64, 70, 33), (128, 5, 40), (256, 65, 30), (256, 133, 17), (512, 33, 7)])
 def test_lstm_resident_kernels_ragged_vs_torch_and_solo(H, B, T):
     """Register-resident recurrences: lstm_seq_resident_kernel (H = 64 / 128), lstm_seq_split_res_kernel with 4 (H = 256) / 16
-    (H = 512) members — B = 40 at H = 256 is 80 (utterance, direction) pairs = two consecutive launches, B = 10 at H = 512 two as
-    well.  Ragged batch against torch.nn.LSTM (packed), and bit-identical to each utterance run alone."""
+    (H = 512) members.  More (utterance, direction) pairs than one launch holds (256 CUs / members): 2 or 4 utterances per member group
+    (lstm_seq_split_res_nb_kernel) — B = 40 / 65 at H = 256 and B = 10 at H = 512 run two per group (65: a ragged last group),
+    B = 133 at H = 256 and B = 33 at H = 512 four per group in two launches.  Ragged batch against torch.nn.LSTM (packed), and
+    bit-identical to each utterance run alone (the one-utterance kernel)."""
     from ttscube_amd.hip_layers import LSTMHip
     torch.manual_seed(H + B + T)
     m = nn.LSTM(input_size=48, hidden_size=H, num_layers=2, bidirectional=True, batch_first=True)
@@ -96,7 +98,7 @@ def test_lstm_resident_kernels_ragged_vs_torch_and_solo(H, B, T):
     h = LSTMHip(m.cuda())
     y = h(x.cuda(), lengths=lens)
     assert float((y.cpu() - ref).abs().max()) < 3e-5
-    for b in (0, 1, B - 1):
+    for b in sorted(v for v in {0, 1, 2, 3, B // 2, B - 2, B - 1} if 0 <= v < B):
         solo = h(x[b:b + 1, :lens[b]].cuda())
         assert torch.equal(y[b, :lens[b]], solo[0])
         assert bool((y[b, lens[b]:] == 0).all())
@@ -126,3 +128,29 @@ def test_two_handles_on_two_streams_do_not_share_handoff_state():
     assert _lib.lib().ttsc_lstm_split_status() == 0
     for ya, yb in outs:
         assert torch.equal(ya, ra) and torch.equal(yb, rb)
+
+
+@pytest.mark.parametrize('H,B,T,n', [(256, 21, 19, 8), (256, 21, 19, 4), (256, 6, 25, 2), (512, 9, 8, 8), (256, 300, 5, 0)])
+def test_lstm_group_size_does_not_change_results(H, B, T, n):
+    """ttsc_lstm_set_group_size: n utterances per member group (8 / 4 / 2, ragged last group; B = 300 at H = 256: automatic -> 4 per group,
+    three launches... and 8 once that is not enough) — bit-identical to one utterance per group, forward and saved training state."""
+    from ttscube_amd import _lib
+    from ttscube_amd.hip_layers import LSTMHip
+    torch.manual_seed(H + B + n)
+    m = nn.LSTM(input_size=32, hidden_size=H, num_layers=1, bidirectional=True, batch_first=True).cuda()
+    h = LSTMHip(m)
+    x = torch.randn(B, T, 32).cuda()
+    lens = [((5 * b) % T) + 1 for b in range(B)]
+    with _lib.lstm_group_size(n):
+        y = h(x, lengths=lens)
+    if n == 0:
+        idx = list(range(0, B, 37)) + [B - 1]
+        for b in idx:
+            solo = h(x[b:b + 1, :lens[b]])
+            assert torch.equal(y[b, :lens[b]], solo[0])
+    else:
+        with _lib.lstm_group_size(1):
+            y1 = h(x, lengths=lens)
+        assert torch.equal(y, y1)
+    assert int(_lib.lib().ttsc_lstm_set_group_size(3)) == -1
+    _lib.check_split_status('test')

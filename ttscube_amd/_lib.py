@@ -146,6 +146,7 @@ SIGNATURES = {
     'ttsc_colsum_workspace_bytes': (C.c_size_t, [C.c_int64, C.c_int64]),
     'ttsc_colsum': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     'ttsc_lstm_split_status': (C.c_int32, []),
+    'ttsc_lstm_set_group_size': (C.c_int32, [C.c_int32]),
     'ttsc_melar_split_status': (C.c_int32, []),
     'ttsc_lstm_pack_whh_device': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     'ttsc_lstm_seq_forward_train': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
@@ -230,6 +231,24 @@ def check_split_status(where):
     if bad:
         raise TTSCError('%s: split %s recurrence aborted on a hand-off timeout (are other kernels occupying the CUs? '
                         'TTSC_LSTM_SPLIT=1 / TTSC_GRU_SPLIT=1 select the single-workgroup kernels)' % (where, '/'.join(bad)))
+
+
+class lstm_group_size:
+    """`with lstm_group_size(8): ...` — utterances per member group of the split LSTM recurrences inside the block (ttsc_lstm_set_group_size:
+    fewer CUs held per padded batch, same results); the previous setting is restored on exit."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __enter__(self):
+        self.prev = int(lib().ttsc_lstm_set_group_size(self.n))
+        if self.prev < 0:
+            raise TTSCError('ttsc_lstm_set_group_size(%r): not one of 0, 1, 2, 4, 8' % (self.n,))
+        return self
+
+    def __exit__(self, *exc):
+        lib().ttsc_lstm_set_group_size(self.prev)
+        return False
 
 
 class DevLengths(list):

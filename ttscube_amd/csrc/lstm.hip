@@ -18,6 +18,7 @@
 //   few sequences, other H   lstm_seq_split_kernel    <= 4 workgroups per sequence streaming their rows, counter hand-off
 //   everything else     lstm_seq_kernel<BT>           one workgroup per (utterance tile, direction), rows streamed from L2
 #include <algorithm>
+#include <atomic>
 
 #include "common.hpp"
 #include "../../include/ttscube_math.h"
@@ -595,6 +596,163 @@ __global__ __launch_bounds__(512) void lstm_seq_split_res_kernel(LstmSplitArgs s
     }
 }
 
+// Several utterances per member group.  A launch of lstm_seq_split_res_kernel holds cus / G (utterance, direction) pairs; a padded batch of 64 sentences
+// (128 pairs at H = 256) therefore took two consecutive launches, each paying the full hand-off latency per step for 128 FMAs per thread.  Here the G
+// members of a group keep the same 128 weights per thread and step NB utterances of one direction together: the exchange latency is paid once per step
+// for NB sequences, the FMAs become v_pk_fma_f32 over {utterance 2p, utterance 2p + 1} with the weight broadcast by op_sel (two chains per
+// instruction), and the k-slice threads 0 .. NB-1 each own one utterance's gate reduction / activations / publication, so those run side by side too.
+// Per utterance the arithmetic is the NB = 1 kernel's — same k-ordered fma chain per slice, slices added in order — so results are bit-identical to it
+// and to the utterance run alone.  Ragged groups: a finished (or absent) utterance is neither polled nor published; its lane of the packed chain runs
+// on stale h and is discarded.
+typedef float lstm_f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void lstm_pkfma_lo(lstm_f2& acc, const lstm_f2& w, const lstm_f2& h) {   // acc += w.x * h   (both halves)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(w), "v"(h));
+}
+__device__ __forceinline__ void lstm_pkfma_hi(lstm_f2& acc, const lstm_f2& w, const lstm_f2& h) {   // acc += w.y * h
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "v"(h));
+}
+
+template <int KL, int NB>
+__global__ __launch_bounds__(512) void lstm_seq_split_res_nb_kernel(LstmSplitArgs s, lstm_u64* ring) {
+    static_assert(NB == 2 || NB == 4 || NB == 8, "utterances per member group");
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // h[H][NB] (utterance-interleaved) | part[NB][KS][4][HU]
+    const LstmArgs& a = s.f;
+    const int H = a.H, H4 = 4 * H, HU = s.HU, KS = s.KS;
+    const int tid = threadIdx.x, u = tid % HU, ks = tid / HU;
+    const int m = blockIdx.x, grp = s.p0 + blockIdx.y, dir = grp % a.ndir, b0 = (grp / a.ndir) * NB;
+    const int j = m * HU + u;
+    float* hs = sm;
+    float* part = sm + NB * H;
+    int len[NB], maxlen = 0;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        len[q] = b0 + q < a.B ? (a.lengths ? a.lengths[b0 + q] : a.T) : 0;
+        maxlen = len[q] > maxlen ? len[q] : maxlen;
+    }
+    // k-slice thread row `ks` owns utterance b0 + ks (KS >= 8 >= NB)
+    const int ob = b0 + ks;
+    const bool owner = ks < NB && ob < a.B;
+    int olen = 0;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) olen = (q == ks) ? len[q] : olen;
+    lstm_u64* org = ring + (size_t)(ob * a.ndir + dir) * 2 * H;
+    float* yb = a.y + (size_t)ob * a.T * a.ldy + a.yoff + dir * H;
+    lstm_f2 w[4][KL / 2];
+    {
+        const float4* w4 = reinterpret_cast<const float4*>(a.whh + (size_t)dir * H * H4) + j;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int kb = 0; kb < KL / 4; ++kb) {
+                const float4 v = w4[(size_t)(ks * (KL / 4) + kb) * H4 + g * H];
+                w[g][2 * kb] = lstm_f2{v.x, v.y};
+                w[g][2 * kb + 1] = lstm_f2{v.z, v.w};
+            }
+    }
+    float c = (owner && a.c_0) ? a.c_0[((size_t)dir * a.B + ob) * H + j] : 0.f;
+    float hlast = (owner && a.h_0) ? a.h_0[((size_t)dir * a.B + ob) * H + j] : 0.f;
+    if (owner)
+        for (int t = olen; t < a.T; ++t) yb[(size_t)t * a.ldy + j] = 0.f;
+    for (int st = 0; st < maxlen; ++st) {
+        const bool mine = owner && st < olen;
+        const int tpos = dir == 0 ? st : (olen - 1 - st);
+        float xv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (mine) {
+            const float* xr = a.xg + ((size_t)ob * a.T + tpos) * ((size_t)a.ndir * H4) + (size_t)dir * H4 + j;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xv[g] = xr[g * H];
+        }
+        bool fail = false;
+        for (int e = tid; e < NB * H; e += 512) {
+            const int q = e / H, i = e - q * H;
+            int lq = 0;
+#pragma unroll
+            for (int r = 0; r < NB; ++r) lq = (r == q) ? len[r] : lq;
+            if (st == 0) {
+                hs[i * NB + q] = (a.h_0 && b0 + q < a.B) ? a.h_0[((size_t)dir * a.B + b0 + q) * H + i] : 0.f;
+            } else if (st < lq) {
+                const lstm_u64* src = ring + (size_t)((b0 + q) * a.ndir + dir) * 2 * H + (size_t)((st - 1) & 1) * H + i;
+                lstm_u64 gq;
+                unsigned spins = 0;
+                for (;;) {
+                    gq = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(gq >> 32) == (unsigned)st) break;
+                    if (++spins > GS_SPIN_LIMIT || ((spins & 63u) == 0u && __hip_atomic_load(s.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                        __hip_atomic_store(s.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(s.abort_word + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sticky copy
+                        fail = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                hs[i * NB + q] = __uint_as_float((unsigned)gq);
+            }
+        }
+        if (__syncthreads_or(fail)) return;
+        lstm_f2 acc[NB / 2][4];
+#pragma unroll
+        for (int p = 0; p < NB / 2; ++p)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[p][g] = lstm_f2{0.f, 0.f};
+        {
+            const lstm_f2* h2 = reinterpret_cast<const lstm_f2*>(hs + (size_t)ks * KL * NB);   // [k][NB / 2] pairs
+#pragma unroll
+            for (int kb = 0; kb < KL / 2; ++kb) {
+                lstm_f2 ha[NB / 2], hb[NB / 2];
+#pragma unroll
+                for (int p = 0; p < NB / 2; ++p) {
+                    ha[p] = h2[(2 * kb) * (NB / 2) + p];
+                    hb[p] = h2[(2 * kb + 1) * (NB / 2) + p];
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int p = 0; p < NB / 2; ++p) {
+                        lstm_pkfma_lo(acc[p][g], w[g][kb], ha[p]);
+                        lstm_pkfma_hi(acc[p][g], w[g][kb], hb[p]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NB / 2; ++p)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                part[(((2 * p) * KS + ks) * 4 + g) * HU + u] = acc[p][g].x;
+                part[(((2 * p + 1) * KS + ks) * 4 + g) * HU + u] = acc[p][g].y;
+            }
+        __syncthreads();
+        if (mine) {
+            float gs[4] = {xv[0], xv[1], xv[2], xv[3]};
+            const float* pq = part + (size_t)ks * KS * 4 * HU;
+            for (int q = 0; q < KS; ++q)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gs[g] += pq[(q * 4 + g) * HU + u];
+            const float ig = ttsc_sigmoidf(gs[0]);
+            const float fg = ttsc_sigmoidf(gs[1]);
+            const float gg = ttsc_tanhf(gs[2]);
+            const float og = ttsc_sigmoidf(gs[3]);
+            c = fmaf(fg, c, ig * gg);
+            hlast = og * ttsc_tanhf(c);
+            __hip_atomic_store(org + (size_t)(st & 1) * H + j, ((lstm_u64)(unsigned)(st + 1) << 32) | (lstm_u64)__float_as_uint(hlast), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            yb[(size_t)tpos * a.ldy + j] = hlast;
+            if (a.gates_out) {
+                float* gp = a.gates_out + ((size_t)ob * a.T + tpos) * ((size_t)a.ndir * H4) + (size_t)dir * H4 + j;
+                gp[0] = ig;
+                gp[H] = fg;
+                gp[2 * H] = gg;
+                gp[3 * H] = og;
+                a.c_out[((size_t)ob * a.T + tpos) * ((size_t)a.ndir * H) + (size_t)dir * H + j] = c;
+            }
+        }
+    }
+    if (owner) {
+        if (a.h_n) a.h_n[((size_t)dir * a.B + ob) * H + j] = hlast;
+        if (a.c_n) a.c_n[((size_t)dir * a.B + ob) * H + j] = c;
+    }
+}
+
 __global__ __launch_bounds__(512) void lstm_bwd_split_kernel(LstmSplitArgs s) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // dg[4H] | part[KS][HU]
     __shared__ int ok_s;
@@ -866,6 +1024,16 @@ static HandoffArea* lstm_area(hipStream_t s, size_t ring_bytes) {
 // Synchronises the device.
 extern "C" int32_t ttsc_lstm_split_status(void) { return handoff_status("lstm"); }
 
+// utterances per member group of the register-resident split recurrence: 0 = automatic (see lstm_forward_impl)
+static std::atomic<int> g_lstm_group_size{getenv("TTSC_LSTM_NB") ? atoi(getenv("TTSC_LSTM_NB")) : 0};
+
+extern "C" int32_t ttsc_lstm_set_group_size(int32_t n) {
+    if (n < 0 || n > 8 || (n & (n - 1)) != 0) return -1;
+    return g_lstm_group_size.exchange(n, std::memory_order_relaxed);
+}
+
+
+
 static int lstm_forward_impl(const float* xg_dev, const float* whh_packed_dev, float* y_dev, const int32_t* lengths_dev,
                              int32_t B, int32_t T, int32_t H, int32_t ndir, int64_t ldy, int32_t yoff, const float* h0_dev,
                              const float* c0_dev, float* hn_dev, float* cn_dev, float* gates_dev, float* c_dev, void* stream);
@@ -997,7 +1165,20 @@ static int lstm_forward_impl(const float* xg_dev, const float* whh_packed_dev, f
         if (cus >= 4) {
             const int Gm = H == 256 ? 4 : 16;
             const int pairs = B * ndir, cap = cus / Gm;
-            if (cap >= 1 && pairs <= 3 * cap && pairs <= 4096) {
+            // utterances per member group (lstm_seq_split_res_nb_kernel: per utterance the same arithmetic as NB = 1).  Default: the smallest of
+            // 1 / 2 / 4 that fits the batch into ONE launch (shortest step), else 4 and up to three launches.  ttsc_lstm_set_group_size(n) asks
+            // for n per group whenever the batch has that many: fewer CUs held for a somewhat longer step — what a caller wants who runs the
+            // recurrence beside a kernel that fills the chip (Cubegan.inference_pipelined).
+            const int pref = g_lstm_group_size.load(std::memory_order_relaxed);
+            int NB = 1;
+            if (pref > 0) {
+                while (NB * 2 <= pref && NB * 2 <= B) NB *= 2;
+                while (NB < 8 && ((B + NB - 1) / NB) * ndir > 3 * cap) NB *= 2;
+            } else {
+                while (NB < 4 && ((B + NB - 1) / NB) * ndir > cap) NB *= 2;
+            }
+            const int groups = ((B + NB - 1) / NB) * ndir;
+            if (cap >= 1 && groups <= 3 * cap && pairs <= 16384) {
                 // granule ring [pairs][2 slots][H]: sized for this launch, grown on demand, one per (device, stream)
                 HandoffArea* ar = lstm_area((hipStream_t)stream, (size_t)pairs * 2 * H * sizeof(lstm_u64));
                 if (!ar) {
@@ -1013,11 +1194,19 @@ static int lstm_forward_impl(const float* xg_dev, const float* whh_packed_dev, f
                 sa.G = Gm;
                 sa.HU = H / Gm;
                 sa.KS = 512 / sa.HU;
-                const size_t lds = ((size_t)H + (size_t)sa.KS * 4 * sa.HU) * sizeof(float);
-                for (int p0 = 0; p0 < pairs; p0 += cap) {
+                const size_t lds = (size_t)NB * ((size_t)H + (size_t)sa.KS * 4 * sa.HU) * sizeof(float);
+                for (int p0 = 0; p0 < groups; p0 += cap) {
                     sa.p0 = p0;
-                    const int n = pairs - p0 < cap ? pairs - p0 : cap;
-                    hipLaunchKernelGGL(lstm_seq_split_res_kernel<32>, dim3((unsigned)Gm, (unsigned)n, 1u), dim3(512), lds, (hipStream_t)stream, sa, ring);
+                    const int n = groups - p0 < cap ? groups - p0 : cap;
+                    const dim3 grid((unsigned)Gm, (unsigned)n, 1u);
+                    if (NB == 1)
+                        hipLaunchKernelGGL(lstm_seq_split_res_kernel<32>, grid, dim3(512), lds, (hipStream_t)stream, sa, ring);
+                    else if (NB == 2)
+                        hipLaunchKernelGGL((lstm_seq_split_res_nb_kernel<32, 2>), grid, dim3(512), lds, (hipStream_t)stream, sa, ring);
+                    else if (NB == 4)
+                        hipLaunchKernelGGL((lstm_seq_split_res_nb_kernel<32, 4>), grid, dim3(512), lds, (hipStream_t)stream, sa, ring);
+                    else
+                        hipLaunchKernelGGL((lstm_seq_split_res_nb_kernel<32, 8>), grid, dim3(512), lds, (hipStream_t)stream, sa, ring);
                 }
                 hipError_t e = hipGetLastError();
                 if (e != hipSuccess) {

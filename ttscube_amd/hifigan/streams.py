@@ -7,6 +7,7 @@ import os
 import torch
 
 DISC_STREAMS = os.environ.get('TTSC_DISC_STREAMS', '1') != '0'
+MAX_SIDE = int(os.environ.get('TTSC_SIDE_STREAMS_MAX', '64'))   # jobs beyond this many share streams round-robin
 _SIDE = {}
 
 
@@ -32,14 +33,17 @@ def fan_out(jobs, dev):
         return [j() for j in jobs]
     main = torch.cuda.current_stream(dev)
     outs = []
-    for st, job in zip(_side_streams(dev, len(jobs)), jobs):
+    pool = _side_streams(dev, min(len(jobs), MAX_SIDE))
+    for st in pool:
         st.wait_stream(main)
+    for i, job in enumerate(jobs):
+        st = pool[i % len(pool)]
         with torch.cuda.stream(st):
             r = job()
         for t in _tensors(r):
             t.record_stream(main)      # allocated on the side stream, consumed (and freed) on the main one
         outs.append((st, r))
-    for st, _ in outs:
+    for st in pool:
         main.wait_stream(st)
     return [r for _, r in outs]
 

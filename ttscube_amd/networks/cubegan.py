@@ -71,7 +71,7 @@ class Cubegan(nn.Module):
             return wav, [self._generator.out_len(f) if f > 0 else 0 for f in flens]
         return wav
 
-    def inference_pipelined(self, batches, check='deferred'):
+    def inference_pipelined(self, batches, check='deferred', lstm_group=8):
         """`inference` over a SEQUENCE of padded batches as a two-stage pipeline on two streams: the text / frame stacks of batch k + 1
         (latency-bound BiLSTM recurrences that occupy a few dozen CUs) run while the generator of batch k (which fills the chip) is still
         running.  Yields (wav [B,1,L], sample counts) per batch, in order; a yielded waveform is complete (its stream has been waited for).
@@ -93,7 +93,9 @@ class Cubegan(nn.Module):
 
         try:                                          # (no_grad only around the compute: a `with` spanning a yield would leak into the consumer)
             for X in batches:
-                with torch.cuda.stream(s_txt), torch.no_grad():
+                # recurrences packed `lstm_group` utterances per member group: they hold that many times fewer CUs (which the generator of the
+                # previous batch is using) for a slightly longer step — the step time is hidden here, the CUs are not
+                with torch.cuda.stream(s_txt), torch.no_grad(), _lib.lstm_group_size(lstm_group):
                     cond, _, flens = self._languasito.inference(X, return_aux=True, check_status=False)   # (waits for ITS stream only: frame counts)
                     if cond.shape[1] == 0:
                         cond = torch.zeros((cond.shape[0], 1, cond.shape[2]), device=dev)

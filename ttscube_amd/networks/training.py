@@ -61,7 +61,9 @@ def wavernn_loss(net, X):
 # `generator_forward_with_grad`).  The explicit flat-arena RCCL exchange (ttscube_amd/distributed.py) replaces Lightning's
 # implicit DDP.
 # =====================================================================================================================
+import contextlib
 import itertools
+import os
 import random
 
 import torch.nn.functional as F
@@ -69,6 +71,19 @@ import torch.nn.functional as F
 from ..hifigan.autograd import generator_forward_with_grad
 from .lstm_autograd import lstm_forward_train
 from .gru_autograd import gru_forward_train
+
+
+TEXT_STREAM = os.environ.get('TTSC_TEXT_STREAM', '1') != '0'
+_TEXT_STREAMS = {}
+
+
+def _text_stream(dev):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _TEXT_STREAMS:
+        _TEXT_STREAMS[key] = torch.cuda.Stream(device=dev, priority=int(os.environ.get('TTSC_TEXT_STREAM_PRIORITY', '0')))
+        # (normal priority on purpose: a high-priority stream gets a hardware queue of its own, and with MORE than the runtime's default four
+        # queues really running side by side this step gets slower, not faster — 77 ms vs 101 ms at b = 16, tools/probes/train_host_bound.py)
+    return _TEXT_STREAMS[key]
 
 
 def _require_device(t, what):
@@ -124,8 +139,11 @@ def _output_linears(net, hidden):
     return hip_linear(pre, net._output.linear_layer.weight, net._output.linear_layer.bias)
 
 
-def languasito_forward_train(lang, X):
-    """Differentiable Languasito2.forward (modules.py:996-999): (output_dur, output_pitch, output_vuv, conditioning)."""
+def _languasito_branches(lang, X):
+    """The two INDEPENDENT halves of the differentiable Languasito2.forward (modules.py:996-999) as closures:
+         text()  -> (output_dur, output_pitch, output_vuv)   phoneme stack `t`, duration and pitch recurrences — the parameters of opt_t
+         cond()  -> conditioning [B, F, 80]                  phoneme stack `g`, conditioning recurrence (target pitch as input) — part of opt_g
+    They share inputs only (no parameter, no activation), so a caller may run them on different streams."""
     if getattr(lang, '_use_cond', False):
         raise NotImplementedError("training with external conditioning ('fasttext:..' / 'hf:..') is not built: the encoders cannot be "
                                   "downloaded here and the conditioning branch (modules.py:963-990) is inference-only; use conditioning=None")
@@ -142,32 +160,47 @@ def languasito_forward_train(lang, X):
         spk = embed(getattr(lang, '_speaker_emb_' + which), x_speaker)
         return torch.cat([h, spk.repeat(1, h.shape[1], 1)], dim=-1)
 
-    def expand(x, alignments):
+    alignments = X['y_frame2phone']
+    m_ = max(len(a) for a in alignments)
+    idx = torch.zeros((len(alignments), m_), dtype=torch.long)
+    for b, a in enumerate(alignments):
+        idx[b, :len(a)] = torch.as_tensor(a)
+        idx[b, len(a):] = a[-1]
+    idx_dev = idx.to(dev)
+    pitch_in = X['y_pitch'].to(dev).float().unsqueeze(2) / lang._max_pitch
+
+    def expand(x):
         """phoneme rows -> frame rows (modules.py:1043-1053).  A row gather whose backward adds the frames of a phoneme in a FIXED order
         (text_autograd.HipEmbeddingFn: ttsc_rows_gather / ttsc_rows_scatter_add) — torch.gather's backward is a scatter of float atomics, and its
         run-to-run rounding noise, amplified by AdamW's normalisation, made the whole step irreproducible (round 4: ~440 of 900 parameter
         tensors differed between two identical 5-step runs)."""
         from .text_autograd import HipEmbeddingFn
         B_, N_, C_ = x.shape
-        m = max(len(a) for a in alignments)
-        idx = torch.zeros((len(alignments), m), dtype=torch.long)
-        for b, a in enumerate(alignments):
-            idx[b, :len(a)] = torch.as_tensor(a)
-            idx[b, len(a):] = a[-1]
-        flat = (idx + torch.arange(B_, dtype=torch.long)[:, None] * N_).to(x.device)
+        flat = idx_dev + torch.arange(B_, dtype=torch.long, device=dev)[:, None] * N_
         return HipEmbeddingFn.apply(x.reshape(B_ * N_, C_), flat, None)
 
-    hcs = stack('t')
-    hd = lstm_forward_train(lang._dur_rnn, hcs)
-    out_dur = linear(hd, lang._dur_output.linear_layer.weight, lang._dur_output.linear_layer.bias)
-    hp = lstm_forward_train(lang._pitch_rnn, expand(hcs, X['y_frame2phone']))
-    op = linear(hp, lang._pitch_output.linear_layer.weight, lang._pitch_output.linear_layer.bias)
-    g = expand(stack('g'), X['y_frame2phone'])
-    pitch = X['y_pitch'].to(dev).float().unsqueeze(2) / lang._max_pitch
-    m = min(g.shape[1], pitch.shape[1])
-    g = lstm_forward_train(lang._cond_rnn, torch.cat([g[:, :m], pitch[:, :m]], dim=-1))
-    cond = linear(g, lang._cond_output.linear_layer.weight, lang._cond_output.linear_layer.bias)
-    return out_dur, torch.sigmoid(op[:, :, 0]), torch.sigmoid(op[:, :, 1]), cond
+    def text():
+        hcs = stack('t')
+        hd = lstm_forward_train(lang._dur_rnn, hcs)
+        out_dur = linear(hd, lang._dur_output.linear_layer.weight, lang._dur_output.linear_layer.bias)
+        hp = lstm_forward_train(lang._pitch_rnn, expand(hcs))
+        op = linear(hp, lang._pitch_output.linear_layer.weight, lang._pitch_output.linear_layer.bias)
+        return out_dur, torch.sigmoid(op[:, :, 0]), torch.sigmoid(op[:, :, 1])
+
+    def cond():
+        g = expand(stack('g'))
+        m = min(g.shape[1], pitch_in.shape[1])
+        g = lstm_forward_train(lang._cond_rnn, torch.cat([g[:, :m], pitch_in[:, :m]], dim=-1))
+        return linear(g, lang._cond_output.linear_layer.weight, lang._cond_output.linear_layer.bias)
+
+    return text, cond
+
+
+def languasito_forward_train(lang, X):
+    """Differentiable Languasito2.forward (modules.py:996-999): (output_dur, output_pitch, output_vuv, conditioning)."""
+    text, cond = _languasito_branches(lang, X)
+    out_dur, p_pitch, p_vuv = text()
+    return out_dur, p_pitch, p_vuv, cond()
 
 
 def cubegan_param_groups(model):
@@ -228,17 +261,35 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
     rng = rng or random
     dev = model.get_device()
     lang = model._languasito
-    p_dur, p_pitch, p_vuv, conditioning = languasito_forward_train(lang, batch)
-    t_dur = batch['y_dur'].to(dev)
-    t_pitch = batch['y_pitch'].to(dev)
-    t_vuv = (t_pitch > 1).float()
-    m = min(t_dur.shape[1], p_dur.shape[1])
-    t_dur, p_dur = t_dur[:, :m], p_dur[:, :m, :]
-    m = min(t_pitch.shape[1], p_pitch.shape[1])
-    t_pitch, p_pitch, t_vuv, p_vuv = t_pitch[:, :m], p_pitch[:, :m], t_vuv[:, :m], p_vuv[:, :m]
-    ignore = int(max(model._encodings.max_pitch, model._encodings.max_duration) + 1)
-    loss_duration = F.cross_entropy(p_dur.reshape(-1, p_dur.shape[2]), t_dur.reshape(-1), ignore_index=ignore)
-    loss_pitch = (torch.abs(t_pitch / lang._max_pitch - p_pitch) * t_vuv).mean() + torch.abs(t_vuv - p_vuv).mean()
+    # The text side (phoneme stack `t`, duration / pitch recurrences, their losses, backward pass and optimizer: opt_t) shares nothing but
+    # inputs with the rest of the step, and it is a chain of latency-bound recurrences on a few dozen CUs.  It runs whole — forward, backward,
+    # exchange, AdamW — on a stream of its own, under the discriminator / generator work (reference order: last, cubegan.py:172-180; the
+    # parameter sets are disjoint, so the updates are the same).  TTSC_TEXT_STREAM=0 keeps it on the current stream.
+    text_fn, cond_fn = _languasito_branches(lang, batch)
+    cur = torch.cuda.current_stream(dev)
+    s_t = _text_stream(dev) if (TEXT_STREAM and dev.type == 'cuda') else None
+    if s_t is not None:
+        s_t.wait_stream(cur)
+    with (torch.cuda.stream(s_t) if s_t is not None else contextlib.nullcontext()):
+        p_dur, p_pitch, p_vuv = text_fn()
+        t_dur = batch['y_dur'].to(dev)
+        t_pitch = batch['y_pitch'].to(dev)
+        t_vuv = (t_pitch > 1).float()
+        m = min(t_dur.shape[1], p_dur.shape[1])
+        t_dur, p_dur = t_dur[:, :m], p_dur[:, :m, :]
+        m = min(t_pitch.shape[1], p_pitch.shape[1])
+        t_pitch, p_pitch, t_vuv, p_vuv = t_pitch[:, :m], p_pitch[:, :m], t_vuv[:, :m], p_vuv[:, :m]
+        ignore = int(max(model._encodings.max_pitch, model._encodings.max_duration) + 1)
+        loss_duration = F.cross_entropy(p_dur.reshape(-1, p_dur.shape[2]), t_dur.reshape(-1), ignore_index=ignore)
+        loss_pitch = (torch.abs(t_pitch / lang._max_pitch - p_pitch) * t_vuv).mean() + torch.abs(t_vuv - p_vuv).mean()
+        loss_text = loss_pitch + loss_duration
+        opt_t.zero_grad()
+        arm(2)
+        loss_text.backward()
+        if reducers:
+            reducers[2].reduce()
+        opt_t.step()
+    conditioning = cond_fn()
     y = batch['y_audio'].to(dev)
     if y.shape[1] > 12000 - 240:   # random 50-frame / 12000-sample crop per item (cubegan.py:116-128)
         ys, cs = [], []
@@ -281,21 +332,16 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
         y_ds_hat_r, y_ds_hat_g, fmap_s_r, fmap_s_g = msd(y, y_g_hat)
         loss_gen_all = (generator_loss(y_ds_hat_g)[0] + generator_loss(y_df_hat_g)[0] + feature_loss(fmap_s_r, fmap_s_g)
                         + feature_loss(fmap_f_r, fmap_f_g) + loss_mel)
-        loss_gen_all.backward(retain_graph=True)
+        loss_gen_all.backward()          # (the reference retains the graph for the text loss; here that graph is a separate one)
     finally:
         for p in d_params:
             p.requires_grad_(True)
     if reducers:
         reducers[0].reduce()
     opt_g.step()
-    opt_t.zero_grad()
-    arm(2)
-    loss_text = loss_pitch + loss_duration
-    loss_text.backward()
-    if reducers:
-        reducers[2].reduce()
-    opt_t.step()
     opt_b.step()
+    if s_t is not None:
+        cur.wait_stream(s_t)          # the step ends when both sides have
     _lib.check_split_status('cubegan_training_step')
     model._global_step += 1
     model._current_lr = model._compute_lr(model._learning_rate, 1e-5, model._global_step)
