@@ -566,7 +566,7 @@ def main():
                     help="'train': the Cubegan adversarial training step (BASELINE configs[3]); 'e2e': text -> audio, sentences sharded over the GPUs (configs[4])")
     ap.add_argument('--sentences-per-gpu', type=int, default=64, help='--mode e2e: sentences in every rank\'s shard')
     ap.add_argument('--e2e-batch', type=int, default=64, help='--mode e2e: sentences per padded batch')
-    ap.add_argument('--lstm-group', type=int, default=8, help='--mode e2e, pipelined pass: utterances per member group of the split LSTM recurrences (ttsc_lstm_set_group_size)')
+    ap.add_argument('--lstm-group', type=int, default=4, help='--mode e2e, pipelined pass: utterances per member group of the split LSTM recurrences (ttsc_lstm_set_group_size)')
     ap.add_argument('--no-pipeline', action='store_true', help='--mode e2e: time the sequential pass only (no two-stream pipelining across batches)')
     ap.add_argument('--train-batch', type=int, default=16, help='utterances per GPU in --mode train')
     ap.add_argument('--miopen-find', action='store_true', help="--mode train: let MIOpen search its convolution algorithms exhaustively "

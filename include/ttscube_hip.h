@@ -376,6 +376,17 @@ void ttsc_wavernn_destroy(ttsc_wavernn* w);
  * ------------------------------------------------------------------------------------------------ */
 int ttsc_linear_forward(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int64_t M, int32_t N,
                         int32_t K, int64_t ldx, int64_t ldy, int32_t act, int32_t accumulate, void* stream);
+/* The same contract on the f16 matrix pipe with fp32-class accuracy (gemm.hip: gemm_nt_f16x3_kernel): operands split into fp16 hi / lo halves on
+ * their way into LDS, three MFMA products per tile (lo.hi + hi.lo + hi.hi, fp32 accumulation) — ~2^-22 relative per product.  Operands must lie
+ * inside the fp16 range (|v| <= 65504): anything beyond sets a sticky per-device status word, read (and cleared; synchronises) by
+ * ttsc_gemm_split_status — 1 = a result since the last call is invalid.  lengths_dev [M / period] or NULL: rows are [utterance][period]; 128-row
+ * tiles that lie wholly at or beyond their utterances' lengths are skipped and stay unwritten (the recurrences never read them).
+ * ttsc_linear_split_supported: K >= 32, K % 4 == 0, ldx % 4 == 0, ldx >= K (and 16-byte aligned x / w); otherwise TTSC_EINVAL — use
+ * ttsc_linear_forward.  Callers: the hoisted input projections of the text-side BiLSTMs at inference (cube/networks/modules.py:873-905). */
+int32_t ttsc_linear_split_supported(int64_t M, int32_t N, int32_t K, int64_t ldx);
+int ttsc_linear_forward_split(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int64_t M, int32_t N, int32_t K,
+                              int64_t ldx, int64_t ldy, int32_t act, int32_t accumulate, const int32_t* lengths_dev, int32_t period, void* stream);
+int32_t ttsc_gemm_split_status(void);
 
 /* General fp32-MFMA GEMM for the backward passes of the Linears and of the hoisted recurrent projections (training, row a9; the
  * reference leaves these to autograd over torch.nn.Linear / nn.GRU / nn.LSTM: cube/networks/modules.py:505-563, cubegan.py:85-189):

@@ -139,6 +139,10 @@ SIGNATURES = {
     'ttsc_wavernn_destroy': (None, [C.c_void_p]),
     'ttsc_linear_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                       C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    'ttsc_linear_split_supported': (C.c_int32, [C.c_int64, C.c_int32, C.c_int32, C.c_int64]),
+    'ttsc_linear_forward_split': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                            C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    'ttsc_gemm_split_status': (C.c_int32, []),
     'ttsc_probe_mfma_tflops': (C.c_int, [C.c_int32, C.c_double, C.POINTER(C.c_double), C.c_void_p]),
     'ttsc_gemm_workspace_bytes': (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
     'ttsc_gemm': (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
@@ -231,6 +235,9 @@ def check_split_status(where):
     if bad:
         raise TTSCError('%s: split %s recurrence aborted on a hand-off timeout (are other kernels occupying the CUs? '
                         'TTSC_LSTM_SPLIT=1 / TTSC_GRU_SPLIT=1 select the single-workgroup kernels)' % (where, '/'.join(bad)))
+    if L.ttsc_gemm_split_status() != 0:
+        raise TTSCError('%s: an operand of a split-precision GEMM (ttsc_linear_forward_split) lay beyond the fp16 range (|v| > 65504) or was not '
+                        'finite — its results are invalid; TTSC_GEMM_SPLIT=0 keeps these projections on the exact fp32 kernel' % where)
 
 
 class lstm_group_size:

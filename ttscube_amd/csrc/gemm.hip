@@ -9,6 +9,9 @@
 // fp32 matrix pipe issuing back to back).  Both operands are K-contiguous, so they are staged the same way:
 // 16-byte global loads -> LDS rows padded to 17 floats (bank-conflict-free column reads for the MFMA fragments).
 #include "common.hpp"
+#include "conv_internal.hpp"
+#include <map>
+#include <mutex>
 
 namespace ttsc {
 
@@ -92,6 +95,141 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
         }
     }
     // C/D layout: col (n) = lane & 31, row (m) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + l31;
+            if (n >= a.N) continue;
+            const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < a.M) {
+                    float* y = a.Y + (size_t)m * a.ldy + n;
+                    float v = acc[i][j][r] + bv;
+                    if (a.accumulate) v += *y;
+                    *y = gemm_act(v, a.act);
+                }
+            }
+        }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same NT contract on the f16 matrix pipe with fp32-class accuracy: every fp32 operand value v is split on its way into LDS into
+// hi = rn16(v), lo = rn16(v - hi) and the product is summed as lo_x.hi_w + hi_x.lo_w + hi_x.hi_w in fp32 accumulators (three
+// v_mfma_f32_32x32x16_f16 per tile and 16 k: the ceiling is a third of the dense f16 peak = 833 TFLOP/s against 157 for the fp32 MFMA above).
+// The dropped lo.lo term and the two roundings leave ~2^-22 relative per product — the split the vocoder convolutions use (conv1d.hip), here
+// without pre-scales: operands must lie inside the fp16 range (|v| <= 65504; anything beyond sets the launch's status word, reported by
+// ttsc_gemm_split_status) and values below 2^-14 keep only an absolute 2^-25.  Callers: the hoisted input projections of the text-side
+// BiLSTMs (activations of tanh / LSTM layers, embeddings, mel frames).  `lengths` / `period`: rows are [utterance][period] and rows at or
+// beyond an utterance's length are padding nobody reads — a 128-row tile that lies wholly in padding returns at once (its outputs stay
+// unwritten).  128 x 128 x 32 tile, 4 waves as 2 x 2, each 2 x 2 MFMA tiles; the next k-slice's global loads are in flight during the MFMAs.
+typedef _Float16 gemm_half8 __attribute__((ext_vector_type(8)));
+constexpr int SK = 32, SLD = SK + 8;   // k-slice, LDS row pitch in halfs (80 bytes: 16-byte aligned fragments)
+
+struct GemmSplitArgs {
+    const float* X;
+    const float* W;
+    const float* bias;
+    float* Y;
+    int M, N, K, ldx, ldy;
+    int act, accumulate;
+    const int* lengths;
+    int period;
+    unsigned* status;
+};
+
+__global__ __launch_bounds__(256) void gemm_nt_f16x3_kernel(GemmSplitArgs a) {
+    __shared__ __attribute__((aligned(16))) _Float16 Ah[GM * SLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Al[GM * SLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Bh[GN * SLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Bl[GN * SLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
+    const int half = lane >> 5, l31 = lane & 31;
+    if (a.lengths) {
+        int live = 0;
+        if (tid < GM && m0 + tid < a.M) {
+            const int b = (m0 + tid) / a.period;
+            live = (m0 + tid) - b * a.period < a.lengths[b];
+        }
+        if (!__syncthreads_or(live)) return;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float4 ra[4], rb[4];
+    unsigned bad = 0;
+    // 128 rows x 8 float4 per operand and k-slice -> 4 per thread and operand; 8 consecutive lanes read one row's 128 bytes
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + it * 256;
+            const int row = idx >> 3, k4 = (idx & 7) * 4;
+            ra[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[it] = ra[it];
+            if (m0 + row < a.M && k0 + k4 < a.K) ra[it] = *reinterpret_cast<const float4*>(a.X + (size_t)(m0 + row) * a.ldx + k0 + k4);
+            if (n0 + row < a.N && k0 + k4 < a.K) rb[it] = *reinterpret_cast<const float4*>(a.W + (size_t)(n0 + row) * a.K + k0 + k4);
+        }
+    };
+    auto put = [&](const float4& v, _Float16* hi_plane, _Float16* lo_plane, int off) {
+        unsigned h0, l0, h1, l1;
+        split2_f16(v.x, v.y, h0, l0);
+        split2_f16(v.z, v.w, h1, l1);
+        // a hi half with an all-ones exponent: the value was beyond the fp16 range (or not finite)
+        bad |= (unsigned)(((h0 & 0x7c00u) == 0x7c00u) | ((h0 & 0x7c000000u) == 0x7c000000u) | ((h1 & 0x7c00u) == 0x7c00u) | ((h1 & 0x7c000000u) == 0x7c000000u));
+        *reinterpret_cast<uint2*>(hi_plane + off) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(lo_plane + off) = make_uint2(l0, l1);
+    };
+    gload(0);
+    for (int k0 = 0; k0 < a.K; k0 += SK) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + it * 256;
+            const int off = (idx >> 3) * SLD + (idx & 7) * 4;
+            put(ra[it], Ah, Al, off);
+            put(rb[it], Bh, Bl, off);
+        }
+        __syncthreads();
+        if (k0 + SK < a.K) gload(k0 + SK);
+#pragma unroll
+        for (int ks = 0; ks < SK / 16; ++ks) {
+            gemm_half8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int off = (wm * 64 + i * 32 + l31) * SLD + ks * 16 + half * 8;
+                ah[i] = *reinterpret_cast<const gemm_half8*>(Ah + off);
+                al[i] = *reinterpret_cast<const gemm_half8*>(Al + off);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int off = (wn * 64 + j * 32 + l31) * SLD + ks * 16 + half * 8;
+                bh[j] = *reinterpret_cast<const gemm_half8*>(Bh + off);
+                bl[j] = *reinterpret_cast<const gemm_half8*>(Bl + off);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (bad) atomicOr(a.status, 1u);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -304,6 +442,69 @@ extern "C" int ttsc_linear_forward(const float* x_dev, const float* w_dev, const
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("gemm_nt_kernel launch failed: %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    return TTSC_OK;
+}
+
+// status word of the split-precision GEMM, one per device (an operand beyond the fp16 range sets it; sticky until read)
+static std::mutex g_split_mu;
+static std::map<int, unsigned*> g_split_words;
+
+static unsigned* split_status_word() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    auto it = g_split_words.find(dev);
+    if (it != g_split_words.end()) return it->second;
+    unsigned* w = nullptr;
+    if (hipMalloc(&w, sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(w, 0, sizeof(unsigned)) != hipSuccess) return nullptr;
+    g_split_words[dev] = w;
+    return w;
+}
+
+extern "C" int32_t ttsc_gemm_split_status(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    unsigned* w = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_split_mu);
+        auto it = g_split_words.find(dev);
+        if (it == g_split_words.end()) return 0;
+        w = it->second;
+    }
+    unsigned v = 0;
+    if (hipMemcpy(&v, w, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;   // synchronises
+    if (v && hipMemset(w, 0, sizeof(unsigned)) != hipSuccess) return -1;
+    return v ? 1 : 0;
+}
+
+extern "C" int32_t ttsc_linear_split_supported(int64_t M, int32_t N, int32_t K, int64_t ldx) {
+    return M > 0 && N > 0 && K >= 32 && K % 4 == 0 && ldx % 4 == 0 && ldx >= K;
+}
+
+// ttsc_linear_forward's contract on the split-precision kernel (gemm_nt_f16x3_kernel).  lengths_dev [M / period] or NULL: row tiles wholly at or beyond
+// their utterances' lengths are skipped (outputs unwritten).  TTSC_EINVAL when the shape / alignment needs the exact kernel.
+extern "C" int ttsc_linear_forward_split(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int64_t M, int32_t N, int32_t K,
+                                         int64_t ldx, int64_t ldy, int32_t act, int32_t accumulate, const int32_t* lengths_dev, int32_t period,
+                                         void* stream) {
+    TTSC_REQUIRE(x_dev && w_dev && y_dev, "ttsc_linear_forward_split: null argument");
+    TTSC_REQUIRE(M > 0 && N > 0 && K > 0 && ldx > 0 && ldy >= N && M < (1ll << 31) && ldx < (1ll << 31) && ldy < (1ll << 31),
+                 "ttsc_linear_forward_split: bad shape M=%lld N=%d K=%d ldx=%lld ldy=%lld", (long long)M, N, K, (long long)ldx, (long long)ldy);
+    TTSC_REQUIRE(!lengths_dev || (period > 0 && M % period == 0), "ttsc_linear_forward_split: rows must be [utterance][period] when lengths are given");
+    if (!ttsc_linear_split_supported(M, N, K, ldx) || (((uintptr_t)x_dev | (uintptr_t)w_dev) & 15) != 0) {
+        set_error("ttsc_linear_forward_split: shape / alignment not supported (K %% 4, ldx %% 4, 16-byte aligned operands, ldx >= K)");
+        return TTSC_EINVAL;
+    }
+    unsigned* st = split_status_word();
+    TTSC_REQUIRE(st, "ttsc_linear_forward_split: cannot allocate the status word");
+    GemmSplitArgs a{x_dev, w_dev, bias_dev, y_dev, (int)M, N, K, (int)ldx, (int)ldy, act, accumulate, lengths_dev, period, st};
+    dim3 grid((unsigned)ceil_div(N, GN), (unsigned)ceil_div(M, GM));
+    hipLaunchKernelGGL(gemm_nt_f16x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("gemm_nt_f16x3_kernel launch failed: %s", hipGetErrorString(e));
         return TTSC_EHIP;
     }
     return TTSC_OK;

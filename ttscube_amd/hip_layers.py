@@ -4,6 +4,7 @@
 (cube/networks/modules.py:37-55), PostNet (modules.py:117-145), the WaveRNN low-res convs (modules.py:416-420)
 and the char CNNs (textcoder.py:44-53, modules.py:850-871)."""
 import ctypes as C
+import os
 
 import torch
 
@@ -108,9 +109,16 @@ class Conv1dHip:
             pass
 
 
-def linear_hip(x, weight, bias=None, act=None, out=None, accumulate=False):
+SPLIT_GEMM = os.environ.get('TTSC_GEMM_SPLIT', '1') != '0'
+
+
+def linear_hip(x, weight, bias=None, act=None, out=None, accumulate=False, split=False, lengths_dev=None, period=0):
     """y[..., :N] = act(x[..., :K] @ weight[N,K]^T + bias) on the MFMA GEMM (ttsc_linear_forward).
-    x: device tensor [..., K] (last dim contiguous, rows at a constant stride); weight/bias: device tensors."""
+    x: device tensor [..., K] (last dim contiguous, rows at a constant stride); weight/bias: device tensors.
+    split: run on the f16 matrix pipe with fp32-class accuracy (ttsc_linear_forward_split: hi / lo fp16 halves, three products — operands
+    must lie inside the fp16 range, checked on the device and reported by _lib.check_split_status); shapes the split kernel does not take
+    run on the exact fp32 kernel.  lengths_dev (int32 device tensor [B]) with period = T for x [B, T, K]: rows t >= lengths[b] are padding
+    nobody reads — whole row tiles of padding are skipped and stay UNWRITTEN (split kernel only)."""
     if not x.is_cuda:
         raise _lib.TTSCError('linear_hip: input must live on a HIP device; no CPU path')
     K = x.shape[-1]
@@ -127,10 +135,17 @@ def linear_hip(x, weight, bias=None, act=None, out=None, accumulate=False):
         assert out.is_cuda and out.dtype == torch.float32 and out.stride(-1) == 1
         out2 = out
         ldy = out.stride(-2) if out.dim() > 1 else N
+    L = _lib.lib()
     with torch.cuda.device(x.device):
-        _lib.check(_lib.lib().ttsc_linear_forward(_lib.dev_ptr(x2), _lib.dev_ptr(w), _lib.dev_ptr(b) if b is not None else None,
-                                                  C.c_void_p(out2.data_ptr()), M, N, K, K, ldy, ACT[act], int(accumulate),
-                                                  _lib.current_stream()), 'ttsc_linear_forward')
+        if split and SPLIT_GEMM and L.ttsc_linear_split_supported(M, N, K, K) and (x2.data_ptr() | w.data_ptr()) % 16 == 0:
+            _lib.check(L.ttsc_linear_forward_split(_lib.dev_ptr(x2), _lib.dev_ptr(w), _lib.dev_ptr(b) if b is not None else None,
+                                                   C.c_void_p(out2.data_ptr()), M, N, K, K, ldy, ACT[act], int(accumulate),
+                                                   _lib.dev_ptr(lengths_dev) if lengths_dev is not None else None, int(period),
+                                                   _lib.current_stream()), 'ttsc_linear_forward_split')
+        else:
+            _lib.check(L.ttsc_linear_forward(_lib.dev_ptr(x2), _lib.dev_ptr(w), _lib.dev_ptr(b) if b is not None else None,
+                                             C.c_void_p(out2.data_ptr()), M, N, K, K, ldy, ACT[act], int(accumulate),
+                                             _lib.current_stream()), 'ttsc_linear_forward')
     if out is None:
         return out2.reshape(tuple(x.shape[:-1]) + (N,))
     return out
@@ -244,7 +259,8 @@ class LSTMHip:
         cn = torch.empty_like(hn) if return_state else None
         cur = x.float().contiguous()
         for l in range(self.num_layers):
-            xg = linear_hip(cur, self._wih[l], self._bias[l])                       # [B, T, nd*4H]
+            # hoisted input projection of all steps: split-precision MFMA GEMM, padding tiles skipped (the recurrence never reads them)
+            xg = linear_hip(cur, self._wih[l], self._bias[l], split=True, lengths_dev=len_dev, period=T)   # [B, T, nd*4H]
             y = torch.empty((B, T, nd * H), dtype=torch.float32, device=x.device)
             h0 = c0 = None
             if hx is not None:

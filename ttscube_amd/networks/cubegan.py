@@ -71,7 +71,7 @@ class Cubegan(nn.Module):
             return wav, [self._generator.out_len(f) if f > 0 else 0 for f in flens]
         return wav
 
-    def inference_pipelined(self, batches, check='deferred', lstm_group=8):
+    def inference_pipelined(self, batches, check='deferred', lstm_group=4):
         """`inference` over a SEQUENCE of padded batches as a two-stage pipeline on two streams: the text / frame stacks of batch k + 1
         (latency-bound BiLSTM recurrences that occupy a few dozen CUs) run while the generator of batch k (which fills the chip) is still
         running.  Yields (wav [B,1,L], sample counts) per batch, in order; a yielded waveform is complete (its stream has been waited for).
