@@ -172,6 +172,19 @@ void ttsc_conv1d_destroy(ttsc_conv1d* c);
 int ttsc_weight_norm_forward(const float* v_dev, const float* g_dev, float* w_dev, float* norm_dev, int32_t rows, int64_t cols, void* stream);
 int ttsc_weight_norm_backward(const float* dw_dev, const float* v_dev, const float* g_dev, const float* norm_dev, float* dv_dev,
                               float* dg_dev, int32_t rows, int64_t cols, void* stream);
+/* torch.nn.utils.spectral_norm of the first scale discriminator ([EXTERNAL hifigan/models.py] MultiScaleDiscriminator:
+ * DiscriminatorS(use_spectral_norm=True), used by cube/networks/cubegan.py:40-41): wn = W / sigma, sigma = u^T W v after one power iteration (v <- normalize(W^T u), u <- normalize(W v)).  The two
+ * mat-vecs run on the MFMA GEMM (ttsc_gemm, N = 1); these are the pieces around them, all with fixed summation orders:
+ *   ttsc_l2_normalize   out[n] = x / max(||x||, eps), norm_dev[0] = ||x|| (either output may be NULL)
+ *   ttsc_dot            out_dev[0] = sum a[i] b[i] (ws_dev >= ttsc_dot_workspace_bytes(n))
+ *   ttsc_div_scalar     out = w / sigma_dev[0]
+ *   ttsc_spectral_norm_backward   dW[r,c] = dWn[r,c] / sigma - (dot_dev[0] / sigma^2) u[r] v[c], dot_dev[0] = sum(dWn . W) */
+int ttsc_l2_normalize(const float* x_dev, int32_t n, float eps, float* out_dev, float* norm_dev, void* stream);
+size_t ttsc_dot_workspace_bytes(int64_t n);
+int ttsc_dot(const float* a_dev, const float* b_dev, int64_t n, float* out_dev, void* ws_dev, size_t ws_bytes, void* stream);
+int ttsc_div_scalar(const float* w_dev, const float* sigma_dev, float* out_dev, int64_t n, void* stream);
+int ttsc_spectral_norm_backward(const float* dwn_dev, const float* u_dev, const float* v_dev, const float* sigma_dev, const float* dot_dev,
+                                float* dw_dev, int32_t rows, int64_t cols, void* stream);
 /* bias gradient db[c] = sum_{b,t} dy[b,c,t] (fixed summation order).  ws_is_fresh = 1 when the workspace was not left by a
  * previous ttsc_bias_grad call with the same shape (its ticket counters are then zeroed on the stream first). */
 size_t ttsc_bias_grad_workspace_bytes(int32_t B, int32_t C, int64_t L);

@@ -152,3 +152,30 @@ def test_fused_deinterleave_equals_the_torch_views(N, C, L, G, s, P, pad, K):
     assert torch.equal(wout, wref)
     gw = torch.randn(wref.shape, generator=g).cuda()
     assert torch.equal(torch.autograd.grad(wout, w, gw)[0], torch.autograd.grad(wref, w, gw)[0])
+
+
+@pytest.mark.parametrize('Cout,Cin,K,groups', [(128, 1, 15, 1), (256, 128, 41, 16), (1024, 1024, 5, 1), (1, 1024, 3, 1)])
+def test_spectral_norm_function_matches_torch_hook(Cout, Cin, K, groups):
+    """HipSpectralNormFn against torch.nn.utils.spectral_norm's own pre-forward hook on a twin module: the normalised weight, the in-place
+    power iteration on weight_u / weight_v (training mode, two consecutive calls), eval mode (no iteration), and the gradient w.r.t.
+    weight_orig — the layers of DiscriminatorS(use_spectral_norm=True)."""
+    import copy
+    import torch.nn as nn
+    from torch.nn.utils import spectral_norm
+    from ttscube_amd.hifigan.disc_hip import _weight
+    torch.manual_seed(Cout + K)
+    a = spectral_norm(nn.Conv1d(Cin, Cout, K, groups=groups)).cuda()
+    b = copy.deepcopy(a)
+    for mode in ('train', 'train', 'eval'):
+        a.train(mode == 'train')
+        b.train(mode == 'train')
+        for hook in a._forward_pre_hooks.values():
+            hook(a, (None,))
+        ref = a.weight
+        got = _weight(b)
+        assert _rel(got, ref) < 2e-6
+        assert _rel(b.weight_u, a.weight_u) < 2e-6 and _rel(b.weight_v, a.weight_v) < 2e-6
+        g = torch.randn_like(ref)
+        gr, = torch.autograd.grad(ref, a.weight_orig, g)
+        gg, = torch.autograd.grad(got, b.weight_orig, g)
+        assert _rel(gg, gr) < 5e-6, mode

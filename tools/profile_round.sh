@@ -21,6 +21,7 @@ python tools/rocpd_stats.py $O/e2e/e_results.db $O/e2e_kernel_stats.csv >> $O/e2
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/train -o r -- python bench.py --mode train --steps 4 --warmup 2 > $O/train.log 2>&1
 # per-kernel stats of the whole run (includes MIOpen's one-time find pass) and of the last ~2 steps (steady state)
 python tools/rocpd_stats.py $O/train/r_results.db $O/train_kernel_stats.csv -300 $O/train_last2steps_kernel_stats.csv >> $O/train.log 2>&1
+python tools/gpu_timeline.py $O/train/r_results.db 100 2 > $O/train_timeline.txt 2>&1   # (kernels of different streams run one at a time under the tracer)
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/wr -o v -- python tools/bench_wavernn.py > $O/wavernn.log 2>&1
 python tools/rocpd_stats.py $O/wr/v_results.db $O/wavernn_kernel_stats.csv >> $O/wavernn.log 2>&1
 rm -rf $O/trace $O/fetch $O/write $O/sq $O/grbm $O/e2e $O/train $O/wr
@@ -52,5 +53,9 @@ rm -rf $O/voc
 (TTSC_HIFIGAN_STAGE=1 timeout 200 $B --steps 5 --warmup 2) > $O/bench_stage_launch_on.log 2>&1
 (TTSC_CHAIN_IL=0 timeout 200 $B --steps 5 --warmup 2) > $O/bench_plain_columns.log 2>&1
 timeout 200 python tools/probes/textcoder_time.py > $O/textcoder_time.log 2>&1
+# the Cubegan step: host enqueue time vs GPU drain, with and without the text side on its own stream; the LSTM recurrence by utterances per member group
+(for t in 1 0; do echo "TTSC_TEXT_STREAM=$t"; TTSC_TEXT_STREAM=$t timeout 200 python tools/probes/train_host_bound.py 2>&1 | tail -1; done) > $O/train_host_bound.log
+(timeout 200 python tools/probes/lstm_group_probe.py 2>&1 | grep -v amdgpu.ids) > $O/lstm_group_probe.log
+(TTSC_GEMM_SPLIT=0 TTSC_LSTM_NB=1 timeout 300 python bench.py --mode e2e --steps 5 --warmup 2 --no-pipeline 2>/dev/null | grep '^{') > $O/bench_e2e_round3_text_side.json
 timeout 600 python bench.py > $O/bench_final.json 2> $O/bench_final.err < /dev/null
 du -sh $O; ls $O; tail -c 300 $O/bench_final.json

@@ -94,6 +94,12 @@ SIGNATURES = {
     'ttsc_weight_norm_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]),
     'ttsc_weight_norm_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                             C.c_int64, C.c_void_p]),
+    'ttsc_l2_normalize': (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ttsc_dot_workspace_bytes': (C.c_size_t, [C.c_int64]),
+    'ttsc_dot': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'ttsc_div_scalar': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'ttsc_spectral_norm_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
+                                              C.c_void_p]),
     'ttsc_adamw_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_float, C.c_int64, C.c_void_p]),
     'ttsc_rows_gather': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
@@ -215,9 +221,47 @@ def require_gpu():
     return n
 
 
+_T = {}
+
+
+def _torch_c():
+    """torch._C entry points behind the two per-launch queries (resolved once): the raw current stream and the current device index straight
+    from the C extension — torch.cuda.current_stream() builds a Stream object through three Python layers (~10 us; ~2300 calls and 7 ms of host
+    time per Cubegan step, tools/probes/train_host_profile.py)"""
+    if not _T:
+        import torch
+        fast = os.environ.get('TTSC_FAST_STREAM_QUERY', '1') != '0'      # (0: the torch.cuda.* path, for A/B measurements)
+        _T['raw'] = getattr(torch._C, '_cuda_getCurrentRawStream', None) if fast else None
+        _T['dev'] = getattr(torch._C, '_cuda_getDevice', None) if fast else None
+        _T['torch'] = torch
+    return _T
+
+
 def current_stream():
-    import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    t = _T or _torch_c()
+    if t['raw'] is not None and t['dev'] is not None:
+        return C.c_void_p(t['raw'](t['dev']()))
+    return C.c_void_p(t['torch'].cuda.current_stream().cuda_stream)
+
+
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on_device(dev):
+    """`with on_device(t.device):` — torch.cuda.device(dev) when `dev` is not the current device, nothing at all when it is (the usual case: one
+    process per GPU)"""
+    t = _T or _torch_c()
+    if t['dev'] is not None and (dev.index is None or dev.index == t['dev']()):
+        return _NO_GUARD
+    return t['torch'].cuda.device(dev)
 
 
 def dev_ptr(t):

@@ -313,6 +313,74 @@ __global__ __launch_bounds__(256) void deinterleave_w_kernel(const float* __rest
     }
 }
 
+// ---- spectral normalisation of a weight (torch.nn.utils.spectral_norm: the first scale discriminator, [EXTERNAL hifigan/models.py]
+//      DiscriminatorS(use_spectral_norm=True), instantiated by cube/networks/cubegan.py:40-41) — the small pieces around the two mat-vecs of the power iteration (those run on the MFMA GEMM):
+// x[n] -> out = x / max(||x||, eps), norm_out[0] = ||x||: one workgroup, squares summed per thread over a fixed stride, fixed LDS tree
+__global__ __launch_bounds__(256) void l2_normalize_kernel(const float* __restrict__ x, int n, float eps, float* __restrict__ out, float* __restrict__ norm_out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s = fmaf(x[i], x[i], s);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    const float nrm = sqrtf(red[0]);
+    if (threadIdx.x == 0 && norm_out) norm_out[0] = nrm;
+    if (out) {
+        const float d = fmaxf(nrm, eps);
+        for (int i = threadIdx.x; i < n; i += 256) out[i] = x[i] / d;
+    }
+}
+
+// sum_i a[i] b[i] in a fixed order: `parts` workgroups over contiguous ranges (per-thread strided chains, LDS tree), then one workgroup over the parts
+__global__ __launch_bounds__(256) void dot_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, long per, float* __restrict__ ws) {
+    __shared__ float red[256];
+    const long beg = (long)blockIdx.x * per, end = beg + per < n ? beg + per : n;
+    float s = 0.f;
+    for (long i = beg + threadIdx.x; i < end; i += 256) s = fmaf(a[i], b[i], s);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ws[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void dot_final_kernel(const float* __restrict__ ws, int parts, float* __restrict__ out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < parts; i += 256) s += ws[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// out = w / sigma (sigma on the device)
+__global__ __launch_bounds__(256) void div_scalar_kernel(const float* __restrict__ w, const float* __restrict__ sigma, float* __restrict__ out, long n) {
+    const float s = sigma[0];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = w[i] / s;
+}
+
+// gradient of wn = w / sigma, sigma = u^T W v (u, v constants): dW[r, c] = dWn[r, c] / sigma - (sum(dWn . W) / sigma^2) u[r] v[c]
+__global__ __launch_bounds__(256) void spectral_bwd_kernel(const float* __restrict__ dwn, const float* __restrict__ u, const float* __restrict__ v,
+                                                           const float* __restrict__ sigma, const float* __restrict__ dotp, float* __restrict__ dw, int R,
+                                                           long Cc) {
+    const float s = sigma[0];
+    const float k = dotp[0] / (s * s);
+    const long n = (long)R * Cc;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long r = i / Cc, c = i - r * Cc;
+        dw[i] = dwn[i] / s - k * (u[r] * v[c]);
+    }
+}
+
 }  // namespace ttsc
 
 using namespace ttsc;
@@ -347,6 +415,43 @@ static int bias_grad_splits(int32_t B, int32_t C, int64_t L) {
     if (s > cap) s = cap;
     if (s < 1) s = 1;
     return (int)s;
+}
+
+extern "C" int ttsc_l2_normalize(const float* x_dev, int32_t n, float eps, float* out_dev, float* norm_dev, void* stream) {
+    TTSC_REQUIRE(x_dev && n > 0 && (out_dev || norm_dev), "ttsc_l2_normalize: bad argument");
+    hipLaunchKernelGGL(l2_normalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x_dev, n, eps, out_dev, norm_dev);
+    return check_launch("l2_normalize_kernel");
+}
+
+static int dot_parts(int64_t n) { return (int)(n >= (1 << 16) ? 256 : (n >= 4096 ? 16 : 1)); }
+
+extern "C" size_t ttsc_dot_workspace_bytes(int64_t n) { return n > 0 ? (size_t)dot_parts(n) * sizeof(float) : 0; }
+
+// out_dev[0] = sum_i a[i] b[i], summed in a fixed order (deterministic)
+extern "C" int ttsc_dot(const float* a_dev, const float* b_dev, int64_t n, float* out_dev, void* ws_dev, size_t ws_bytes, void* stream) {
+    TTSC_REQUIRE(a_dev && b_dev && out_dev && ws_dev && n > 0, "ttsc_dot: bad argument");
+    const int parts = dot_parts(n);
+    TTSC_REQUIRE(ws_bytes >= (size_t)parts * sizeof(float), "ttsc_dot: workspace too small");
+    const long per = (long)((n + parts - 1) / parts);
+    hipLaunchKernelGGL(dot_partial_kernel, dim3((unsigned)parts), dim3(256), 0, (hipStream_t)stream, a_dev, b_dev, (long)n, per, (float*)ws_dev);
+    hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws_dev, parts, out_dev);
+    return check_launch("dot kernels");
+}
+
+extern "C" int ttsc_div_scalar(const float* w_dev, const float* sigma_dev, float* out_dev, int64_t n, void* stream) {
+    TTSC_REQUIRE(w_dev && sigma_dev && out_dev && n > 0, "ttsc_div_scalar: bad argument");
+    hipLaunchKernelGGL(div_scalar_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, w_dev, sigma_dev, out_dev,
+                       (long)n);
+    return check_launch("div_scalar_kernel");
+}
+
+extern "C" int ttsc_spectral_norm_backward(const float* dwn_dev, const float* u_dev, const float* v_dev, const float* sigma_dev, const float* dot_dev,
+                                           float* dw_dev, int32_t rows, int64_t cols, void* stream) {
+    TTSC_REQUIRE(dwn_dev && u_dev && v_dev && sigma_dev && dot_dev && dw_dev && rows > 0 && cols > 0, "ttsc_spectral_norm_backward: bad argument");
+    const long n = (long)rows * cols;
+    hipLaunchKernelGGL(spectral_bwd_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, dwn_dev, u_dev, v_dev,
+                       sigma_dev, dot_dev, dw_dev, rows, (long)cols);
+    return check_launch("spectral_bwd_kernel");
 }
 
 extern "C" size_t ttsc_bias_grad_workspace_bytes(int32_t B, int32_t C, int64_t L) {

@@ -250,6 +250,7 @@ class ArenaReducer:
             elif _mode == 'current+default':
                 join_side_streams(g.device, include_default=True)
         try:
+            self.opt.gather(c['s'], c['e'])   # the chunk's gradients, from autograd's tensors into the arena (no-op for those already there)
             if c['buf'] is None:   # ragged tail: stage into a padded buffer
                 if 'stage' not in c:
                     c['stage'] = torch.zeros(c['pad'], dtype=torch.float32, device=g.device)
@@ -292,6 +293,7 @@ class ArenaReducer:
             if c['buf'] is None:
                 self.opt.g[c['s']:c['e']].copy_(c['flat'][:c['e'] - c['s']])
             c['work'] = None
+        self.opt.grads_in_arena()      # `.grad` of every live parameter = its (averaged) slice of the arena
 
 
 def broadcast_parameters(module, src=0, group=None):

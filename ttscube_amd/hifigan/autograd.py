@@ -112,7 +112,7 @@ def _bias_grad(tc, dy):
         ws = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=dy.device)
         tc._bg_ws = {key: ws}
     db = torch.empty(Cc, dtype=torch.float32, device=dy.device)
-    with torch.cuda.device(dy.device):
+    with _lib.on_device(dy.device):
         _lib.check(Lb.ttsc_bias_grad(_lib.dev_ptr(dy), _lib.dev_ptr(db), B, Cc, L, _lib.dev_ptr(ws), nbytes, int(fresh),
                                      _lib.current_stream()), 'ttsc_bias_grad')
     return db
@@ -129,7 +129,7 @@ def _wgrad(P, Q, A, Bc, J, base, step, q_scale, q_slope, groups=1, amax=None, p_
     if SPLIT_TRAIN and groups == 1 and L.ttsc_conv_wgrad_split_supported(A, Bc, J, step):   # dense layer: fp16 hi/lo x 3 on MFMA, 128 x 64 tiles
         nbytes = int(L.ttsc_conv_wgrad_split_workspace_bytes(N, A, Bc, LP, J))
         ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=P.device)
-        with torch.cuda.device(P.device):
+        with _lib.on_device(P.device):
             aq = _lib.dev_ptr(amax[0:1]) if amax is not None else None
             ap = _lib.dev_ptr(amax[2:3]) if amax is not None else None
             _lib.check(L.ttsc_conv_wgrad_split(_lib.dev_ptr(P), _lib.dev_ptr(Q), _lib.dev_ptr(G), N, A, Bc, LP, LQ, J, base, step, q_scale, q_slope,
@@ -138,7 +138,7 @@ def _wgrad(P, Q, A, Bc, J, base, step, q_scale, q_slope, groups=1, amax=None, p_
         return G
     nbytes = int(L.ttsc_conv_wgrad_workspace_bytes(N, A, Bg, LP, J))
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=P.device)
-    with torch.cuda.device(P.device):
+    with _lib.on_device(P.device):
         _lib.check(L.ttsc_conv_wgrad_grouped(_lib.dev_ptr(P), _lib.dev_ptr(Q), _lib.dev_ptr(G), N, A, Bg, groups, LP, LQ, J, base, step,
                                              q_scale, q_slope, _lib.dev_ptr(ws), nbytes, _lib.current_stream()), 'ttsc_conv_wgrad')
     return G
@@ -164,7 +164,7 @@ def _conv_split(x, w, b, resid, gate, Cin, Cout, K, padding, dilation, flip, in_
     nbytes = int(L.ttsc_conv_train_workspace_bytes(Cin, Cout, K, groups))
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
     ptr = lambda t: _lib.dev_ptr(t) if t is not None else None
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         _lib.check(L.ttsc_conv_train(ptr(x), ptr(w), ptr(b), ptr(resid), ptr(gate), ptr(y), B, Cin, Cout, K, Lin, padding, dilation, groups, int(flip),
                                      float(in_scale), float(in_slope), float(out_scale), float(gate_slope), ptr(amax_x), ptr(amax_w), int(measure),
                                      ptr(ws), nbytes, _lib.current_stream()), 'ttsc_conv_train')
@@ -254,7 +254,7 @@ class HipWeightNormFn(torch.autograd.Function):
         Cc = v.numel() // R
         w = torch.empty_like(v)
         n = torch.empty(R, dtype=torch.float32, device=v.device)
-        with torch.cuda.device(v.device):
+        with _lib.on_device(v.device):
             _lib.check(_lib.lib().ttsc_weight_norm_forward(_lib.dev_ptr(v), _lib.dev_ptr(g), _lib.dev_ptr(w), _lib.dev_ptr(n), R, Cc,
                                                            _lib.current_stream()), 'ttsc_weight_norm_forward')
         ctx.save_for_backward(v, g, n)
@@ -268,7 +268,7 @@ class HipWeightNormFn(torch.autograd.Function):
         Cc = v.numel() // R
         dv = torch.empty_like(v)
         dg = torch.empty_like(g)
-        with torch.cuda.device(v.device):
+        with _lib.on_device(v.device):
             _lib.check(_lib.lib().ttsc_weight_norm_backward(_lib.dev_ptr(dw), _lib.dev_ptr(v), _lib.dev_ptr(g), _lib.dev_ptr(n),
                                                             _lib.dev_ptr(dv), _lib.dev_ptr(dg), R, Cc, _lib.current_stream()),
                        'ttsc_weight_norm_backward')

@@ -35,7 +35,7 @@ class _DeintX(torch.autograd.Function):
         x = x.contiguous()
         N, C, LP = x.shape
         out = torch.empty((N, s * C, M * P), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().ttsc_deinterleave_x(_lib.dev_ptr(x), _lib.dev_ptr(out), N, C, LP // P, G, s, P, pad, M, 0, _lib.current_stream()),
                        'ttsc_deinterleave_x')
         ctx.meta = (N, C, LP, G, s, P, pad, M)
@@ -46,7 +46,7 @@ class _DeintX(torch.autograd.Function):
         N, C, LP, G, s, P, pad, M = ctx.meta
         g = g.contiguous()
         dx = torch.empty((N, C, LP), dtype=torch.float32, device=g.device)
-        with torch.cuda.device(g.device):
+        with _lib.on_device(g.device):
             _lib.check(_lib.lib().ttsc_deinterleave_x(_lib.dev_ptr(g), _lib.dev_ptr(dx), N, C, LP // P, G, s, P, pad, M, 1, _lib.current_stream()),
                        'ttsc_deinterleave_x')
         return dx, None, None, None, None, None
@@ -61,7 +61,7 @@ class _DeintW(torch.autograd.Function):
         Cout, Cg, K = w.shape
         J = -(-K // s)
         out = torch.empty((Cout, s * Cg, J), dtype=torch.float32, device=w.device)
-        with torch.cuda.device(w.device):
+        with _lib.on_device(w.device):
             _lib.check(_lib.lib().ttsc_deinterleave_w(_lib.dev_ptr(w), _lib.dev_ptr(out), Cout, Cg, K, s, 0, _lib.current_stream()), 'ttsc_deinterleave_w')
         ctx.meta = (Cout, Cg, K, s)
         return out
@@ -71,7 +71,7 @@ class _DeintW(torch.autograd.Function):
         Cout, Cg, K, s = ctx.meta
         g = g.contiguous()
         dw = torch.empty((Cout, Cg, K), dtype=torch.float32, device=g.device)
-        with torch.cuda.device(g.device):
+        with _lib.on_device(g.device):
             _lib.check(_lib.lib().ttsc_deinterleave_w(_lib.dev_ptr(g), _lib.dev_ptr(dw), Cout, Cg, K, s, 1, _lib.current_stream()), 'ttsc_deinterleave_w')
         return dw, None
 
@@ -108,13 +108,69 @@ class HipStridedConv:
         return hip_conv(self.tc, xr, wp, b, in_slope=in_slope)
 
 
+class HipSpectralNormFn(torch.autograd.Function):
+    """torch.nn.utils.spectral_norm's weight (SpectralNorm.compute_weight, dim = 0, one power iteration, eps 1e-12) on HIP kernels:
+    training mode updates the module's `weight_u` / `weight_v` buffers in place exactly where torch's pre-forward hook does —
+    v <- normalize(W^T u), u <- normalize(W v) — then wn = W / sigma with sigma = u^T W v; u and v are constants of the backward pass:
+    dW = dWn / sigma - (sum(dWn . W) / sigma^2) u v^T.  The mat-vecs run on the MFMA GEMM (ttsc_gemm, N = 1), the rest on the small fixed-order
+    kernels of csrc/train_ops.hip (no library call: torch's hook used rocBLAS gemv)."""
+
+    @staticmethod
+    def forward(ctx, w, u, v, training, eps):
+        from ..hip_layers import gemm_hip
+        L = _lib.lib()
+        R = w.shape[0]
+        W2 = w.detach().contiguous().reshape(R, -1)
+        Cc = W2.shape[1]
+        P, S = _lib.dev_ptr, _lib.current_stream
+        sigma = torch.empty(1, dtype=torch.float32, device=w.device)
+        with _lib.on_device(w.device):
+            if training:
+                t1 = gemm_hip(W2, u.reshape(R, 1), trans_a=True)                       # W^T u  [Cc, 1]
+                _lib.check(L.ttsc_l2_normalize(P(t1), Cc, eps, P(v), None, S()), 'ttsc_l2_normalize')
+                t2 = gemm_hip(W2, v.reshape(Cc, 1))                                     # W v    [R, 1]
+                _lib.check(L.ttsc_l2_normalize(P(t2), R, eps, P(u), None, S()), 'ttsc_l2_normalize')
+            else:
+                t2 = gemm_hip(W2, v.reshape(Cc, 1))
+            ws = torch.empty(max(int(L.ttsc_dot_workspace_bytes(R)) // 4, 1), dtype=torch.float32, device=w.device)
+            _lib.check(L.ttsc_dot(P(u), P(t2), R, P(sigma), P(ws), ws.numel() * 4, S()), 'ttsc_dot')                  # sigma = u . (W v)
+            wn = torch.empty_like(W2)
+            _lib.check(L.ttsc_div_scalar(P(W2), P(sigma), P(wn), W2.numel(), S()), 'ttsc_div_scalar')
+        ctx.save_for_backward(W2, u.clone(), v.clone(), sigma)      # (the buffers move on with the next power iteration)
+        ctx.shape = w.shape
+        return wn.view(w.shape)
+
+    @staticmethod
+    def backward(ctx, dwn):
+        W2, u, v, sigma = ctx.saved_tensors
+        L = _lib.lib()
+        R, Cc = W2.shape
+        P, S = _lib.dev_ptr, _lib.current_stream
+        d2 = dwn.contiguous().reshape(R, Cc)
+        dot = torch.empty(1, dtype=torch.float32, device=W2.device)
+        dw = torch.empty_like(W2)
+        with _lib.on_device(W2.device):
+            ws = torch.empty(max(int(L.ttsc_dot_workspace_bytes(W2.numel())) // 4, 1), dtype=torch.float32, device=W2.device)
+            _lib.check(L.ttsc_dot(P(d2), P(W2), W2.numel(), P(dot), P(ws), ws.numel() * 4, S()), 'ttsc_dot')
+            _lib.check(L.ttsc_spectral_norm_backward(P(d2), P(u), P(v), P(sigma), P(dot), P(dw), R, Cc, S()), 'ttsc_spectral_norm_backward')
+        return dw.view(ctx.shape), None, None, None, None
+
+
+def _spectral_eps(l):
+    for hook in l._forward_pre_hooks.values():
+        if hasattr(hook, 'eps') and hasattr(hook, 'n_power_iterations'):
+            if hook.n_power_iterations != 1 or hook.dim != 0:
+                raise _lib.TTSCError('spectral norm: only dim = 0 with one power iteration is built (torch defaults; got dim %d, %d iterations)'
+                                     % (hook.dim, hook.n_power_iterations))
+            return float(hook.eps)
+    return 1e-12
+
+
 def _weight(l):
-    """the layer's effective weight, differentiable w.r.t. its parameters: weight-norm on the fused kernel, spectral norm through
-    torch's own pre-forward hook (power iteration included, as a module call would do)"""
+    """the layer's effective weight, differentiable w.r.t. its parameters: weight norm and spectral norm (power iteration included, in place on
+    the module's buffers, as a module call would do) on the fused kernels"""
     if hasattr(l, 'weight_orig'):
-        for hook in l._forward_pre_hooks.values():
-            hook(l, (None,))
-        return l.weight
+        return HipSpectralNormFn.apply(l.weight_orig, l.weight_u, l.weight_v, l.training, _spectral_eps(l))
     if hasattr(l, 'weight_g'):   # torch.nn.utils.weight_norm keeps a stale plain `weight` attribute beside (weight_g, weight_v): never read it
         return HipWeightNormFn.apply(l.weight_v, l.weight_g)
     return l.weight

@@ -41,7 +41,7 @@ class _ListLoss(torch.autograd.Function):
         ws = torch.empty(int(L.ttsc_gan_loss_workspace_bytes(n)), dtype=torch.uint8, device=dev)
         P = C.c_void_p * n
         ptrs = lambda ts: P(*[(t.data_ptr() if t is not None else None) for t in ts])
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(L.ttsc_gan_loss(kind, n, ptrs(a), ptrs(b) if kind == 0 else None, ptrs(ga), ptrs(gb) if kind == 0 else None,
                                        (C.c_int64 * n)(*sizes), (C.c_float * n)(*([float(weight)] * n)), float(target),
                                        _lib.dev_ptr(out), _lib.dev_ptr(ws), ws.numel(), _lib.current_stream()), 'ttsc_gan_loss')

@@ -254,7 +254,7 @@ class Generator(nn.Module):
         L = _lib.lib()
         self._sync()
         assert check in ('sync', 'deferred', None)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             self.finish_range_check()             # (verdict of the previous deferred call, before anything new is enqueued)
         mode = {'sync': 1, 'deferred': 2, None: 0}[check]
         if mode != getattr(self, '_range_mode', 1):
@@ -269,7 +269,7 @@ class Generator(nn.Module):
             self._ws = None
             self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
         y = torch.empty((B, 1, Lout), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             fr = None
             if frames is not None:
                 assert len(frames) == B
@@ -293,7 +293,7 @@ class Generator(nn.Module):
             self._ws = None
             self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
         y = torch.empty((B, 1, self.out_len(T)), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(L.ttsc_hifigan_calibrate(self._handle, _lib.dev_ptr(x), B, T, _lib.dev_ptr(y), _lib.dev_ptr(self._ws),
                                                 self._ws.numel() * 4, _lib.current_stream()), 'ttsc_hifigan_calibrate')
         return y

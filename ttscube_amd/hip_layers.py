@@ -57,7 +57,7 @@ class Conv1dHip:
             raise _lib.TTSCError('Conv1dHip.set_weight_device: need a contiguous fp32 device tensor of shape %s' % (exp,))
         if bias is not None and (bias.numel() != self.cfg.out_channels or not bias.is_cuda or bias.dtype != torch.float32):
             raise _lib.TTSCError('Conv1dHip.set_weight_device: bias must be an fp32 device tensor with %d elements' % self.cfg.out_channels)
-        with torch.cuda.device(weight.device):
+        with _lib.on_device(weight.device):
             _lib.check(_lib.lib().ttsc_conv1d_set_weight_device(self._h, _lib.dev_ptr(weight),
                                                                 _lib.dev_ptr(bias.contiguous()) if bias is not None else None,
                                                                 _lib.current_stream()), 'ttsc_conv1d_set_weight_device')
@@ -68,7 +68,7 @@ class Conv1dHip:
         exp = (self.cfg.in_channels, self.cfg.out_channels // self.groups, self.cfg.kernel_size)   # the forward layer's [Cout, Cin / groups, K]
         if tuple(fwd_weight.shape) != exp or not fwd_weight.is_cuda or fwd_weight.dtype != torch.float32 or not fwd_weight.is_contiguous():
             raise _lib.TTSCError('Conv1dHip.set_weight_device_dgrad: need a contiguous fp32 device tensor of shape %s' % (exp,))
-        with torch.cuda.device(fwd_weight.device):
+        with _lib.on_device(fwd_weight.device):
             _lib.check(_lib.lib().ttsc_conv1d_set_weight_device_dgrad(self._h, _lib.dev_ptr(fwd_weight), _lib.current_stream()),
                        'ttsc_conv1d_set_weight_device_dgrad')
 
@@ -96,7 +96,7 @@ class Conv1dHip:
             assert gate.is_contiguous() and gate.dtype == torch.float32 and tuple(gate.shape) == tuple(out.shape)
         ep = _lib.Conv1dEpilogue(in_scale, in_slope, out_scale, ACT[act], int(accumulate),
                                  gate.data_ptr() if gate is not None else None, gate_slope)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().ttsc_conv1d_forward(self._h, _lib.dev_ptr(x), B, Lin, _lib.dev_ptr(out),
                                                       _lib.dev_ptr(resid) if resid is not None else None,
                                                       C.byref(ep), _lib.current_stream()), 'ttsc_conv1d_forward')
@@ -136,7 +136,7 @@ def linear_hip(x, weight, bias=None, act=None, out=None, accumulate=False, split
         out2 = out
         ldy = out.stride(-2) if out.dim() > 1 else N
     L = _lib.lib()
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         if split and SPLIT_GEMM and L.ttsc_linear_split_supported(M, N, K, K) and (x2.data_ptr() | w.data_ptr()) % 16 == 0:
             _lib.check(L.ttsc_linear_forward_split(_lib.dev_ptr(x2), _lib.dev_ptr(w), _lib.dev_ptr(b) if b is not None else None,
                                                    C.c_void_p(out2.data_ptr()), M, N, K, K, ldy, ACT[act], int(accumulate),
@@ -171,7 +171,7 @@ def gemm_hip(a, b, trans_a=False, trans_b=False, out=None, accumulate=False, b_r
     L = _lib.lib()
     wsb = int(L.ttsc_gemm_workspace_bytes(M, N, K))
     ws = torch.empty((wsb // 4,), dtype=torch.float32, device=a.device) if wsb else None
-    with torch.cuda.device(a.device):
+    with _lib.on_device(a.device):
         _lib.check(L.ttsc_gemm(int(trans_a), int(trans_b), M, N, K, C.c_void_p(a.data_ptr()), a.stride(0), C.c_void_p(b.data_ptr()), b.stride(0),
                                C.c_void_p(out.data_ptr()), out.stride(0), int(accumulate), int(b_row_shift), int(b_period),
                                C.c_void_p(ws.data_ptr()) if ws is not None else None, wsb, _lib.current_stream()), 'ttsc_gemm')
@@ -188,7 +188,7 @@ def colsum_hip(x, out=None, accumulate=False):
     L = _lib.lib()
     wsb = int(L.ttsc_colsum_workspace_bytes(R, Cn))
     ws = torch.empty((max(wsb // 4, 1),), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         _lib.check(L.ttsc_colsum(C.c_void_p(x.data_ptr()), R, Cn, x.stride(0), C.c_void_p(out.data_ptr()), int(accumulate),
                                  C.c_void_p(ws.data_ptr()), wsb, _lib.current_stream()), 'ttsc_colsum')
     return out
@@ -267,7 +267,7 @@ class LSTMHip:
                 h0 = hx[0][l * nd:(l + 1) * nd].float().contiguous()
                 c0 = hx[1][l * nd:(l + 1) * nd].float().contiguous()
             P = _lib.dev_ptr
-            with torch.cuda.device(x.device):
+            with _lib.on_device(x.device):
                 _lib.check(_lib.lib().ttsc_lstm_seq_forward(
                     P(xg), self._whh[l], P(y), P(len_dev) if len_dev is not None else None, B, T, H, nd, nd * H, 0,
                     P(h0) if h0 is not None else None, P(c0) if c0 is not None else None,

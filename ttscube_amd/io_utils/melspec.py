@@ -87,7 +87,7 @@ class _MelFn(torch.autograd.Function):
         mag = torch.empty((B, F_, ldm), dtype=torch.float32, device=yp.device)
         lin = torch.empty((B, F_, n_mels), dtype=torch.float32, device=yp.device)
         out = torch.empty((B, F_, n_mels), dtype=torch.float32, device=yp.device)
-        with torch.cuda.device(yp.device):
+        with _lib.on_device(yp.device):
             s = _lib.current_stream()
             for b in range(B):   # rows of one utterance sit at a constant stride `hop` inside its padded signal: no gather
                 _gemm(C.c_void_p(yp[b].data_ptr()), dft, reim[b], F_, 2 * nb, n_fft, hop, s)
@@ -111,7 +111,7 @@ class _MelFn(torch.autograd.Function):
         dreim = torch.empty_like(reim)
         dfr = torch.empty((B, F_, n_fft), dtype=torch.float32, device=reim.device)
         dy = torch.empty((B, Lp), dtype=torch.float32, device=reim.device)
-        with torch.cuda.device(reim.device):
+        with _lib.on_device(reim.device):
             s = _lib.current_stream()
             _lib.check(L.ttsc_log_clamp_backward(_lib.dev_ptr(g), _lib.dev_ptr(lin), lin.numel(), minv, scale, _lib.dev_ptr(dlin), s), 'log_bwd')
             _gemm(_lib.dev_ptr(dlin), mel_t, dmag, B * F_, ldm, n_mels, n_mels, s)                 # dmag = dlin . mel_basis

@@ -17,7 +17,7 @@ from ..hip_layers import colsum_hip, gemm_hip, linear_hip
 def _pack(whh, transpose):
     H = whh.shape[1]
     out = torch.empty(3 * H * H, dtype=torch.float32, device=whh.device)
-    with torch.cuda.device(whh.device):
+    with _lib.on_device(whh.device):
         _lib.check(_lib.lib().ttsc_gru_pack_whh_device(_lib.dev_ptr(whh), H, int(transpose), _lib.dev_ptr(out), _lib.current_stream()),
                    'ttsc_gru_pack_whh_device')
     return out
@@ -35,7 +35,7 @@ class HipGRUFn(torch.autograd.Function):
         xg = linear_hip(x, wih, b_ih.detach())
         y = torch.empty((B, T, H), dtype=torch.float32, device=x.device)
         saved = torch.empty((B, T, 4 * H), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().ttsc_gru_seq_forward(_lib.dev_ptr(xg), _lib.dev_ptr(_pack(whh, False)), _lib.dev_ptr(b_hh.detach().contiguous()),
                                                        _lib.dev_ptr(y), _lib.dev_ptr(saved), None, B, T, H, _lib.current_stream()),
                        'ttsc_gru_seq_forward')
@@ -50,7 +50,7 @@ class HipGRUFn(torch.autograd.Function):
         dy = dy.contiguous()
         dgi = torch.empty((B, T, 3 * H), dtype=torch.float32, device=x.device)
         dgh = torch.empty_like(dgi)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().ttsc_gru_seq_backward(_lib.dev_ptr(dy), _lib.dev_ptr(saved), _lib.dev_ptr(y), None, _lib.dev_ptr(_pack(whh, True)),
                                                         _lib.dev_ptr(dgi), _lib.dev_ptr(dgh), B, T, H, _lib.current_stream()),
                        'ttsc_gru_seq_backward')

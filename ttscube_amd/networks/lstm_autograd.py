@@ -19,7 +19,7 @@ from ..hip_layers import colsum_hip, gemm_hip, linear_hip
 def _pack(whh, transpose):
     nd, H4, H = whh.shape
     out = torch.empty(nd * H4 * H, dtype=torch.float32, device=whh.device)
-    with torch.cuda.device(whh.device):
+    with _lib.on_device(whh.device):
         _lib.check(_lib.lib().ttsc_lstm_pack_whh_device(_lib.dev_ptr(whh), nd, H, int(transpose), _lib.dev_ptr(out),
                                                         _lib.current_stream()), 'ttsc_lstm_pack_whh_device')
     return out
@@ -43,7 +43,7 @@ class HipLSTMLayerFn(torch.autograd.Function):
         y = torch.empty((B, T, nd * H), dtype=torch.float32, device=x.device)
         gates = torch.empty((B, T, nd * 4 * H), dtype=torch.float32, device=x.device)
         cst = torch.empty((B, T, nd * H), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().ttsc_lstm_seq_forward_train(_lib.dev_ptr(xg), _lib.dev_ptr(_pack(whh, False)), _lib.dev_ptr(y), None,
                                                               B, T, H, nd, nd * H, 0, _lib.dev_ptr(gates), _lib.dev_ptr(cst),
                                                               _lib.current_stream()), 'ttsc_lstm_seq_forward_train')
@@ -58,7 +58,7 @@ class HipLSTMLayerFn(torch.autograd.Function):
         B, T, _ = x.shape
         dy = dy.contiguous()
         dG = torch.empty_like(gates)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().ttsc_lstm_seq_backward(_lib.dev_ptr(dy), _lib.dev_ptr(gates), _lib.dev_ptr(cst),
                                                          _lib.dev_ptr(_pack(whh, True)), _lib.dev_ptr(dG), None, B, T, H, nd, nd * H, 0,
                                                          _lib.current_stream()), 'ttsc_lstm_seq_backward')

@@ -147,7 +147,7 @@ class WaveRNN(nn.Module):
         if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != mel.device:
             self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
         P = _lib.dev_ptr
-        with torch.cuda.device(mel.device):
+        with _lib.on_device(mel.device):
             _lib.check(L.ttsc_wavernn_decode(self._handle, P(mel), P(x_low) if x_low is not None else None, B, T, Tl, m,
                                              P(nz) if nz is not None else None, C.c_uint64(seed),
                                              P(fx) if fx is not None else None, P(idx), P(wav),
@@ -362,7 +362,7 @@ def align_durations(out_dur, lengths):
     f2p = torch.empty((B, fcap), dtype=torch.int32, device=dev)
     flen = torch.empty((B,), dtype=torch.int32, device=dev)
     len_t = _lib.lengths_dev(lengths, dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(_lib.lib().ttsc_align_durations(_lib.dev_ptr(out_dur), _lib.dev_ptr(len_t) if len_t is not None else None, B, N, D,
                                                    _lib.dev_ptr(durs), _lib.dev_ptr(f2p), _lib.dev_ptr(flen), fcap, _lib.current_stream()),
                    'ttsc_align_durations')
@@ -383,7 +383,7 @@ def _expand_rows(x, alignments, stride=1):
         x = x.float().contiguous()
         B, N, C_ = x.shape
         out = torch.empty((B, m, C_), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().ttsc_expand_rows(_lib.dev_ptr(x), _lib.dev_ptr(al.f2p), _lib.dev_ptr(al.flen_dev), B, N, C_, al.f2p.shape[1],
                                                    stride, m, _lib.dev_ptr(out), _lib.current_stream()), 'ttsc_expand_rows')
         return out, flens

@@ -48,7 +48,7 @@ class HipEmbeddingFn(torch.autograd.Function):
         i32 = idx.reshape(-1).to(torch.int32).contiguous()
         V, Cc = table.shape
         out = torch.empty((i32.numel(), Cc), dtype=torch.float32, device=table.device)
-        with torch.cuda.device(table.device):
+        with _lib.on_device(table.device):
             _lib.check(_lib.lib().ttsc_rows_gather(_lib.dev_ptr(table.detach().contiguous()), _lib.dev_ptr(i32), _lib.dev_ptr(out), i32.numel(), Cc, V,
                                                    _lib.current_stream()), 'ttsc_rows_gather')
         ctx.save_for_backward(i32)
@@ -60,7 +60,7 @@ class HipEmbeddingFn(torch.autograd.Function):
         i32, = ctx.saved_tensors
         g2 = g.reshape(-1, ctx.Cc).contiguous()
         gt = torch.empty((ctx.V, ctx.Cc), dtype=torch.float32, device=g.device)
-        with torch.cuda.device(g.device):
+        with _lib.on_device(g.device):
             _lib.check(_lib.lib().ttsc_rows_scatter_add(_lib.dev_ptr(g2), _lib.dev_ptr(i32), _lib.dev_ptr(gt), i32.numel(), ctx.Cc, ctx.V, ctx.pad,
                                                         _lib.current_stream()), 'ttsc_rows_scatter_add')
         return gt, None, None

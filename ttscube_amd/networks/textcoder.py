@@ -120,7 +120,7 @@ class CubenetTextcoder(nn.Module):
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         st = torch.as_tensor(steps, dtype=torch.int32, device=h.device) if steps is not None else None
-        with torch.cuda.device(h.device):
+        with _lib.on_device(h.device):
             _lib.check(_lib.lib().ttsc_melar_decode(hnd, _lib.dev_ptr(xg1), B, S, _lib.dev_ptr(m) if m is not None else None,
                                                     C.c_uint64(seed), _lib.dev_ptr(st) if st is not None else None, _lib.dev_ptr(y),
                                                     _lib.current_stream()), 'ttsc_melar_decode')

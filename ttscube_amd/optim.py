@@ -1,10 +1,11 @@
 """AdamW over flat arenas — the optimizers of `Cubegan.configure_optimizers` (cube/networks/cubegan.py:275-311: three
 torch.optim.AdamW(betas=(0.8, 0.99)) over ~900 parameter tensors) as ONE HIP kernel per group and step.
 
-Layout: the live parameters of a group are re-pointed (``p.data``) into one contiguous fp32 arena; their gradients accumulate
-straight into a second arena (``p.grad`` are permanent views of it — that arena is also the gradient-exchange bucket of
-`ttscube_amd.distributed.ArenaReducer`, so nothing is packed or copied before the RCCL exchange); the two moment estimates are
-two more arenas.  `step()` = `ttsc_adamw_step` over the four arenas (csrc/train_ops.hip), `zero_grad()` = one memset.
+Layout: the live parameters of a group are re-pointed (``p.data``) into one contiguous fp32 arena; their gradients are gathered into a
+second arena — the gradient-exchange bucket of `ttscube_amd.distributed.ArenaReducer` — chunk by chunk as they become ready (a few fused
+copy launches per chunk; `zero_grad()` sets ``.grad = None`` so that autograd hands gradient tensors over without a `+=` launch each), and
+``p.grad`` is the arena view again once the arena holds the step's gradients; the two moment estimates are two more arenas.
+`step()` = `ttsc_adamw_step` over the four arenas (csrc/train_ops.hip).
 
 "Live" = has a gradient on some rank after the first backward pass (decided once, collectively): a parameter nobody
 differentiates keeps ``.grad is None`` and is never touched, exactly like torch.optim.AdamW skips it.  A parameter that turns up
@@ -33,6 +34,7 @@ class FlatAdamW:
         self.p = self.g = self.m = self.v = None
         self._pending = None      # state loaded before the arenas exist
         self._hooks = []          # called once the arenas exist (the reducer registers its gradient hooks there)
+        self._dirty = False       # gradients of the current step are still in autograd's own tensors (see zero_grad / gather)
 
     # ---- arenas ----------------------------------------------------------------------------------------------------------
     @property
@@ -68,10 +70,14 @@ class FlatAdamW:
             torch._foreach_copy_(dst_p, src_p)
             if dst_g:
                 torch._foreach_copy_(dst_g, src_g)
+        self._gviews = []
         for i, o, vp in zip(self.live, offs, dst_p):
             p = ps[i]
             p.data = vp                                             # the parameter now IS its slice of the arena
-            p.grad = self.g[o:o + p.numel()].view_as(p)            # ... and its gradient accumulates into the gradient arena
+            self._gviews.append(self.g[o:o + p.numel()].view_as(p))
+            p.grad = self._gviews[-1]                               # this step's gradient was just copied there
+        self._dirty = False
+        self._seg_cache = {}
         if self._pending is not None:
             self._apply_state(self._pending)
             self._pending = None
@@ -100,11 +106,69 @@ class FlatAdamW:
 
     # ---- torch.optim surface -------------------------------------------------------------------------------------------------
     def zero_grad(self, set_to_none=True):
+        """Gradients are dropped, not cleared: with `.grad is None` autograd hands the gradient tensor of a backward pass over as it is (no
+        kernel), where a standing view of the arena cost one `+=` launch per parameter and step (~900 per Cubegan step) plus the memset.
+        `gather()` — called per exchange chunk by distributed.ArenaReducer, or by step() — copies them into the arena in a few fused launches."""
         if not self.built:
             for p in self.params:
                 p.grad = None
             return
-        self.g.zero_()            # ONE memset; the .grad views stay in place (autograd accumulates into them)
+        for i in self.live:
+            self.params[i].grad = None
+        self._dirty = True
+
+    def _segments(self, s, e):
+        """live parameters overlapping the arena range [s, e), laid out once per range: parameters that lie wholly inside it as
+        (parameter, its arena view), parameters cut by a range boundary as (parameter, first element, one past the last element, arena slice)"""
+        key = (s, e)
+        if key not in self._seg_cache:
+            whole, parts = [], []
+            for k, (i, o) in enumerate(zip(self.live, self.offsets)):
+                n = self.params[i].numel()
+                a, b = max(s, o), min(e, o + n)
+                if a >= b:
+                    continue
+                if a == o and b == o + n:
+                    whole.append((self.params[i], self._gviews[k]))
+                else:
+                    parts.append((self.params[i], a - o, b - o, self.g[a:b]))
+            self._seg_cache[key] = (whole, parts)
+        return self._seg_cache[key]
+
+    @torch.no_grad()
+    def gather(self, s=0, e=None):
+        """bring the gradients autograd left in `.grad` into the arena range [s, e) (the whole arena by default); a parameter without a gradient
+        contributes zeros.  Runs on the current stream."""
+        whole, parts = self._segments(s, self.numel if e is None else e)
+        dst, src, zero = [], [], []
+        for p, view in whole:
+            g = p.grad
+            if g is view:
+                continue
+            if g is None:
+                zero.append(view)
+            else:
+                dst.append(view)
+                src.append(g)
+        for p, a, b, d in parts:
+            g = p.grad
+            if g is None:
+                zero.append(d)
+            else:
+                gv = g.reshape(-1)[a:b]
+                if gv.data_ptr() != d.data_ptr():
+                    dst.append(d)
+                    src.append(gv)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        if zero:
+            torch._foreach_zero_(zero)
+
+    def grads_in_arena(self):
+        """after the arena holds this step's (gathered, possibly averaged) gradients: `.grad` of every live parameter is its arena view again"""
+        for k, i in enumerate(self.live):
+            self.params[i].grad = self._gviews[k]
+        self._dirty = False
 
     @torch.no_grad()
     def step(self):
@@ -113,9 +177,12 @@ class FlatAdamW:
         self._check_no_stragglers()
         if self.p.device.type != 'cuda':
             raise _lib.TTSCError('FlatAdamW.step: parameters live on the CPU; move the model to a HIP device first (no CPU path)')
+        if self._dirty:               # no exchange brought the gradients in: do it now
+            self.gather()
+            self.grads_in_arena()
         self.step_count += 1
         pg = self.param_groups[0]
-        with torch.cuda.device(self.p.device):
+        with _lib.on_device(self.p.device):
             _lib.check(_lib.lib().ttsc_adamw_step(_lib.dev_ptr(self.p), _lib.dev_ptr(self.g), _lib.dev_ptr(self.m), _lib.dev_ptr(self.v),
                                                   self.numel, float(pg['lr']), float(pg['betas'][0]), float(pg['betas'][1]), float(pg['eps']),
                                                   float(pg['weight_decay']), self.step_count, _lib.current_stream()), 'ttsc_adamw_step')
