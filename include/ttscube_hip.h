@@ -174,11 +174,15 @@ int ttsc_weight_norm_backward(const float* dw_dev, const float* v_dev, const flo
                               float* dg_dev, int32_t rows, int64_t cols, void* stream);
 /* torch.nn.utils.spectral_norm of the first scale discriminator ([EXTERNAL hifigan/models.py] MultiScaleDiscriminator:
  * DiscriminatorS(use_spectral_norm=True), used by cube/networks/cubegan.py:40-41): wn = W / sigma, sigma = u^T W v after one power iteration (v <- normalize(W^T u), u <- normalize(W v)).  The two
- * mat-vecs run on the MFMA GEMM (ttsc_gemm, N = 1); these are the pieces around them, all with fixed summation orders:
+ * mat-vecs and the pieces around them, all with fixed summation orders:
+ *   ttsc_matvec         W [rows, cols] row-major: out = W x (transpose 0) or W^T x (transpose 1; ws_dev >= ttsc_matvec_workspace_bytes)
  *   ttsc_l2_normalize   out[n] = x / max(||x||, eps), norm_dev[0] = ||x|| (either output may be NULL)
  *   ttsc_dot            out_dev[0] = sum a[i] b[i] (ws_dev >= ttsc_dot_workspace_bytes(n))
  *   ttsc_div_scalar     out = w / sigma_dev[0]
  *   ttsc_spectral_norm_backward   dW[r,c] = dWn[r,c] / sigma - (dot_dev[0] / sigma^2) u[r] v[c], dot_dev[0] = sum(dWn . W) */
+size_t ttsc_matvec_workspace_bytes(int32_t rows, int64_t cols);
+int ttsc_matvec(const float* w_dev, int32_t rows, int64_t cols, const float* x_dev, int32_t transpose, float* out_dev, void* ws_dev, size_t ws_bytes,
+                void* stream);
 int ttsc_l2_normalize(const float* x_dev, int32_t n, float eps, float* out_dev, float* norm_dev, void* stream);
 size_t ttsc_dot_workspace_bytes(int64_t n);
 int ttsc_dot(const float* a_dev, const float* b_dev, int64_t n, float* out_dev, void* ws_dev, size_t ws_bytes, void* stream);
@@ -208,6 +212,8 @@ int ttsc_adamw_step(float* p_dev, const float* g_dev, float* m_dev, float* v_dev
 int ttsc_rows_gather(const float* table_dev, const int32_t* idx_dev, float* out_dev, int64_t n, int32_t C, int32_t V, void* stream);
 int ttsc_rows_scatter_add(const float* gout_dev, const int32_t* idx_dev, float* gtable_dev, int64_t n, int32_t C, int32_t V, int32_t skip_row,
                           void* stream);
+/* the same adjoint for a NON-DECREASING index list (phoneme rows -> frame rows, cube/networks/modules.py:1043-1053): O(n C) instead of O(V n C) */
+int ttsc_rows_segment_sum(const float* gout_dev, const int32_t* idx_sorted_dev, float* gtable_dev, int64_t n, int32_t C, int32_t V, void* stream);
 /* Polyphase de-interleave of a strided Conv1d's operands (the discriminators' stride-2/3/4 layers [EXTERNAL hifigan/models.py DiscriminatorP /
  * DiscriminatorS; call sites cube/networks/cubegan.py:144-149,160-167]): the layer runs as a stride-1 convolution over
  *   xr[n, (g, r, ci), m P + w] = x[n, (g, ci), ((m s + r) - pad) P + w]   (zero outside; P = 1 or MPD's period, rows of P samples)

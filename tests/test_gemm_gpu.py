@@ -120,3 +120,46 @@ def test_split_linear_skips_padding_tiles_and_guards_the_range():
     with pytest.raises(_lib.TTSCError):
         _lib.check_split_status('test')
     _lib.check_split_status('test')
+
+
+@pytest.mark.parametrize('R,Cc', [(128, 15), (1024, 5120), (1, 3072), (512, 656), (40, 7)])
+def test_matvec_both_directions(R, Cc):
+    import ctypes as C
+    from ttscube_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(R + Cc)
+    W = torch.randn(R, Cc, generator=g).cuda()
+    x = torch.randn(Cc, generator=g).cuda()
+    u = torch.randn(R, generator=g).cuda()
+    o0 = torch.empty(R, device='cuda')
+    o1 = torch.empty(Cc, device='cuda')
+    ws = torch.empty(max(int(L.ttsc_matvec_workspace_bytes(R, Cc)) // 4, 1), device='cuda')
+    P = _lib.dev_ptr
+    _lib.check(L.ttsc_matvec(P(W), R, Cc, P(x), 0, P(o0), None, 0, _lib.current_stream()), 'matvec')
+    _lib.check(L.ttsc_matvec(P(W), R, Cc, P(u), 1, P(o1), P(ws), ws.numel() * 4, _lib.current_stream()), 'matvec')
+    assert _rel(o0, W.double() @ x.double()) < 2e-6 and _rel(o1, W.double().t() @ u.double()) < 2e-6
+    o2 = torch.empty_like(o1)
+    _lib.check(L.ttsc_matvec(P(W), R, Cc, P(u), 1, P(o2), P(ws), ws.numel() * 4, _lib.current_stream()), 'matvec')
+    assert torch.equal(o1, o2)
+
+
+def test_rows_segment_sum_equals_the_scatter_for_sorted_indices():
+    """phoneme rows -> frame rows (training expand): the O(n C) adjoint for a non-decreasing index list gives the bits of the general kernel"""
+    from ttscube_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(9)
+    V, Cc = 700, 640
+    counts = torch.randint(0, 12, (V,), generator=g)
+    counts[5] = 0
+    counts[V - 1] = 0
+    idx = torch.repeat_interleave(torch.arange(V), counts).to(torch.int32).cuda()
+    n = idx.numel()
+    gout = torch.randn(n, Cc, generator=g).cuda()
+    a = torch.empty(V, Cc, device='cuda')
+    b = torch.full((V, Cc), 3.0, device='cuda')
+    P = _lib.dev_ptr
+    _lib.check(L.ttsc_rows_scatter_add(P(gout), P(idx), P(a), n, Cc, V, -1, _lib.current_stream()), 'scatter')
+    _lib.check(L.ttsc_rows_segment_sum(P(gout), P(idx), P(b), n, Cc, V, _lib.current_stream()), 'segment')
+    assert torch.equal(a, b) and bool((b[5] == 0).all()) and bool((b[V - 1] == 0).all())
+    ref = torch.zeros(V, Cc, dtype=torch.float64, device='cuda').index_add_(0, idx.long(), gout.double())
+    assert _rel(b, ref) < 1e-6

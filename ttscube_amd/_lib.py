@@ -94,6 +94,9 @@ SIGNATURES = {
     'ttsc_weight_norm_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]),
     'ttsc_weight_norm_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                             C.c_int64, C.c_void_p]),
+    'ttsc_matvec_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int64]),
+    'ttsc_matvec': (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'ttsc_rows_segment_sum': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     'ttsc_l2_normalize': (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ttsc_dot_workspace_bytes': (C.c_size_t, [C.c_int64]),
     'ttsc_dot': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -315,6 +315,64 @@ __global__ __launch_bounds__(256) void deinterleave_w_kernel(const float* __rest
 
 // ---- spectral normalisation of a weight (torch.nn.utils.spectral_norm: the first scale discriminator, [EXTERNAL hifigan/models.py]
 //      DiscriminatorS(use_spectral_norm=True), instantiated by cube/networks/cubegan.py:40-41) — the small pieces around the two mat-vecs of the power iteration (those run on the MFMA GEMM):
+// out[r] = sum_c W[r, c] x[c]: one workgroup per row (per-thread strided chains, fixed LDS tree)
+__global__ __launch_bounds__(256) void matvec_rows_kernel(const float* __restrict__ W, const float* __restrict__ x, float* __restrict__ out, long Cc) {
+    __shared__ float red[256];
+    const float* w = W + (size_t)blockIdx.x * Cc;
+    float s = 0.f;
+    for (long c = threadIdx.x; c < Cc; c += 256) s = fmaf(w[c], x[c], s);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
+// ws[part][c] = sum_{r in part} W[r, c] u[r] (rows ascending), then out[c] = sum_part ws[part][c] (parts ascending): W^T u in a fixed order
+__global__ __launch_bounds__(256) void matvec_cols_partial_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ ws, int R, long Cc,
+                                                                  int rows_per_part) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= Cc) return;
+    const int r0 = blockIdx.y * rows_per_part, r1 = r0 + rows_per_part < R ? r0 + rows_per_part : R;
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s = fmaf(W[(size_t)r * Cc + c], u[r], s);
+    ws[(size_t)blockIdx.y * Cc + c] = s;
+}
+
+__global__ __launch_bounds__(256) void matvec_cols_final_kernel(const float* __restrict__ ws, float* __restrict__ out, int parts, long Cc) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= Cc) return;
+    float s = 0.f;
+    for (int p = 0; p < parts; ++p) s += ws[(size_t)p * Cc + c];
+    out[c] = s;
+}
+
+// gtable[v, :] = sum of gout[i, :] over the CONTIGUOUS run of i with idx[i] == v (idx non-decreasing), i ascending: the adjoint of a row gather
+// whose index list is sorted (phoneme rows -> frame rows) in O(n C) — rows_scatter_add_kernel walks the whole index list per table row
+__global__ __launch_bounds__(256) void rows_segment_sum_kernel(const float* __restrict__ gout, const int* __restrict__ idx, float* __restrict__ gtable, long n,
+                                                               int C) {
+    const int v = blockIdx.x;
+    long lo = 0, hi = n;                    // first i with idx[i] >= v
+    while (lo < hi) {
+        const long mid = (lo + hi) >> 1;
+        if (idx[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    const long beg = lo;
+    hi = n;                                 // first i with idx[i] > v
+    while (lo < hi) {
+        const long mid = (lo + hi) >> 1;
+        if (idx[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    const long end = lo;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc = 0.f;
+        for (long i = beg; i < end; ++i) acc += gout[(size_t)i * C + c];
+        gtable[(size_t)v * C + c] = acc;
+    }
+}
+
 // x[n] -> out = x / max(||x||, eps), norm_out[0] = ||x||: one workgroup, squares summed per thread over a fixed stride, fixed LDS tree
 __global__ __launch_bounds__(256) void l2_normalize_kernel(const float* __restrict__ x, int n, float eps, float* __restrict__ out, float* __restrict__ norm_out) {
     __shared__ float red[256];
@@ -415,6 +473,36 @@ static int bias_grad_splits(int32_t B, int32_t C, int64_t L) {
     if (s > cap) s = cap;
     if (s < 1) s = 1;
     return (int)s;
+}
+
+static int matvec_parts(int R) { return R >= 64 ? (R / 32 > 32 ? 32 : R / 32) : 1; }
+
+extern "C" size_t ttsc_matvec_workspace_bytes(int32_t rows, int64_t cols) { return rows > 0 && cols > 0 ? (size_t)matvec_parts(rows) * cols * sizeof(float) : 0; }
+
+// W [rows, cols] row-major.  transpose = 0: out[rows] = W x (x [cols]);  transpose = 1: out[cols] = W^T x (x [rows]; ws_dev >=
+// ttsc_matvec_workspace_bytes).  One pass over W, fixed summation order.
+extern "C" int ttsc_matvec(const float* w_dev, int32_t rows, int64_t cols, const float* x_dev, int32_t transpose, float* out_dev, void* ws_dev,
+                           size_t ws_bytes, void* stream) {
+    TTSC_REQUIRE(w_dev && x_dev && out_dev && rows > 0 && cols > 0, "ttsc_matvec: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (!transpose) {
+        hipLaunchKernelGGL(matvec_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, w_dev, x_dev, out_dev, (long)cols);
+        return check_launch("matvec_rows_kernel");
+    }
+    const int parts = matvec_parts(rows);
+    TTSC_REQUIRE(ws_dev && ws_bytes >= (size_t)parts * cols * sizeof(float), "ttsc_matvec: workspace too small");
+    const int rpp = (rows + parts - 1) / parts;
+    const unsigned gx = (unsigned)((cols + 255) / 256);
+    hipLaunchKernelGGL(matvec_cols_partial_kernel, dim3(gx, (unsigned)parts), dim3(256), 0, s, w_dev, x_dev, (float*)ws_dev, rows, (long)cols, rpp);
+    hipLaunchKernelGGL(matvec_cols_final_kernel, dim3(gx), dim3(256), 0, s, (const float*)ws_dev, out_dev, parts, (long)cols);
+    return check_launch("matvec_cols kernels");
+}
+
+// the adjoint of ttsc_rows_gather for a NON-DECREASING index list: gtable [V, C] = per-row sums of gout [n, C] (rows without an index get zeros)
+extern "C" int ttsc_rows_segment_sum(const float* gout_dev, const int32_t* idx_sorted_dev, float* gtable_dev, int64_t n, int32_t C, int32_t V, void* stream) {
+    TTSC_REQUIRE(gout_dev && idx_sorted_dev && gtable_dev && n > 0 && C > 0 && V > 0, "ttsc_rows_segment_sum: bad argument");
+    hipLaunchKernelGGL(rows_segment_sum_kernel, dim3((unsigned)V), dim3(256), 0, (hipStream_t)stream, gout_dev, idx_sorted_dev, gtable_dev, (long)n, C);
+    return check_launch("rows_segment_sum_kernel");
 }
 
 extern "C" int ttsc_l2_normalize(const float* x_dev, int32_t n, float eps, float* out_dev, float* norm_dev, void* stream) {

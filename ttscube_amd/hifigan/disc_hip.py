@@ -112,28 +112,30 @@ class HipSpectralNormFn(torch.autograd.Function):
     """torch.nn.utils.spectral_norm's weight (SpectralNorm.compute_weight, dim = 0, one power iteration, eps 1e-12) on HIP kernels:
     training mode updates the module's `weight_u` / `weight_v` buffers in place exactly where torch's pre-forward hook does —
     v <- normalize(W^T u), u <- normalize(W v) — then wn = W / sigma with sigma = u^T W v; u and v are constants of the backward pass:
-    dW = dWn / sigma - (sum(dWn . W) / sigma^2) u v^T.  The mat-vecs run on the MFMA GEMM (ttsc_gemm, N = 1), the rest on the small fixed-order
-    kernels of csrc/train_ops.hip (no library call: torch's hook used rocBLAS gemv)."""
+    dW = dWn / sigma - (sum(dWn . W) / sigma^2) u v^T.  Mat-vecs, normalisations, the dot product and the two element-wise passes are the
+    fixed-order kernels of csrc/train_ops.hip (no library call: torch's hook goes through rocBLAS gemv)."""
 
     @staticmethod
     def forward(ctx, w, u, v, training, eps):
-        from ..hip_layers import gemm_hip
         L = _lib.lib()
         R = w.shape[0]
         W2 = w.detach().contiguous().reshape(R, -1)
         Cc = W2.shape[1]
         P, S = _lib.dev_ptr, _lib.current_stream
         sigma = torch.empty(1, dtype=torch.float32, device=w.device)
+        t2 = torch.empty(R, dtype=torch.float32, device=w.device)
         with _lib.on_device(w.device):
             if training:
-                t1 = gemm_hip(W2, u.reshape(R, 1), trans_a=True)                       # W^T u  [Cc, 1]
+                t1 = torch.empty(Cc, dtype=torch.float32, device=w.device)
+                ws = torch.empty(max(int(L.ttsc_matvec_workspace_bytes(R, Cc)) // 4, 1), dtype=torch.float32, device=w.device)
+                _lib.check(L.ttsc_matvec(P(W2), R, Cc, P(u), 1, P(t1), P(ws), ws.numel() * 4, S()), 'ttsc_matvec')       # W^T u
                 _lib.check(L.ttsc_l2_normalize(P(t1), Cc, eps, P(v), None, S()), 'ttsc_l2_normalize')
-                t2 = gemm_hip(W2, v.reshape(Cc, 1))                                     # W v    [R, 1]
+                _lib.check(L.ttsc_matvec(P(W2), R, Cc, P(v), 0, P(t2), None, 0, S()), 'ttsc_matvec')                      # W v
                 _lib.check(L.ttsc_l2_normalize(P(t2), R, eps, P(u), None, S()), 'ttsc_l2_normalize')
             else:
-                t2 = gemm_hip(W2, v.reshape(Cc, 1))
-            ws = torch.empty(max(int(L.ttsc_dot_workspace_bytes(R)) // 4, 1), dtype=torch.float32, device=w.device)
-            _lib.check(L.ttsc_dot(P(u), P(t2), R, P(sigma), P(ws), ws.numel() * 4, S()), 'ttsc_dot')                  # sigma = u . (W v)
+                _lib.check(L.ttsc_matvec(P(W2), R, Cc, P(v), 0, P(t2), None, 0, S()), 'ttsc_matvec')
+            wd = torch.empty(max(int(L.ttsc_dot_workspace_bytes(R)) // 4, 1), dtype=torch.float32, device=w.device)
+            _lib.check(L.ttsc_dot(P(u), P(t2), R, P(sigma), P(wd), wd.numel() * 4, S()), 'ttsc_dot')                  # sigma = u . (W v)
             wn = torch.empty_like(W2)
             _lib.check(L.ttsc_div_scalar(P(W2), P(sigma), P(wn), W2.numel(), S()), 'ttsc_div_scalar')
         ctx.save_for_backward(W2, u.clone(), v.clone(), sigma)      # (the buffers move on with the next power iteration)

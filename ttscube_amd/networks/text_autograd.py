@@ -44,7 +44,7 @@ class HipEmbeddingFn(torch.autograd.Function):
     """table[idx] (nn.Embedding with padding_idx: that row gets no gradient)"""
 
     @staticmethod
-    def forward(ctx, table, idx, padding_idx):
+    def forward(ctx, table, idx, padding_idx, sorted_idx=False):
         i32 = idx.reshape(-1).to(torch.int32).contiguous()
         V, Cc = table.shape
         out = torch.empty((i32.numel(), Cc), dtype=torch.float32, device=table.device)
@@ -53,6 +53,7 @@ class HipEmbeddingFn(torch.autograd.Function):
                                                    _lib.current_stream()), 'ttsc_rows_gather')
         ctx.save_for_backward(i32)
         ctx.V, ctx.Cc, ctx.pad = V, Cc, -1 if padding_idx is None else int(padding_idx)
+        ctx.sorted_idx = bool(sorted_idx) and padding_idx is None   # non-decreasing index list: the adjoint is a segmented sum, O(n C)
         return out.view(*idx.shape, Cc)
 
     @staticmethod
@@ -61,9 +62,13 @@ class HipEmbeddingFn(torch.autograd.Function):
         g2 = g.reshape(-1, ctx.Cc).contiguous()
         gt = torch.empty((ctx.V, ctx.Cc), dtype=torch.float32, device=g.device)
         with _lib.on_device(g.device):
-            _lib.check(_lib.lib().ttsc_rows_scatter_add(_lib.dev_ptr(g2), _lib.dev_ptr(i32), _lib.dev_ptr(gt), i32.numel(), ctx.Cc, ctx.V, ctx.pad,
-                                                        _lib.current_stream()), 'ttsc_rows_scatter_add')
-        return gt, None, None
+            if ctx.sorted_idx:
+                _lib.check(_lib.lib().ttsc_rows_segment_sum(_lib.dev_ptr(g2), _lib.dev_ptr(i32), _lib.dev_ptr(gt), i32.numel(), ctx.Cc, ctx.V,
+                                                            _lib.current_stream()), 'ttsc_rows_segment_sum')
+            else:
+                _lib.check(_lib.lib().ttsc_rows_scatter_add(_lib.dev_ptr(g2), _lib.dev_ptr(i32), _lib.dev_ptr(gt), i32.numel(), ctx.Cc, ctx.V, ctx.pad,
+                                                            _lib.current_stream()), 'ttsc_rows_scatter_add')
+        return gt, None, None, None
 
 
 def hip_embedding(emb, idx):

@@ -166,6 +166,9 @@ def _languasito_branches(lang, X):
     for b, a in enumerate(alignments):
         idx[b, :len(a)] = torch.as_tensor(a)
         idx[b, len(a):] = a[-1]
+    # frame -> phoneme maps are monotone; with the utterance offsets added the flat index list is non-decreasing, which lets the backward pass
+    # sum each phoneme's frames as one contiguous run (checked here, on the host copy: anything else takes the general scatter kernel)
+    idx_sorted = bool((idx[:, 1:] >= idx[:, :-1]).all()) if idx.shape[1] > 1 else True
     idx_dev = idx.to(dev)
     pitch_in = X['y_pitch'].to(dev).float().unsqueeze(2) / lang._max_pitch
 
@@ -177,7 +180,7 @@ def _languasito_branches(lang, X):
         from .text_autograd import HipEmbeddingFn
         B_, N_, C_ = x.shape
         flat = idx_dev + torch.arange(B_, dtype=torch.long, device=dev)[:, None] * N_
-        return HipEmbeddingFn.apply(x.reshape(B_ * N_, C_), flat, None)
+        return HipEmbeddingFn.apply(x.reshape(B_ * N_, C_), flat, None, idx_sorted and bool(int(idx.max()) < N_))
 
     def text():
         hcs = stack('t')
