@@ -14,7 +14,10 @@
 // Kernel choice (lstm_forward_impl):
 //   H = 64 / 128        lstm_seq_resident_kernel      one thread per gate row, W_hh in registers, no stream at all
 //   H = 256 / 512       lstm_seq_split_res_kernel     4 / 16 workgroups per (utterance, direction), 128 weights per thread in
-//                                                      registers, tagged-granule hand-off; up to three consecutive launches
+//                                                      registers, tagged-granule hand-off
+//                       lstm_seq_split_res_nb_kernel  the same member groups stepping 2 / 4 / 8 utterances of one direction together when the
+//                                                      batch has more pairs than a launch holds (or the caller asks: ttsc_lstm_set_group_size);
+//                                                      per utterance the same arithmetic; up to three consecutive launches
 //   few sequences, other H   lstm_seq_split_kernel    <= 4 workgroups per sequence streaming their rows, counter hand-off
 //   everything else     lstm_seq_kernel<BT>           one workgroup per (utterance tile, direction), rows streamed from L2
 #include <algorithm>
