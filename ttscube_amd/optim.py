@@ -161,6 +161,13 @@ class FlatAdamW:
                     src.append(gv)
         if dst:
             torch._foreach_copy_(dst, src)
+            if self.g.is_cuda:
+                # the gradient tensors were allocated by autograd on whatever stream produced them (side streams of hifigan/streams.py, the text
+                # stream) and are dropped right after this copy (`grads_in_arena`): tell the allocator that THIS stream still reads them, or their
+                # memory goes back to the producing stream's pool and can be rewritten before the copy has run
+                cur = torch.cuda.current_stream(self.g.device)
+                for t in src:
+                    t.record_stream(cur)
         if zero:
             torch._foreach_zero_(zero)
 
