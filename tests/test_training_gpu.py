@@ -373,3 +373,21 @@ def test_text_stack_training_ops_match_torch():
     gy = torch.randn(ref.shape, generator=g).cuda()
     for u, v in zip(torch.autograd.grad(out, ps, gy), torch.autograd.grad(ref, ps, gy)):
         assert _rel(u, v) < 1e-5
+
+
+def test_cubegan_step_is_reproducible_with_eight_hardware_queues():
+    """Round 4: with the runtime's default four hardware queues several of the step's streams share a queue and serialise by accident; with
+    eight, every stream really runs beside the others — which exposed two latent races (inputs of side-stream jobs given back to the allocator
+    while a side stream still read them; one gradient tensor shared by the three ResBlock branches and accumulated into in place by the last of
+    them).  The queue count is read when the HIP runtime starts, so this runs tools/probes/train_determinism_poisoned.py in a process of its own:
+    three 3-step runs from identical weights, fresh allocations poisoned with NaN / large values, must give identical parameters."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES='8', PROBE_STEPS='3', PROBE_PRIO='1')
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'probes', 'train_determinism_poisoned.py')], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('run ')]
+    assert len(lines) == 2 and all(' 0 of ' in l for l in lines), out.stdout[-2000:]

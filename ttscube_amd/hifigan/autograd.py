@@ -310,6 +310,26 @@ def _train_convs(gen):
     return tcs
 
 
+class _BranchSum(torch.autograd.Function):
+    """r0 + r1 + ... (left to right) for branches that ran on DIFFERENT streams.  A plain `+` hands the SAME gradient tensor to every branch; each
+    branch's last node (a convolution with a residual input) passes it on unchanged as the residual's gradient, and autograd then accumulates the
+    other contribution INTO it in place once it holds the only reference — while kernels of the other branches, on their own streams, may still be
+    reading it.  (Round 4, found with more than the runtime's four hardware queues running side by side: two identical 5-step runs differed in 400
+    of 496 parameter tensors.)  Every branch but the first therefore gets a copy of its own."""
+
+    @staticmethod
+    def forward(ctx, *rs):
+        ctx.n = len(rs)
+        xs = rs[0]
+        for r in rs[1:]:
+            xs = xs + r
+        return xs
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g,) + tuple(g.clone() for _ in range(ctx.n - 1))
+
+
 def generator_forward_with_grad(gen, x):
     """Differentiable HiFi-GAN generator forward on the HIP kernels (same math as `ttsc_hifigan_forward`)."""
     from .models import ResBlock1
@@ -335,10 +355,7 @@ def generator_forward_with_grad(gen, x):
             return r
 
         # the nk ResBlocks of a stage are independent branches: one stream each (training crops are small launches, see streams.py)
-        rs = fan_out([(lambda j=j: branch(j)) for j in range(nk)], x.device)
-        xs = rs[0]
-        for r in rs[1:]:
-            xs = xs + r
-        x = xs
+        rs = fan_out([(lambda j=j: branch(j)) for j in range(nk)], x.device, inputs=[x], tag='gen')
+        x = _BranchSum.apply(*rs)
     x = hip_conv(T['conv_post'], x, _wn(gen.conv_post), gen.conv_post.bias, in_scale=1.0 / nk, in_slope=0.01)
     return torch.tanh(x)

@@ -172,6 +172,10 @@ def _weight(l):
     """the layer's effective weight, differentiable w.r.t. its parameters: weight norm and spectral norm (power iteration included, in place on
     the module's buffers, as a module call would do) on the fused kernels"""
     if hasattr(l, 'weight_orig'):
+        if os.environ.get('TTSC_SPECTRAL_NATIVE', '1') == '0':   # (measurement switch: torch's own hook)
+            for hook in l._forward_pre_hooks.values():
+                hook(l, (None,))
+            return l.weight
         return HipSpectralNormFn.apply(l.weight_orig, l.weight_u, l.weight_v, l.training, _spectral_eps(l))
     if hasattr(l, 'weight_g'):   # torch.nn.utils.weight_norm keeps a stale plain `weight` attribute beside (weight_g, weight_v): never read it
         return HipWeightNormFn.apply(l.weight_v, l.weight_g)
@@ -235,7 +239,7 @@ def mpd_forward(mpd, y, y_hat, want_fmap=True):
         raise _lib.TTSCError('discriminators: inputs must live on a HIP device; no CPU path')
     res = ([], [], [], [])
     jobs = [(lambda d=d: _pair(d, 'p', _fold(y, d.period), _fold(y_hat, d.period), True, want_fmap)) for d in mpd.discriminators]
-    for r in fan_out(jobs, y.device):
+    for r in fan_out(jobs, y.device, inputs=[y, y_hat], tag='mpd'):
         for acc, v in zip(res, (r[0], r[2], r[1], r[3])):
             acc.append(v)
     return res
@@ -254,7 +258,7 @@ def msd_forward(msd, y, y_hat, want_fmap=True):
         ins.append((y, y_hat))
     # discriminator 0 is spectrally normed: two calls, two power iterations
     jobs = [(lambda i=i, d=d: _pair(d, 's', ins[i][0], ins[i][1], i != 0, want_fmap)) for i, d in enumerate(msd.discriminators)]
-    for r in fan_out(jobs, y.device):
+    for r in fan_out(jobs, y.device, inputs=[t for pair in ins for t in pair], tag='msd'):
         for acc, v in zip(res, (r[0], r[2], r[1], r[3])):
             acc.append(v)
     return res

@@ -9,6 +9,7 @@ import torch
 DISC_STREAMS = os.environ.get('TTSC_DISC_STREAMS', '1') != '0'
 MAX_SIDE = int(os.environ.get('TTSC_SIDE_STREAMS_MAX', '64'))   # jobs beyond this many share streams round-robin
 _SIDE = {}
+_OFF_TAGS = set(v for v in os.environ.get('TTSC_STREAMS_OFF', '').split(',') if v)   # measurement switch: 'gen', 'mpd', 'msd'
 
 
 def _side_streams(dev, n):
@@ -27,15 +28,23 @@ def _tensors(nest):
             yield from _tensors(v)
 
 
-def fan_out(jobs, dev):
-    """run the thunks `jobs` (each returns a nest of tensors) on one side stream each; results are safe to use on the current stream afterwards"""
-    if not DISC_STREAMS or len(jobs) < 2:
+def fan_out(jobs, dev, inputs=(), tag=''):
+    """run the thunks `jobs` (each returns a nest of tensors) on one side stream each; results are safe to use on the current stream afterwards.
+    inputs: the tensors the jobs read that were allocated OUTSIDE (on the current stream).  They are marked as used by every side stream
+    (`record_stream`): autograd keeps them as saved tensors and reads them again in the backward pass ON the side stream, then drops them — without
+    the mark their memory returns to the current stream's pool at that moment and can be handed out and rewritten while the side stream's kernel
+    is still reading it (round 4: with more than the runtime's four hardware queues really running side by side, two identical 5-step runs
+    differed in 400 of 496 parameter tensors; tools/probes/train_determinism_poisoned.py)."""
+    if not DISC_STREAMS or len(jobs) < 2 or tag in _OFF_TAGS:
         return [j() for j in jobs]
     main = torch.cuda.current_stream(dev)
     outs = []
     pool = _side_streams(dev, min(len(jobs), MAX_SIDE))
     for st in pool:
         st.wait_stream(main)
+        for t in _tensors(list(inputs)):
+            if t.is_cuda:
+                t.record_stream(st)
     for i, job in enumerate(jobs):
         st = pool[i % len(pool)]
         with torch.cuda.stream(st):

@@ -196,6 +196,7 @@ def _languasito_branches(lang, X):
         g = lstm_forward_train(lang._cond_rnn, torch.cat([g[:, :m], pitch_in[:, :m]], dim=-1))
         return linear(g, lang._cond_output.linear_layer.weight, lang._cond_output.linear_layer.bias)
 
+    text.shared_inputs = cond.shared_inputs = [x_char, x_speaker, idx_dev, pitch_in]   # allocated here, read by both closures
     return text, cond
 
 
@@ -273,6 +274,9 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
     s_t = _text_stream(dev) if (TEXT_STREAM and dev.type == 'cuda') else None
     if s_t is not None:
         s_t.wait_stream(cur)
+        for t_ in text_fn.shared_inputs:      # allocated on the current stream, read (forward and backward) on the text stream
+            if t_.is_cuda:
+                t_.record_stream(s_t)
     with (torch.cuda.stream(s_t) if s_t is not None else contextlib.nullcontext()):
         p_dur, p_pitch, p_vuv = text_fn()
         t_dur = batch['y_dur'].to(dev)

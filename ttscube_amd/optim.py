@@ -19,6 +19,7 @@ import torch.distributed as dist
 from . import _lib
 
 _ALIGN = 64   # elements: every parameter starts on a 256-byte boundary of the arena
+GATHER_GRADS = __import__('os').environ.get('TTSC_GRAD_GATHER', '1') != '0'
 
 
 class FlatAdamW:
@@ -112,6 +113,10 @@ class FlatAdamW:
         if not self.built:
             for p in self.params:
                 p.grad = None
+            return
+        if not GATHER_GRADS:      # (measurement switch: the round-3 scheme — standing arena views, one memset, autograd accumulates with `+=`)
+            self.grads_in_arena()
+            self.g.zero_()
             return
         for i in self.live:
             self.params[i].grad = None
