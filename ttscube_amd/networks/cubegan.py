@@ -93,6 +93,11 @@ class Cubegan(nn.Module):
 
         try:                                          # (no_grad only around the compute: a `with` spanning a yield would leak into the consumer)
             for X in batches:
+                # the caller may have produced X on ITS stream (host-to-device copies of the next batch while this generator was suspended)
+                s_txt.wait_stream(main)
+                for v in X.values():
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(s_txt)
                 # recurrences packed `lstm_group` utterances per member group: they hold that many times fewer CUs (which the generator of the
                 # previous batch is using) for a slightly longer step — the step time is hidden here, the CUs are not
                 with torch.cuda.stream(s_txt), torch.no_grad(), _lib.lstm_group_size(lstm_group):
