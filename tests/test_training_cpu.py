@@ -58,3 +58,43 @@ def test_conv_transpose_phase_maps_reproduce_torch_gradients(cfg):
         G[:, :, jj] = torch.einsum('bvt,bct->vc', dyp, xs)
     gw1 = G.reshape(-1)[g_map]
     assert gw1.shape == gw0.shape and float((gw1 - gw0).abs().max()) < 1e-3
+
+
+def test_flat_adamw_gathers_gradients_into_the_arena():
+    """FlatAdamW (round 4): zero_grad drops the gradients, autograd hands its own tensors over, gather() brings them into the arena — whole,
+    or range by range as the exchange chunks ask for them, with a parameter cut by a range boundary and one without a gradient (zeros) —
+    and afterwards `.grad` is the arena view again.  Layout logic only: runs on CPU tensors (step() itself needs the HIP kernel)."""
+    from ttscube_amd.optim import FlatAdamW
+    torch.manual_seed(0)
+    a, b, c = (torch.nn.Parameter(torch.randn(n)) for n in (70, 130, 5))
+    opt = FlatAdamW([a, b, c], lr=1e-3)
+    x = torch.randn(3)
+
+    def backward(with_c=True):
+        loss = (a * x[0]).sum() + (b * b).sum() * x[1] + ((c * x[2]).sum() if with_c else 0.0)
+        loss.backward()
+
+    backward()
+    opt.ensure_built()                       # first backward decides who is live; its gradients are copied in
+    assert opt.live == [0, 1, 2] and opt.offsets == [0, 128, 320] and not opt._dirty
+    assert a.grad.data_ptr() == opt.g.data_ptr() and torch.equal(opt.g[128:258], b.grad)
+    want = [p.grad.clone() for p in (a, b, c)]
+    opt.zero_grad()
+    assert a.grad is None and b.grad is None and opt._dirty
+    backward()
+    assert a.grad.data_ptr() != opt.g.data_ptr()      # autograd's own tensor, not an accumulation into the arena
+    opt.g.fill_(7.0)
+    opt.gather(0, 200)                                # a chunk boundary inside b
+    assert torch.equal(opt.g[:70], want[0]) and torch.equal(opt.g[128:200], want[1][:72]) and bool((opt.g[200:258] == 7).all())
+    opt.gather(200, opt.numel)
+    opt.grads_in_arena()
+    for p, w in zip((a, b, c), want):
+        assert torch.equal(p.grad, w) and opt.g.data_ptr() <= p.grad.data_ptr() < opt.g.data_ptr() + opt.g.numel() * 4
+    assert not opt._dirty
+    # a live parameter that gets no gradient in some step contributes zeros; gathering twice changes nothing
+    opt.zero_grad()
+    backward(with_c=False)
+    opt.gather()
+    opt.gather()
+    opt.grads_in_arena()
+    assert torch.equal(a.grad, want[0]) and torch.equal(b.grad, want[1]) and bool((c.grad == 0).all())

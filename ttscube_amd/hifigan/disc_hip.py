@@ -172,10 +172,6 @@ def _weight(l):
     """the layer's effective weight, differentiable w.r.t. its parameters: weight norm and spectral norm (power iteration included, in place on
     the module's buffers, as a module call would do) on the fused kernels"""
     if hasattr(l, 'weight_orig'):
-        if os.environ.get('TTSC_SPECTRAL_NATIVE', '1') == '0':   # (measurement switch: torch's own hook)
-            for hook in l._forward_pre_hooks.values():
-                hook(l, (None,))
-            return l.weight
         return HipSpectralNormFn.apply(l.weight_orig, l.weight_u, l.weight_v, l.training, _spectral_eps(l))
     if hasattr(l, 'weight_g'):   # torch.nn.utils.weight_norm keeps a stale plain `weight` attribute beside (weight_g, weight_v): never read it
         return HipWeightNormFn.apply(l.weight_v, l.weight_g)
