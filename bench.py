@@ -125,36 +125,39 @@ def extra_legs(g, h, sd, rank_dev, R):
                                                    'note': 'per-step latency chain (two dependent products + three hand-offs); weights stay on chip, HBM traffic negligible'}
     except Exception as e:
         legs['wavernn_decode_b256'] = {'error': str(e)[:200]}
-    try:   # BASELINE configs[3] per-GPU share: one full Cubegan training step (no exchange at N = 1; `--mode train` runs it under RCCL)
-        import random
-        from ttscube_amd.io_utils.io_cubegan import CubeganCollate
-        from ttscube_amd.io_utils.synthetic import synthetic_encodings, synthetic_examples
-        from ttscube_amd.networks import training as T
-        from ttscube_amd.networks.cubegan import Cubegan
-        enc = synthetic_encodings()
-        torch.manual_seed(1234)
-        model = Cubegan(enc, conditioning=None, train=True).to(rank_dev)
-        model.train()
-        opts = T.cubegan_configure_optimizers(model)
-        batch = CubeganCollate(enc).collate_fn(list(synthetic_examples(16, 777, min_ph=30, max_ph=50)))
-        crop = random.Random(99)
-        for _ in range(2):
-            out = T.cubegan_training_step(model, batch, opts, rng=crop)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            out = T.cubegan_training_step(model, batch, opts, rng=crop)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 3
-        tfl, _ = cubegan_step_conv_flops(16)
-        legs['cubegan_training_step_b16'] = {'ms_per_step': dt * 1e3, 'samples_per_s': 16 * 12000 / dt,
-                                             'losses': {k: round(float(v), 5) for k, v in out.items()},
-                                             'roofline': {'bound': 'mfma', 'achieved': tfl / dt / 1e12, 'peak': PEAK_F16_MFMA_TFLOPS / 3, 'unit': 'TFLOP/s',
-                                                          'frac': tfl / dt / 1e12 / (PEAK_F16_MFMA_TFLOPS / 3), 'traffic': None, 'flops_per_step': tfl,
-                                                          'note': 'convolution FLOPs of the step (bench.py::cubegan_step_conv_flops) over the whole step time'}}
-        del model, opts
-    except Exception as e:
-        legs['cubegan_training_step_b16'] = {'error': str(e)[:200]}
+    # BASELINE configs[3] per-GPU share: full Cubegan training steps (no exchange at N = 1; `--mode train` runs them under RCCL) at b = 16 (the
+    # reference script's default batch) and b = 128 (the per-GPU batch configs[3] names), through the class surface the reference's trainer drives
+    for b_tr in (16, 128):
+        tag = 'cubegan_training_step_b%d' % b_tr
+        try:
+            import random
+            from ttscube_amd.io_utils.io_cubegan import CubeganCollate
+            from ttscube_amd.io_utils.synthetic import synthetic_encodings, synthetic_examples
+            from ttscube_amd.networks.cubegan import Cubegan
+            enc = synthetic_encodings()
+            torch.manual_seed(1234)
+            model = Cubegan(enc, conditioning=None, train=True).to(rank_dev)
+            model.train()
+            batch = CubeganCollate(enc).collate_fn(list(synthetic_examples(b_tr, 777, min_ph=30, max_ph=50)))
+            crop = random.Random(99)
+            for _ in range(2):
+                out = model.training_step(batch, 0, rng=crop)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                out = model.training_step(batch, 0, rng=crop)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 3
+            tfl, _ = cubegan_step_conv_flops(b_tr)
+            legs[tag] = {'ms_per_step': dt * 1e3, 'samples_per_s': b_tr * 12000 / dt, 'losses': {k: round(float(v), 5) for k, v in out.items()},
+                         'roofline': {'bound': 'mfma', 'achieved': tfl / dt / 1e12, 'peak': PEAK_F16_MFMA_TFLOPS / 3, 'unit': 'TFLOP/s',
+                                      'frac': tfl / dt / 1e12 / (PEAK_F16_MFMA_TFLOPS / 3), 'traffic': None, 'flops_per_step': tfl,
+                                      'note': 'convolution FLOPs of the step (bench.py::cubegan_step_conv_flops) over the whole step time'}}
+            model._optimizers = None
+            del model
+            torch.cuda.empty_cache()
+        except Exception as e:
+            legs[tag] = {'error': str(e)[:200]}
     try:   # BASELINE configs[4] per-GPU share: text features -> audio (Languasito2 + generator), 64 random sentences and one sentence
         import numpy as np
         from oracle import meldecoder_ref as MO   # synthetic weights only
@@ -266,7 +269,7 @@ def bench_train(args):
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
+    assert world == args.gpus, '--gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world)
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
@@ -333,7 +336,7 @@ def bench_train(args):
         samples = world * b * 12000
         nparam = sum(p.numel() for p in model.parameters())
         res = {'metric': 'audio samples/sec (HiFi-GAN adversarial training step, Cubegan)', 'value': samples * args.steps / elapsed,
-               'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': max(1, args.warmup),
+               'unit': 'samples/s', 'n_gpus': world, 'rccl_ranks': (dist.get_world_size() if dist.is_initialized() else 0), 'steps': args.steps, 'warmup': max(1, args.warmup),
                'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': 'f32 (convolutions: split fp16 hi/lo x3 MFMA with per-launch device-side ranges; TTSC_TRAIN_SPLIT=0 = exact fp32 MFMA)', 'data': 'synthetic',
                'config': {'workload': 'Cubegan.training_step (D + G + text steps, 4 optimizers), %d utterances x 12000-sample crops per GPU, '
@@ -420,7 +423,7 @@ def bench_e2e(args):
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
+    assert world == args.gpus, '--gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world)
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
@@ -537,7 +540,7 @@ def bench_e2e(args):
         value = nsamp_all * args.steps / elapsed
         print(json.dumps({
             'metric': 'audio samples/sec (end-to-end synthesize(): phonemes -> BiLSTM mel decoder -> HiFi-GAN)', 'value': value, 'unit': 'samples/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': max(1, args.warmup), 'ms_per_step': elapsed / args.steps * 1e3,
+            'n_gpus': world, 'rccl_ranks': (dist.get_world_size() if dist.is_initialized() else 0), 'steps': args.steps, 'warmup': max(1, args.warmup), 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 (generator: split fp16 hi/lo x3 MFMA)', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[4]: %d random sentences per GPU (20-120 phonemes, %d in all), Languasito2 + HiFi-GAN V1, '
                                    'length-bucketed padded batches of %d' % (per_gpu, per_gpu * world, bs),
@@ -580,6 +583,19 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the secondary legs (fp32, B=1, WaveRNN)')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, torch.distributed.run, rendezvous on
+        # 127.0.0.1 — the container hostname may not resolve) and hand their exit code back.  Under a launcher WORLD_SIZE is set and this is skipped.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=env).returncode)
     if args.mode == 'train':
         return bench_train(args)
     if args.mode == 'e2e':
@@ -594,7 +610,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
+    assert world == args.gpus, '--gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world)
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
@@ -661,7 +677,7 @@ def main():
         traffic = measured_traffic(precision, B, T)
         res = {
             'metric': 'audio samples/sec (HiFi-GAN vocoder inference)', 'value': value, 'unit': 'samples/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'n_gpus': world, 'rccl_ranks': (dist.get_world_size() if dist.is_initialized() else 0), 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32 (split fp16 hi/lo x3 MFMA, fp32 accumulate)' if precision == 'f16x3' else 'f32',
             'data': 'synthetic',

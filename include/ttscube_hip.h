@@ -456,6 +456,11 @@ int ttsc_lstm_seq_forward(const float* xg_dev, const float* whh_packed_dev, floa
  * ttsc_lstm_split_status: 0 = every hand-off since the last call completed, 1 = a bounded spin timed out (sticky until read:
  * later split launches give up at once, so callers that care check it once per step / synthesis).  Synchronises the device. */
 int32_t ttsc_lstm_split_status(void);
+/* The same verdict for the split recurrences (LSTM, GRU, mel-AR) launched on ONE stream, waiting for that stream only: bit 0 LSTM, bit 1 GRU,
+ * bit 2 mel-AR; reported once, then re-armed; < 0 on a HIP error.  For a training step that runs its text side on a stream of its own and must know
+ * that this stream's backward pass is sound BEFORE its gradients are exchanged and applied (cube/networks/cubegan.py:172-180 is the update it guards),
+ * without draining the other streams. */
+int32_t ttsc_split_status_stream(void* stream);
 /* Utterances per member group of the register-resident split recurrence (H = 256 / 512: 4 / 16 workgroups per group hold W_hh in registers).
  * 0 (default) = automatic: the smallest of 1 / 2 / 4 that takes the padded batch in one launch — the shortest step.  n = 1 / 2 / 4 / 8: n per
  * group whenever the batch has that many — n times fewer CUs held for a somewhat longer step, for callers that run the recurrence beside a

@@ -8,8 +8,10 @@ cases; these run the shapes the metric is quoted on and check them against the o
   C5  per-GPU share of the end-to-end path: 64 ragged sentences (20..120 phonemes) through Cubegan.inference (cubegan.py:74-83):
       {shortest, longest, 2 random} against the meldecoder_ref -> hifigan_ref oracle chain (identical durations, <= 4 LSB int16),
       all 64 against their solo runs.
-  C4  per-GPU share of train_cubegan.py: ONE b = 16 Cubegan.training_step (cubegan.py:85-189) whose losses equal the torch-op
-      formulation of the same step (torch.nn.LSTM, F.conv1d generator, torch.stft mel) within 1e-4 relative.
+  C4  per-GPU share of train_cubegan.py: ONE Cubegan.training_step (cubegan.py:85-189) at b = 16 (the reference script's default) AND at b = 128 (the
+      per-GPU batch configs[3] names) whose losses equal the torch-op formulation of the same step (torch.nn.LSTM, F.conv1d generator and
+      discriminators, torch.stft mel) within 1e-4 relative.
+  C1  the reference's own CPU-runnable case: ONE utterance of 300 frames (3 s) through Generator.forward — all 72 064 samples against the oracle.
 """
 import random
 from concurrent.futures import ThreadPoolExecutor
@@ -104,7 +106,34 @@ def test_c5_64_ragged_sentences_match_oracle_chain_and_solo_runs():
         assert d.max() <= 4, (b, int(d.max()))   # 1e-4 of full scale = 3.3 LSB
 
 
-def test_c4_b16_training_step_losses_match_torch_formulation(monkeypatch):
+def test_c1_single_3s_utterance_whole_output_matches_the_oracle():
+    """BASELINE configs[0] shape on the GPU: [1, 80, 300] -> [1, 1, 72064], the call shape of cube/io_utils/runtime.py:78 and cubegan.py:83 —
+    every sample against oracle/hifigan_ref.py (1e-4 RMS gate of north_star; max error reported too), both precisions, and the int16 the API
+    hands out within 4 LSB"""
+    from ttscube_amd.hifigan.env import AttrDict
+    from ttscube_amd.hifigan.models import Generator
+    h = dict(R.CONFIG_V1)
+    sd = R.synthetic_state_dict(h, seed=1234)
+    g = Generator(AttrDict(h))
+    g.load_state_dict(sd)
+    g = g.cuda().eval()
+    mel = R.synthetic_mel(1, 300, seed=77)
+    with torch.no_grad():
+        ref = R.generator_forward(R.fold_state_dict(sd), h, mel)
+    assert tuple(ref.shape) == (1, 1, 72064)
+    for prec in ('f16x3', 'fp32'):
+        g.set_precision(prec)
+        with torch.no_grad():
+            out = g(mel.cuda()).cpu()
+        assert out.shape == ref.shape
+        rms = float((out - ref).pow(2).mean().sqrt())
+        assert rms < 1e-4 and float((out - ref).abs().max()) < 1e-4, (prec, rms, float((out - ref).abs().max()))
+        to16 = lambda a: np.asarray(a.numpy().squeeze() * 32767, dtype=np.int16).astype(np.int32)
+        assert int(np.abs(to16(out) - to16(ref)).max()) <= 4
+
+
+@pytest.mark.parametrize('b', [16, 128])
+def test_c4_training_step_losses_match_torch_formulation(monkeypatch, b):
     from ttscube_amd.io_utils.io_cubegan import CubeganCollate
     from ttscube_amd.io_utils.synthetic import synthetic_encodings, synthetic_examples
     from ttscube_amd.networks import training as T
@@ -116,9 +145,10 @@ def test_c4_b16_training_step_losses_match_torch_formulation(monkeypatch):
     twin = Cubegan(enc, conditioning=None, train=True).cuda()   # (weight-normed modules cannot be deep-copied)
     twin.load_state_dict(model.state_dict())
     twin.train()
-    batch = CubeganCollate(enc).collate_fn(list(synthetic_examples(16, 777, min_ph=30, max_ph=50)))
-    assert batch['x_char'].shape[0] == 16
-    out = T.cubegan_training_step(model, batch, T.cubegan_configure_optimizers(model), rng=random.Random(99))
+    batch = CubeganCollate(enc).collate_fn(list(synthetic_examples(b, 777, min_ph=30, max_ph=50)))
+    assert batch['x_char'].shape[0] == b
+    out = model.training_step(batch, 0, rng=random.Random(99))   # the class surface (cubegan.py:85) -> networks/training.py::cubegan_training_step
+    assert all(np.isfinite(v) for v in out.values())
     # the same step with every native piece swapped for its torch-op formulation, same weights, same crops
     from tests import torch_reference
     torch_reference.install(monkeypatch)   # generator, discriminators, LSTMs, text stacks, mel loss, GAN losses, AdamW: all torch ops

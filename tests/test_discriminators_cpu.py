@@ -1,7 +1,10 @@
-"""hifigan/discriminators.py: a weight-normed sub-discriminator may see real and generated audio as one batch (the discriminator
-step of `cubegan_training_step`) — outputs, feature maps, loss and parameter gradients must equal two separate calls."""
+"""CPU: (i) the batching identity the discriminator step relies on (hifigan/disc_hip.py::_pair: a weight-normed sub-discriminator sees real and
+generated audio as ONE batch — outputs, feature maps, loss and parameter gradients equal two separate calls), shown on the torch-op formulation of
+the same modules (tests/torch_reference.py); (ii) the drop-in classes of hifigan/discriminators.py: the reference's state_dict layout, and no CPU path."""
+import pytest
 import torch
 
+from tests import torch_reference as TR
 from ttscube_amd.hifigan import discriminators as D
 
 
@@ -17,8 +20,8 @@ def test_batched_pair_equals_two_calls():
         outs = []
         for batched in (False, True):
             d.zero_grad(set_to_none=True)
-            r, fr, g, fg = D._pair(d, y, y_hat, batched)
-            loss, _, _ = D.discriminator_loss([r], [g])
+            r, fr, g, fg = TR.disc_pair(d, y, y_hat, batched)
+            loss, _, _ = TR.discriminator_loss([r], [g])
             loss = loss + sum(f.abs().mean() for f in fr) + sum(f.abs().mean() for f in fg)
             loss.backward()
             outs.append((r.detach(), g.detach(), [f.detach() for f in fr + fg], float(loss), _grads(d)))
@@ -34,18 +37,30 @@ def test_generated_branch_with_grad_is_never_batched():
     torch.manual_seed(1)
     d = D.DiscriminatorP(2)
     calls = []
-    orig = d.forward
-    d.forward = lambda x: (calls.append(x.shape[0]), orig(x))[1]
+    fwd = lambda x: (calls.append(x.shape[0]), TR.disc_p_forward(d, x))[1]
     y, y_hat = torch.randn(2, 1, 600), torch.randn(2, 1, 600, requires_grad=True)
-    D._pair(d, y, y_hat, True)
+    TR.disc_pair(d, y, y_hat, True, fwd=fwd)
     assert calls == [2, 2]
     calls.clear()
-    D._pair(d, y, y_hat.detach(), True)
+    TR.disc_pair(d, y, y_hat.detach(), True, fwd=fwd)
     assert calls == [4]
 
 
-def test_losses_return_tensors_not_host_scalars():
-    """no .item() in the GAN losses: 16 host syncs per training step would drain the launch queue"""
-    a, b = [torch.randn(2, 10)], [torch.randn(2, 10)]
-    _, r, g = D.discriminator_loss(a, b)
-    assert all(torch.is_tensor(v) for v in r + g)
+def test_drop_in_classes_keep_the_public_layout_and_have_no_cpu_path():
+    """state_dict keys / shapes of hifigan.models' discriminators (what a reference checkpoint's `_mpd.` / `_msd.` entries hold, cubegan.py:46-47);
+    the forwards and the loss functions are the HIP ones: CPU tensors raise instead of silently running torch ops"""
+    from ttscube_amd._lib import TTSCError
+    mpd, msd = D.MultiPeriodDiscriminator(), D.MultiScaleDiscriminator()
+    sd = mpd.state_dict()
+    assert [d.period for d in mpd.discriminators] == [2, 3, 5, 7, 11]
+    assert tuple(sd['discriminators.0.convs.0.weight_v'].shape) == (32, 1, 5, 1) and tuple(sd['discriminators.4.conv_post.weight_g'].shape) == (1, 1, 1, 1)
+    assert tuple(sd['discriminators.2.convs.4.weight_v'].shape) == (1024, 1024, 5, 1)
+    sd = msd.state_dict()
+    assert {'discriminators.0.convs.0.weight_orig', 'discriminators.0.convs.0.weight_u', 'discriminators.0.convs.0.weight_v',
+            'discriminators.1.convs.1.weight_g', 'discriminators.2.conv_post.bias'} <= set(sd)
+    assert tuple(sd['discriminators.1.convs.3.weight_v'].shape) == (512, 16, 41)
+    y = torch.zeros(1, 1, 600)
+    for mod in (mpd, msd, mpd.discriminators[0], msd.discriminators[1]):
+        with pytest.raises(TTSCError, match='no CPU path'):
+            mod(y, y) if mod in (mpd, msd) else mod(y)
+    assert D.feature_loss.__module__.endswith('losses_hip') and D.mel_spectrogram.__module__.endswith('io_utils.melspec')

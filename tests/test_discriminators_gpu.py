@@ -63,28 +63,36 @@ def test_group_shapes_that_do_not_tile_are_rejected():
 @pytest.mark.parametrize('which', ['mpd', 'msd'])
 def test_native_discriminators_match_torch_modules(which):
     from ttscube_amd.hifigan import discriminators as D
-    from ttscube_amd.hifigan import disc_hip as H
+    from tests import torch_reference as TR          # the torch-op formulation of the same modules (test infrastructure)
     torch.manual_seed(7)
     m = (D.MultiPeriodDiscriminator() if which == 'mpd' else D.MultiScaleDiscriminator()).cuda()
     B, T = 2, 6000
     g = torch.Generator().manual_seed(8)
     y = (torch.rand(B, 1, T, generator=g) - 0.5).cuda()
     y_hat = (torch.rand(B, 1, T, generator=g) - 0.5).cuda().requires_grad_(True)
+    ref_fwd = TR.mpd_forward if which == 'mpd' else TR.msd_forward
     with torch.no_grad():
         for _ in range(4):                          # spectral norm: let the power iteration settle (a fresh module's u, v are random),
-            m(y, y_hat)
+            ref_fwd(m, y, y_hat)
     m.eval()                                        # ... then freeze it: no iteration between the two evaluations compared below
-    fwd = H.mpd_forward if which == 'mpd' else H.msd_forward
+    fwd = lambda mod, a_, b_, **kw: mod(a_, b_, **kw)   # the drop-in classes dispatch to the HIP kernels themselves (cubegan.py:144,160 call shape)
     params = [p for p in m.parameters() if p.requires_grad]
 
     def losses(outs):
         rs, gs, fr, fg = outs
-        ld = D.discriminator_loss(rs, gs)[0]
-        lg = D.generator_loss(gs)[0] + D.feature_loss(fr, fg)
+        ld = TR.discriminator_loss(rs, gs)[0]
+        lg = TR.generator_loss(gs)[0] + TR.feature_loss(fr, fg)
         return ld, lg
 
-    ref = m(y, y_hat)
+    ref = ref_fwd(m, y, y_hat)
     nat = fwd(m, y, y_hat)
+    sub = m.discriminators[1]                       # a sub-discriminator called on its own takes the HIP path too
+    xin = y if which == 'mpd' else m.meanpools[0](y)
+    o_sub, f_sub = sub(xin)
+    o_ref, f_ref = (TR.disc_p_forward if which == 'mpd' else TR.disc_s_forward)(sub, xin)
+    assert _rel(o_sub, o_ref) < 2e-5 and all(a_.shape == b_.shape and _rel(a_, b_) < 2e-5 for a_, b_ in zip(f_sub, f_ref))
+    with pytest.raises(Exception, match='no CPU path'):
+        m(y.cpu(), y_hat.detach().cpu())
     for i, d in enumerate(m.discriminators):
         for a, b_ in ((nat[0][i], ref[0][i]), (nat[1][i], ref[1][i])):
             assert a.shape == b_.shape and _rel(a, b_) < 2e-5, (which, i)
@@ -114,7 +122,7 @@ def test_native_discriminators_match_torch_modules(which):
     m64.load_state_dict(m.state_dict())
     m64 = m64.double().eval()
     yh64 = y_hat.detach().double().requires_grad_(True)
-    gx64 = torch.autograd.grad(losses(m64(y.double(), yh64))[1], yh64)[0]
+    gx64 = torch.autograd.grad(losses(ref_fwd(m64, y.double(), yh64))[1], yh64)[0]
     assert _rel(gx1, gx64) < 10 * _rel(gx0, gx64) + 1e-3, (_rel(gx1, gx64), _rel(gx0, gx64))   # (a): a plausibility bound — which gates flip differs run to run on the torch side
     if A.SPLIT_TRAIN:
         try:
@@ -125,7 +133,7 @@ def test_native_discriminators_match_torch_modules(which):
         assert _rel(gx1, gx2) < 2e-6
     # discriminator step: generated audio carries no graph -> real + generated run as ONE batch; same values
     nat_d = fwd(m, y, y_hat.detach(), want_fmap=False)
-    ld2 = D.discriminator_loss(nat_d[0], nat_d[1])[0]
+    ld2 = D.discriminator_loss(nat_d[0], nat_d[1])[0]   # (the product's loss: gan_loss_kernel)
     assert abs(float(ld2) - float(ld0)) < 1e-4 * abs(float(ld0)) and nat_d[2][0] == []
 
 

@@ -33,8 +33,8 @@ def test_feature_extraction_matches_oracle(B, L):
 
 def test_loss_mel_forward_and_backward():
     """hifigan mel_spectrogram (cubegan.py:137-138): forward vs the oracle, gradient of the 45 x L1 loss vs torch autograd over
-    the torch.stft formulation (hifigan/discriminators.py::mel_spectrogram)."""
-    from ttscube_amd.hifigan.discriminators import mel_spectrogram as mel_torch
+    the torch.stft formulation (tests/torch_reference.py::mel_spectrogram)."""
+    from tests.torch_reference import mel_spectrogram as mel_torch
     from ttscube_amd.io_utils.melspec import mel_spectrogram as mel_hip
     y = torch.from_numpy(_audio(4, 12000, 2)).cuda()
     tgt = torch.from_numpy(_audio(4, 12000, 3)).cuda()

@@ -161,6 +161,107 @@ def test_cubegan_training_step_runs_and_updates_all_groups(tmp_path):
     assert wav.dim() == 3 and bool(torch.isfinite(wav).all())
 
 
+def test_reference_shaped_step_body_runs_the_same_kernels_as_the_step_function():
+    """The drop-in boundary of row a9: a training step written the way the reference writes it — `self._languasito(batch)`,
+    `self._generator(cond)`, `self._mpd(y, y_g_hat.detach())`, `discriminator_loss(...)`, `mel_spectrogram(...)`, `feature_loss`, `generator_loss`,
+    `self.optimizers()`, cube/networks/cubegan.py:93,131-180, with the names imported from hifigan/discriminators.py as cubegan.py:18-21 imports them
+    from hifigan.models / hifigan.meldataset — must land on the HIP kernels by itself: its losses are bit-identical to
+    `Cubegan.training_step` (= networks/training.py::cubegan_training_step) over two steps (the second step's losses see the first one's updates of all
+    three parameter groups), and a CPU tensor anywhere raises instead of falling back to torch ops."""
+    import random
+    import torch.nn.functional as F
+    from ttscube_amd.hifigan.discriminators import discriminator_loss, feature_loss, generator_loss, mel_spectrogram
+    from ttscube_amd.networks.cubegan import Cubegan
+    batch, enc = _batch(2, 12, np.random.RandomState(3))
+    torch.manual_seed(0)
+    a = Cubegan(enc, conditioning=None, train=True).cuda().train()
+    b = Cubegan(enc, conditioning=None, train=True).cuda().train()
+    b.load_state_dict(a.state_dict())
+
+    def reference_shaped_step(self, batch, rng):
+        opt_g, opt_d, opt_t, opt_b = self.optimizers()
+        dev = self.get_device()
+        p_dur, p_pitch, p_vuv, conditioning = self._languasito(batch)
+        t_dur = batch['y_dur'].to(dev)
+        t_pitch = batch['y_pitch'].to(dev)
+        t_vuv = (t_pitch > 1).float()
+        m_size = min(t_dur.shape[1], p_dur.shape[1])
+        t_dur, p_dur = t_dur[:, :m_size], p_dur[:, :m_size, :]
+        m_size = min(t_pitch.shape[1], p_pitch.shape[1])
+        t_pitch, p_pitch, t_vuv, p_vuv = t_pitch[:, :m_size], p_pitch[:, :m_size], t_vuv[:, :m_size], p_vuv[:, :m_size]
+        ignore = int(max(self._encodings.max_pitch, self._encodings.max_duration) + 1)
+        loss_duration = F.cross_entropy(p_dur.reshape(-1, p_dur.shape[2]), t_dur.reshape(-1), ignore_index=ignore)
+        loss_pitch = (torch.abs(t_pitch / self._languasito._max_pitch - p_pitch) * t_vuv).mean() + torch.abs(t_vuv - p_vuv).mean()
+        y = batch['y_audio'].to(dev)
+        if y.shape[1] > 12000 - 240:
+            y_t_list, c_list = [], []
+            for ii in range(y.shape[0]):
+                max_frame = len(batch['y_frame2phone'][ii])
+                r = rng.randint(0, max_frame - 50 - 1) if max_frame > 51 else 0
+                c_list.append(conditioning[ii, r:r + 50, :].unsqueeze(0))
+                y_t_list.append(y[ii, r * 240:r * 240 + 12000].unsqueeze(0))
+            y = torch.cat(y_t_list, dim=0)
+            conditioning = torch.cat(c_list, dim=0)
+        y = y.unsqueeze(1)
+        y_g_hat = self._generator(conditioning.permute(0, 2, 1))
+        m_size = min(y.shape[2], y_g_hat.shape[2])
+        y, y_g_hat = y[:, :, :m_size], y_g_hat[:, :, :m_size]
+        y_mel = mel_spectrogram(y.squeeze(1), 1024, 80, 24000, 240, 1024, 0, 12000)
+        y_g_hat_mel = mel_spectrogram(y_g_hat.squeeze(1), 1024, 80, 24000, 240, 1024, 0, 12000)
+        opt_b.zero_grad()
+        opt_d.zero_grad()
+        y_df_hat_r, y_df_hat_g, _, _ = self._mpd(y, y_g_hat.detach())
+        loss_disc_f, _, _ = discriminator_loss(y_df_hat_r, y_df_hat_g)
+        y_ds_hat_r, y_ds_hat_g, _, _ = self._msd(y, y_g_hat.detach())
+        loss_disc_s, _, _ = discriminator_loss(y_ds_hat_r, y_ds_hat_g)
+        loss_disc_all = loss_disc_s + loss_disc_f
+        loss_disc_all.backward()
+        opt_d.step()
+        opt_g.zero_grad()
+        loss_mel = self._loss_l1(y_mel, y_g_hat_mel) * 45
+        y_df_hat_r, y_df_hat_g, fmap_f_r, fmap_f_g = self._mpd(y, y_g_hat)
+        y_ds_hat_r, y_ds_hat_g, fmap_s_r, fmap_s_g = self._msd(y, y_g_hat)
+        loss_fm_f = feature_loss(fmap_f_r, fmap_f_g)
+        loss_fm_s = feature_loss(fmap_s_r, fmap_s_g)
+        loss_gen_f, _ = generator_loss(y_df_hat_g)
+        loss_gen_s, _ = generator_loss(y_ds_hat_g)
+        loss_gen_all = loss_gen_s + loss_gen_f + loss_fm_s + loss_fm_f + loss_mel
+        loss_gen_all.backward(retain_graph=True)
+        opt_g.step()
+        opt_t.zero_grad()
+        loss_text = loss_pitch + loss_duration
+        loss_text.backward(retain_graph=True)
+        opt_t.step()
+        opt_b.step()
+        self._global_step += 1
+        self._current_lr = self._compute_lr(self._learning_rate, 1e-5, self._global_step)
+        for o in (opt_d, opt_g, opt_t):
+            o.param_groups[0]['lr'] = self._current_lr
+        return {'loss_g': float(loss_gen_all), 'loss_t': float(loss_text), 'loss_d': float(loss_disc_all)}
+
+    ra, rb = random.Random(5), random.Random(5)
+    for step in range(2):
+        oa = a.training_step(batch, step, rng=ra)
+        ob = reference_shaped_step(b, batch, rb)
+        for k in ('loss_d', 'loss_g', 'loss_t'):
+            assert oa[k] == ob[k], (step, k, oa[k], ob[k])
+        assert oa['loss'] == oa['loss_g'] + oa['loss_d'] + oa['loss_t']
+    # same parameters after two steps, bit for bit, in all three groups
+    from ttscube_amd.networks import training as T
+    for ga, gb in zip(T.cubegan_param_groups(a), T.cubegan_param_groups(b)):
+        assert all(torch.equal(p.detach(), q.detach()) for p, q in zip(ga, gb))
+    from ttscube_amd._lib import TTSCError
+    with pytest.raises(TTSCError):
+        a._mpd(torch.zeros(1, 1, 600), torch.zeros(1, 1, 600))
+    with pytest.raises(TTSCError):
+        discriminator_loss([torch.zeros(2, 3)], [torch.zeros(2, 3)])
+    # validation through the class surface (cubegan.py:191-273): finite mel-L1, _val_loss from validation_epoch_end
+    a.eval()
+    v = a.validation_step(batch, 0, rng=random.Random(1))
+    a.validation_epoch_end([v])
+    assert np.isfinite(v['loss_mel']) and a._val_loss == v['loss_mel']
+
+
 def test_vocoder_training_step_and_teacher_forced_logits_agree():
     from ttscube_amd.networks.vocoder import CubenetVocoder
     from ttscube_amd.networks import training as T
@@ -304,8 +405,8 @@ def test_flat_adamw_matches_torch_adamw_and_speaks_its_state_dict():
 
 
 def test_fused_gan_losses_match_torch_formulations():
-    from ttscube_amd.hifigan import discriminators as D
-    from ttscube_amd.hifigan import losses_hip as H
+    from tests import torch_reference as D                # torch-op formulations (test infrastructure)
+    from ttscube_amd.hifigan import discriminators as H   # the drop-in names: gan_loss_kernel underneath
     g = torch.Generator().manual_seed(5)
     shapes = [(4, 32, 700, 2), (4, 128, 234, 2), (4, 1, 77, 3), (4, 1024, 9, 5), (4, 16, 12000)]
     mk = lambda: [[torch.randn(s, generator=g).cuda().requires_grad_(True) for s in shapes[:3]], [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in shapes[3:]]]

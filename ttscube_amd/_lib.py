@@ -159,6 +159,7 @@ SIGNATURES = {
     'ttsc_colsum_workspace_bytes': (C.c_size_t, [C.c_int64, C.c_int64]),
     'ttsc_colsum': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     'ttsc_lstm_split_status': (C.c_int32, []),
+    'ttsc_split_status_stream': (C.c_int32, [C.c_void_p]),
     'ttsc_lstm_set_group_size': (C.c_int32, [C.c_int32]),
     'ttsc_melar_split_status': (C.c_int32, []),
     'ttsc_lstm_pack_whh_device': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -274,10 +275,20 @@ def dev_ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
-def check_split_status(where):
+def check_split_status(where, stream=None):
     """Raise if a multi-workgroup recurrence (split LSTM / GRU kernels) gave up on an inter-workgroup hand-off since the last
-    check — its outputs are then invalid.  Synchronises the device: call once per training step / synthesis, not per layer."""
+    check — its outputs are then invalid.  Synchronises the device: call once per training step / synthesis, not per layer.
+    stream (a raw HIP stream handle): only the recurrences launched on that stream, waiting for that stream alone."""
     L = lib()
+    if stream is not None:
+        m = int(L.ttsc_split_status_stream(C.c_void_p(stream)))
+        if m < 0:
+            raise TTSCError('%s: ttsc_split_status_stream failed: %s' % (where, L.ttsc_last_error().decode()))
+        if m:
+            kinds = '/'.join(n for b, n in ((1, 'LSTM'), (2, 'GRU'), (4, 'mel-AR'), (8, 'other')) if m & b)
+            raise TTSCError('%s: split %s recurrence aborted on a hand-off timeout (are other kernels occupying the CUs? '
+                            'TTSC_LSTM_SPLIT=1 / TTSC_GRU_SPLIT=1 select the single-workgroup kernels)' % (where, kinds))
+        return
     bad = [n for n, f in (('LSTM', L.ttsc_lstm_split_status), ('GRU', L.ttsc_gru_split_status), ('mel-AR', L.ttsc_melar_split_status)) if f() != 0]
     if bad:
         raise TTSCError('%s: split %s recurrence aborted on a hand-off timeout (are other kernels occupying the CUs? '

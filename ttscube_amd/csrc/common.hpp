@@ -52,6 +52,8 @@ HandoffArea* handoff_area(const char* tag, hipStream_t stream, size_t nwords, si
 // OR of the abort words of every area of `tag` on the CURRENT device, each cleared once reported; synchronises the device.
 // 0 = every hand-off completed, 1 = a bounded spin timed out, -1 = HIP error.
 int handoff_status(const char* tag);
+// the same for the areas of every tag that belong to `stream`, waiting for that stream only; bit mask lstm 1 | gru 2 | melar 4
+int handoff_status_stream(hipStream_t stream);
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }

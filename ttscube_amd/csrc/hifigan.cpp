@@ -449,6 +449,9 @@ extern "C" int ttsc_hifigan_forward_ragged(ttsc_hifigan* g, const float* mel, in
     const int64_t nmel = (int64_t)B * g->cfg.num_mels * T;
     if (g->range_check == 2) {   // deferred: sticky words, see ttsc_hifigan_range_status
         if (split_guarded && mel && nmel > 0) {
+            // word 1 may still hold the maximum of an earlier SYNCHRONOUS forward (that path clears it only at its own start): the
+            // atomicMax below must start from zero, or a too-quiet input hides behind the stale value
+            TTSC_HIP_CHECK(hipMemsetAsync(g->flag_dev + 1, 0, sizeof(unsigned), s));
             int arc = ttsc_absmax(mel, nmel, reinterpret_cast<float*>(g->flag_dev + 1), stream);
             if (arc) return arc;
             hipLaunchKernelGGL(fold_input_range_kernel, dim3(1), dim3(1), 0, s, g->flag_dev);

@@ -111,7 +111,31 @@ int handoff_status(const char* tag) {
     }
     return any;
 }
+
+int handoff_status_stream(hipStream_t stream) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    std::lock_guard<std::mutex> lk(g_state_mu);
+    int mask = 0;
+    for (auto& kv : areas()) {
+        if (kv.first.dev != dev || kv.first.stream != stream || !kv.second.words) continue;
+        unsigned v = 0;
+        if (hipMemcpyAsync(&v, kv.second.abort_word() + 1, sizeof(unsigned), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess)
+            return -1;
+        if (v) {
+            mask |= kv.first.tag == "lstm" ? 1 : kv.first.tag == "gru" ? 2 : kv.first.tag == "melar" ? 4 : 8;
+            if (hipMemsetAsync(kv.second.abort_word() + 1, 0, sizeof(unsigned), stream) != hipSuccess) return -1;
+        }
+    }
+    return mask;
+}
 }  // namespace ttsc
+
+// Status of the split recurrences launched on ONE stream (every kind), waiting for that stream only: bit 0 LSTM, bit 1 GRU, bit 2 mel-AR
+// (reported once, then re-armed); < 0 on a HIP error.  For callers that drive several streams and must know whether one stream's
+// backward pass is sound before its gradients are exchanged and applied, without draining the device (networks/training.py).
+extern "C" int32_t ttsc_split_status_stream(void* stream) { return ttsc::handoff_status_stream((hipStream_t)stream); }
 
 extern "C" const char* ttsc_version(void) { return "ttscube_hip 0.1.0 (gfx950)"; }
 extern "C" const char* ttsc_last_error(void) { return ttsc::g_err; }

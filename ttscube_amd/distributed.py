@@ -221,6 +221,9 @@ class ArenaReducer:
         self.launched_early = 0
         self._next = 0
         self._seen = []
+        # the stream this backward pass is started from (a caller may run the whole step under a non-default stream; the Cubegan step arms its
+        # text-side reducer under the text stream): gradients produced there must be ordered before an early chunk's gather / div / send too
+        self._arm_stream = torch.cuda.current_stream(self.opt.g.device) if (self.opt.built and self.opt.g.is_cuda) else None
 
     @torch.no_grad()
     def _launch(self, c):
@@ -241,6 +244,8 @@ class ArenaReducer:
                 ex = self._ex_stream
                 ex.wait_stream(torch.cuda.current_stream(g.device))
                 ex.wait_stream(torch.cuda.default_stream(g.device))
+                if getattr(self, '_arm_stream', None) is not None:
+                    ex.wait_stream(self._arm_stream)
                 for st in side_streams_of(g.device):
                     ex.wait_stream(st)
                 ctx = torch.cuda.stream(ex)

@@ -21,6 +21,8 @@ class _ListLoss(torch.autograd.Function):
         a = [t.contiguous() for t in tensors[:n]]
         b = [t.contiguous() for t in tensors[n:]] if kind == 0 else []
         dev = a[0].device
+        if dev.type != 'cuda':
+            raise _lib.TTSCError('GAN losses: tensors must live on a HIP device (got %s); no CPU path' % dev)
         need_a = [ctx.needs_input_grad[3 + i] for i in range(n)]
         need_b = [ctx.needs_input_grad[3 + n + i] for i in range(n)] if kind == 0 else []
         # one flat gradient buffer, carved into per-tensor views

@@ -237,15 +237,21 @@ class Generator(nn.Module):
             return generator_forward_with_grad(self, x)
         return self._forward_hip(x, frames, check)
 
-    def finish_range_check(self):
+    def range_check_pending(self):
+        """True while a forward run with check='deferred' has not had its verdict collected"""
+        return self._handle is not None and bool(getattr(self, '_deferred_pending', False))
+
+    def finish_range_check(self, raise_on_trip=True):
         """collect the verdict of the deferred range guard (synchronises the current stream); raises if a forward since the last
-        collection emitted non-finite audio"""
-        if self._handle is None or not getattr(self, '_deferred_pending', False):
-            return
+        collection emitted non-finite audio (raise_on_trip=False: returns the verdict instead — for clean-up paths that must not raise)"""
+        if not self.range_check_pending():
+            return False
         self._deferred_pending = False
         st = int(_lib.lib().ttsc_hifigan_range_status(self._handle, _lib.current_stream()))
-        if st < 0:
+        if st < 0 and raise_on_trip:
             _lib.check(st, 'ttsc_hifigan_range_status')
+        if not raise_on_trip:
+            return st != 0
         if st:
             raise _lib.TTSCError('Generator: a forward run with check="deferred" produced non-finite audio (an activation left the fp16 range its '
                                  'pre-scale was calibrated for, or the input was non-finite); rerun that batch with check="sync"')

@@ -49,6 +49,7 @@ class Cubegan(nn.Module):
         if train:
             self._dummy = nn.Linear(1, 1)
         self._loss_l1 = nn.L1Loss()
+        self._loss_cross = nn.CrossEntropyLoss(ignore_index=int(max(encodings.max_pitch, encodings.max_duration) + 1))
         self.automatic_optimization = False
 
     def inference(self, X, return_lengths=False, timers=None, check='sync'):
@@ -120,14 +121,21 @@ class Cubegan(nn.Module):
                     done.record(s_gen)
                 wav.record_stream(main)
                 pending = (wav, [self._generator.out_len(f) if f > 0 else 0 for f in flens], done)
-            if pending is not None:
-                yield finish(pending)
+            # the verdicts of the deferred range guard and of the split recurrences are collected BEFORE the last batch is handed out: a consumer
+            # that stops pulling after the last result (zip, islice) never resumes this generator, so nothing may be left to do behind that yield
+            last = finish(pending) if pending is not None else None
+            pending = None
             with torch.cuda.stream(s_gen):
                 self._generator.finish_range_check()
+            _lib.check_split_status('Cubegan.inference_pipelined')
+            if last is not None:
+                yield last
         finally:                                      # also when the consumer stops early: whatever is still queued is ordered before the caller's stream
             main.wait_stream(s_gen)
             main.wait_stream(s_txt)
-        _lib.check_split_status('Cubegan.inference_pipelined')
+            if self._generator.range_check_pending():  # consumer stopped early: do not leave a stale verdict for the next, unrelated forward
+                with torch.cuda.stream(s_gen):
+                    self._generator.finish_range_check(raise_on_trip=False)
 
     def forward(self, X):
         """cubegan.py:65-72: forced alignment path (X carries y_frame2phone / y_pitch)."""
@@ -135,6 +143,53 @@ class Cubegan(nn.Module):
         with torch.no_grad():
             _, _, _, cond = languasito_forward(self._languasito, X)
             return self._generator(cond.permute(0, 2, 1).contiguous())
+
+    # ---- the LightningModule surface the reference's trainer drives (scripts/train_cubegan.py:138-145 of the reference: pl.Trainer.fit(model)) ----
+    # The step logic lives in networks/training.py (HIP kernels end to end); these methods are the reference's entry points onto it, usable with or
+    # without a trainer object: `optimizers()` hands out the tuple `configure_optimizers()` built (what Lightning's own accessor returns under
+    # manual optimisation), `log_dict` is a no-op unless a logger was attached with `set_logger`.
+    def configure_optimizers(self):
+        """cubegan.py:275-311: AdamW(0.8, 0.99) over the generator side, the discriminators and the text side + Adam(1e-6) on the dummy — as flat-arena
+        HIP optimizers (optim.FlatAdamW, torch.optim.AdamW's state_dict layout); restores `.opt.last` states queued in `_loaded_optimizer_states`"""
+        from .training import cubegan_configure_optimizers
+        self._optimizers = cubegan_configure_optimizers(self)
+        return self._optimizers
+
+    def optimizers(self):
+        if getattr(self, '_optimizers', None) is None:
+            self.configure_optimizers()
+        return self._optimizers
+
+    def set_gradient_exchange(self, reducers):
+        """data-parallel training: the three reducers of training.cubegan_reducers(self, self.optimizers()) (one exchange per backward pass)"""
+        self._reducers = reducers
+
+    def set_logger(self, fn):
+        self._log_fn = fn
+
+    def log_dict(self, d, **kw):
+        fn = getattr(self, '_log_fn', None)
+        if fn is not None:
+            fn(d)
+
+    def training_step(self, batch, batch_ids=None, rng=None):
+        """cubegan.py:85-189: discriminator step, generator step (adversarial + feature matching + 45 x mel-L1), text step; returns the
+        reference's dict (values as floats: the step has already read them back)"""
+        from .training import cubegan_training_step
+        out = cubegan_training_step(self, batch, self.optimizers(), getattr(self, '_reducers', None), rng=rng)
+        out['loss_v'] = out['loss_g'] + out['loss_d']
+        out['loss'] = out['loss_v'] + out['loss_t']
+        self.log_dict(out, prog_bar=True)
+        return out
+
+    def validation_step(self, batch, batch_ids=None, rng=None):
+        """cubegan.py:191-273 (the quantity `.best` is selected on is loss_mel; the adversarial terms the reference only logs are not evaluated)"""
+        from .training import cubegan_validation_step
+        return cubegan_validation_step(self, batch, rng=rng)
+
+    def validation_epoch_end(self, outputs) -> None:
+        """cubegan.py:270-273"""
+        self._val_loss = sum(x['loss_mel'] for x in outputs) / len(outputs)
 
     @torch.jit.ignore
     def save(self, path):

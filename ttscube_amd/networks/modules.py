@@ -479,6 +479,16 @@ class Languasito2(nn.Module):
             h = torch.cat([h, sel], dim=-1)
         return h.contiguous()
 
+    def forward(self, X, hf_cond=None):
+        """modules.py:996-999 (teacher-forced: X carries y_frame2phone / y_pitch): (output_dur [B, N, D + 1], output_pitch [B, F], output_vuv [B, F],
+        conditioning [B, F, 80]).  With gradients enabled in training mode the differentiable path runs (HIP kernels behind autograd,
+        networks/training.py::languasito_forward_train — what Cubegan.training_step's first line calls, cubegan.py:93); otherwise the
+        inference kernels (validation, forced-alignment synthesis)."""
+        from . import training as T
+        if torch.is_grad_enabled() and self.training:
+            return T.languasito_forward_train(self, X)
+        return T.languasito_forward(self, X)
+
     def inference(self, X, hf_cond=None, return_aux=False, check_status=True, timers=None):
         """modules.py:1001-1009.  X: 'x_char' long [B,N] (0 = pad), 'x_speaker' long [B,1].  Returns conditioning [B,F,80]
         (zero rows beyond each utterance's own frame count); X['y_frame2phone'] / X['y_pitch'] are (re)written like

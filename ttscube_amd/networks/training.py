@@ -293,9 +293,19 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
         opt_t.zero_grad()
         arm(2)
         loss_text.backward()
-        if reducers:
-            reducers[2].reduce()
-        opt_t.step()
+
+    def text_update():
+        # Exchange + AdamW of the text side, still on its stream — but only after THIS stream's split recurrences have reported that every
+        # hand-off completed (they share the chip with the chip-filling discriminator / generator launches; a timed-out recurrence has
+        # produced garbage gradients, which must neither reach the other ranks' sums nor AdamW: ADVICE r4).  The check waits for the text
+        # stream alone, and it is made after the discriminator step has been queued, when the text backward has long finished: the host
+        # never stalls on it and nothing on the other streams is drained.
+        with (torch.cuda.stream(s_t) if s_t is not None else contextlib.nullcontext()):
+            if dev.type == 'cuda':
+                _lib.check_split_status('cubegan_training_step (text side, before its update)', stream=_lib.current_stream().value or 0)
+            if reducers:
+                reducers[2].reduce()
+            opt_t.step()
     conditioning = cond_fn()
     y = batch['y_audio'].to(dev)
     if y.shape[1] > 12000 - 240:   # random 50-frame / 12000-sample crop per item (cubegan.py:116-128)
@@ -325,6 +335,7 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
     if reducers:
         reducers[1].reduce()
     opt_d.step()
+    text_update()
     opt_g.zero_grad()
     arm(0)
     loss_mel = F.l1_loss(y_mel, y_g_hat_mel) * 45
@@ -343,6 +354,10 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
     finally:
         for p in d_params:
             p.requires_grad_(True)
+    if dev.type == 'cuda':
+        # the generator side holds the `g` phoneme stack's split recurrences: the same question before ITS exchange and update.  (The step
+        # reads its losses back a few lines further down anyway, so waiting for the current stream here costs the queueing of two launches.)
+        _lib.check_split_status('cubegan_training_step (generator side, before its update)', stream=_lib.current_stream().value or 0)
     if reducers:
         reducers[0].reduce()
     opt_g.step()

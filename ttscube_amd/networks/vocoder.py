@@ -71,6 +71,50 @@ class CubenetVocoder(nn.Module):
         return {'mel': m, 'x_low': xl}
 
     @torch.jit.ignore
+    # ---- the LightningModule surface of vocoder.py:133-176 (pl.Trainer.fit(model) in the reference's scripts/train_vocoder.py) ----
+    def configure_optimizers(self):
+        """vocoder.py:169-173: two Adam optimizers (low-resolution net first)"""
+        self._optimizers = [torch.optim.Adam(self._wavernn_lr.parameters(), lr=self._learning_rate),
+                            torch.optim.Adam(self._wavernn_hr.parameters(), lr=self._learning_rate)]
+        return self._optimizers
+
+    def optimizers(self):
+        if getattr(self, '_optimizers', None) is None:
+            self.configure_optimizers()
+        return self._optimizers
+
+    def set_gradient_exchange(self, reducers):
+        self._reducers = reducers
+
+    def log_dict(self, d, **kw):
+        fn = getattr(self, '_log_fn', None)
+        if fn is not None:
+            fn(d)
+
+    def log(self, name, value, **kw):
+        self.log_dict({name: value})
+
+    def training_step(self, batch, batch_idx=None):
+        """vocoder.py:136-156: both networks' teacher-forced CE losses, clip_grad_norm 5, Adam x 2, lr decay — on the HIP GRU / GEMM / convolution
+        kernels behind autograd (networks/training.py::vocoder_training_step)"""
+        from .training import vocoder_training_step
+        out = vocoder_training_step(self, batch, self.optimizers(), getattr(self, '_reducers', None))
+        self.log_dict(out, prog_bar=True)
+        return out
+
+    def validation_step(self, batch, batch_idx=None):
+        """vocoder.py:133-134"""
+        with torch.no_grad():
+            return self.forward(batch)
+
+    def validation_epoch_end(self, outputs) -> None:
+        """vocoder.py:158-165"""
+        loss_lr = sum(float(x['lr']) for x in outputs) / len(outputs)
+        loss_hr = sum(float(x['hr']) for x in outputs) / len(outputs)
+        self.log('val_loss', (loss_hr + loss_lr) / 2)
+        self._val_loss_hr = loss_hr
+        self._val_loss_lr = loss_lr
+
     def save(self, path):
         torch.save(self.state_dict(), path)
 

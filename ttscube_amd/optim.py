@@ -71,6 +71,13 @@ class FlatAdamW:
             torch._foreach_copy_(dst_p, src_p)
             if dst_g:
                 torch._foreach_copy_(dst_g, src_g)
+        if dev.type == 'cuda':
+            # the old parameter / gradient storages are dropped a few lines below and go back to the pool of the stream they were ALLOCATED on;
+            # the copies above run on the CURRENT stream (the text side builds under its own stream): tell the allocator, or the next
+            # allocation on the other stream may overwrite a source before its copy has executed (gather() does the same)
+            cs = torch.cuda.current_stream(dev)
+            for t_ in src_p + src_g:
+                t_.record_stream(cs)
         self._gviews = []
         for i, o, vp in zip(self.live, offs, dst_p):
             p = ps[i]
