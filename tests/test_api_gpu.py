@@ -118,6 +118,47 @@ def test_pipelined_inference_equals_batch_by_batch(tmp_path):
         assert all(torch.equal(again[0][b, 0, :n], want[1][0][b, 0, :n]) for b, n in enumerate(want[1][1]))
 
 
+def test_pipelined_guard_trip_on_the_last_batch_reaches_a_consumer_that_stops_pulling(tmp_path):
+    """a consumer that takes exactly as many results as it fed batches (zip) never resumes the generator behind its last
+    yield — the deferred range guard's verdict for the LAST batch and the split-recurrence status must therefore be collected before that
+    yield.  The last batch's conditioning is blown out of the fp16 range here; the consumer must see TTSCError instead of audio, no verdict
+    may stay pending for the next, unrelated forward, and the model must work afterwards."""
+    from ttscube_amd._lib import TTSCError
+    from ttscube_amd.io_utils.io_cubegan import CubeganEncodings
+    from ttscube_amd.io_utils.synthetic import synthetic_sentences
+    from ttscube_amd.networks.cubegan import Cubegan
+    base, _, _ = _make_model_dir(tmp_path)
+    m = Cubegan(CubeganEncodings(base + '.encodings'), conditioning=None, train=False)
+    m.load(base + '.model')
+    m = m.cuda().eval()
+    batches = []
+    for seed, n in ((1, 3), (2, 2), (3, 4)):
+        xc, _ = synthetic_sentences(n, seed=seed, nphones=16, min_ph=6, max_ph=20)
+        batches.append({'x_char': torch.from_numpy(xc).cuda(), 'x_speaker': torch.full((n, 1), 1, dtype=torch.long).cuda()})
+    with torch.no_grad():
+        want0 = m.inference(batches[0], return_lengths=True)
+    real, calls = m._languasito.inference, []
+
+    def blown(X, **kw):
+        cond, aux, flens = real(X, **kw)
+        calls.append(1)
+        return (cond * 3e38 if len(calls) == len(batches) else cond), aux, flens
+
+    m._languasito.inference = blown
+    try:
+        got = []
+        with pytest.raises(TTSCError, match='check="sync"'):
+            for X, res in zip(batches, m.inference_pipelined(iter(batches))):   # zip: stops pulling after the last result
+                got.append(res)
+        assert len(got) == len(batches) - 1            # the bad batch was never handed out as audio
+    finally:
+        m._languasito.inference = real
+    assert not m._generator.range_check_pending()
+    with torch.no_grad():
+        again = m.inference(batches[0], return_lengths=True)     # (the handle re-calibrates on its probe: same scales, same bits)
+    assert all(torch.equal(again[0][b, 0, :n], want0[0][b, 0, :n]) for b, n in enumerate(want0[1]))
+
+
 def test_cubegan_load_is_non_strict_and_device_checked(tmp_path):
     from ttscube_amd._lib import TTSCError
     from ttscube_amd.io_utils.io_cubegan import CubeganEncodings
