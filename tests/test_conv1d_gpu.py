@@ -305,7 +305,10 @@ def test_conv1d_f16x3_wide_tile_kernel(C, k, d, L, B, monkeypatch):
     out = s0.clone().cuda()
     conv(x.cuda(), resid=r.cuda(), out=out, in_scale=1.0 / 3.0, in_slope=0.1, accumulate=True)
     ref = s0 + F.conv1d(F.leaky_relu(x / 3.0, 0.1), w, b, padding=pad, dilation=d) + r
-    assert float((out.cpu() - ref).abs().max()) < F16X3_TOL
+    # residual + running sum + bias are the INITIAL value of the accumulators (round 5: their loads leave in the prologue, all at once, instead
+    # of as 32 dependent round trips in the epilogue), so the K * C / 16 accumulation steps round at the magnitude of the whole sum (here up to
+    # ~8: N(0,1) residual + N(0,1) running sum + the convolution) instead of the convolution's alone: a few ulp of the RESULT — the bound is relative
+    assert float((out.cpu() - ref).abs().max()) < max(F16X3_TOL, 3e-6 * float(ref.abs().max()))
     y = conv(x.cuda(), in_slope=0.1)
     ref = F.conv1d(F.leaky_relu(x, 0.1), w, b, padding=pad, dilation=d)
     assert float((y.cpu() - ref).abs().max()) < F16X3_TOL

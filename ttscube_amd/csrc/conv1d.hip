@@ -59,14 +59,111 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_wide_kernel(ConvArgs a) {
     const int lin = a.in_len ? a.in_len[b] : a.Lin;
     if (a.out_len && q0 >= a.out_len[b]) return;
     const int cotg = blockIdx.y * (WM * MI);        // first 32-row tile of the workgroup
+#ifdef TTSC_ABLATE
+    const unsigned wg_lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+#endif
+    TTSC_STAMP(a, wg_lin, 0);
+    TTSC_STAMP_HWID(a, wg_lin, 15);
 
+    // Accumulators.  With `acc_init` they START at (bias + residual + running sum) / w_unscale (w_unscale is a power of two: exact), so the
+    // epilogue is 128 independent stores per lane.  Why: as epilogue operands the residual tile was fetched four rows at a time, load ->
+    // wait -> store, 32 dependent round trips per wave with 1 KB in flight each — the workgroup timeline (tools/wg_timeline.py, round 5) put
+    // 41-45 % of a workgroup's life into that epilogue for the K = 3 / K = 7 layers (56 us for 256 KB), and since the workgroups of a launch
+    // run in step, the whole chip sat in it together.  Here all of a lane's 128 (256 with the running sum) loads leave back to back at the top
+    // of the kernel, in front of the first activation chunk's, and land while the prologue waits for that chunk anyway.
     f32x16 acc[MI][NJ];
+    // acc_init: operand sources and this lane's element offsets (32-bit: B * C * L < 2^32 checked by the host)
+    const float* ai_first = a.acc_init ? (a.resid ? a.resid : (a.accumulate ? a.y : nullptr)) : nullptr;
+    const float* ai_second = (a.acc_init && a.resid && a.accumulate) ? a.y : nullptr;
+    const unsigned ai_L = (unsigned)a.Lout;
+    const unsigned ai_row0 = ((unsigned)b * a.Cout + (cotg + wm * MI) * 32 + 4 * half) * ai_L;
+    const int ai_qw = q0 + wn * (NJ * 32) + l31;
+    // row tile i of the accumulators <- first operand (or zero); the loads of a row tile leave back to back
+    auto acc_load_first = [&](int i) __attribute__((always_inline)) {
+        if (ai_first) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+            for (int n = 0; n < NJ; ++n) {
+                const int q = ai_qw + n * 32;
+                const unsigned o = ai_row0 + (unsigned)(i * 32) * ai_L + (unsigned)(q < a.Lout ? q : 0);   // (columns beyond the row are never stored)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+                for (int g = 0; g < 4; ++g) {
+                    unsigned og = o + (unsigned)(8 * g) * ai_L;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                    for (int e = 0; e < 4; ++e) {
+                        acc[i][n][4 * g + e] = ai_first[og];
+                        og += ai_L;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < NJ; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
+        }
+    };
+    // the rest of the initial value: + running sum (when both operands are present), + bias, / weight scale
+    auto acc_init_finish = [&]() __attribute__((always_inline)) {
+        const float inv = 1.f / a.w_unscale;
+        if (ai_second) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int n0 = 0; n0 < NJ; n0 += 2) {
+                    float t[2][16];
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const int q = ai_qw + (n0 + n) * 32;
+                        const unsigned o = ai_row0 + (unsigned)(i * 32) * ai_L + (unsigned)(q < a.Lout ? q : 0);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) t[n][r] = ai_second[o + (unsigned)((r & 3) + 8 * (r >> 2)) * ai_L];
+                    }
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][n0 + n][r] += t[n][r];
+                }
+        }
+        if (a.bias) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                float bv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bv[r] = a.bias[(cotg + wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+#pragma unroll
+                for (int n = 0; n < NJ; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][n][r] += bv[r];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int n = 0; n < NJ; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][n][r] *= inv;
+    };
+    if (a.acc_init) {
+        // (filled in the prologue below, between the activation loads: see acc_load_first / acc_init_finish)
+    } else if (a.epi_prefetch && a.bias && (a.resid || a.accumulate)) {
+        // prefetched epilogue: the bias starts the sum (divided by the weight scale, a power of two: exact), so the epilogue holds no bias registers
+        const float inv = 1.f / a.w_unscale;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float bv = a.bias[(cotg + wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] * inv;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j][r] = bv;
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
 
     const float* xb = a.x + (size_t)b * C * a.Lin;
     const int lo = q0 - D * ((K - 1) / 2);
@@ -202,15 +299,30 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_wide_kernel(ConvArgs a) {
     stage_A(0, 0, 0);
 #pragma unroll
     for (int e = 0; e < XIT; ++e) x_issue_item(e, 0);
+    if (a.acc_init) {
+        // the first row tile's operand loads leave BEHIND the first chunk's (loads return in order: the chunk's conversion below then waits for
+        // its own loads only), the second row tile's behind the second chunk's; the arithmetic on them comes last
+        __builtin_amdgcn_sched_barrier(0);
+        acc_load_first(0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int e = 0; e < XIT; ++e) x_commit_item(e, Xp);
 #pragma unroll
     for (int e = 0; e < XIT; ++e) x_issue_item(e, 1);
+    if (a.acc_init) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 1; i < MI; ++i) acc_load_first(i);
+        acc_init_finish();
+    }
     __syncthreads();
+    TTSC_STAMP(a, wg_lin, 1);
     for (int c = 0; c < NCHUNK; c += 2) {
         chunk(c, std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
         chunk(c + 1, std::integral_constant<int, 1>(), std::integral_constant<int, (K & 1)>());
     }
+    TTSC_STAMP(a, wg_lin, 2);
 
     if (TTSC_DBG(a, 4)) {
         float t = 0.f;
@@ -221,14 +333,109 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_wide_kernel(ConvArgs a) {
         if (t == 12345.678f) a.y[0] = 1.f;   // keep the accumulators alive
         return;
     }
+    if (a.acc_init) {
+        // everything but the weight scale is already in the sum: independent stores, nothing to wait for
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int n = 0; n < NJ; ++n) {
-            const int q = q0 + wn * (NJ * 32) + n * 32 + l31;
-            epilogue_tile(acc[i][n], a, b, (cotg + wm * MI + i) * 32, q, q < a.Lout, half, a.w_unscale);
+            for (int n = 0; n < NJ; ++n) {
+                const int q = q0 + wn * (NJ * 32) + n * 32 + l31;
+                if (q < a.Lout) {
+                    float* yp = a.y + ((size_t)b * a.Cout + (cotg + wm * MI + i) * 32 + 4 * half) * a.Lout + q;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) yp[(size_t)((r & 3) + 8 * (r >> 2)) * a.Lout] = acc[i][n][r] * a.w_unscale;
+                }
+            }
+    } else if (a.epi_prefetch && (a.resid || a.accumulate)) {
+        // Deep-prefetched epilogue, same arithmetic as epilogue_tile (bit-identical): the residual (and running-sum) operands of the NEXT tiles
+        // are in flight while a tile is finished and stored — four tiles ahead with one operand, two with both (64 registers: the fragment and
+        // staging registers of the main loop are free now).  epilogue_tile fetched four rows at a time, load -> wait -> store: 32 dependent
+        // round trips per wave with 1 KB in flight each; the workgroup timeline (tools/wg_timeline.py, round 5) put 41-45 % of a workgroup's
+        // life into that for the K = 3 / K = 7 layers (56 us for 256 KB), and the workgroups of a launch run in step, so the chip sat in it together.
+        const float* rsrc = a.resid;
+        const float* ysrc = a.accumulate ? a.y : nullptr;
+        constexpr int NTILE = MI * NJ;
+        // 32-bit element offsets from the tensor base (B * C * L < 2^32 is checked by the host); the 16 rows of a tile follow from its first by adds
+        const unsigned L1 = (unsigned)a.Lout;
+        const unsigned row0 = ((unsigned)b * a.Cout + (cotg + wm * MI) * 32 + 4 * half) * L1;
+        const int qw = q0 + wn * (NJ * 32) + l31;
+        auto tile_off = [&](int t) __attribute__((always_inline)) -> unsigned {
+            const int i = t / NJ, n = t % NJ;
+            const int q = qw + n * 32;
+            return row0 + (unsigned)(i * 32) * L1 + (unsigned)(q < a.Lout ? q : 0);
+        };
+        // MODE 0: residual only, 1: running sum only, 2: both (compile-time: no per-element selects)
+        auto body = [&](auto mode_tag) __attribute__((always_inline)) {
+            constexpr int MODE = decltype(mode_tag)::value;
+            constexpr bool BOTH = MODE == 2;
+            constexpr int DEPTH = BOTH ? 1 : 3;   // (register budget: 128 accumulators + 48 / 32 operand registers)
+            const float* s0 = MODE == 1 ? ysrc : rsrc;
+            float t0[DEPTH][16], t1[BOTH ? DEPTH : 1][16];
+            auto issue = [&](int t) __attribute__((always_inline)) {
+                unsigned o = tile_off(t);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    unsigned og = o + (unsigned)(8 * g) * L1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        t0[t % DEPTH][4 * g + e] = s0[og];
+                        if constexpr (BOTH) t1[t % DEPTH][4 * g + e] = ysrc[og];
+                        og += L1;
+                    }
+                }
+            };
+            // (the bias is already in the accumulators: see their initialisation)
+#pragma unroll
+            for (int t = 0; t < DEPTH; ++t) issue(t);
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) {
+                const int i = t / NJ, n = t % NJ;
+                float res[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float u = acc[i][n][r] * a.w_unscale;
+                    if constexpr (MODE == 0) res[r] = (u + t0[t % DEPTH][r]) * a.out_scale + 0.f;
+                    if constexpr (MODE == 1) res[r] = (u + 0.f) * a.out_scale + t0[t % DEPTH][r];
+                    if constexpr (MODE == 2) res[r] = (u + t0[t % DEPTH][r]) * a.out_scale + t1[t % DEPTH][r];
+                }
+                if (qw + n * 32 < a.Lout) {
+                    unsigned o = tile_off(t);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        unsigned og = o + (unsigned)(8 * g) * L1;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            a.y[og] = res[4 * g + e];
+                            og += L1;
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);   // (the next tile's loads stay behind this tile's stores)
+                if (t + DEPTH < NTILE) issue(t + DEPTH);
+            }
+        };
+        if (rsrc && ysrc)
+            body(std::integral_constant<int, 2>());
+        else if (rsrc)
+            body(std::integral_constant<int, 0>());
+        else
+            body(std::integral_constant<int, 1>());
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int n = 0; n < NJ; ++n) {
+                const int q = q0 + wn * (NJ * 32) + n * 32 + l31;
+                epilogue_tile(acc[i][n], a, b, (cotg + wm * MI + i) * 32, q, q < a.Lout, half, a.w_unscale);
+            }
         }
     }
+#ifdef TTSC_ABLATE
+    if (a.prof) {
+        __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): the stores have been accepted
+        TTSC_STAMP(a, wg_lin, 3);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -414,6 +621,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 2)) void respair32_f16x3_ke
     ea.accumulate = a.accumulate;
     ea.dbg = 0;
     ea.skew = 0;
+    ea.acc_init = 0;
+    ea.epi_prefetch = 0;
+    ea.swz_nx = ea.swz_ny = 0;
     ea.gate = nullptr;
     ea.gate_slope = 1.f;
     ea.vphase = 0;
@@ -550,6 +760,13 @@ static int launch_f16_wide(const ConvArgs& a0, int B, hipStream_t s) {
     // start skew of the second resident workgroup per CU (see the kernel): only when the launch has several full rounds
     static const int skew_env = getenv("TTSC_CONV_SKEW") ? atoi(getenv("TTSC_CONV_SKEW")) : 6;
     a.skew = ((size_t)grid.x * grid.y * grid.z >= 1024) ? skew_env : 0;
+    // epilogue operands as the accumulators' initial value (see the kernel) whenever the epilogue is the plain affine one; TTSC_CONV_ACC_INIT=0
+    // keeps the operand loads in the epilogue (measurement switch)
+    static const int acc_init_env = getenv("TTSC_CONV_ACC_INIT") ? atoi(getenv("TTSC_CONV_ACC_INIT")) : 1;
+    a.acc_init = (acc_init_env && a.out_act == TTSC_ACT_NONE && !a.gate && a.out_scale == 1.f && a.Cout == C && (size_t)B * C * a.Lout < (1ull << 32)) ? 1 : 0;
+    // deep-prefetched epilogue operands (bit-identical to the plain epilogue; TTSC_CONV_EPI_PREFETCH=0 restores the four-rows-at-a-time one)
+    static const int epi_env = getenv("TTSC_CONV_EPI_PREFETCH") ? atoi(getenv("TTSC_CONV_EPI_PREFETCH")) : 1;
+    a.epi_prefetch = (epi_env && !a.gate && a.out_act == TTSC_ACT_NONE && a.Cout == C && (size_t)B * C * a.Lout < (1ull << 32)) ? 1 : 0;   // (32-bit element offsets)
     constexpr size_t lds = (size_t)2 * (4 * SPAN + 2) * 16 + (size_t)2 * (2 * 2 * 2 * 64) * 16;   // activations + 2 weight slots
     if (int rc = ensure_full_lds((const void*)conv_f16x3_wide_kernel<C, K, D>)) return rc;   // once per (device, kernel)
     hipLaunchKernelGGL((conv_f16x3_wide_kernel<C, K, D>), grid, dim3(256), lds, s, a);
@@ -585,11 +802,27 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_tall_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.z;
-    const int q0 = a.q_lo + blockIdx.x * NT;          // first INPUT position of the tile
+    // Which tile?  The row tiles of a transposed convolution are its PHASES: they write interleaved samples of the same output rows, every
+    // 128-byte line of the output gets a fifth (stride 5) / a third (stride 3) of its bytes from each of them.  Dispatched as a 3-D grid the
+    // phases of a q tile land on different XCDs — workgroup i runs on XCD i mod 8 (tools/probes/xcc_probe.hip) — whose L2s cannot merge the
+    // partial lines: the 512 -> 256, k16 s5 upsampler wrote 1311 MB for a 262 MB tensor (round-4 PMC).  As a 1-D launch the id is decoded so
+    // that the phases of one q tile are consecutive workgroups of ONE XCD: its L2 sees all pieces of a line within a few microseconds.
+    int bx, by, bz;
+    if (a.swz_nx > 0) {
+        const unsigned id = blockIdx.x, xcd = id & 7u, u = id >> 3;
+        by = (int)(u % (unsigned)a.swz_ny);
+        const unsigned t = (u / (unsigned)a.swz_ny) * 8u + xcd;      // q tile x utterance, linear
+        bx = (int)(t % (unsigned)a.swz_nx);
+        bz = (int)(t / (unsigned)a.swz_nx);
+        if (bz >= a.fold_B) return;   // (padding of the launch to a multiple of 8 tiles; fold_B carries the batch size here)
+    } else {
+        bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    }
+    const int b = bz;
+    const int q0 = a.q_lo + bx * NT;          // first INPUT position of the tile
     const int lin = a.in_len ? a.in_len[b] : a.Lin;
     if (a.out_len && (long)q0 * a.out_stride + a.out_off >= a.out_len[b]) return;
-    const int cotg = blockIdx.y * (WM * MI);
+    const int cotg = by * (WM * MI);
     const int cotN = a.CoutP >> 5;
 
     f32x16 acc[MI][NJ];
@@ -729,9 +962,18 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_tall_kernel(ConvArgs a) {
 }
 
 template <int CIN, int J, int MI, int NJ>
-static int launch_f16_tall(const ConvArgs& a, int B, hipStream_t s) {
+static int launch_f16_tall(const ConvArgs& a0, int B, hipStream_t s) {
     constexpr int NT = 2 * NJ * 32, SPAN = NT + (J - 1), MT = 2 * MI * 32;
+    ConvArgs a = a0;
     dim3 grid((unsigned)ceil_div(a.q_cnt, NT), (unsigned)(a.CoutP / MT), (unsigned)B);
+    static const int swz_env = getenv("TTSC_TALL_SWIZZLE") ? atoi(getenv("TTSC_TALL_SWIZZLE")) : 1;
+    if (swz_env && grid.y > 1) {   // XCD-aware 1-D launch (see the kernel): the row tiles of a q tile on one XCD, back to back
+        a.swz_nx = (int)grid.x;
+        a.swz_ny = (int)grid.y;
+        a.fold_B = B;
+        const unsigned tiles = (unsigned)round_up((int64_t)grid.x * B, 8);
+        grid = dim3(tiles * grid.y, 1, 1);
+    }
     constexpr size_t lds = (size_t)2 * (4 * SPAN + 2) * 16 + (size_t)2 * (2 * MI * 2 * 64) * 16;
     if (int rc = ensure_full_lds((const void*)conv_f16x3_tall_kernel<CIN, J, MI, NJ>)) return rc;
     hipLaunchKernelGGL((conv_f16x3_tall_kernel<CIN, J, MI, NJ>), grid, dim3(256), lds, s, a);
@@ -1286,10 +1528,15 @@ extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, 
         a.out_len = out_len_dev;
         a.dbg = 0;
         a.skew = 0;
+        a.acc_init = 0;
+        a.epi_prefetch = 0;
+        a.swz_nx = a.swz_ny = 0;
         a.fold_S = a.fold_B = 0;
         a.amax_x = a.amax_w = nullptr;
 #ifdef TTSC_ABLATE
         if (const char* ev = getenv("TTSC_CONV_DBG")) a.dbg = atoi(ev);
+        a.prof = nullptr;
+        if (const char* ev = getenv("TTSC_PROF_PTR")) a.prof = reinterpret_cast<unsigned long long*>(strtoull(ev, nullptr, 0));
 #endif
         a.vphase = c->vfused ? ((c->vrow4 && c->precision == TTSC_PREC_F16X3) ? -4 : g.out_channels) : 0;
         if (a.vphase == -4) {

@@ -13,8 +13,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // them to constants, so no environment variable can make a shipped kernel skip work.
 #ifdef TTSC_ABLATE
 #define TTSC_DBG(args, bit) (((args).dbg & (bit)) != 0)
+// phase timeline of a workgroup (tools/wg_timeline.py): thread 0 writes the 100 MHz wall clock into slot `i` of its workgroup's 16-slot record
+#define TTSC_STAMP(args, wg, i)                                                                              \
+    do {                                                                                                     \
+        if ((args).prof && threadIdx.x == 0) (args).prof[(size_t)(wg) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#define TTSC_STAMP_HWID(args, wg, i)                                                                         \
+    do {                                                                                                     \
+        if ((args).prof && threadIdx.x == 0) {                                                               \
+            unsigned hw, xcc;                                                                                \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                 \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                               \
+            (args).prof[(size_t)(wg) * 16 + (i)] = ((unsigned long long)(xcc & 0xf) << 32) | hw;            \
+        }                                                                                                    \
+    } while (0)
 #else
 #define TTSC_DBG(args, bit) false
+#define TTSC_STAMP(args, wg, i) do {} while (0)
+#define TTSC_STAMP_HWID(args, wg, i) do {} while (0)
 #endif
 
 static constexpr int KC = 16;  // input channels staged per LDS chunk
@@ -41,8 +57,16 @@ struct ConvArgs {
     int out_act, accumulate;
     int vphase;       // fused ConvTranspose1d phases: GEMM row v = r * vphase + co (vphase = real Cout), output o += r; 0 = off;
                       // -4 = rows interleaved v = co * 4 + r (kernel_size == stride == 4): see epilogue_tile_v4
+    int acc_init;     // wide kernel: bias, residual and running sum enter the sum as the INITIAL value of the accumulators (loaded in the prologue,
+                      // all at once) instead of in the epilogue; requires out_scale == 1, no activation, no gate (set by launch_f16_wide)
+    int epi_prefetch; // wide kernel: residual / running-sum operands of the epilogue fetched several tiles ahead (same arithmetic as epilogue_tile)
+    int swz_nx, swz_ny;   // tall kernel, XCD-aware 1-D launch (swz_nx > 0): workgroup id -> (q tile, row tile, utterance) such that the row tiles (= the
+                          // phases of a transposed convolution) of one q tile run on ONE XCD, back to back: see conv_f16x3_tall_kernel
     int skew;         // wide kernel: start delay of the second resident workgroup per CU, in units of ~4 us (0 = off)
     int dbg;          // ablation switches, ONLY in -DTTSC_ABLATE builds (tools/ablate.cpp; never in libttscube_hip.so): see TTSC_DBG
+#ifdef TTSC_ABLATE
+    unsigned long long* prof;   // workgroup phase timeline (TTSC_STAMP) or null; env TTSC_PROF_PTR
+#endif
     unsigned* nf_flag;  // conv_cout1_kernel: set to 1 when a non-finite output sample is produced (split-precision range guard), or null
     const float* gate;  // data-gradient launches: [B,Cout,Lout] pre-activation saved by the forward; the conv result is
     float gate_slope;   // multiplied by d lrelu/dx = (gate > 0 ? 1 : gate_slope) BEFORE the residual is added; null = off

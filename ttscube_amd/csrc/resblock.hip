@@ -60,6 +60,9 @@ struct ChainArgs {
     float post_in_scale, post_slope, post_out_scale;
     int post_act;
     unsigned* nf_flag;    // range-guard word (conv_cout1_kernel) or null
+#ifdef TTSC_ABLATE
+    unsigned long long* prof;   // workgroup phase timeline (TTSC_STAMP) or null; env TTSC_PROF_PTR
+#endif
     int dbg;              // -DTTSC_ABLATE builds: 1 skip the epilogue -> image conversions, 2 skip barriers, 4 skip the final store, 8 skip the x load, 16 skip weight loads in the loop
 };
 
@@ -119,6 +122,11 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
     const int q0 = blockIdx.x * a.nto;
     const int lin = a.len ? a.len[b] : a.L;
     if (q0 >= lin) return;
+#ifdef TTSC_ABLATE
+    const unsigned wg_lin = blockIdx.x + gridDim.x * blockIdx.y;
+#endif
+    TTSC_STAMP(a, wg_lin, 0);
+    TTSC_STAMP_HWID(a, wg_lin, 15);
     const int wm = wv / WN;                          // this wave's row-tile group
     const int mi0 = wm * MIW;                        // its first row tile
     const int colw = (wv % WN) * (CT * 32);          // first tile column of this wave
@@ -264,18 +272,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
     // acc = sum over taps j and 16-channel chunks c of  W[j][c] x image[c][column + (j - (K-1)/2) * d]   (three split products).
     // Precondition: weight group 0 of `w` sits in slot 0, published by a barrier.  Ends with a barrier (every wave has
     // finished reading the image and the weight slots).
-    // c0 (or null = zeros): initial value of every accumulator tile of row tile mi — the first MFMA of a tile reads it as its C operand, so a
-    // per-channel constant (conv2's bias, pre-divided by the epilogue factor) joins the sum without a single extra instruction
+    // c0: initial value of every accumulator tile of row tile mi — the first MFMA of a tile reads it as its C operand, so a per-channel
+    // constant (the bias, pre-divided by the epilogue factor) joins the sum without a single extra instruction
     auto conv = [&](const half8* w, auto dtag, int d, f32x16 (&acc)[MIW][CT], const f32x16* c0) __attribute__((always_inline)) {
         constexpr int D = decltype(dtag)::value;   // IL: the dilation (compile time); plain layout: unused (d is a run-time value)
-        if (!c0) {
-#pragma unroll
-            for (int mi = 0; mi < MIW; ++mi)
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mi][ct][r] = 0.f;
-        }
         const half8* base = IL ? P + (size_t)(half * 2) * PW + MARGQ + qw + l31 : P + (size_t)(half * 2) * PW + MARG + colw + l31 - d * ((K - 1) / 2);
         // B fragment of step s (tap s / NCH, chunk s % NCH), plane pl (0 hi, 1 lo), column tile ct
         auto bfrag = [&](int s, int pl, int ct) __attribute__((always_inline)) -> const half8* {
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
             for (int q = 0; q < NM; ++q) {
                 const int term = q / (MIW * CT), mi = (q / CT) % MIW, ct = q % CT;
                 acc[mi][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[s & 1][mi][term == 0 ? 1 : 0], Bf[s & 1][term == 1 ? 1 : 0][ct],
-                                                                   (s == 0 && term == 0 && c0) ? c0[mi] : acc[mi][ct], 0, 0, 0);
+                                                                   (s == 0 && term == 0) ? c0[mi] : acc[mi][ct], 0, 0, 0);
                 if (q < 2 * CT && s + 1 < NS) Bf[(s + 1) & 1][q / CT][q % CT] = *bfrag(s + 1, q / CT, q % CT);
                 // weights of the next step: same group, or (three slots) the next group, published one barrier ago
                 if (q >= 2 * CT && q < 2 * CT + 2 * MIW && s + 1 < NS && ((s + 1) % GRP != 0 || NSLOT >= 3)) {
@@ -335,32 +335,57 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
         }
     };
 
+    // Both convolutions' biases ride in the accumulators: the first MFMA of a tile takes `bias * factor` as its C operand (the factor undoes the
+    // epilogue's power-of-two scale: exact).  Their 16 loads per row tile are issued one epilogue EARLY — before the image conversion that
+    // precedes the convolution — so that they land behind ~300 vector-ALU instructions instead of stalling the first MFMA (conv2) or the
+    // epilogue itself (conv1): the round-5 workgroup timeline showed ~1 us of exposed L2 latency at each of the six places.
+    f32x16 bias_c[MIW];
+    // (the loads only: the scaling — the first use of the loaded registers, hence the wait — happens in scale_bias_c right in front of the convolution)
+    auto load_bias_c = [&](const float* bias) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < MIW; ++mi)
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 32 * (mi0 + mi) + 8 * gi + 4 * half);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bias_c[mi][4 * gi + e] = bv[e];
+            }
+    };
+    auto scale_bias_c = [&](float factor) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < MIW; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bias_c[mi][r] *= factor;
+    };
+    load_bias_c(a.b1[0]);
     xres_to_image(a.xs[0]);
     if (!TTSC_DBG(a, 2)) __syncthreads();
+    TTSC_STAMP(a, wg_lin, 1);
     for (int p = 0; p < a.npairs; ++p) {
         f32x16 acc[MIW][CT];
+        scale_bias_c(a.bs1[p] / a.us1[p]);
         if constexpr (IL) {                    // (ends with a barrier: the image may be overwritten in place)
-            if (a.d1[p] == 1) conv(a.w1[p], IntTag<1>(), 1, acc, nullptr);
-            else if (a.d1[p] == 3) conv(a.w1[p], IntTag<3>(), 3, acc, nullptr);
-            else conv(a.w1[p], IntTag<5>(), 5, acc, nullptr);
+            if (a.d1[p] == 1) conv(a.w1[p], IntTag<1>(), 1, acc, bias_c);
+            else if (a.d1[p] == 3) conv(a.w1[p], IntTag<3>(), 3, acc, bias_c);
+            else conv(a.w1[p], IntTag<5>(), 5, acc, bias_c);
         } else {
-            conv(a.w1[p], IntTag<0>(), a.d1[p], acc, nullptr);
+            conv(a.w1[p], IntTag<0>(), a.d1[p], acc, bias_c);
         }
+        TTSC_STAMP(a, wg_lin, 2 + 4 * p);
         stage_first(a.w2[p]);                  // conv2's first weight group(s) travel while the epilogue runs
+        load_bias_c(a.b2[p]);                  // ... and so does its bias
         {
             const float us = a.us1[p];
-            const float* bias = a.b1[p];
 #pragma unroll
             for (int mi = 0; mi < MIW; ++mi)
 #pragma unroll
                 for (int gi = 0; gi < 4; ++gi) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 32 * (mi0 + mi) + 8 * gi + 4 * half) * a.bs1[p];
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {
                         float v[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float t = __builtin_fmaf(acc[mi][ct][4 * gi + e], us, bv[e]);
+                            const float t = acc[mi][ct][4 * gi + e] * us;
                             v[e] = fmaxf(t, t * 0.1f);
                         }
                         store_split(mi, ct, gi, v[0], v[1], v[2], v[3]);
@@ -368,22 +393,14 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
                 }
         }
         if (!TTSC_DBG(a, 2)) __syncthreads();
-        {
-            // conv2's bias rides in the accumulators (divided by the epilogue factor, a power of two: exact), the residual add is the epilogue's fma
-            f32x16 bias_c[MIW];
-            const float inv_us = 1.f / a.us2[p];
-            const float* bias = a.b2[p];
-#pragma unroll
-            for (int mi = 0; mi < MIW; ++mi)
-#pragma unroll
-                for (int gi = 0; gi < 4; ++gi) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 32 * (mi0 + mi) + 8 * gi + 4 * half);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) bias_c[mi][4 * gi + e] = bv[e] * inv_us;
-                }
-            conv(a.w2[p], IntTag<1>(), 1, acc, bias_c);
+        TTSC_STAMP(a, wg_lin, 3 + 4 * p);
+        scale_bias_c(1.f / a.us2[p]);
+        conv(a.w2[p], IntTag<1>(), 1, acc, bias_c);   // (the residual add is the epilogue's fma)
+        TTSC_STAMP(a, wg_lin, 4 + 4 * p);
+        if (p + 1 < a.npairs) {
+            stage_first(a.w1[p + 1]);
+            load_bias_c(a.b1[p + 1]);
         }
-        if (p + 1 < a.npairs) stage_first(a.w1[p + 1]);
         {
             const float us = a.us2[p];
 #pragma unroll
@@ -397,6 +414,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
             xres_to_image(a.xs[p + 1]);
             if (!TTSC_DBG(a, 2)) __syncthreads();
         }
+        TTSC_STAMP(a, wg_lin, 5 + 4 * p);
     }
 
     // store the nto central columns (all loads of a 32x32 tile before its stores)
@@ -508,6 +526,12 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
                 if (ok) *reinterpret_cast<fvecT*>(yb + (size_t)(32 * (mi0_f + mi) + (r & 3) + 8 * (r >> 2)) * a.L + voff) = o;
             }
         }
+#ifdef TTSC_ABLATE
+        if (a.prof) {
+            __builtin_amdgcn_s_waitcnt(0);
+            TTSC_STAMP(a, wg_lin, 14);
+        }
+#endif
         return;
     }
 #pragma unroll
@@ -689,6 +713,7 @@ static int chain_forward(const ttsc_conv1d* const* convs1, const ttsc_conv1d* co
     a.accumulate = accumulate;
 #ifdef TTSC_ABLATE
     if (const char* ev = getenv("TTSC_CHAIN_DBG")) a.dbg = atoi(ev);
+    if (const char* ev = getenv("TTSC_PROF_PTR")) a.prof = reinterpret_cast<unsigned long long*>(strtoull(ev, nullptr, 0));
 #endif
     const int C = convs1[0]->cfg.in_channels, k = convs1[0]->cfg.kernel_size;
     for (int p = 0; p < npairs; ++p) {
