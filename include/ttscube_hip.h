@@ -143,21 +143,6 @@ int ttsc_rbchain_post_supported(const ttsc_conv1d* const* convs1, const ttsc_con
 int ttsc_rbchain_post_forward(const ttsc_conv1d* const* convs1, const ttsc_conv1d* const* convs2, int32_t npairs, const float* x_dev, int32_t B,
                               int64_t L, const float* ysum_dev, const ttsc_conv1d* post, const ttsc_conv1d_epilogue* post_ep, float* wav_dev,
                               const int32_t* len_dev, void* stream);
-/* One launch per generator STAGE of the 32-channel part: the three ResBlock1 chains (kernel sizes 3, 7, 11; three (conv1, conv2)
- * pairs each) of a time tile back to back, `xs = sum_j resblock_j(x)` kept in registers — hifigan.models.Generator.forward
- * [EXTERNAL; call sites cube/networks/cubegan.py:72,83,131, cube/io_utils/runtime.py:78]: `xs += self.resblocks[i*nk+j](x)`.
- * convs1 / convs2: [nblocks = 3][npairs = 3] layer handles, block-major.  Without `post`: y_dev [B,32,L] <- xs (the division by
- * nk rides in the next layer's in_scale, as in the layer-by-layer path).  With `post` (the generator's conv_post: 32 -> 1, k = 7,
- * padding 3, host-set weights): wav_dev [B,1,L] <- act((conv_post(lrelu(xs * in_scale, in_slope)) + bias) * out_scale) with the
- * scales / activation of post_ep, and the layer's range-guard word (ttsc_conv1d_set_nonfinite_flag) is honoured — bit-identical
- * to three ttsc_rbchain_forward launches + ttsc_conv1d_forward.  tile_shape: 0 = eight waves x 96 columns, 1 = four waves x 192
- * columns (768-column tiles either way).  Requires L * 128 < 2^31.  `supported` returns 1 when the fused stage applies. */
-int ttsc_rbstage_supported(const ttsc_conv1d* const* convs1, const ttsc_conv1d* const* convs2, int32_t nblocks, int32_t npairs,
-                           const ttsc_conv1d* post);
-int ttsc_rbstage_forward(const ttsc_conv1d* const* convs1, const ttsc_conv1d* const* convs2, int32_t nblocks, int32_t npairs,
-                         const float* x_dev, int32_t B, int64_t L, float* y_dev, const ttsc_conv1d* post,
-                         const ttsc_conv1d_epilogue* post_ep, float* wav_dev, const int32_t* len_dev, int32_t tile_shape,
-                         void* stream);
 void ttsc_conv1d_destroy(ttsc_conv1d* c);
 
 /* Weight gradient of the generator's convolutions (training: `Cubegan.training_step`, cube/networks/cubegan.py:85-189,

@@ -139,40 +139,6 @@ def test_generator_config2_size_properties():
         assert float(d.pow(2).mean().sqrt()) < RMS_TOL
 
 
-@pytest.mark.parametrize('shape', ['0', '1'])
-def test_stage_launch_is_bit_identical_to_the_chain_launches(shape, monkeypatch):
-    """resstage.hip (the 32-channel stage + conv_post + tanh as ONE launch) against three rbchain launches + conv_post:
-    same k-order, same term order, same conv_post fmaf chain -> identical bits; full batch, ragged batch, tile edges."""
-    h = dict(R.CONFIG_V1)
-    sd = R.synthetic_state_dict(h, seed=31)
-    warm = R.synthetic_mel(1, 2, seed=1).cuda()
-    monkeypatch.setenv('TTSC_HIFIGAN_STAGE', '0')
-    g0 = _gen(h, sd)
-    with torch.no_grad():
-        g0(warm)    # (the C handle reads the switches when the first forward creates it)
-    monkeypatch.setenv('TTSC_HIFIGAN_STAGE', '1')   # (off by default: see hifigan.cpp)
-    monkeypatch.setenv('TTSC_HIFIGAN_STAGE_SHAPE', shape)
-    g1 = _gen(h, sd)
-    with torch.no_grad():
-        g1(warm)
-    for B, T in ((1, 3), (2, 11), (3, 57)):   # 57 frames = 13 744 samples: 22 stage tiles with a ragged last one
-        mel = R.synthetic_mel(B, T, seed=40 + T).cuda()
-        with torch.no_grad():
-            y0, y1 = g0(mel), g1(mel)
-        assert y0.shape == y1.shape == (B, 1, 240 * T + 64)
-        assert torch.equal(y0, y1), (B, T, float((y0 - y1).abs().max()))
-    # ragged batch through the module's own lengths argument, when it has one
-    mel = R.synthetic_mel(3, 40, seed=77).cuda()
-    frames = [40, 17, 29]
-    with torch.no_grad():
-        r0, r1 = g0(mel, frames=frames), g1(mel, frames=frames)
-    for b in range(3):
-        n = 240 * int(frames[b]) + 64
-        assert torch.equal(r0[b, :, :n], r1[b, :, :n]), b
-    ref = R.generator_forward(R.fold_state_dict(sd), h, mel[:1].cpu())
-    assert float((r1[0].cpu() - ref[0]).pow(2).mean().sqrt()) < RMS_TOL
-
-
 def test_conv_post_fused_into_the_last_chain_is_bit_identical(monkeypatch):
     """round 4: conv_post + tanh as the epilogue of the last ResBlock chain of the last stage (resblock.hip POST) against the separate
     conv_cout1_kernel launch: same block sum, same ci-major fmaf chain -> identical bits; batches, tile edges, ragged lengths, the guard word."""

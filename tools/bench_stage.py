@@ -3,7 +3,6 @@
   chains   : three ttsc_rbchain_forward launches (K = 3, 7, 11; default tile shapes) + conv_post        (round-3 path)
   chain sN : every chain with tile shape N (0: 4 waves x 512 columns, 1: 8 x 1024, 2: 8 x 1024 with 6-step weight groups,
              3 / 4: 8 waves x 768 columns with half- / whole-convolution weight groups), per K
-  stage sN : ONE ttsc_rbstage_forward launch (resstage.hip) incl. conv_post, tile shape N (0: 8 waves x 96, 1: 4 waves x 192)
 
     python tools/bench_stage.py [--B 64] [--L 192064] [--iters 5] [--shapes 0,1,2,3,4]
 """
@@ -92,29 +91,6 @@ def main():
                 row.append('K=%2d n/a' % k)
         print('chain shape %d: ' % sh + '   '.join(row), flush=True)
 
-    c1all = arr([c for _, c1s, _ in blocks for c in c1s])
-    c2all = arr([c for _, _, c2s in blocks for c in c2s])
-    ep = _lib.Conv1dEpilogue(1.0 / 3, 0.01, 1.0, 1, 0, None, 1.0)
-    if not L_.ttsc_rbstage_supported(c1all, c2all, 3, 3, post._h):
-        print('stage kernel: not supported for these layers')
-        return
-    for sh in (0, 1):
-        def stage(out=wav2, sh=sh):
-            _lib.check(L_.ttsc_rbstage_forward(c1all, c2all, 3, 3, _lib.dev_ptr(x), B, L, None, post._h, C.byref(ep), _lib.dev_ptr(out), None, sh,
-                                               _lib.current_stream()), 'rbstage')
-        ms = timed(stage, a.iters)
-        chains_default(wav)
-        stage()
-        torch.cuda.synchronize()
-        same = bool(torch.equal(wav, wav2))
-        print('stage launch shape %d (incl. conv_post)  %.3f ms  %.0f TF/s (%.3f)   bit-identical to the chain path: %s  (max diff %.3e)' % (
-            sh, ms, flops / ms / 1e9, flops / ms / 1e9 / ceiling, same, float((wav - wav2).abs().max())), flush=True)
-
-        def stage_nopost(sh=sh):
-            _lib.check(L_.ttsc_rbstage_forward(c1all, c2all, 3, 3, _lib.dev_ptr(x), B, L, _lib.dev_ptr(y), None, None, None, None, sh,
-                                               _lib.current_stream()), 'rbstage')
-        ms = timed(stage_nopost, a.iters)
-        print('stage launch shape %d (block sum only)   %.3f ms' % (sh, ms), flush=True)
 
 
 if __name__ == '__main__':

@@ -50,7 +50,6 @@ rm -rf $O/voc
 (TTSC_CHAIN_IL=0 timeout 300 python tools/bench_stage.py --iters 5 --shapes 0,1,2,10,11,12 2>&1 | grep -v amdgpu.ids) > $O/bench_stage_random.log
 (TTSC_CHAIN_IL=0 timeout 300 python tools/bench_stage.py --iters 5 --shapes 0,1,10,12 --data zeros 2>&1 | grep -v amdgpu.ids) > $O/bench_stage_zeros.log
 (BENCH_CHAIN_SHAPES=10,11 timeout 300 python tools/bench_layers.py --stages 1,2,3 2>&1 | grep -v amdgpu.ids) > $O/layer_bench.log
-(TTSC_HIFIGAN_STAGE=1 timeout 200 $B --steps 5 --warmup 2) > $O/bench_stage_launch_on.log 2>&1
 (TTSC_CHAIN_IL=0 timeout 200 $B --steps 5 --warmup 2) > $O/bench_plain_columns.log 2>&1
 timeout 200 python tools/probes/textcoder_time.py > $O/textcoder_time.log 2>&1
 # the Cubegan step: host enqueue time vs GPU drain, with and without the text side on its own stream; the LSTM recurrence by utterances per member group

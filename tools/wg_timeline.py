@@ -46,7 +46,7 @@ def main():
     torch.manual_seed(0)
     x = torch.randn(B, Cc, L, device='cuda')
     y = torch.zeros_like(x)
-    NSLOT = 16
+    NSLOT = 24
     prof = torch.zeros(1 << 16, NSLOT, dtype=torch.int64, device='cuda')
     if chain:
         c1s, c2s = [], []
@@ -110,6 +110,10 @@ def main():
     for i, nm in enumerate(names):
         d = dur[:, i]
         print('  %-26s mean %7.2f us  p10 %7.2f  p90 %7.2f   %5.1f%% of the lifetime' % (nm, d.mean(), np.percentile(d, 10), np.percentile(d, 90), 100 * d.mean() / tot.mean()))
+    if chain and P[:, 16].max() > 0:
+        d = (P[:, [16, 17, 18, 1]] - P[:, [0, 16, 17, 18]]) * 0.01
+        for nm, col in zip(('start -> x loads issued (margins zeroed, first weights sent)', 'x loads issued -> landed', 'landed -> image written (wave 0)', 'image written -> barrier passed'), d.T):
+            print('    prologue detail: %-62s mean %6.2f us  p10 %6.2f  p90 %6.2f' % (nm, col.mean(), np.percentile(col, 10), np.percentile(col, 90)))
     mf = sum(dur[:, i] for i in mfma_phases)
     print('  MFMA phases together: %.1f us = %.1f%% of the lifetime' % (mf.mean(), 100 * mf.mean() / tot.mean()))
     # chip-wide phase census over time

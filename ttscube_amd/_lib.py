@@ -77,10 +77,6 @@ SIGNATURES = {
     'ttsc_rbchain_post_supported': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
     'ttsc_rbchain_post_forward': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p,
                                             C.c_void_p, C.POINTER(Conv1dEpilogue), C.c_void_p, C.c_void_p, C.c_void_p]),
-    'ttsc_rbstage_supported': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),
-    'ttsc_rbstage_forward': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
-                                       C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(Conv1dEpilogue), C.c_void_p, C.c_void_p, C.c_int32,
-                                       C.c_void_p]),
     'ttsc_respair_supported': (C.c_int, [C.c_void_p, C.c_void_p]),
     'ttsc_respair_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int32,
                                        C.c_void_p, C.c_void_p]),

@@ -762,8 +762,8 @@ static int launch_f16_wide(const ConvArgs& a0, int B, hipStream_t s) {
     a.skew = ((size_t)grid.x * grid.y * grid.z >= 1024) ? skew_env : 0;
     // epilogue operands as the accumulators' initial value (see the kernel) whenever the epilogue is the plain affine one; TTSC_CONV_ACC_INIT=0
     // keeps the operand loads in the epilogue (measurement switch)
-    static const int acc_init_env = getenv("TTSC_CONV_ACC_INIT") ? atoi(getenv("TTSC_CONV_ACC_INIT")) : 1;
-    a.acc_init = (acc_init_env && a.out_act == TTSC_ACT_NONE && !a.gate && a.out_scale == 1.f && a.Cout == C && (size_t)B * C * a.Lout < (1ull << 32)) ? 1 : 0;
+    // (a.acc_init — the operands as the accumulators' initial value, see the kernel — is decided by the caller for the LAYER, not per kernel: the
+    // general kernel evaluates the same layer with the same arithmetic when the machine-fill rule sends it there)
     // deep-prefetched epilogue operands (bit-identical to the plain epilogue; TTSC_CONV_EPI_PREFETCH=0 restores the four-rows-at-a-time one)
     static const int epi_env = getenv("TTSC_CONV_EPI_PREFETCH") ? atoi(getenv("TTSC_CONV_EPI_PREFETCH")) : 1;
     a.epi_prefetch = (epi_env && !a.gate && a.out_act == TTSC_ACT_NONE && a.Cout == C && (size_t)B * C * a.Lout < (1ull << 32)) ? 1 : 0;   // (32-bit element offsets)
@@ -1631,6 +1631,11 @@ extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, 
                                     (g.kernel_size == 3 || g.kernel_size == 7 || g.kernel_size == 11) &&
                                     (g.dilation == 1 || g.dilation == 3 || g.dilation == 5) &&
                                     g.padding == g.dilation * (g.kernel_size - 1) / 2;
+            // these layers start their sums at (residual + running sum + bias) / w_unscale in BOTH kernels that may run them (same bits whichever
+            // the fill rule picks); TTSC_CONV_ACC_INIT=0 puts the operands back into the epilogue (measurement switch)
+            static const int acc_init_env = getenv("TTSC_CONV_ACC_INIT") ? atoi(getenv("TTSC_CONV_ACC_INIT")) : 1;
+            a.acc_init = (acc_init_env && wide_env && wide_shape && a.out_act == TTSC_ACT_NONE && a.out_scale == 1.f && c->CoutP == g.out_channels &&
+                          (size_t)B * g.out_channels * Lout < (1ull << 32)) ? 1 : 0;
             // the first upsamplers of the V1 generator: tall tiles (256 virtual rows x 128 input positions)
             static const bool tall_on = !(getenv("TTSC_CONV_TALL") && atoi(getenv("TTSC_CONV_TALL")) == 0);
             const bool tall0 = g.in_channels == 512 && ph.ntaps == 4 && c->CoutP % 256 == 0;    // ups.0: 256-row tiles

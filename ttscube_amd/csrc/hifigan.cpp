@@ -46,10 +46,7 @@ struct ttsc_hifigan {
     bool use_chain = true;      // env TTSC_HIFIGAN_CHAIN=0 disables the whole-ResBlock fused chain kernel (resblock.hip)
     bool use_chain128 = true;   // env TTSC_HIFIGAN_CHAIN128=0: keep the 128-channel K=3 block on the layer-by-layer wide kernel (A/B)
     int chain_shape = -1;       // env TTSC_HIFIGAN_CHAIN_SHAPE: tile shape of the chain kernel (-1 = by halo)
-    bool use_stage = false;     // env TTSC_HIFIGAN_STAGE=1: the 32-channel stage as ONE stage launch (resstage.hip) instead of three chain launches + conv_post
-                                // (bit-identical; measured 10.60 ms against 10.35 ms for the chain launches with interleaved columns at config[1]: off by default)
     bool fuse_post = true;      // env TTSC_HIFIGAN_FUSE_POST=0: conv_post + tanh as their own launch instead of the epilogue of the last chain launch
-    int stage_shape = 0;        // env TTSC_HIFIGAN_STAGE_SHAPE: 0 = 8 waves x 96 columns, 1 = 4 waves x 192 columns (one wave per SIMD)
     int precision = TTSC_PREC_FP32;
     // Split precision keeps activations as fp16 (hi, lo) pairs, so every layer's input gets a power-of-two pre-scale that
     // centres it in fp16's range (ttsc_conv1d_set_activation_scale).  The scales come from ONE calibration forward, run layer
@@ -129,8 +126,6 @@ extern "C" int ttsc_hifigan_create(const ttsc_hifigan_cfg* cfg, ttsc_hifigan** o
     if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN")) g->use_chain = atoi(ev) != 0;
     if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN128")) g->use_chain128 = atoi(ev) != 0;
     if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN_SHAPE")) g->chain_shape = atoi(ev);
-    if (const char* ev = getenv("TTSC_HIFIGAN_STAGE")) g->use_stage = atoi(ev) != 0;
-    if (const char* ev = getenv("TTSC_HIFIGAN_STAGE_SHAPE")) g->stage_shape = atoi(ev);
     if (const char* ev = getenv("TTSC_HIFIGAN_FUSE_POST")) g->fuse_post = atoi(ev) != 0;
     if (const char* ev = getenv("TTSC_HIFIGAN_CALIBRATE")) {
         const std::string v(ev);
@@ -620,30 +615,6 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
         if (rc) return rc;
         L = ttsc_conv1d_out_len(up, L);
         const int32_t* ln = lens[i + 1];
-        if (chain_stage && g->use_stage && c.num_kernels == 3 && (int64_t)L * ch * 4 < (1ll << 31)) {
-            // the whole stage — three ResBlock1 chains, their sum, and for the last stage conv_post + tanh — as ONE launch (resstage.hip)
-            const ttsc_conv1d *c1[9], *c2[9];
-            bool ok = true;
-            for (int j = 0; ok && j < 3; ++j) {
-                ok = c.num_dilations[j] == 3;
-                for (int m = 0; ok && m < 3; ++m) {
-                    const std::string rb = "resblocks." + std::to_string(i * c.num_kernels + j);
-                    c1[j * 3 + m] = layer(rb + ".convs1." + std::to_string(m));
-                    c2[j * 3 + m] = layer(rb + ".convs2." + std::to_string(m));
-                }
-            }
-            const bool last = i == c.num_upsamples - 1;
-            ttsc_conv1d* post = last ? layer("conv_post") : nullptr;
-            if (ok && ttsc_rbstage_supported(c1, c2, 3, 3, post)) {
-                ttsc_conv1d_epilogue epost{inv_nk, 0.01f, 1.f, TTSC_ACT_TANH, 0};
-                rc = ttsc_rbstage_forward(c1, c2, 3, 3, X, B, L, last ? nullptr : S, post, last ? &epost : nullptr, last ? wav : nullptr, ln,
-                                          g->stage_shape, stream);
-                if (rc) return rc;
-                if (last) return TTSC_OK;
-                sum_scale = inv_nk;
-                continue;
-            }
-        }
         for (int j = 0; j < c.num_kernels; ++j) {
             const std::string rb = "resblocks." + std::to_string(i * c.num_kernels + j);
             const int nd = c.num_dilations[j];

@@ -219,6 +219,13 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
         }
     }
 
+#ifdef TTSC_ABLATE
+    if (a.prof) {
+        TTSC_STAMP(a, wg_lin, 16);           // x loads issued
+        __builtin_amdgcn_s_waitcnt(0);
+        TTSC_STAMP(a, wg_lin, 17);           // ... and landed (this wave's)
+    }
+#endif
     // four channels (one lane's share of 8-channel group 4*mi + gi) of one column -> (hi, lo) halves in the image.
     // Written pairwise so that the conversions are packed: cvt_pk (hi), two cvt back, two subtractions, cvt_pk (lo).
     // The image columns outside the sequence hold zeros (the convolutions pad with zeros): they are zeroed ONCE below and never written
@@ -269,12 +276,30 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
                     store_split(mi, ct, gi, v[0], v[1], v[2], v[3]);
                 }
     };
+    // Both convolutions' biases ride in the accumulators: the first MFMA of a tile takes `bias * factor` as its C operand (the factor undoes the
+    // epilogue's power-of-two scale: exact).  The 32 * MI values come through the SCALAR cache (wave-uniform addresses; a lane picks its
+    // half's four of every eight with v_cndmask): a vector load at this point queues behind the weight group that stage_first has just sent by
+    // LDS-DMA — loads return in order — and the round-5 workgroup timeline showed ~1 us of that at each of the six places (the first MFMA of
+    // conv2, the epilogue of conv1); scalar loads have their own path and counter, and no vector register is held across an epilogue.
+    const int mi0u = __builtin_amdgcn_readfirstlane(mi0);
+    // the 16 initial values of row tile mi's accumulators, built where the first MFMA of that row tile is issued (16 registers live for CT MFMAs)
+    auto bias_tile = [&](const float* bias, float factor, int mi) __attribute__((always_inline)) -> f32x16 {
+        f32x16 c;
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lo = bias[32 * (mi0u + mi) + 8 * gi + e], hi = bias[32 * (mi0u + mi) + 8 * gi + 4 + e];
+                c[4 * gi + e] = (half ? hi : lo) * factor;
+            }
+        return c;
+    };
     // acc = sum over taps j and 16-channel chunks c of  W[j][c] x image[c][column + (j - (K-1)/2) * d]   (three split products).
     // Precondition: weight group 0 of `w` sits in slot 0, published by a barrier.  Ends with a barrier (every wave has
     // finished reading the image and the weight slots).
     // c0: initial value of every accumulator tile of row tile mi — the first MFMA of a tile reads it as its C operand, so a per-channel
     // constant (the bias, pre-divided by the epilogue factor) joins the sum without a single extra instruction
-    auto conv = [&](const half8* w, auto dtag, int d, f32x16 (&acc)[MIW][CT], const f32x16* c0) __attribute__((always_inline)) {
+    auto conv = [&](const half8* w, auto dtag, int d, f32x16 (&acc)[MIW][CT], const float* bias, float bfac) __attribute__((always_inline)) {
         constexpr int D = decltype(dtag)::value;   // IL: the dilation (compile time); plain layout: unused (d is a run-time value)
         const half8* base = IL ? P + (size_t)(half * 2) * PW + MARGQ + qw + l31 : P + (size_t)(half * 2) * PW + MARG + colw + l31 - d * ((K - 1) / 2);
         // B fragment of step s (tap s / NCH, chunk s % NCH), plane pl (0 hi, 1 lo), column tile ct
@@ -317,11 +342,13 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
             __builtin_amdgcn_sched_barrier(0);
             // issue order of a step, pinned: (MFMA, one LDS read for the next step) pairs, then the rest of the MFMAs.
             // Term order lo_w*hi_x, hi_w*lo_x, hi_w*hi_x; consecutive MFMAs go to different accumulators.
+            f32x16 c0;
 #pragma unroll
             for (int q = 0; q < NM; ++q) {
                 const int term = q / (MIW * CT), mi = (q / CT) % MIW, ct = q % CT;
+                if (s == 0 && term == 0 && ct == 0) c0 = bias_tile(bias, bfac, mi);
                 acc[mi][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[s & 1][mi][term == 0 ? 1 : 0], Bf[s & 1][term == 1 ? 1 : 0][ct],
-                                                                   (s == 0 && term == 0) ? c0[mi] : acc[mi][ct], 0, 0, 0);
+                                                                   (s == 0 && term == 0) ? c0 : acc[mi][ct], 0, 0, 0);
                 if (q < 2 * CT && s + 1 < NS) Bf[(s + 1) & 1][q / CT][q % CT] = *bfrag(s + 1, q / CT, q % CT);
                 // weights of the next step: same group, or (three slots) the next group, published one barrier ago
                 if (q >= 2 * CT && q < 2 * CT + 2 * MIW && s + 1 < NS && ((s + 1) % GRP != 0 || NSLOT >= 3)) {
@@ -335,45 +362,22 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
         }
     };
 
-    // Both convolutions' biases ride in the accumulators: the first MFMA of a tile takes `bias * factor` as its C operand (the factor undoes the
-    // epilogue's power-of-two scale: exact).  Their 16 loads per row tile are issued one epilogue EARLY — before the image conversion that
-    // precedes the convolution — so that they land behind ~300 vector-ALU instructions instead of stalling the first MFMA (conv2) or the
-    // epilogue itself (conv1): the round-5 workgroup timeline showed ~1 us of exposed L2 latency at each of the six places.
-    f32x16 bias_c[MIW];
-    // (the loads only: the scaling — the first use of the loaded registers, hence the wait — happens in scale_bias_c right in front of the convolution)
-    auto load_bias_c = [&](const float* bias) __attribute__((always_inline)) {
-#pragma unroll
-        for (int mi = 0; mi < MIW; ++mi)
-#pragma unroll
-            for (int gi = 0; gi < 4; ++gi) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 32 * (mi0 + mi) + 8 * gi + 4 * half);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bias_c[mi][4 * gi + e] = bv[e];
-            }
-    };
-    auto scale_bias_c = [&](float factor) __attribute__((always_inline)) {
-#pragma unroll
-        for (int mi = 0; mi < MIW; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) bias_c[mi][r] *= factor;
-    };
-    load_bias_c(a.b1[0]);
     xres_to_image(a.xs[0]);
+    TTSC_STAMP(a, wg_lin, 18);               // image written by this wave
     if (!TTSC_DBG(a, 2)) __syncthreads();
     TTSC_STAMP(a, wg_lin, 1);
     for (int p = 0; p < a.npairs; ++p) {
         f32x16 acc[MIW][CT];
-        scale_bias_c(a.bs1[p] / a.us1[p]);
+        const float bf1 = a.bs1[p] / a.us1[p];
         if constexpr (IL) {                    // (ends with a barrier: the image may be overwritten in place)
-            if (a.d1[p] == 1) conv(a.w1[p], IntTag<1>(), 1, acc, bias_c);
-            else if (a.d1[p] == 3) conv(a.w1[p], IntTag<3>(), 3, acc, bias_c);
-            else conv(a.w1[p], IntTag<5>(), 5, acc, bias_c);
+            if (a.d1[p] == 1) conv(a.w1[p], IntTag<1>(), 1, acc, a.b1[p], bf1);
+            else if (a.d1[p] == 3) conv(a.w1[p], IntTag<3>(), 3, acc, a.b1[p], bf1);
+            else conv(a.w1[p], IntTag<5>(), 5, acc, a.b1[p], bf1);
         } else {
-            conv(a.w1[p], IntTag<0>(), a.d1[p], acc, bias_c);
+            conv(a.w1[p], IntTag<0>(), a.d1[p], acc, a.b1[p], bf1);
         }
         TTSC_STAMP(a, wg_lin, 2 + 4 * p);
         stage_first(a.w2[p]);                  // conv2's first weight group(s) travel while the epilogue runs
-        load_bias_c(a.b2[p]);                  // ... and so does its bias
         {
             const float us = a.us1[p];
 #pragma unroll
@@ -394,13 +398,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
         }
         if (!TTSC_DBG(a, 2)) __syncthreads();
         TTSC_STAMP(a, wg_lin, 3 + 4 * p);
-        scale_bias_c(1.f / a.us2[p]);
-        conv(a.w2[p], IntTag<1>(), 1, acc, bias_c);   // (the residual add is the epilogue's fma)
+        conv(a.w2[p], IntTag<1>(), 1, acc, a.b2[p], 1.f / a.us2[p]);   // (the residual add is the epilogue's fma)
         TTSC_STAMP(a, wg_lin, 4 + 4 * p);
-        if (p + 1 < a.npairs) {
-            stage_first(a.w1[p + 1]);
-            load_bias_c(a.b1[p + 1]);
-        }
+        if (p + 1 < a.npairs) stage_first(a.w1[p + 1]);
         {
             const float us = a.us2[p];
 #pragma unroll
