@@ -110,6 +110,13 @@ int ttsc_conv1d_forward(const ttsc_conv1d* c, const float* x_dev, int32_t B, int
 int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x_dev, int32_t B, int64_t Lin, float* y_dev,
                                const float* resid_dev, const ttsc_conv1d_epilogue* ep, const int32_t* in_len_dev,
                                const int32_t* out_len_dev, void* stream);
+/* The same with an explicit ROW PITCH of the output tensors: y_dev / resid_dev are [B,Cout,Lout_pitch] (Lout_pitch = 0: the natural
+ * output length of Lin).  With per-utterance lengths in in_len_dev / out_len_dev, Lin and Lout_pitch are pitches only — that is how
+ * ttsc_hifigan_forward keeps the rows of its intermediate tensors on 128-byte boundaries (4001 / 12004 samples per row otherwise: every
+ * 128-byte store of the 256- and 128-channel stages straddled two lines).  Lout_pitch must cover every utterance's real output length. */
+int ttsc_conv1d_forward_pitched(const ttsc_conv1d* c, const float* x_dev, int32_t B, int64_t Lin, float* y_dev,
+                                const float* resid_dev, const ttsc_conv1d_epilogue* ep, const int32_t* in_len_dev,
+                                const int32_t* out_len_dev, int64_t Lout_pitch, void* stream);
 /* Fused residual pair  y = x + conv2(lrelu(conv1(lrelu(x), 0.1), 0.1)) [+ y if accumulate]  of a HiFi-GAN ResBlock1
  * (both layers 32 -> 32 channels, odd kernel 3/7/11, conv2 undilated, both in TTSC_PREC_F16X3): the inner activation
  * stays in LDS, which removes two of the five HBM passes of the unfused pair.  `supported` returns 1 when the fused

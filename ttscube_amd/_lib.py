@@ -71,6 +71,8 @@ SIGNATURES = {
                                       C.POINTER(Conv1dEpilogue), C.c_void_p]),
     'ttsc_conv1d_forward_ragged': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
                                              C.POINTER(Conv1dEpilogue), C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ttsc_conv1d_forward_pitched': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
+                                              C.POINTER(Conv1dEpilogue), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'ttsc_rbchain_supported': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32]),
     'ttsc_rbchain_forward': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int32, C.c_int64,
                                        C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),

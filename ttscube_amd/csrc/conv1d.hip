@@ -1502,7 +1502,15 @@ extern "C" int ttsc_absmax(const float* x_dev, int64_t n, float* out_dev, void* 
 extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, int32_t B, int64_t Lin, float* y,
                                           const float* resid, const ttsc_conv1d_epilogue* ep, const int32_t* in_len_dev,
                                           const int32_t* out_len_dev, void* stream) {
+    return ttsc_conv1d_forward_pitched(c, x, B, Lin, y, resid, ep, in_len_dev, out_len_dev, 0, stream);
+}
+
+extern "C" int ttsc_conv1d_forward_pitched(const ttsc_conv1d* c, const float* x, int32_t B, int64_t Lin, float* y,
+                                           const float* resid, const ttsc_conv1d_epilogue* ep, const int32_t* in_len_dev,
+                                           const int32_t* out_len_dev, int64_t Lout_pitch, void* stream) {
     TTSC_REQUIRE(c && x && y, "ttsc_conv1d_forward: null argument");
+    TTSC_REQUIRE(Lout_pitch == 0 || (Lout_pitch > 0 && in_len_dev && out_len_dev),
+                 "ttsc_conv1d_forward_pitched: an output pitch needs per-utterance lengths (in_len_dev, out_len_dev)");
     if (!c->has_weight) {
         set_error("ttsc_conv1d_forward: weights not set");
         return TTSC_ESTATE;
@@ -1510,7 +1518,8 @@ extern "C" int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x, 
     TTSC_REQUIRE(B > 0 && Lin > 0, "ttsc_conv1d_forward: bad B/Lin (%d, %lld)", B, (long long)Lin);
     TTSC_REQUIRE(!ep || (ep->in_slope >= 0.f && ep->in_slope <= 1.f), "ttsc_conv1d_forward: in_slope must be in [0,1]");
     const auto& g = c->cfg;
-    const int64_t Lout = ttsc_conv1d_out_len(c, Lin);
+    // (with a pitch, positions between an utterance's real length and the pitch are computed from zero-padded input and land in the row's padding)
+    const int64_t Lout = Lout_pitch > 0 ? Lout_pitch : ttsc_conv1d_out_len(c, Lin);
     TTSC_REQUIRE(Lout > 0, "ttsc_conv1d_forward: output length %lld <= 0", (long long)Lout);
     TTSC_REQUIRE(Lin < (1ll << 30) && Lout < (1ll << 30), "ttsc_conv1d_forward: length too large");
     hipStream_t s = (hipStream_t)stream;

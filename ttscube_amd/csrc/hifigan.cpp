@@ -46,6 +46,7 @@ struct ttsc_hifigan {
     bool use_chain = true;      // env TTSC_HIFIGAN_CHAIN=0 disables the whole-ResBlock fused chain kernel (resblock.hip)
     bool use_chain128 = true;   // env TTSC_HIFIGAN_CHAIN128=0: keep the 128-channel K=3 block on the layer-by-layer wide kernel (A/B)
     int chain_shape = -1;       // env TTSC_HIFIGAN_CHAIN_SHAPE: tile shape of the chain kernel (-1 = by halo)
+    bool pad_pitch = true;      // env TTSC_HIFIGAN_PITCH=0: intermediate tensors with their natural row pitch (rows not on 128-byte boundaries)
     bool fuse_post = true;      // env TTSC_HIFIGAN_FUSE_POST=0: conv_post + tanh as their own launch instead of the epilogue of the last chain launch
     int precision = TTSC_PREC_FP32;
     // Split precision keeps activations as fp16 (hi, lo) pairs, so every layer's input gets a power-of-two pre-scale that
@@ -126,6 +127,7 @@ extern "C" int ttsc_hifigan_create(const ttsc_hifigan_cfg* cfg, ttsc_hifigan** o
     if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN")) g->use_chain = atoi(ev) != 0;
     if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN128")) g->use_chain128 = atoi(ev) != 0;
     if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN_SHAPE")) g->chain_shape = atoi(ev);
+    if (const char* ev = getenv("TTSC_HIFIGAN_PITCH")) g->pad_pitch = atoi(ev) != 0;
     if (const char* ev = getenv("TTSC_HIFIGAN_FUSE_POST")) g->fuse_post = atoi(ev) != 0;
     if (const char* ev = getenv("TTSC_HIFIGAN_CALIBRATE")) {
         const std::string v(ev);
@@ -234,16 +236,29 @@ extern "C" int64_t ttsc_hifigan_out_len(const ttsc_hifigan* g, int64_t T) {
     return L;
 }
 
+// Row pitch of the intermediate tensors of stage i + 1 (the output of upsampler i) for rows of L samples: a multiple of 32 floats, so that
+// every row starts on a 128-byte line (4001 / 12004 / 48016 samples per row at BASELINE config[1]: the 128-byte stores of a tile straddled two
+// lines, the wide kernels wrote 1.23-1.26x their tensor — round-4 PMC).  The LAST stage keeps its natural pitch: its rows are the caller's waveform.
+static int64_t stage_pitch(const ttsc_hifigan* g, int i, int64_t L) {
+    return (g->pad_pitch && i + 1 < g->cfg.num_upsamples) ? round_up(L, 32) : L;
+}
+
 static size_t buf_elems(const ttsc_hifigan* g, int32_t B, int64_t T) {
     size_t mx = (size_t)B * g->cfg.upsample_initial_channel * T;
     int64_t L = T;
     for (int i = 0; i < g->cfg.num_upsamples; ++i) {
         const int u = g->cfg.upsample_rates[i], k = g->cfg.upsample_kernel_sizes[i];
         L = (L - 1) * u - 2 * ((k - u) / 2) + k;
-        size_t e = (size_t)B * g->stage_ch[i] * L;
+        size_t e = (size_t)B * g->stage_ch[i] * stage_pitch(g, i, L);
         if (e > mx) mx = e;
     }
     return (size_t)round_up((int64_t)mx, 64);
+}
+
+// length table of a DENSE batch written on the device (no host buffer whose lifetime a stream would have to outlive): row i = stage i's length
+__global__ void fill_lens_kernel(int32_t* tab, int B, int rows, const int32_t* __restrict__ unused, int l0, int l1, int l2, int l3, int l4, int l5, int l6, int l7, int l8) {
+    const int v[9] = {l0, l1, l2, l3, l4, l5, l6, l7, l8};
+    for (int i = threadIdx.x + blockIdx.x * blockDim.x; i < B * rows; i += blockDim.x * gridDim.x) tab[i] = v[i / B];
 }
 
 static size_t len_table_bytes(const ttsc_hifigan* g, int32_t B) {
@@ -554,11 +569,33 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
         TTSC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));  // `tab` is pageable host memory going out of scope
         for (int i = 0; i <= c.num_upsamples; ++i) lens[i] = dtab + (size_t)i * B;
     }
+    // real length (of the longest utterance) and row pitch of every stage; the calibration forward reduces whole buffers, so it keeps natural pitches
+    int64_t Lr[TTSC_HIFIGAN_MAX_UPS + 1], Pp[TTSC_HIFIGAN_MAX_UPS + 1];
+    Lr[0] = Pp[0] = T;
+    bool any_pad = false;
+    for (int i = 0; i < c.num_upsamples; ++i) {
+        const int u = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
+        Lr[i + 1] = (Lr[i] - 1) * u - 2 * ((k - u) / 2) + k;
+        Pp[i + 1] = calib ? Lr[i + 1] : stage_pitch(g, i, Lr[i + 1]);
+        any_pad = any_pad || Pp[i + 1] != Lr[i + 1];
+    }
+    if (!frames) last_lens_mult4 = Lr[c.num_upsamples] % 4 == 0;
+    if (any_pad && !frames) {   // a padded pitch needs per-utterance lengths: the dense batch's table, written by a kernel
+        static_assert(TTSC_HIFIGAN_MAX_UPS + 1 <= 9, "fill_lens_kernel takes nine rows");
+        int32_t* dtab = (int32_t*)(S + be);
+        int v[9] = {0};
+        for (int i = 0; i <= c.num_upsamples; ++i) v[i] = (int)Lr[i];
+        hipLaunchKernelGGL(fill_lens_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, dtab, (int)B, c.num_upsamples + 1, (const int32_t*)nullptr, v[0], v[1],
+                           v[2], v[3], v[4], v[5], v[6], v[7], v[8]);
+        TTSC_HIP_CHECK(hipGetLastError());
+        for (int i = 0; i <= c.num_upsamples; ++i) lens[i] = dtab + (size_t)i * B;
+    }
     auto layer = [&](const std::string& n) -> ttsc_conv1d* { return g->layers.at(n)->c; };
     int rc;
 
+    // Lin: row pitch of x (= its length when no lengths are given); Lout_pitch: row pitch of y (0 = natural)
     auto conv = [&](ttsc_conv1d* l, const float* x, int64_t Lin, float* y, const float* resid, const ttsc_conv1d_epilogue& e, const int32_t* il,
-                    const int32_t* ol) {
+                    const int32_t* ol, int64_t Lout_pitch = 0) {
         if (calib) {   // calibration forward: abs-max of this layer's input -> its pre-scale, then the layer
             float m = 0.f;
             if (hipMemsetAsync(calib_stat, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return (int)TTSC_EHIP;
@@ -572,7 +609,7 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
             arc = ttsc_conv1d_set_activation_scale(l, calib_scale(m * fabsf(e.in_scale)));
             if (arc) return arc;
         }
-        return ttsc_conv1d_forward_ragged(l, x, B, Lin, y, resid, &e, il, ol, stream);
+        return ttsc_conv1d_forward_pitched(l, x, B, Lin, y, resid, &e, il, ol, (il && ol) ? Lout_pitch : 0, stream);
     };
     const float inv_nk = 1.f / (float)c.num_kernels;
     ttsc_conv1d_epilogue ep{1.f, 1.f, 1.f, TTSC_ACT_NONE, 0};
@@ -611,9 +648,10 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
         if (chain_stage) fused_stage = false;
         // x = ups[i](lrelu(x / nk_prev, 0.1))
         ttsc_conv1d_epilogue eu{sum_scale, 0.1f, 1.f, TTSC_ACT_NONE, 0};
-        rc = conv(up, S, L, X, nullptr, eu, lens[i], lens[i + 1]);
+        rc = conv(up, S, L, X, nullptr, eu, lens[i], lens[i + 1], Pp[i + 1]);
         if (rc) return rc;
-        L = ttsc_conv1d_out_len(up, L);
+        TTSC_REQUIRE(ttsc_conv1d_out_len(up, Lr[i]) == Lr[i + 1], "ttsc_hifigan_forward: upsampler %d disagrees with the configured rates about its output length", i);
+        L = Pp[i + 1];   // from here on L is the ROW PITCH of the stage's tensors; the real lengths are in `ln`
         const int32_t* ln = lens[i + 1];
         for (int j = 0; j < c.num_kernels; ++j) {
             const std::string rb = "resblocks." + std::to_string(i * c.num_kernels + j);
