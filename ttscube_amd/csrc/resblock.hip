@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float* row = xb + (size_t)(32 * (mi0 + mi) + (r & 3) + 8 * (r >> 2)) * a.L;
-                const fvecT v = TTSC_DBG(a, 8) ? fvecT(1e-3f) : *reinterpret_cast<const fvecT*>(row + voff);
+                const fvecT v = TTSC_DBG(a, 8) ? fvecT(1e-3f) : *reinterpret_cast<const fvecT*>(row + voff);   // (a non-temporal hint on these loads measured nothing: round 5)
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) xres[mi][ct][r] = v[ct];
             }
