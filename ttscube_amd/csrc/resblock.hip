@@ -600,6 +600,8 @@ static int launch_chain_k(ChainArgs& a, int B, int shape, hipStream_t s) {
     constexpr int G768 = K == 3 ? 6 : (K == 7 ? 7 : 11), G768W = K == 3 ? 6 : (K == 7 ? 14 : 11);
     if constexpr (MI == 1) {
         if (shape == 22) return launch_chain<1, K, 4, 8, 2, 6, 2, 1, true, true>(a, B, s);   // (internal) + conv_post epilogue
+        // (round 5, measured and dropped: 256-column tiles with three / four workgroups per CU for the K = 3 block — 1.81 / 1.76 ms against 1.65 ms: the block
+        // is bound by how fast a CU can fill a tile (~13.5 GB/s per CU: ~64 outstanding 128-byte lines x ~600 ns), not by how many workgroups take turns)
         if (shape == 12) return launch_chain<1, K, 4, 8, 2, 6, 2, 1, true>(a, B, s);
         if (shape == 11) return launch_chain<1, K, 4, 8, 2, 2, 2, 1, true>(a, B, s);
         if (shape == 10) return launch_chain<1, K, 4, 4, 2, 2, 2, 1, true>(a, B, s);
