@@ -23,11 +23,11 @@ if ROOT not in sys.path:
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (no sparsity)
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_CSV = os.path.join(ROOT, 'profiles', 'r04_bench_hbm_pmc.csv')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this workload
+TRAFFIC_CSV = os.path.join(ROOT, 'profiles', 'r05_bench_hbm_pmc.csv')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this workload
 
 
 def measured_traffic(precision, B, T):
-    """HBM bytes of ONE forward from the committed PMC summary (profiles/r02_bench_hbm_pmc.csv: separate FETCH_SIZE and
+    """HBM bytes of ONE forward from the committed PMC summary (profiles/rNN_bench_hbm_pmc.csv: separate FETCH_SIZE and
     WRITE_SIZE passes over `bench.py --steps 1`, summed over all kernels of a forward, gfx950 corrections of
     MI355X_MICROARCH.md applied in the file's `bytes_per_forward` row).  None when the file does not describe this
     configuration — the number is never a literal in this script."""

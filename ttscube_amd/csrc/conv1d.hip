@@ -39,9 +39,11 @@ namespace ttsc {
 //     (the conversion's VALU work sits between MFMAs of the same wave);
 //   * the global loads of chunk c+2 are issued right after chunk c+1 left the staging registers.
 // K and the dilation are template parameters: the tap loop is unrolled and every LDS address is base register + immediate.
-// NSL = weight slots in LDS: 2 (one barrier per tap publishes the next tap's fragments) or 4 (round 5: the fragments of TWO steps travel together,
-// a barrier every second step and at chunk ends — 4 / 8 / 12 barriers per two chunks for K = 3 / 7 / 11 instead of 6 / 14 / 22).
-template <int C, int K, int D, int NSL = 2>
+// (Round 5, measured and dropped: FOUR weight slots with the fragments of two steps travelling together and a barrier every second step —
+// 4 / 8 / 12 barriers per two chunks for K = 3 / 7 / 11 instead of 6 / 14 / 22: 42.84-42.93 ms per forward against 42.96-43.03 with two slots in
+// the product build, i.e. inside the noise, and 30-55 % SLOWER in the -DTTSC_ABLATE build of the very same source (profiles/r05_wg_timeline_slots.log) —
+// a schedule that fragile is not worth 0.1 ms.)
+template <int C, int K, int D>
 __global__ __launch_bounds__(256, 2) void conv_f16x3_wide_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int WM = 2, WN = 2;                   // 128 output channels x 256 positions per workgroup (grid.y = C / 128)
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_wide_kernel(ConvArgs a) {
     constexpr int NCHUNK = C / 16, COTN = C / 32;
     constexpr int AITEMS = WM * MI * 2 * 64;        // weight items of one (tap, chunk) for the workgroup's 128 rows (8 KB)
     half8* Xp = reinterpret_cast<half8*>(smem_raw);   // [2 buffers][plane (h, pl)][SPAN] 16-byte items
-    half8* Aw = Xp + 2 * BUFSZ;                       // [NSL slots][AITEMS] weight fragments
+    half8* Aw = Xp + 2 * BUFSZ;                       // [2 slots][AITEMS] weight fragments
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, l31 = lane & 31;
@@ -250,29 +252,16 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_wide_kernel(ConvArgs a) {
     // next tap's weights and, after the last tap, the next chunk's activations.
     auto chunk = [&](int c, auto buf_tag, auto par_tag) __attribute__((always_inline)) {
         constexpr int BUF = decltype(buf_tag)::value;
-        constexpr int PAR = decltype(par_tag)::value;   // global step number of the chunk's first tap, modulo NSL
+        constexpr int PAR = decltype(par_tag)::value;
         half8* nxt = Xp + (1 - BUF) * BUFSZ;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const int slot = (PAR + j) & (NSL - 1);
+            const int slot = (PAR + j) & 1;
             // the next step's weights leave first, then (staging taps) the loads of chunk c+2 ...
-            if constexpr (NSL == 2) {
-                if (j + 1 < K)
-                    stage_A(c, j + 1, slot ^ 1);
-                else
-                    stage_A(c + 1 < NCHUNK ? c + 1 : c, 0, slot ^ 1);
-            } else if (((PAR + j) & 1) == 0) {
-                // even step g: the fragments of steps g + 2 and g + 3 leave for the slots that steps g - 2 and g - 1 read (retired by the barrier
-                // that ended step g - 1); the barrier at the end of step g + 1 publishes them
-#pragma unroll
-                for (int t = 2; t <= 3; ++t) {
-                    const int jj = j + t;
-                    if (jj < K)
-                        stage_A(c, jj, (PAR + jj) & 3);
-                    else
-                        stage_A(c + 1 < NCHUNK ? c + 1 : c, jj - K, (PAR + jj) & 3);
-                }
-            }
+            if (j + 1 < K)
+                stage_A(c, j + 1, slot ^ 1);
+            else
+                stage_A(c + 1 < NCHUNK ? c + 1 : c, 0, slot ^ 1);
             __builtin_amdgcn_sched_barrier(0);
             half8 ah[MI], al[MI], bh[NJ], bl[NJ];
 #pragma unroll
@@ -306,13 +295,12 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_wide_kernel(ConvArgs a) {
 #pragma unroll
                 for (int n = 0; n < NJ; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[n], acc[i][n], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if ((NSL == 2 || ((PAR + j) & 1) == 1 || j == K - 1) && !TTSC_DBG(a, 2)) __syncthreads();   // (chunk end: publishes the next chunk's activations)
+            if (!TTSC_DBG(a, 2)) __syncthreads();
         }
     };
 
-    // prologue: chunk 0 -> buffer 0, chunk 1 into the staging registers, first weight step(s)
+    // prologue: chunk 0 -> buffer 0, chunk 1 into the staging registers, first weight step
     stage_A(0, 0, 0);
-    if constexpr (NSL == 4) stage_A(0, 1, 1);
 #pragma unroll
     for (int e = 0; e < XIT; ++e) x_issue_item(e, 0);
     if (a.acc_init) {
@@ -334,19 +322,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_wide_kernel(ConvArgs a) {
     }
     __syncthreads();
     TTSC_STAMP(a, wg_lin, 1);
-    if constexpr (NSL == 2) {
-        for (int c = 0; c < NCHUNK; c += 2) {
-            chunk(c, std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
-            chunk(c + 1, std::integral_constant<int, 1>(), std::integral_constant<int, (K & 1)>());
-        }
-    } else {
-        static_assert(NCHUNK % 4 == 0, "slot phase repeats every four chunks");
-        for (int c = 0; c < NCHUNK; c += 4) {
-            chunk(c, std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
-            chunk(c + 1, std::integral_constant<int, 1>(), std::integral_constant<int, (K & 3)>());
-            chunk(c + 2, std::integral_constant<int, 0>(), std::integral_constant<int, ((2 * K) & 3)>());
-            chunk(c + 3, std::integral_constant<int, 1>(), std::integral_constant<int, ((3 * K) & 3)>());
-        }
+    for (int c = 0; c < NCHUNK; c += 2) {
+        chunk(c, std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
+        chunk(c + 1, std::integral_constant<int, 1>(), std::integral_constant<int, (K & 1)>());
     }
     TTSC_STAMP(a, wg_lin, 2);
 
@@ -777,8 +755,8 @@ static int launch_f16_t(const ConvArgs& a, int B, hipStream_t s) {
     return TTSC_OK;
 }
 
-template <int C, int K, int D, int NSL>
-static int launch_f16_wide_n(const ConvArgs& a0, int B, hipStream_t s) {
+template <int C, int K, int D>
+static int launch_f16_wide(const ConvArgs& a0, int B, hipStream_t s) {
     constexpr int NT = 256;
     constexpr int SPAN = NT + (K - 1) * D;
     dim3 grid((unsigned)ceil_div(a0.Lout, NT), (unsigned)(C / 128), (unsigned)B);
@@ -793,23 +771,15 @@ static int launch_f16_wide_n(const ConvArgs& a0, int B, hipStream_t s) {
     // deep-prefetched epilogue operands (bit-identical to the plain epilogue; TTSC_CONV_EPI_PREFETCH=0 restores the four-rows-at-a-time one)
     static const int epi_env = getenv("TTSC_CONV_EPI_PREFETCH") ? atoi(getenv("TTSC_CONV_EPI_PREFETCH")) : 1;
     a.epi_prefetch = (epi_env && !a.gate && a.out_act == TTSC_ACT_NONE && a.Cout == C && (size_t)B * C * a.Lout < (1ull << 32)) ? 1 : 0;   // (32-bit element offsets)
-    constexpr size_t lds = (size_t)2 * (4 * SPAN + 2) * 16 + (size_t)NSL * (2 * 2 * 2 * 64) * 16;   // activations + NSL weight slots
-    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
-    if (int rc = ensure_full_lds((const void*)conv_f16x3_wide_kernel<C, K, D, NSL>)) return rc;   // once per (device, kernel)
-    hipLaunchKernelGGL((conv_f16x3_wide_kernel<C, K, D, NSL>), grid, dim3(256), lds, s, a);
+    constexpr size_t lds = (size_t)2 * (4 * SPAN + 2) * 16 + (size_t)2 * (2 * 2 * 2 * 64) * 16;   // activations + 2 weight slots
+    if (int rc = ensure_full_lds((const void*)conv_f16x3_wide_kernel<C, K, D>)) return rc;   // once per (device, kernel)
+    hipLaunchKernelGGL((conv_f16x3_wide_kernel<C, K, D>), grid, dim3(256), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("conv_f16x3_wide_kernel launch failed: %s", hipGetErrorString(e));
         return TTSC_EHIP;
     }
     return TTSC_OK;
-}
-
-template <int C, int K, int D>
-static int launch_f16_wide(const ConvArgs& a, int B, hipStream_t s) {
-    // four weight slots (half the barriers) unless TTSC_CONV_WIDE_SLOTS=2
-    static const int slots = getenv("TTSC_CONV_WIDE_SLOTS") ? atoi(getenv("TTSC_CONV_WIDE_SLOTS")) : 4;
-    return slots == 2 ? launch_f16_wide_n<C, K, D, 2>(a, B, s) : launch_f16_wide_n<C, K, D, 4>(a, B, s);
 }
 
 

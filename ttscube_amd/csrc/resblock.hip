@@ -560,6 +560,12 @@ __global__ __launch_bounds__(64 * NW, WPS) void rbchain_f16x3_kernel(ChainArgs a
             }
         }
     }
+#ifdef TTSC_ABLATE
+    if (a.prof) {
+        __builtin_amdgcn_s_waitcnt(0);
+        TTSC_STAMP(a, wg_lin, 14);
+    }
+#endif
 }
 
 #ifdef TTSC_RB_PROBE   // development: compile ONE instantiation (tools/isa_stats.py -DTTSC_RB_PROBE=1,11,4,4,2)
