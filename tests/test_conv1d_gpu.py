@@ -419,3 +419,61 @@ def test_conv_transpose1d_tall_tile_kernel(cin, cout, k, s, L, B, monkeypatch):
     conv.set_precision('fp32')
     y32 = conv(x.cuda(), in_slope=0.1).cpu()
     assert float((y - y32).abs().max()) < F16X3_TOL
+
+
+@pytest.mark.parametrize('kind', ['conv256', 'conv128_resid', 'ups_tall', 'ups_k4s4'])
+def test_pitched_forward_equals_the_dense_call_on_the_valid_region(kind, monkeypatch):
+    """ttsc_conv1d_forward_pitched (round 5: the generator's intermediate tensors have 128-byte row pitches): the same layer on tensors whose rows are
+    padded to a multiple of 32 floats, real lengths in the per-utterance tables, must give the dense call's bits on every valid position — stride-1
+    layers on the wide kernel (input and output pitch = the padded length) and transposed layers (explicit output pitch) alike."""
+    import ctypes as C_
+    from ttscube_amd import _lib
+    from ttscube_amd.hip_layers import Conv1dHip
+    monkeypatch.setenv('TTSC_CONV_WIDE', '2')
+    B = 2
+    if kind == 'conv256':
+        Cin, Cout, L, conv = 256, 256, 301, Conv1dHip(256, 256, 7, padding=9, dilation=3)
+        w, Lo = _mk((256, 256, 7), 1, 1.0 / (256 * 7) ** 0.5), 301
+    elif kind == 'conv128_resid':
+        Cin, Cout, L, conv = 128, 128, 517, Conv1dHip(128, 128, 3, padding=1)
+        w, Lo = _mk((128, 128, 3), 2, 1.0 / (128 * 3) ** 0.5), 517
+    elif kind == 'ups_tall':
+        Cin, Cout, L, conv = 512, 256, 101, Conv1dHip(512, 256, 16, stride=5, padding=5, transposed=True)
+        w, Lo = _mk((512, 256, 16), 3, 1.0 / (512 * 16 / 5) ** 0.5), 101 * 5 + 1
+    else:
+        Cin, Cout, L, conv = 128, 64, 203, Conv1dHip(128, 64, 4, stride=4, padding=0, transposed=True)
+        w, Lo = _mk((128, 64, 4), 4, 1.0 / (128 * 4 / 4) ** 0.5), 203 * 4
+    conv.set_precision('f16x3')
+    conv.set_weight(w, _mk((Cout,), 5, 0.1))
+    assert conv.out_len(L) == Lo
+    x = _mk((B, Cin, L), 6).cuda()
+    r = _mk((B, Cout, Lo), 7).cuda() if kind == 'conv128_resid' else None
+    dense = conv(x, resid=r, in_slope=0.1)
+    Pi, Po = (L + 31) // 32 * 32, (Lo + 31) // 32 * 32
+    xp = torch.full((B, Cin, Pi), float('nan'), device='cuda')      # whatever sits in the padding must never be read as data
+    xp[:, :, :L] = x
+    rp = None
+    if r is not None:
+        rp = torch.zeros((B, Cout, Po), device='cuda')
+        rp[:, :, :Lo] = r
+    yp = torch.full((B, Cout, Po), 7.0, device='cuda')
+    il = torch.full((B,), L, dtype=torch.int32, device='cuda')
+    ol = torch.full((B,), Lo, dtype=torch.int32, device='cuda')
+    ep = _lib.Conv1dEpilogue(1.0, 0.1, 1.0, _lib.ACT_NONE, 0, None, 1.0)
+    _lib.check(_lib.lib().ttsc_conv1d_forward_pitched(conv._h, _lib.dev_ptr(xp), B, Pi, _lib.dev_ptr(yp), _lib.dev_ptr(rp) if rp is not None else None,
+                                                      C_.byref(ep), _lib.dev_ptr(il), _lib.dev_ptr(ol), Po, _lib.current_stream()), 'pitched')
+    assert torch.equal(yp[:, :, :Lo], dense)
+    assert bool(torch.isfinite(yp[:, :, :Lo]).all())
+    # an output pitch without length tables is refused (the pitch alone cannot bound the rows)
+    with pytest.raises(_lib.TTSCError):
+        _lib.check(_lib.lib().ttsc_conv1d_forward_pitched(conv._h, _lib.dev_ptr(xp), B, Pi, _lib.dev_ptr(yp), None, C_.byref(ep), None, None, Po,
+                                                          _lib.current_stream()), 'pitched')
+
+
+def test_split_status_of_one_stream_is_clean_and_cheap():
+    """ttsc_split_status_stream: the verdict of the split recurrences launched on ONE stream (what the Cubegan step asks before each side's update);
+    an idle / unknown stream reports nothing"""
+    from ttscube_amd import _lib
+    s = torch.cuda.Stream()
+    assert int(_lib.lib().ttsc_split_status_stream(s.cuda_stream)) == 0
+    _lib.check_split_status('test', stream=s.cuda_stream)

@@ -400,3 +400,31 @@ def test_inputs_far_below_the_calibration_range_keep_relative_accuracy(shift):
     assert int(_lib.lib().ttsc_hifigan_recalibrations(g._handle)) == nrecal          # ... without another re-calibration
     ref2 = R.generator_forward(w, h, mel2)
     assert float((out2.cpu() - ref2).pow(2).mean().sqrt()) < 2e-5
+
+
+def test_padded_row_pitches_do_not_change_a_bit(monkeypatch):
+    """round 5: stages 1-3 keep their tensors on 128-byte row pitches (hifigan.cpp::stage_pitch) — same launches, same arithmetic, rows padded:
+    dense and ragged batches whose stage lengths are NOT multiples of 32 must come out bit-identical with and without (TTSC_HIFIGAN_PITCH=0)"""
+    h = dict(R.CONFIG_V1)
+    sd = R.synthetic_state_dict(h, seed=77)
+    warm = R.synthetic_mel(1, 2, seed=1).cuda()
+    monkeypatch.setenv('TTSC_HIFIGAN_PITCH', '0')
+    g0 = _gen(h, sd)
+    with torch.no_grad():
+        g0(warm)    # (the C handle reads the switch when the first forward creates it)
+    monkeypatch.setenv('TTSC_HIFIGAN_PITCH', '1')
+    g1 = _gen(h, sd)
+    with torch.no_grad():
+        g1(warm)
+    for B, T in ((1, 7), (3, 33), (2, 100)):    # stage lengths 36 / 109 / 436 ..., 166 / 499 ..., 501 / 1504 ...: none a multiple of 32
+        mel = R.synthetic_mel(B, T, seed=50 + T).cuda()
+        with torch.no_grad():
+            y0, y1 = g0(mel), g1(mel)
+        assert torch.equal(y0, y1), (B, T)
+    mel = R.synthetic_mel(3, 41, seed=9).cuda()
+    frames = [41, 17, 30]
+    with torch.no_grad():
+        r0, r1 = g0(mel, frames=frames), g1(mel, frames=frames)
+    for b in range(3):
+        n = 240 * frames[b] + 64
+        assert torch.equal(r0[b, :, :n], r1[b, :, :n]), b
