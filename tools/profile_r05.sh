@@ -25,7 +25,7 @@ for cfg in "--stage 1 --k 3 --L 4032" "--stage 2 --k 7 --L 12032"; do TTSC_CONV_
 (for env in "TTSC_CONV_ACC_INIT=1" "TTSC_CONV_ACC_INIT=0" "TTSC_CONV_ACC_INIT=0 TTSC_CONV_EPI_PREFETCH=0" "TTSC_HIFIGAN_PITCH=0" "TTSC_TALL_SWIZZLE=0" "TTSC_CONV_ACC_INIT=1"; do
   echo "== $env"; env $env timeout 300 $B --steps 20 --warmup 3 2>/dev/null | python -c "
 import json,sys; r=json.loads(sys.stdin.read()); print('ms_per_step %.3f  frac %.4f  rms_vs_oracle %.3e' % (r['ms_per_step'], r['roofline']['frac'], r['self_check_rms_vs_oracle']))"; done) > $O/bench_switches.log 2>&1
-./tools/probes/lobits.bin > $O/mfma_lo_bits_probe.log 2>&1
+/opt/rocm/bin/hipcc -O3 -w --offload-arch=gfx950 -o /tmp/lobits tools/probes/mfma_lo_bits_probe.hip 2>/dev/null && /tmp/lobits > $O/mfma_lo_bits_probe.log 2>&1
 timeout 300 python bench.py --mode e2e --steps 5 --warmup 2 2>/dev/null | grep '^{' > $O/bench_e2e.json
 timeout 300 python bench.py --mode train --steps 6 --warmup 2 2>/dev/null | grep '^{' > $O/bench_train_b16.json
 timeout 900 python bench.py > $O/bench_final.json 2> $O/bench_final.err < /dev/null
