@@ -428,3 +428,32 @@ def test_padded_row_pitches_do_not_change_a_bit(monkeypatch):
     for b in range(3):
         n = 240 * frames[b] + 64
         assert torch.equal(r0[b, :, :n], r1[b, :, :n]), b
+
+
+def test_split_chain_launches_do_not_change_a_bit(monkeypatch):
+    """round 5: the K = 7 / K = 11 ResBlock1 of the 64-channel stage run as two chain launches with smaller halos (hifigan.cpp::chain_first_pairs) when the
+    batch fills the chip several times over — every column goes through the same arithmetic, so the output must be bit-identical to the one-launch chains
+    (TTSC_HIFIGAN_CHAIN_SPLIT=0): forced on small dense / ragged batches (=2), and by the default rule on a batch large enough to trigger it"""
+    h = dict(R.CONFIG_V1)
+    sd = R.synthetic_state_dict(h, seed=78)
+    warm = R.synthetic_mel(1, 2, seed=1).cuda()
+    gens = {}
+    for mode in ('0', '2', '1'):
+        monkeypatch.setenv('TTSC_HIFIGAN_CHAIN_SPLIT', mode)
+        gens[mode] = _gen(h, sd)
+        with torch.no_grad():
+            gens[mode](warm)    # (the C handle reads the switch when the first forward creates it)
+    for B, T in ((1, 7), (3, 33), (2, 100)):
+        mel = R.synthetic_mel(B, T, seed=60 + T).cuda()
+        with torch.no_grad():
+            assert torch.equal(gens['0'](mel), gens['2'](mel)), (B, T)
+    mel = R.synthetic_mel(3, 41, seed=10).cuda()
+    frames = [41, 17, 30]
+    with torch.no_grad():
+        r0, r2 = gens['0'](mel, frames=frames), gens['2'](mel, frames=frames)
+    for b in range(3):
+        n = 240 * frames[b] + 64
+        assert torch.equal(r0[b, :, :n], r2[b, :, :n]), b
+    mel = R.synthetic_mel(8, 900, seed=11).cuda()    # 8 x 54 016 columns at 64 channels = 1 088 tiles: the default rule splits
+    with torch.no_grad():
+        assert torch.equal(gens['0'](mel), gens['1'](mel))

@@ -46,6 +46,7 @@ struct ttsc_hifigan {
     bool use_chain = true;      // env TTSC_HIFIGAN_CHAIN=0 disables the whole-ResBlock fused chain kernel (resblock.hip)
     bool use_chain128 = true;   // env TTSC_HIFIGAN_CHAIN128=0: keep the 128-channel K=3 block on the layer-by-layer wide kernel (A/B)
     int chain_shape = -1;       // env TTSC_HIFIGAN_CHAIN_SHAPE: tile shape of the chain kernel (-1 = by halo)
+    int split_chain = 1;        // env TTSC_HIFIGAN_CHAIN_SPLIT=0: every chained ResBlock1 as ONE launch; 2: split whatever the batch size (see chain_first_pairs)
     bool pad_pitch = true;      // env TTSC_HIFIGAN_PITCH=0: intermediate tensors with their natural row pitch (rows not on 128-byte boundaries)
     bool fuse_post = true;      // env TTSC_HIFIGAN_FUSE_POST=0: conv_post + tanh as their own launch instead of the epilogue of the last chain launch
     int precision = TTSC_PREC_FP32;
@@ -127,6 +128,7 @@ extern "C" int ttsc_hifigan_create(const ttsc_hifigan_cfg* cfg, ttsc_hifigan** o
     if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN")) g->use_chain = atoi(ev) != 0;
     if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN128")) g->use_chain128 = atoi(ev) != 0;
     if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN_SHAPE")) g->chain_shape = atoi(ev);
+    if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN_SPLIT")) g->split_chain = atoi(ev);
     if (const char* ev = getenv("TTSC_HIFIGAN_PITCH")) g->pad_pitch = atoi(ev) != 0;
     if (const char* ev = getenv("TTSC_HIFIGAN_FUSE_POST")) g->fuse_post = atoi(ev) != 0;
     if (const char* ev = getenv("TTSC_HIFIGAN_CALIBRATE")) {
@@ -253,6 +255,19 @@ static size_t buf_elems(const ttsc_hifigan* g, int32_t B, int64_t T) {
         if (e > mx) mx = e;
     }
     return (size_t)round_up((int64_t)mx, 64);
+}
+
+// A chained ResBlock1 recomputes `halo` columns per tile side — the summed half receptive fields of ALL its convolutions: 36 / 60 columns at K = 7 / 11, 14 % / 23 %
+// of the 512-column tile of the 64-channel kernel.  Cut in two launches (first `n` pairs X -> R, the rest R -> S) the halos are 6 + 30 (K = 7 as 1 + 2) / 30 + 30 columns (K = 11 as 2 + 1): 6 % /
+// 13 % fewer MFMAs for one more tile fill and store, and at this operating point a chain launch costs what its MFMAs cost.  Measured at config[1]
+// (tools/bench_chain_split.py, bit-identical results): 64 channels K = 11 5.30 -> 4.77 ms as 2 + 1, K = 7 3.60 -> 3.39 ms as 1 + 2; 32 channels (twice the bytes
+// per MFMA, 1024-column tile): 3.65 -> 3.71 ms, 4.96 -> 5.96 ms — not split; K = 3: halo 12, nothing to win (64 channels 1.59 -> 1.83 ms; 128 channels 1.57 -> 1.42-1.52 ms
+// alone, nothing in the whole forward).  Whole forward on one box, three alternations: 43.54-43.68 ms as single launches, 43.00-43.11 ms split.  Only when the launch fills the chip several times
+// over: a short batch pays the second launch's latency instead.  Returns the number of pairs of the first launch, 0 = one launch.
+static int chain_first_pairs(const ttsc_hifigan* g, int ch, int k, int nd, int32_t B, int64_t L) {
+    if (!g->split_chain || ch != 64 || nd != 3 || (k != 7 && k != 11)) return 0;
+    if (g->split_chain < 2 && (int64_t)B * ceil_div(L, (int64_t)400) < 1024) return 0;   // < 4 rounds of workgroups over the 256 CUs
+    return k == 11 ? 2 : 1;
 }
 
 // length table of a DENSE batch written on the device (no host buffer whose lifetime a stream would have to outlive): row i = stage i's length
@@ -670,7 +685,14 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
                     ttsc_conv1d_epilogue epost{inv_nk, 0.01f, 1.f, TTSC_ACT_TANH, 0};
                     return ttsc_rbchain_post_forward(c1, c2, nd, X, B, L, j > 0 ? S : nullptr, layer("conv_post"), &epost, wav, ln, stream);
                 }
-                rc = ttsc_rbchain_forward(c1, c2, nd, X, B, L, S, j > 0 ? 1 : 0, ln, g->chain_shape, stream);
+                const int nf = chain_first_pairs(g, ch, c.resblock_kernel_sizes[j], nd, B, L);
+                if (nf > 0 && ttsc_rbchain_supported(c1, c2, nf) && ttsc_rbchain_supported(c1 + nf, c2 + nf, nd - nf)) {
+                    rc = ttsc_rbchain_forward(c1, c2, nf, X, B, L, R, 0, ln, g->chain_shape, stream);
+                    if (rc) return rc;
+                    rc = ttsc_rbchain_forward(c1 + nf, c2 + nf, nd - nf, R, B, L, S, j > 0 ? 1 : 0, ln, g->chain_shape, stream);
+                } else {
+                    rc = ttsc_rbchain_forward(c1, c2, nd, X, B, L, S, j > 0 ? 1 : 0, ln, g->chain_shape, stream);
+                }
                 if (rc) return rc;
                 continue;
             }
