@@ -22,9 +22,10 @@ for cfg in "--stage 1 --k 3 --L 4032" "--stage 1 --k 11 --L 4032" "--stage 2 --k
 done > $O/wg_timeline.log 2>&1
 for cfg in "--stage 1 --k 3 --L 4032" "--stage 2 --k 7 --L 12032"; do TTSC_CONV_ACC_INIT=0 TTSC_CONV_EPI_PREFETCH=0 timeout 120 python tools/wg_timeline.py $cfg 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids\|census\|mfma :\|other:"; done > $O/wg_timeline_round4_epilogue.log 2>&1
 # A/B switches of the round, whole forward
-(for env in "TTSC_CONV_ACC_INIT=1" "TTSC_CONV_ACC_INIT=0" "TTSC_CONV_ACC_INIT=0 TTSC_CONV_EPI_PREFETCH=0" "TTSC_HIFIGAN_PITCH=0" "TTSC_TALL_SWIZZLE=0" "TTSC_CONV_ACC_INIT=1"; do
+(for env in "TTSC_CONV_ACC_INIT=1" "TTSC_CONV_ACC_INIT=0" "TTSC_CONV_ACC_INIT=0 TTSC_CONV_EPI_PREFETCH=0" "TTSC_HIFIGAN_PITCH=0" "TTSC_TALL_SWIZZLE=0" "TTSC_HIFIGAN_CHAIN_SPLIT=0" "TTSC_CONV_ACC_INIT=1"; do
   echo "== $env"; env $env timeout 300 $B --steps 20 --warmup 3 2>/dev/null | python -c "
 import json,sys; r=json.loads(sys.stdin.read()); print('ms_per_step %.3f  frac %.4f  rms_vs_oracle %.3e' % (r['ms_per_step'], r['roofline']['frac'], r['self_check_rms_vs_oracle']))"; done) > $O/bench_switches.log 2>&1
+timeout 300 python tools/bench_chain_split.py --stages 3,4 --ks 3,7,11 2>&1 | grep -v amdgpu.ids > $O/chain_split.log
 /opt/rocm/bin/hipcc -O3 -w --offload-arch=gfx950 -o /tmp/lobits tools/probes/mfma_lo_bits_probe.hip 2>/dev/null && /tmp/lobits > $O/mfma_lo_bits_probe.log 2>&1
 timeout 300 python bench.py --mode e2e --steps 5 --warmup 2 2>/dev/null | grep '^{' > $O/bench_e2e.json
 timeout 300 python bench.py --mode train --steps 6 --warmup 2 2>/dev/null | grep '^{' > $O/bench_train_b16.json
