@@ -7,8 +7,9 @@ CPU restatement (explicit fp32 torch tensor algebra, no fused nn.LSTM) of the re
   PreNet (dropout p=0.5 ALWAYS on; masks injected)                     cube/networks/modules.py:148-164
   PostNet (Conv k5 + BatchNorm1d(eval) + tanh, x5)                     cube/networks/modules.py:117-145
 
-Pinned against the reference itself (imported here) by tools/gen_golden_meldecoder.py ->
-tests/golden/languasito2_*.npz / textcoder_*.npz -> tests/test_oracle_meldecoder.py.
+Pinned against the reference itself (imported here) by tools/gen_golden_meldecoder.py / tools/gen_golden_training.py ->
+tests/golden/languasito2_*.npz / textcoder_*.npz -> tests/test_oracle_meldecoder.py (inference, teacher-forced forward, text losses and their
+parameter gradients, the external-conditioning branch).
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 """
 import numpy as np
@@ -114,13 +115,56 @@ def expand_i(x, alignments):
 
 
 # ---- Languasito2 ---------------------------------------------------------------------------------------------
-def languasito2_inference(sd, x_char, x_speaker, max_pitch):
-    """modules.py:1001-1009 with cond_type=None.  Returns (conditioning [1,F,80], durations, pitch [1,F])."""
+def text_stack(sd, which, x_char, x_speaker, x_words=None, x_phon2word=None):
+    """The phoneme-level stack shared by _text_forward / _cond_forward (modules.py:917-943 / 963-990): embedding -> 3 x conv+tanh -> BiLSTM,
+    + speaker embedding, + (cond_type 'fasttext' / 'hf') the `_lm_<which>` BiLSTM over the word vectors gathered per phoneme
+    (`_get_cond_selection`, modules.py:1079-1082: cond[b, phon2word[b, n]])."""
+    # nn.Embedding(padding_idx=0) (modules.py:845-849): row 0 is read like any other row but never receives a gradient
+    spk = F.embedding(x_speaker, sd['_speaker_emb_%s.weight' % which], padding_idx=0)           # [B,1,128]
+    h = char_cnn(F.embedding(x_char, sd['_phon_emb_%s.weight' % which], padding_idx=0), sd, '_char_cnn_' + which)
+    h, _ = lstm(h, sd, '_char_rnn_' + which, 2, True)
+    h = torch.cat([h, spk.repeat(1, h.shape[1], 1)], dim=-1)        # [B,N,640]
+    if x_words is not None:
+        cond, _ = lstm(x_words, sd, '_lm_' + which, 2, True)        # [B,Nw,512]
+        sel = torch.stack([cond[b, x_phon2word[b]] for b in range(cond.shape[0])])
+        h = torch.cat([h, sel], dim=-1)
+    return h
+
+
+def languasito2_forward(sd, x_char, x_speaker, frame2phone, y_pitch, max_pitch, x_words=None, x_phon2word=None):
+    """Languasito2.forward, teacher-forced (modules.py:996-999): X carries the alignments and the target pitch.  Padded batches run exactly like
+    the reference's (no masking: the recurrences walk the padding).  -> (output_dur [B,N,D+1], output_pitch [B,F], output_vuv [B,F],
+    conditioning [B,min(F,Fp),80]).  Plain differentiable torch algebra: autograd through it gives the oracle's gradients."""
+    hcs = text_stack(sd, 't', x_char, x_speaker, x_words, x_phon2word)
+    hd, _ = lstm(hcs, sd, '_dur_rnn', 2, True)
+    out_dur = linear(hd, sd, '_dur_output')
+    hp, _ = lstm(expand_i(hcs, frame2phone), sd, '_pitch_rnn', 2, True)
+    op = linear(hp, sd, '_pitch_output')
+    g = expand_i(text_stack(sd, 'g', x_char, x_speaker, x_words, x_phon2word), frame2phone)
+    p = y_pitch.unsqueeze(2) / max_pitch
+    m = min(g.shape[1], p.shape[1])
+    g, _ = lstm(torch.cat([g[:, :m], p[:, :m]], dim=-1), sd, '_cond_rnn', 2, True)
+    return out_dur, torch.sigmoid(op[:, :, 0]), torch.sigmoid(op[:, :, 1]), linear(g, sd, '_cond_output')
+
+
+def text_losses(p_dur, p_pitch, p_vuv, y_dur, y_pitch, max_pitch, max_duration):
+    """The text-side losses of Cubegan.training_step (cubegan.py:94-112): CE over durations (ignore_index = max(max_pitch, max_duration) + 1,
+    modules.py:910) and masked L1 pitch + L1 voicing.  -> (loss_duration, loss_pitch)."""
+    t_vuv = (y_pitch > 1).float()
+    m = min(y_dur.shape[1], p_dur.shape[1])
+    t_dur, p_dur = y_dur[:, :m], p_dur[:, :m, :]
+    m = min(y_pitch.shape[1], p_pitch.shape[1])
+    t_pitch, p_pitch, t_vuv, p_vuv = y_pitch[:, :m], p_pitch[:, :m], t_vuv[:, :m], p_vuv[:, :m]
+    loss_duration = F.cross_entropy(p_dur.reshape(-1, p_dur.shape[2]), t_dur.reshape(-1), ignore_index=int(max(max_pitch, max_duration) + 1))
+    loss_pitch = (torch.abs(t_pitch / max_pitch - p_pitch) * t_vuv).mean() + torch.abs(t_vuv - p_vuv).mean()
+    return loss_duration, loss_pitch
+
+
+def languasito2_inference(sd, x_char, x_speaker, max_pitch, x_words=None, x_phon2word=None):
+    """modules.py:1001-1009 (cond_type=None; with x_words / x_phon2word: cond_type='fasttext' / 'hf' given the word vectors).
+    Returns (conditioning [1,F,80], durations, pitch [1,F])."""
     assert x_char.shape[0] == 1, 'the reference inference path is B=1 (modules.py:946-953)'
-    spk = sd['_speaker_emb_t.weight'][x_speaker]                    # [1,1,128]
-    h = char_cnn(sd['_phon_emb_t.weight'][x_char], sd, '_char_cnn_t')
-    h, _ = lstm(h, sd, '_char_rnn_t', 2, True)
-    hcs = torch.cat([h, spk.repeat(1, h.shape[1], 1)], dim=-1)      # [1,N,640]
+    hcs = text_stack(sd, 't', x_char, x_speaker, x_words, x_phon2word)      # [1,N,640(+512)]
     hd, _ = lstm(hcs, sd, '_dur_rnn', 2, True)
     out_dur = linear(hd, sd, '_dur_output')
     durs = torch.argmax(out_dur, dim=-1).reshape(-1).tolist()
@@ -132,11 +176,7 @@ def languasito2_inference(sd, x_char, x_speaker, max_pitch):
     vuv = torch.round(torch.sigmoid(op[:, :, 1]))
     pitch = (torch.sigmoid(op[:, :, 0]) * max_pitch) * vuv
     # conditioning stack (the _g copies), modules.py:962-994
-    spk_g = sd['_speaker_emb_g.weight'][x_speaker]
-    g = char_cnn(sd['_phon_emb_g.weight'][x_char], sd, '_char_cnn_g')
-    g, _ = lstm(g, sd, '_char_rnn_g', 2, True)
-    g = torch.cat([g, spk_g.repeat(1, g.shape[1], 1)], dim=-1)
-    g = expand_i(g, [f2p])
+    g = expand_i(text_stack(sd, 'g', x_char, x_speaker, x_words, x_phon2word), [f2p])
     p = pitch.unsqueeze(2) / max_pitch
     m = min(g.shape[1], p.shape[1])
     g = torch.cat([g[:, :m], p[:, :m]], dim=-1)

@@ -50,3 +50,63 @@ def test_lstm_restatement_matches_torch_lstm():
         ref, (h, c) = m(x)
         y, (h2, c2) = M.lstm(x, {'r.' + k: v for k, v in m.state_dict().items()}, 'r', 2, True)
     assert float((y - ref).abs().max()) < 1e-6 and float((h - h2).abs().max()) < 1e-6 and float((c - c2).abs().max()) < 1e-6
+
+
+# ---- round 6: teacher-forced forward, text losses + parameter gradients, external conditioning, a long sentence --------------------------
+def _f2ps(z):
+    out, o = [], 0
+    for n in z['f2p_len']:
+        out.append([int(v) for v in z['f2p_flat'][o:o + int(n)]])
+        o += int(n)
+    return out
+
+
+@pytest.mark.parametrize('name', ['languasito2_train_a', 'languasito2_train_b'])
+def test_languasito2_forward_losses_and_gradients_match_reference(golden_dir, name):
+    """Languasito2.forward (modules.py:996-999) + cubegan.py:94-112 + autograd through the REFERENCE module (tools/gen_golden_training.py)
+    vs autograd through the oracle's restatement: outputs, both losses, and the gradient fingerprint of every parameter."""
+    from oracle.fingerprint import compare
+    z, sd = _load(golden_dir, name)
+    cfg = json.loads(str(z['cfg']))
+    names = json.loads(str(z['grad_names']))
+    for k in names:
+        sd[k].requires_grad_(True)
+    y_pitch = torch.from_numpy(z['y_pitch'])
+    p_dur, p_pitch, p_vuv, cond = M.languasito2_forward(sd, torch.from_numpy(z['x_char']), torch.from_numpy(z['x_speaker']), _f2ps(z),
+                                                        y_pitch, cfg['max_pitch'])
+    for got, key in ((p_dur, 'p_dur'), (p_pitch, 'p_pitch'), (p_vuv, 'p_vuv'), (cond, 'conditioning')):
+        assert got.shape == z[key].shape, key
+        assert float((got.detach() - torch.from_numpy(z[key])).abs().max()) < 2e-5, key
+    l_dur, l_pitch = M.text_losses(p_dur, p_pitch, p_vuv, torch.from_numpy(z['y_dur']), y_pitch, cfg['max_pitch'], cfg['max_duration'])
+    assert abs(float(l_dur) - float(z['loss_duration'])) < 1e-5 and abs(float(l_pitch) - float(z['loss_pitch'])) < 1e-5
+    l_cond = (cond * torch.from_numpy(z['cond_probe'])).sum() / cond.numel()
+    (l_dur + l_pitch + l_cond).backward()
+    worst = {}
+    for k in names:
+        fp = {f: z['grad/%s/%s' % (k, f)] for f in ('norm', 'sum', 'probe', 'idx', 'samples', 'size')}
+        dev = compare(sd[k].grad.numpy(), k, fp)
+        worst[k] = max(dev.values())
+    bad = {k: v for k, v in worst.items() if v > 1e-4}
+    assert not bad, bad
+
+
+def test_languasito2_external_conditioning_matches_reference(golden_dir):
+    """cond_type='fasttext': the `_lm_t/_lm_g` BiLSTMs over x_words and `_get_cond_selection` (modules.py:932-940, 1079-1082)."""
+    z, sd = _load(golden_dir, 'languasito2_ft_a')
+    cfg = json.loads(str(z['cfg']))
+    with torch.no_grad():
+        cond, durs, pitch = M.languasito2_inference(sd, torch.from_numpy(z['x_char']), torch.from_numpy(z['x_speaker']), cfg['max_pitch'],
+                                                    x_words=torch.from_numpy(z['x_words']), x_phon2word=torch.from_numpy(z['x_phon2word']))
+    assert list(durs) == list(z['durs'])
+    assert cond.shape == z['cond'].shape and float((cond - torch.from_numpy(z['cond'])).pow(2).mean().sqrt()) < 1e-5
+    assert float((pitch - torch.from_numpy(z['pitch'])).abs().max()) < 1e-3
+
+
+def test_languasito2_long_sentence_matches_reference(golden_dir):
+    """B = 1, 64 phonemes -> 576 frames (the two earlier goldens are 17 and 5 phonemes)."""
+    z, sd = _load(golden_dir, 'languasito2_long')
+    cfg = json.loads(str(z['cfg']))
+    with torch.no_grad():
+        cond, durs, pitch = M.languasito2_inference(sd, torch.from_numpy(z['x_char']), torch.from_numpy(z['x_speaker']), cfg['max_pitch'])
+    assert list(durs) == list(z['durs']) and cond.shape[1] == 576
+    assert float((cond - torch.from_numpy(z['cond'])).pow(2).mean().sqrt()) < 1e-5

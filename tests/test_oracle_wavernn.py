@@ -145,3 +145,40 @@ def test_normal_quantile_and_beta_sampler_distribution():
         assert 0.0 <= xs.min() and xs.max() <= 1.0
         ks = stats.kstest(xs, stats.beta(a_, b_).cdf)
         assert ks.pvalue > 1e-3, (a_, b_, ks)
+
+
+@pytest.mark.parametrize('name', ['vocoder_step_h64', 'vocoder_step_h64_clipped'])
+def test_vocoder_training_step_restatement_matches_reference(golden_dir, name):
+    """CubenetVocoder.training_step run UNMODIFIED from the imported reference (tools/gen_golden_training.py: two consecutive steps from fixed
+    weights; the second case has gradient norms of 100-190 so that clip_grad_norm(5) acts) vs oracle/vocoder_step_ref.py: losses, gradient
+    norms before clipping, learning rate, every parameter after every step."""
+    import json
+    import torch
+    from oracle import vocoder_step_ref as V
+    from oracle.fingerprint import compare
+    z = np.load(os.path.join(golden_dir, name + '.npz'))
+    H, N, steps = int(z['H']), int(z['N']), int(z['steps'])
+    sd = {}
+    for pre, low, s in (('_wavernn_hr.', True, int(z['seed'])), ('_wavernn_lr.', False, int(z['seed']) + 100)):
+        for k, v in O.synthetic_state_dict(H=H, num_layers=N, use_lowres=low, seed=s).items():
+            sd[pre + k] = torch.from_numpy(v) * (float(z['out_gain']) if k == '_output.linear_layer.weight' else 1.0)
+    assert list(sd.keys()) == json.loads(str(z['keys']))
+    batches = [{k: torch.from_numpy(z['%s%d' % (k, s)]) for k in ('x', 'x_low', 'mel')} for s in range(steps)]
+    recs = V.vocoder_training_steps(sd, batches[:1], float(z['lr']))
+    for k in sd:        # after the first step: fingerprints
+        fp = {f: z['fp0/%s/%s' % (k, f)] for f in ('norm', 'sum', 'probe', 'idx', 'samples', 'size')}
+        assert max(compare(sd[k].numpy(), k, fp).values()) < 1e-5, k
+    # second step continues from the reference's state after the first only through the oracle's own Adam moments: run both from scratch
+    sd2 = {}
+    for pre, low, s in (('_wavernn_hr.', True, int(z['seed'])), ('_wavernn_lr.', False, int(z['seed']) + 100)):
+        for k, v in O.synthetic_state_dict(H=H, num_layers=N, use_lowres=low, seed=s).items():
+            sd2[pre + k] = torch.from_numpy(v) * (float(z['out_gain']) if k == '_output.linear_layer.weight' else 1.0)
+    recs = V.vocoder_training_steps(sd2, batches, float(z['lr']))
+    for s, r in enumerate(recs):
+        for key in ('loss_lr', 'loss_hr', 'norm_lr', 'norm_hr'):
+            assert abs(r[key] - float(z['%s%d' % (key, s)])) < 2e-4 * max(1.0, abs(float(z['%s%d' % (key, s)]))), (s, key, r[key])
+        assert abs(r['alpha'] - float(z['alpha%d' % s])) < 1e-15
+    for k in sd2:
+        ref = torch.from_numpy(z['p%d/%s' % (steps - 1, k)])
+        # one Adam step moves a weight by ~lr = 1e-3: the update itself is held to 1 %
+        assert float((sd2[k] - ref).abs().max()) < 2e-5, (k, float((sd2[k] - ref).abs().max()))

@@ -207,6 +207,20 @@ def languasito_forward_train(lang, X):
     return out_dur, p_pitch, p_vuv, cond()
 
 
+def text_losses(p_dur, p_pitch, p_vuv, t_dur, t_pitch, max_pitch, ignore_index):
+    """The text-side losses of Cubegan.training_step (cubegan.py:94-112): duration cross-entropy (padding carries `ignore_index` =
+    max(max_pitch, max_duration) + 1, modules.py:910) and the voiced-masked L1 pitch + L1 voicing losses.  -> (loss_duration, loss_pitch);
+    held to values and gradients made by the reference itself (tests/golden/languasito2_train_*.npz)."""
+    t_vuv = (t_pitch > 1).float()
+    m = min(t_dur.shape[1], p_dur.shape[1])
+    t_dur, p_dur = t_dur[:, :m], p_dur[:, :m, :]
+    m = min(t_pitch.shape[1], p_pitch.shape[1])
+    t_pitch, p_pitch, t_vuv, p_vuv = t_pitch[:, :m], p_pitch[:, :m], t_vuv[:, :m], p_vuv[:, :m]
+    loss_duration = F.cross_entropy(p_dur.reshape(-1, p_dur.shape[2]), t_dur.reshape(-1), ignore_index=ignore_index)
+    loss_pitch = (torch.abs(t_pitch / max_pitch - p_pitch) * t_vuv).mean() + torch.abs(t_vuv - p_vuv).mean()
+    return loss_duration, loss_pitch
+
+
 def cubegan_param_groups(model):
     """The three parameter groups of cubegan.py:275-298 (generator side, discriminators, text side)."""
     l = model._languasito
@@ -279,16 +293,8 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
                 t_.record_stream(s_t)
     with (torch.cuda.stream(s_t) if s_t is not None else contextlib.nullcontext()):
         p_dur, p_pitch, p_vuv = text_fn()
-        t_dur = batch['y_dur'].to(dev)
-        t_pitch = batch['y_pitch'].to(dev)
-        t_vuv = (t_pitch > 1).float()
-        m = min(t_dur.shape[1], p_dur.shape[1])
-        t_dur, p_dur = t_dur[:, :m], p_dur[:, :m, :]
-        m = min(t_pitch.shape[1], p_pitch.shape[1])
-        t_pitch, p_pitch, t_vuv, p_vuv = t_pitch[:, :m], p_pitch[:, :m], t_vuv[:, :m], p_vuv[:, :m]
-        ignore = int(max(model._encodings.max_pitch, model._encodings.max_duration) + 1)
-        loss_duration = F.cross_entropy(p_dur.reshape(-1, p_dur.shape[2]), t_dur.reshape(-1), ignore_index=ignore)
-        loss_pitch = (torch.abs(t_pitch / lang._max_pitch - p_pitch) * t_vuv).mean() + torch.abs(t_vuv - p_vuv).mean()
+        loss_duration, loss_pitch = text_losses(p_dur, p_pitch, p_vuv, batch['y_dur'].to(dev), batch['y_pitch'].to(dev), lang._max_pitch,
+                                                int(max(model._encodings.max_pitch, model._encodings.max_duration) + 1))
         loss_text = loss_pitch + loss_duration
         opt_t.zero_grad()
         arm(2)

@@ -70,7 +70,6 @@ class CubenetVocoder(nn.Module):
         xl[1:, 0:self._upsample_low] = x_low_split[:-1, -self._upsample_low:]
         return {'mel': m, 'x_low': xl}
 
-    @torch.jit.ignore
     # ---- the LightningModule surface of vocoder.py:133-176 (pl.Trainer.fit(model) in the reference's scripts/train_vocoder.py) ----
     def configure_optimizers(self):
         """vocoder.py:169-173: two Adam optimizers (low-resolution net first)"""
@@ -115,6 +114,7 @@ class CubenetVocoder(nn.Module):
         self._val_loss_hr = loss_hr
         self._val_loss_lr = loss_lr
 
+    @torch.jit.ignore
     def save(self, path):
         torch.save(self.state_dict(), path)
 
