@@ -143,6 +143,7 @@ class ArenaReducer:
         self.launched_early = 0      # chunks whose reduce_scatter left from a gradient hook during the last backward pass
         self._chunks = None
         self._order = None           # agreed issue order of the chunks (list of chunk indices), None until recorded
+        self._n_early = 0            # how many chunks at the head of _order may leave from gradient hooks (see _agree_on_order)
         self._seen = []              # recording pass: chunks in the order they completed on this rank
         self._next = 0               # position in _order of the next chunk to issue
         self._ex_stream = None       # the stream early chunks are prepared and sent from (see _launch)
@@ -193,7 +194,7 @@ class ArenaReducer:
         """launch, in the agreed order, every chunk that is complete and whose predecessors have all left"""
         if _EARLY_OFF:   # (measurement switch TTSC_EXCHANGE_EARLY=0: the hooks count, nothing leaves before reduce())
             return
-        while self._next < len(self._order):
+        while self._next < self._n_early:
             c = self._chunks[self._order[self._next]]
             if c['left'] != 0 or c['work'] is not None:
                 break
@@ -202,15 +203,31 @@ class ArenaReducer:
             self._next += 1
 
     def _agree_on_order(self):
-        """rank 0's completion order of the recording pass (chunks it never saw complete appended by index) becomes everybody's issue order"""
+        """rank 0's completion order of the recording pass becomes everybody's issue order — restricted to the chunks that completed during
+        backward() on EVERY rank (MIN over the ranks of a per-chunk flag).  The others (a parameter without a gradient on some rank keeps its
+        chunk from completing there) go to the END of the order and are `late`: they never leave from a hook, on any rank, even where they do
+        complete.  Why (round 6): several reducers of one step share a communicator (the Cubegan step arms the text-side reducer, then the
+        discriminators'); a chunk that left early on one rank and from reduce() on another would sit on different sides of the OTHER reducer's
+        collectives in the two ranks' launch sequences — mispaired operations.  With this rule every rank's sequence is: the common chunks in the
+        agreed order (from hooks or, under skew, from reduce() — nothing else is launched in between), then the late chunks from reduce()."""
+        n = len(self._chunks)
+        mine = torch.zeros(n, dtype=torch.int64, device=self.opt.g.device)
         seen = list(dict.fromkeys(self._seen))
-        order = seen + [k for k in range(len(self._chunks)) if k not in set(seen)]
-        t = torch.tensor(order, dtype=torch.int64, device=self.opt.g.device)
+        if seen:
+            mine[torch.tensor(seen, dtype=torch.int64, device=mine.device)] = 1
+        dist.all_reduce(mine, op=dist.ReduceOp.MIN, group=self.group)
+        common = set(int(k) for k in torch.nonzero(mine).flatten().tolist())
+        first = [k for k in seen if k in common]
+        order = first + [k for k in range(n) if k not in set(first)]
+        t = torch.tensor([len(first)] + order, dtype=torch.int64, device=self.opt.g.device)
         dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
-        order = [int(v) for v in t.tolist()]
-        if sorted(order) != list(range(len(self._chunks))):
-            raise RuntimeError('ArenaReducer: the broadcast issue order is not a permutation of the chunks (ranks built different arenas?)')
+        vals = [int(v) for v in t.tolist()]
+        n_early, order = vals[0], vals[1:]
+        if sorted(order) != list(range(n)) or not set(order[:n_early]) <= common:
+            raise RuntimeError('ArenaReducer: the broadcast issue order is not a permutation of the chunks, or names an early chunk this rank '
+                               'never saw complete (ranks built different arenas?)')
         self._order = order
+        self._n_early = n_early      # chunks order[:n_early] may leave from hooks; the rest only from reduce()
 
     def arm(self):
         """call before a backward pass (right after zero_grad): chunk counters restart"""
