@@ -113,7 +113,13 @@ int ttsc_conv1d_forward_ragged(const ttsc_conv1d* c, const float* x_dev, int32_t
 /* The same with an explicit ROW PITCH of the output tensors: y_dev / resid_dev are [B,Cout,Lout_pitch] (Lout_pitch = 0: the natural
  * output length of Lin).  With per-utterance lengths in in_len_dev / out_len_dev, Lin and Lout_pitch are pitches only — that is how
  * ttsc_hifigan_forward keeps the rows of its intermediate tensors on 128-byte boundaries (4001 / 12004 samples per row otherwise: every
- * 128-byte store of the 256- and 128-channel stages straddled two lines).  Lout_pitch must cover every utterance's real output length. */
+ * 128-byte store of the 256- and 128-channel stages straddled two lines).  Lout_pitch must cover every utterance's real output length. 
+ * Rounding note (TTSC_PREC_F16X3, square 128- / 256-channel layers on the wide-tile kernel, out_scale == 1, no activation): by default the
+ * residual, the running sum and the bias are the accumulators' INITIAL value (TTSC_CONV_ACC_INIT=1), so the K * Cin / 16 accumulation steps
+ * round at the magnitude of the whole sum rather than of the convolution alone (self-check RMS against the fp32 oracle 6.4e-7 instead of 4.3e-7
+ * for the whole generator; per-layer tolerance in tests 3e-6 relative).  TTSC_CONV_ACC_INIT=0 adds them after the sum (prefetched epilogue; the
+ * bias still starts the sum there, so the bits differ from the general kernel's, which adds the bias last).  A layer's bits therefore depend on
+ * which kernel the machine-fill rule selects; results are deterministic for a given (shape, batch, environment). */
 int ttsc_conv1d_forward_pitched(const ttsc_conv1d* c, const float* x_dev, int32_t B, int64_t Lin, float* y_dev,
                                 const float* resid_dev, const ttsc_conv1d_epilogue* ep, const int32_t* in_len_dev,
                                 const int32_t* out_len_dev, int64_t Lout_pitch, void* stream);

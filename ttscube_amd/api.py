@@ -72,9 +72,17 @@ class TTSCube:
             # the generator's range guard runs deferred: nothing waits for the GPU until the audio is copied back — where a synchronisation happens
             # anyway — and the guard's verdict is collected right behind that copy; a tripped guard reruns the sentence with the self-repairing
             # synchronous check (re-calibration on this input)
-            audio = self._model.inference(X, check='deferred')
-            host = audio.detach().cpu()
-            if self._model._generator.finish_range_check(raise_on_trip=False):
+            gen = self._model._generator
+            tripped = False
+            try:
+                audio = self._model.inference(X, check='deferred')
+                host = audio.detach().cpu()
+            finally:
+                # whatever happens between the deferred forward and here (an exception in the copy, a KeyboardInterrupt), the pending verdict is
+                # collected: a stale one would be blamed on the next, unrelated call
+                if gen.range_check_pending():
+                    tripped = gen.finish_range_check(raise_on_trip=False)
+            if tripped:
                 host = self._model.inference(X, check='sync').detach().cpu()
             return np.asarray(host.numpy().squeeze() * 32767, dtype=np.int16)
 

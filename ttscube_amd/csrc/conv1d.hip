@@ -351,7 +351,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_wide_kernel(ConvArgs a) {
                 }
             }
     } else if (a.epi_prefetch && (a.resid || a.accumulate)) {
-        // Deep-prefetched epilogue, same arithmetic as epilogue_tile (bit-identical): the residual (and running-sum) operands of the NEXT tiles
+        // Deep-prefetched epilogue.  Same arithmetic as epilogue_tile EXCEPT that the bias already sits in the accumulators (it started the sum, see their
+        // initialisation: not bit-identical to the general kernel, which adds the bias after the sum — ADVICE r5): the residual (and running-sum) operands of the NEXT tiles
         // are in flight while a tile is finished and stored — four tiles ahead with one operand, two with both (64 registers: the fragment and
         // staging registers of the main loop are free now).  epilogue_tile fetched four rows at a time, load -> wait -> store: 32 dependent
         // round trips per wave with 1 KB in flight each; the workgroup timeline (tools/wg_timeline.py, round 5) put 41-45 % of a workgroup's

@@ -115,19 +115,30 @@ int handoff_status(const char* tag) {
 int handoff_status_stream(hipStream_t stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
-    std::lock_guard<std::mutex> lk(g_state_mu);
-    int mask = 0;
-    for (auto& kv : areas()) {
-        if (kv.first.dev != dev || kv.first.stream != stream || !kv.second.words) continue;
-        unsigned v = 0;
-        if (hipMemcpyAsync(&v, kv.second.abort_word() + 1, sizeof(unsigned), hipMemcpyDeviceToHost, stream) != hipSuccess ||
-            hipStreamSynchronize(stream) != hipSuccess)
-            return -1;
-        if (v) {
-            mask |= kv.first.tag == "lstm" ? 1 : kv.first.tag == "gru" ? 2 : kv.first.tag == "melar" ? 4 : 8;
-            if (hipMemsetAsync(kv.second.abort_word() + 1, 0, sizeof(unsigned), stream) != hipSuccess) return -1;
+    // The matching areas' abort words are COLLECTED under the lock and read outside it: the lock also guards handoff_area(), which every
+    // recurrence launch of every host thread takes (an autograd backward thread, for one) — held across the stream drain it would stall them
+    // all for as long as this stream is busy.  std::map nodes are address-stable and areas are never freed, so the pointers stay valid.
+    struct Hit { unsigned* word; int bit; };
+    Hit hits[64];
+    int n = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_state_mu);
+        for (auto& kv : areas()) {
+            if (kv.first.dev != dev || kv.first.stream != stream || !kv.second.words) continue;
+            if (n == 64) break;
+            hits[n++] = {kv.second.abort_word() + 1, kv.first.tag == "lstm" ? 1 : kv.first.tag == "gru" ? 2 : kv.first.tag == "melar" ? 4 : 8};
         }
     }
+    unsigned v[64] = {0};
+    for (int i = 0; i < n; ++i)
+        if (hipMemcpyAsync(&v[i], hits[i].word, sizeof(unsigned), hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
+    if (n && hipStreamSynchronize(stream) != hipSuccess) return -1;   // ONE wait for all the words
+    int mask = 0;
+    for (int i = 0; i < n; ++i)
+        if (v[i]) {
+            mask |= hits[i].bit;
+            if (hipMemsetAsync(hits[i].word, 0, sizeof(unsigned), stream) != hipSuccess) return -1;   // reported once, then re-armed
+        }
     return mask;
 }
 }  // namespace ttsc

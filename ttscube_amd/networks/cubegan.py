@@ -135,7 +135,13 @@ class Cubegan(nn.Module):
             main.wait_stream(s_txt)
             if self._generator.range_check_pending():  # consumer stopped early: do not leave a stale verdict for the next, unrelated forward
                 with torch.cuda.stream(s_gen):
-                    self._generator.finish_range_check(raise_on_trip=False)
+                    tripped = self._generator.finish_range_check(raise_on_trip=False)
+                if tripped:
+                    # batches ALREADY handed out may hold non-finite audio; raising from a generator's clean-up (GeneratorExit) is not allowed,
+                    # so the verdict is reported as a warning rather than swallowed
+                    import warnings
+                    warnings.warn('Cubegan.inference_pipelined was stopped early and its deferred range guard had tripped: audio already '
+                                  'yielded by this call may be non-finite; rerun those batches with check="sync"', RuntimeWarning)
 
     def forward(self, X):
         """cubegan.py:65-72: forced alignment path (X carries y_frame2phone / y_pitch)."""
