@@ -236,7 +236,8 @@ int ttsc_conv_wgrad(const float* p_dev, const float* q_dev, float* g_dev, int32_
  * training step (cubegan.py:137-170: every parameter gradient of MPD / MSD and of the generator), operands carried as fp16 hi + lo with
  * device-side ranges per launch, 128 x 64 tiles on v_mfma_f32_32x32x16_f16; agrees with ttsc_conv_wgrad to ~1e-6 of the largest entry.
  * `ttsc_conv_wgrad_split_supported` says whether a shape is taken (A >= 64 rows, Bc >= 32 columns, J <= 16 taps).  Range words as for
- * ttsc_conv_train: `measure` bit 0 = reduce max |Q| now, bit 1 = max |P| now; null pointers = workspace words measured by this call. */
+ * ttsc_conv_train: `measure` bit 0 = reduce max |Q| now, bit 1 = max |P| now, bit 2 = the caller's words were zeroed by the caller (pooled
+ * words: no memset launch); null pointers = workspace words measured by this call. */
 int32_t ttsc_conv_wgrad_split_supported(int32_t A, int32_t B, int32_t J, int32_t step);
 size_t ttsc_conv_wgrad_split_workspace_bytes(int32_t N, int32_t A, int32_t B, int64_t LP, int32_t J);
 int ttsc_conv_wgrad_split(const float* p_dev, const float* q_dev, float* g_dev, int32_t N, int32_t A, int32_t B, int64_t LP, int64_t LQ, int32_t J,
@@ -263,6 +264,41 @@ int ttsc_conv_train(const float* x_dev, const float* w_dev, const float* bias_de
                     int32_t B, int32_t Cin, int32_t Cout, int32_t K, int64_t Lin, int32_t padding, int32_t dilation, int32_t groups, int32_t flip, float in_scale,
                     float in_slope, float out_scale, float gate_slope, float* amax_x_dev, float* amax_w_dev, int32_t measure, void* ws_dev, size_t ws_bytes,
                     void* stream);
+
+/* The same convolution on weight fragments prepared by a weight bank (below): no weight reduction, no packing launch, no workspace.
+ * wfrag_dev / amax_w_dev: the bank entry's `pack_fwd` (forward) or `pack_dgrad` (data gradient: pass the differentiated layer's Cout as Cin and
+ * vice versa, as for flip = 1) and its `amax` word.  `measure` bit 0 = reduce max |x| into *amax_x_dev now; bit 2 = the caller zeroed that word
+ * (words handed out from a pool zeroed once per step: no memset launch). */
+int ttsc_conv_train_packed(const float* x_dev, const void* wfrag_dev, const float* bias_dev, const float* resid_dev, const float* gate_dev, float* y_dev,
+                           int32_t B, int32_t Cin, int32_t Cout, int32_t K, int64_t Lin, int32_t padding, int32_t dilation, int32_t groups,
+                           float in_scale, float in_slope, float out_scale, float gate_slope, float* amax_x_dev, const float* amax_w_dev,
+                           int32_t measure, void* stream);
+
+/* Weight bank: the per-step weight preparation of ALL convolutions of one module in three launches (csrc/conv_train.hip) — what the reference
+ * leaves to torch.nn.utils.weight_norm's pre-forward hooks and to the cuDNN / MIOpen filter transforms inside every nn.Conv1d / nn.Conv2d call of
+ * Generator / MultiPeriodDiscriminator / MultiScaleDiscriminator [EXTERNAL hifigan/models.py; cubegan.py:131,144-149,160-167].
+ * Per entry (all pointers device memory owned by the caller, valid until ttsc_wbank_destroy):
+ *   v [Cout][Cin/groups][K] fp32 and g [Cout] (weight_v / weight_g; g NULL: v is the plain weight);
+ *   w (same shape as v) and norm [Cout]: receive g * v / ||v|| and the row norms (ttsc_weight_norm_forward's outputs; unused when g is NULL);
+ *   amax: one float, receives max |w|;  pack_fwd / pack_dgrad: ttsc_conv_train_workspace_bytes(stride * Cin, Cout, ceil(K / stride), groups) - 256
+ *   bytes (resp. with the two channel counts swapped), either may be NULL;
+ *   stride > 1: the layer is a strided convolution evaluated as a stride-1 convolution over the phase-de-interleaved input
+ *   (ttsc_deinterleave_x); the fragments hold w'[co][(r, ci)][j] = w[co][ci][stride * j + r] (zero beyond K) = ttsc_deinterleave_w's output.
+ * ttsc_wbank_prepare re-reads v / g and refills every output (call it after the parameters changed, on the stream the convolutions follow on). */
+typedef struct ttsc_wbank ttsc_wbank;
+typedef struct ttsc_wbank_entry {
+    const float* v;
+    const float* g;
+    float* w;
+    float* norm;
+    float* amax;
+    void* pack_fwd;
+    void* pack_dgrad;
+    int32_t Cin, Cout, K, groups, stride;
+} ttsc_wbank_entry;
+int ttsc_wbank_create(const ttsc_wbank_entry* entries_host, int32_t n, ttsc_wbank** out);
+int ttsc_wbank_prepare(ttsc_wbank* bank, void* stream);
+void ttsc_wbank_destroy(ttsc_wbank* bank);
 
 /* ------------------------------------------------------------------------------------------------
  * HiFi-GAN generator.  Replaces `hifigan.models.Generator(h)` [EXTERNAL submodule]:

@@ -25,6 +25,12 @@ class Conv1dEpilogue(C.Structure):
 MAX_UPS, MAX_RB, MAX_DIL = 8, 8, 8
 
 
+class WBankEntry(C.Structure):
+    """ttsc_wbank_entry (include/ttscube_hip.h)"""
+    _fields_ = [('v', C.c_void_p), ('g', C.c_void_p), ('w', C.c_void_p), ('norm', C.c_void_p), ('amax', C.c_void_p), ('pack_fwd', C.c_void_p),
+                ('pack_dgrad', C.c_void_p), ('Cin', C.c_int32), ('Cout', C.c_int32), ('K', C.c_int32), ('groups', C.c_int32), ('stride', C.c_int32)]
+
+
 class HifiganCfg(C.Structure):
     _fields_ = [('num_mels', C.c_int32), ('upsample_initial_channel', C.c_int32), ('resblock', C.c_int32),
                 ('num_upsamples', C.c_int32), ('upsample_rates', C.c_int32 * MAX_UPS),
@@ -124,6 +130,12 @@ SIGNATURES = {
     'ttsc_conv_train': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                   C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'ttsc_conv_train_packed': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                         C.c_int32, C.c_void_p]),
+    'ttsc_wbank_create': (C.c_int, [C.POINTER(WBankEntry), C.c_int32, C.POINTER(C.c_void_p)]),
+    'ttsc_wbank_prepare': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'ttsc_wbank_destroy': (None, [C.c_void_p]),
     'ttsc_hifigan_create': (C.c_int, [C.POINTER(HifiganCfg), C.POINTER(C.c_void_p)]),
     'ttsc_hifigan_set_weight': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
     'ttsc_hifigan_set_precision': (C.c_int, [C.c_void_p, C.c_int32]),

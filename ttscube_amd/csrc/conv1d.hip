@@ -1000,6 +1000,10 @@ static int launch_f16_wide_d(const ConvArgs& a, int B, int d, hipStream_t s) {
 template <int C>
 static int launch_f16_wide_k(const ConvArgs& a, int B, int d, hipStream_t s) {
     if (a.ntaps == 3) return launch_f16_wide_d<C, 3>(a, B, d, s);
+#ifdef TTSC_PROBE_EVENK
+    if (a.ntaps == 4) return launch_f16_wide<C, 4, 1>(a, B, s);
+    if (a.ntaps == 6) return launch_f16_wide<C, 6, 1>(a, B, s);
+#endif
     if (a.ntaps == 7) return launch_f16_wide_d<C, 7>(a, B, d, s);
     return launch_f16_wide_d<C, 11>(a, B, d, s);
 }
@@ -1642,7 +1646,11 @@ extern "C" int ttsc_conv1d_forward_pitched(const ttsc_conv1d* c, const float* x,
             // the wide-tile kernel (activation window staged once for all output channels)
             const bool wide_shape = !g.transposed && !a.gate && g.in_channels == g.out_channels &&
                                     (g.out_channels == 128 || g.out_channels == 256) &&
-                                    (g.kernel_size == 3 || g.kernel_size == 7 || g.kernel_size == 11) &&
+                                    ((g.kernel_size == 3 || g.kernel_size == 7 || g.kernel_size == 11)
+#ifdef TTSC_PROBE_EVENK
+                                     || ((g.kernel_size == 4 || g.kernel_size == 6) && g.dilation == 1)
+#endif
+                                     ) &&
                                     (g.dilation == 1 || g.dilation == 3 || g.dilation == 5) &&
                                     g.padding == g.dilation * (g.kernel_size - 1) / 2;
             // these layers start their sums at (residual + running sum + bias) / w_unscale in BOTH kernels that may run them (same bits whichever

@@ -91,7 +91,7 @@ __device__ __forceinline__ float pow2_to(float m, int target) {
     return __uint_as_float((unsigned)(127 + s) << 23);
 }
 // conv_train.hip: *out_x = max |x|, *out_w = max |w| in one launch; a null tensor is skipped (its word was measured by an earlier launch of the layer)
-int launch_amax2(const float* x, long nx, float* out_x, const float* w, long nw, float* out_w, hipStream_t s);
+int launch_amax2(const float* x, long nx, float* out_x, const float* w, long nw, float* out_w, hipStream_t s, bool prezeroed = false);
 static constexpr int SPLIT_X_TARGET = 15, SPLIT_W_TARGET = 10;   // |x| < 2^15 (fp16 max 65504), |w| < 2^10 (as the host-side packing)
 
 __device__ __forceinline__ float apply_act(float v, int act) {

@@ -509,7 +509,8 @@ extern "C" int ttsc_conv_wgrad_split(const float* p_dev, const float* q_dev, flo
     float* ws_words = reinterpret_cast<float*>(ws_dev);
     if (!amax_q) { amax_q = ws_words; measure |= 1; }
     if (!amax_p) { amax_p = ws_words + 1; measure |= 2; }
-    if (int rc = launch_amax2((measure & 1) ? q_dev : nullptr, (long)N * Bc * LQ, amax_q, (measure & 2) ? p_dev : nullptr, (long)N * A * LP, amax_p, s)) return rc;
+    // (bit 2: the caller's words come from a pool it zeroed with one launch for the whole step — no memset here)
+    if (int rc = launch_amax2((measure & 1) ? q_dev : nullptr, (long)N * Bc * LQ, amax_q, (measure & 2) ? p_dev : nullptr, (long)N * A * LP, amax_p, s, (measure & 4) != 0)) return rc;
     WgsArgs a;
     a.P = p_dev;
     a.Q = q_dev;

@@ -118,7 +118,7 @@ def _bias_grad(tc, dy):
     return db
 
 
-def _wgrad(P, Q, A, Bc, J, base, step, q_scale, q_slope, groups=1, amax=None, p_measured=False):
+def _wgrad(P, Q, A, Bc, J, base, step, q_scale, q_slope, groups=1, amax=None, p_measured=False, pooled=False):
     """G [A, Bc / groups, J]: weight gradient of a (grouped) Conv1d, torch layout.  amax: the layer's range words [max |Q|, max |w|, max |P|] from
     the forward launch (max |Q| valid; max |P| valid when `p_measured`), None = measured here"""
     Bg = Bc // groups
@@ -133,7 +133,7 @@ def _wgrad(P, Q, A, Bc, J, base, step, q_scale, q_slope, groups=1, amax=None, p_
             aq = _lib.dev_ptr(amax[0:1]) if amax is not None else None
             ap = _lib.dev_ptr(amax[2:3]) if amax is not None else None
             _lib.check(L.ttsc_conv_wgrad_split(_lib.dev_ptr(P), _lib.dev_ptr(Q), _lib.dev_ptr(G), N, A, Bc, LP, LQ, J, base, step, q_scale, q_slope,
-                                               aq, ap, 0 if amax is None else (0 if p_measured else 2), _lib.dev_ptr(ws), nbytes,
+                                               aq, ap, 0 if amax is None else ((0 if p_measured else 2) | (4 if pooled else 0)), _lib.dev_ptr(ws), nbytes,
                                                _lib.current_stream()), 'ttsc_conv_wgrad_split')
         return G
     nbytes = int(L.ttsc_conv_wgrad_workspace_bytes(N, A, Bg, LP, J))
@@ -171,12 +171,44 @@ def _conv_split(x, w, b, resid, gate, Cin, Cout, K, padding, dilation, flip, in_
     return y
 
 
+def _conv_packed(x, frag, amax_w, b, resid, gate, Cin, Cout, K, padding, dilation, amax_x, measure, in_scale=1.0, in_slope=1.0, out_scale=1.0,
+                 gate_slope=1.0, groups=1):
+    """ttsc_conv_train_packed: the same convolution on fragments a WeightBank prepared (wbank.py) — the range reduction of x and the convolution,
+    nothing else.  measure: bit 0 = reduce max |x| into amax_x now, bit 2 = amax_x is a pre-zeroed pooled word"""
+    L = _lib.lib()
+    B, _, Lin = x.shape
+    Lout = Lin + 2 * padding - dilation * (K - 1)
+    y = torch.empty((B, Cout, Lout), dtype=torch.float32, device=x.device)
+    ptr = lambda t: _lib.dev_ptr(t) if t is not None else None
+    with _lib.on_device(x.device):
+        _lib.check(L.ttsc_conv_train_packed(ptr(x), ptr(frag), ptr(b), ptr(resid), ptr(gate), ptr(y), B, Cin, Cout, K, Lin, padding, dilation, groups,
+                                            float(in_scale), float(in_slope), float(out_scale), float(gate_slope), ptr(amax_x), ptr(amax_w), int(measure),
+                                            _lib.current_stream()), 'ttsc_conv_train_packed')
+    return y
+
+
+USE_BANK = os.environ.get('TTSC_TRAIN_WBANK', '1') != '0'      # (measurement switch: 0 = per-launch weight preparation, round 5's path)
+
+
 class HipConvFn(torch.autograd.Function):
     """y = conv(leaky_relu(in_scale * x, in_slope); w) + b [+ resid]  with HIP forward / dgrad / wgrad."""
 
     @staticmethod
-    def forward(ctx, x, w, b, resid, tc, in_scale, in_slope):
+    def forward(ctx, x, w, b, resid, tc, in_scale, in_slope, pack=None):
         x = x.contiguous()
+        ctx.pack = pack
+        if pack is not None:
+            # weight fragments of both orders and max |w| prepared for the whole module by a WeightBank; the range words of x and dy come from the
+            # step's pre-zeroed pool (one memset per step instead of one per launch)
+            from .wbank import AmaxPool
+            ctx.amax = AmaxPool.of(x.device).take()
+            y = _conv_packed(x, pack[0], pack[2], b.detach().contiguous() if b is not None else None, resid.contiguous() if resid is not None else None,
+                             None, tc.Cin, tc.Cout, tc.K, tc.padding, tc.dilation, ctx.amax[0:1], 5, in_scale=in_scale, in_slope=in_slope,
+                             groups=tc.groups)
+            ctx.save_for_backward(x)
+            ctx.tc, ctx.in_scale, ctx.in_slope = tc, in_scale, in_slope
+            ctx.has_b, ctx.has_r = b is not None, resid is not None
+            return y
         wd = w.detach().contiguous()
         if not tc.transposed and tc.stride == 1 and _split_ok(tc.Cin, tc.Cout, tc.K, tc.dilation, tc.groups):
             # range words of this layer for this step: [max |x|, max |w|, max |dy|] — each tensor is reduced once, by the first launch that needs it
@@ -196,9 +228,25 @@ class HipConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
         tc, sc, sl = ctx.tc, ctx.in_scale, ctx.in_slope
         dy = dy.contiguous()
+        if ctx.pack is not None:
+            (x,) = ctx.saved_tensors
+            dx = dw = db = None
+            am = ctx.amax
+            dy_measured = False
+            if ctx.needs_input_grad[0]:
+                pd = tc.dilation * (tc.K - 1) - tc.padding
+                dx = _conv_packed(dy, ctx.pack[1], ctx.pack[2], None, None, x if sl != 1.0 else None, tc.Cout, tc.Cin, tc.K, pd, tc.dilation, am[2:3], 5,
+                                  out_scale=sc, gate_slope=sl, groups=tc.groups)
+                dy_measured = True
+            if ctx.needs_input_grad[1]:
+                dw = _wgrad(dy, x, tc.Cout, tc.Cin, tc.K, -tc.padding, tc.dilation, sc, sl, tc.groups, amax=am, p_measured=dy_measured, pooled=True)
+            if ctx.has_b and ctx.needs_input_grad[2]:
+                db = _bias_grad(tc, dy)
+            dr = dy if (ctx.has_r and ctx.needs_input_grad[3]) else None
+            return dx, dw, db, dr, None, None, None, None
+        x, w = ctx.saved_tensors
         B, _, Lin = x.shape
         dx = dw = db = None
         dy_measured = False
@@ -236,11 +284,15 @@ class HipConvFn(torch.autograd.Function):
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = _bias_grad(tc, dy)
         dr = dy if (ctx.has_r and ctx.needs_input_grad[3]) else None
-        return dx, dw, db, dr, None, None, None
+        return dx, dw, db, dr, None, None, None, None
 
 
 def hip_conv(tc, x, w, b=None, resid=None, in_scale=1.0, in_slope=1.0):
-    return HipConvFn.apply(x, w, b, resid, tc, float(in_scale), float(in_slope))
+    """w from WeightBank.weight(i) carries the prepared fragments (`_ttsc_pack`); any other weight tensor is prepared per launch"""
+    pack = getattr(w, '_ttsc_pack', None)
+    if pack is not None and not (SPLIT_TRAIN and not tc.transposed and tc.stride == 1):
+        raise _lib.TTSCError('hip_conv: a banked weight needs the split-precision stride-1 path')
+    return HipConvFn.apply(x, w, b, resid, tc, float(in_scale), float(in_slope), pack)
 
 
 class HipWeightNormFn(torch.autograd.Function):
@@ -310,6 +362,43 @@ def _train_convs(gen):
     return tcs
 
 
+def _generator_weights(gen, T):
+    """-> weight(layer): the effective weights of the generator's stride-1 convolutions out of ONE WeightBank.prepare() (three launches for all 74
+    layers and both operand orders); ConvTranspose1d layers and anything the split path does not take keep the per-layer weight norm"""
+    if not (USE_BANK and SPLIT_TRAIN):
+        return _wn
+    from .models import ResBlock1
+    bank = getattr(gen, '_wbank', None)
+    if bank is None:
+        from .wbank import WeightBank
+        nk = gen.num_kernels
+        layers = [('conv_pre', gen.conv_pre), ('conv_post', gen.conv_post)]
+        for n, rb in enumerate(gen.resblocks):
+            if isinstance(rb, ResBlock1):
+                for m, (c1, c2) in enumerate(zip(rb.convs1, rb.convs2)):
+                    layers += [('rb.%d.c1.%d' % (n, m), c1), ('rb.%d.c2.%d' % (n, m), c2)]
+            else:
+                layers += [('rb.%d.c.%d' % (n, m), c) for m, c in enumerate(rb.convs)]
+        specs, index = [], {}
+        for name, l in layers:
+            tc = T[name]
+            if hasattr(l, 'weight_g') and _split_ok(tc.Cin, tc.Cout, tc.K, tc.dilation) and _split_ok(tc.Cout, tc.Cin, tc.K, tc.dilation):
+                index[id(l)] = len(specs)
+                specs.append((l, tc.Cin, tc.Cout, tc.K, 1, 1))
+        bank = WeightBank(specs) if specs else False
+        object.__setattr__(gen, '_wbank', bank)
+        object.__setattr__(gen, '_wbank_index', index)
+    if bank is False:
+        return _wn
+    bank.prepare()
+    index = gen._wbank_index
+
+    def weight(l):
+        i = index.get(id(l))
+        return bank.weight(i) if i is not None else _wn(l)
+    return weight
+
+
 class _BranchSum(torch.autograd.Function):
     """r0 + r1 + ... (left to right) for branches that ran on DIFFERENT streams.  A plain `+` hands the SAME gradient tensor to every branch; each
     branch's last node (a convolution with a residual input) passes it on unchanged as the residual's gradient, and autograd then accumulates the
@@ -339,6 +428,7 @@ def generator_forward_with_grad(gen, x):
     h = gen.h
     T = _train_convs(gen)
     nk = gen.num_kernels
+    _wn = _generator_weights(gen, T)           # (shadows the per-layer weight-norm launch: banked layers come prepared)
     x = hip_conv(T['conv_pre'], x.float(), _wn(gen.conv_pre), gen.conv_pre.bias)
     for i in range(len(h['upsample_rates'])):
         x = hip_conv(T['ups.%d' % i], x, _wn(gen.ups[i]), gen.ups[i].bias, in_scale=(1.0 / nk) if i > 0 else 1.0, in_slope=0.1)

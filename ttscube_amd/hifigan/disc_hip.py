@@ -90,14 +90,18 @@ class HipStridedConv:
             self.tc = TrainConv(stride * Cin, Cout, self.J, padding=0, dilation=period, groups=groups)
 
     def __call__(self, x, w, b, in_slope=1.0):
+        banked = getattr(w, '_ttsc_pack', None) is not None      # weight out of a WeightBank: already in the layout the convolution sees
         if self.s == 1:
-            return hip_conv(self.tc, x, w.contiguous(), b, in_slope=in_slope)
+            return hip_conv(self.tc, x, w if banked else w.contiguous(), b, in_slope=in_slope)
         s, K, J, G, P = self.s, self.K, self.J, self.G, self.P
         N, Cin, LP = x.shape
         L = LP // P                                                     # rows of P samples
         Lout = (L + 2 * self.p - K) // s + 1
         M = Lout + J - 1
-        if FUSED_DEINTERLEAVE:   # one gather per operand and direction (csrc/train_ops.hip)
+        if banked:               # (the tap de-interleave of the weight is folded into the bank's fragment packing)
+            xr = _DeintX.apply(x, G, s, P, self.p, M)
+            wp = w
+        elif FUSED_DEINTERLEAVE:   # one gather per operand and direction (csrc/train_ops.hip)
             xr = _DeintX.apply(x, G, s, P, self.p, M)
             wp = _DeintW.apply(w, s)
         else:                    # the same maps as torch views + copies (kept as the formulation the kernels are tested against)
@@ -191,7 +195,29 @@ def _layers(d, kind):
     return cache
 
 
-def _run(d, kind, x, want_fmap):
+def _bank_of(module, kind):
+    """the WeightBank over every weight-normed layer of all sub-discriminators of `module` (MultiPeriodDiscriminator / MultiScaleDiscriminator) that
+    the split-precision path takes in both directions, and {id(layer): entry index}; (False, {}) when there is nothing to bank"""
+    from .autograd import USE_BANK, SPLIT_TRAIN, _split_ok
+    cached = getattr(module, '_wbank', None)
+    if cached is not None:
+        return cached
+    specs, index = [], {}
+    if USE_BANK and SPLIT_TRAIN:
+        from .wbank import WeightBank
+        for d in module.discriminators:
+            for l, h in zip(list(d.convs) + [d.conv_post], _layers(d, kind)):
+                tc = h.tc
+                if hasattr(l, 'weight_g') and not hasattr(l, 'weight_orig') and _split_ok(tc.Cin, tc.Cout, tc.K, tc.dilation, tc.groups) and \
+                        _split_ok(tc.Cout, tc.Cin, tc.K, tc.dilation, tc.groups) and tc.dilation * (tc.K - 1) - tc.padding >= 0:
+                    index[id(l)] = len(specs)
+                    specs.append((l, h.Cin, h.Cout, h.K, h.G, h.s))
+    cached = (WeightBank(specs), index) if specs else (False, {})
+    object.__setattr__(module, '_wbank', cached)
+    return cached
+
+
+def _run(d, kind, x, want_fmap, bank=None, index=None):
     """x [N, 1, L] -> (scores [N, L'], fmap list; MPD: feature maps as [N, C, H, period] views, the reference's layout).  Layer i's leaky-relu is applied by layer i+1's staging pass; the activated
     feature maps are only materialised when the caller needs them (the generator step's feature-matching loss)."""
     hl = _layers(d, kind)
@@ -199,9 +225,13 @@ def _run(d, kind, x, want_fmap):
     fmap = []
     slope = 1.0
     for i, (l, h) in enumerate(zip(mods, hl)):
-        w = _weight(l)
-        if w.dim() == 4:
-            w = w.squeeze(-1)
+        bi = index.get(id(l)) if bank else None
+        if bi is not None:
+            w = bank.weight(bi)
+        else:
+            w = _weight(l)
+            if w.dim() == 4:
+                w = w.squeeze(-1)
         x = h(x, w, l.bias, in_slope=slope)
         slope = LRELU_SLOPE
         if want_fmap:
@@ -216,13 +246,13 @@ def _fold(x, p):
     return F.pad(x, (0, p - (t % p)), 'reflect') if t % p != 0 else x
 
 
-def _pair(d, kind, y, y_hat, batch_ok, want_fmap):
+def _pair(d, kind, y, y_hat, batch_ok, want_fmap, bank=None, index=None):
     if batch_ok and not y_hat.requires_grad and y.shape == y_hat.shape:   # discriminator step: real + generated as one batch
         n = y.shape[0]
-        out, fmap = _run(d, kind, torch.cat([y, y_hat], dim=0), want_fmap)
+        out, fmap = _run(d, kind, torch.cat([y, y_hat], dim=0), want_fmap, bank, index)
         return out[:n], [f[:n] for f in fmap], out[n:], [f[n:] for f in fmap]
-    out_r, fmap_r = _run(d, kind, y, want_fmap)
-    out_g, fmap_g = _run(d, kind, y_hat, want_fmap)
+    out_r, fmap_r = _run(d, kind, y, want_fmap, bank, index)
+    out_g, fmap_g = _run(d, kind, y_hat, want_fmap, bank, index)
     return out_r, fmap_r, out_g, fmap_g
 
 
@@ -234,7 +264,10 @@ def mpd_forward(mpd, y, y_hat, want_fmap=True):
     if not y.is_cuda:
         raise _lib.TTSCError('discriminators: inputs must live on a HIP device; no CPU path')
     res = ([], [], [], [])
-    jobs = [(lambda d=d: _pair(d, 'p', _fold(y, d.period), _fold(y_hat, d.period), True, want_fmap)) for d in mpd.discriminators]
+    bank, index = _bank_of(mpd, 'p')
+    if bank:
+        bank.prepare()      # one preparation for all five sub-discriminators, on the current stream: the side streams fork behind it
+    jobs = [(lambda d=d: _pair(d, 'p', _fold(y, d.period), _fold(y_hat, d.period), True, want_fmap, bank, index)) for d in mpd.discriminators]
     for r in fan_out(jobs, y.device, inputs=[y, y_hat], tag='mpd'):
         for acc, v in zip(res, (r[0], r[2], r[1], r[3])):
             acc.append(v)
@@ -253,7 +286,10 @@ def msd_forward(msd, y, y_hat, want_fmap=True):
             y_hat = msd.meanpools[i - 1](y_hat)
         ins.append((y, y_hat))
     # discriminator 0 is spectrally normed: two calls, two power iterations
-    jobs = [(lambda i=i, d=d: _pair(d, 's', ins[i][0], ins[i][1], i != 0, want_fmap)) for i, d in enumerate(msd.discriminators)]
+    bank, index = _bank_of(msd, 's')
+    if bank:
+        bank.prepare()
+    jobs = [(lambda i=i, d=d: _pair(d, 's', ins[i][0], ins[i][1], i != 0, want_fmap, bank, index)) for i, d in enumerate(msd.discriminators)]
     for r in fan_out(jobs, y.device, inputs=[t for pair in ins for t in pair], tag='msd'):
         for acc, v in zip(res, (r[0], r[2], r[1], r[3])):
             acc.append(v)

@@ -279,6 +279,9 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
     rng = rng or random
     dev = model.get_device()
     lang = model._languasito
+    if dev.type == 'cuda':
+        from ..hifigan.wbank import AmaxPool
+        AmaxPool.of(dev).reset()       # the convolution launches' range words of this step: one zeroing launch for all of them
     # The text side (phoneme stack `t`, duration / pitch recurrences, their losses, backward pass and optimizer: opt_t) shares nothing but
     # inputs with the rest of the step, and it is a chain of latency-bound recurrences on a few dozen CUs.  It runs whole — forward, backward,
     # exchange, AdamW — on a stream of its own, under the discriminator / generator work (reference order: last, cubegan.py:172-180; the
