@@ -243,6 +243,12 @@ size_t ttsc_conv_wgrad_split_workspace_bytes(int32_t N, int32_t A, int32_t B, in
 int ttsc_conv_wgrad_split(const float* p_dev, const float* q_dev, float* g_dev, int32_t N, int32_t A, int32_t B, int64_t LP, int64_t LQ, int32_t J,
                           int32_t base, int32_t step, float q_scale, float q_slope, float* amax_q_dev, float* amax_p_dev, int32_t measure, void* ws_dev,
                           size_t ws_bytes, void* stream);
+/* The same call that also leaves the layer's bias gradient db[a] = sum_{n,t} p[n,a,t] in db_dev [A] (NULL = plain ttsc_conv_wgrad_split): its
+ * slices are summed by surplus workgroups of the first weight-gradient launch and added in index order by surplus workgroups of the reduction —
+ * the bits of ttsc_bias_grad, no launch of its own (same workspace size). */
+int ttsc_conv_wgrad_split_bias(const float* p_dev, const float* q_dev, float* g_dev, float* db_dev, int32_t N, int32_t A, int32_t B, int64_t LP, int64_t LQ,
+                               int32_t J, int32_t base, int32_t step, float q_scale, float q_slope, float* amax_q_dev, float* amax_p_dev, int32_t measure,
+                               void* ws_dev, size_t ws_bytes, void* stream);
 
 /* Split-precision convolution of the training step (csrc/conv_train.hip): forward and data gradient of a dense, stride-1, dilated Conv1d
  * of the generator [EXTERNAL hifigan/models.py; trained by cube/networks/cubegan.py:131-170] and of the MPD / MSD discriminators
@@ -267,12 +273,14 @@ int ttsc_conv_train(const float* x_dev, const float* w_dev, const float* bias_de
 
 /* The same convolution on weight fragments prepared by a weight bank (below): no weight reduction, no packing launch, no workspace.
  * wfrag_dev / amax_w_dev: the bank entry's `pack_fwd` (forward) or `pack_dgrad` (data gradient: pass the differentiated layer's Cout as Cin and
- * vice versa, as for flip = 1) and its `amax` word.  `measure` bit 0 = reduce max |x| into *amax_x_dev now; bit 2 = the caller zeroed that word
- * (words handed out from a pool zeroed once per step: no memset launch). */
+ * vice versa, as for flip = 1) and its `amax` word.  `measure` bit 0 = reduce max |x| into *amax_x_dev now (clear: the word already holds it — e.g.
+ * the `amax_y_dev` word of the launch that produced x); bit 2 = the caller zeroed that word (words handed out from a pool zeroed once per step: no
+ * memset launch).  amax_y_dev (or NULL): a ZEROED word that receives max |y| over the stored elements from the convolution's own epilogue, so that
+ * the launches that read y next (the following layer, the preceding layer's data gradient, the weight gradient) need no reduction launch over it. */
 int ttsc_conv_train_packed(const float* x_dev, const void* wfrag_dev, const float* bias_dev, const float* resid_dev, const float* gate_dev, float* y_dev,
                            int32_t B, int32_t Cin, int32_t Cout, int32_t K, int64_t Lin, int32_t padding, int32_t dilation, int32_t groups,
                            float in_scale, float in_slope, float out_scale, float gate_slope, float* amax_x_dev, const float* amax_w_dev,
-                           int32_t measure, void* stream);
+                           int32_t measure, float* amax_y_dev, void* stream);
 
 /* Weight bank: the per-step weight preparation of ALL convolutions of one module in three launches (csrc/conv_train.hip) — what the reference
  * leaves to torch.nn.utils.weight_norm's pre-forward hooks and to the cuDNN / MIOpen filter transforms inside every nn.Conv1d / nn.Conv2d call of

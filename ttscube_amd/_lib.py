@@ -122,6 +122,9 @@ SIGNATURES = {
     'ttsc_conv_wgrad_split': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
                                         C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t,
                                         C.c_void_p]),
+    'ttsc_conv_wgrad_split_bias': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
+                                             C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t,
+                                             C.c_void_p]),
     'ttsc_deinterleave_x': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_void_p]),
     'ttsc_deinterleave_w': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
@@ -132,7 +135,7 @@ SIGNATURES = {
                                   C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     'ttsc_conv_train_packed': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
-                                         C.c_int32, C.c_void_p]),
+                                         C.c_int32, C.c_void_p, C.c_void_p]),
     'ttsc_wbank_create': (C.c_int, [C.POINTER(WBankEntry), C.c_int32, C.POINTER(C.c_void_p)]),
     'ttsc_wbank_prepare': (C.c_int, [C.c_void_p, C.c_void_p]),
     'ttsc_wbank_destroy': (None, [C.c_void_p]),

@@ -1551,6 +1551,7 @@ extern "C" int ttsc_conv1d_forward_pitched(const ttsc_conv1d* c, const float* x,
         a.swz_nx = a.swz_ny = 0;
         a.fold_S = a.fold_B = 0;
         a.amax_x = a.amax_w = nullptr;
+        a.amax_out = nullptr;
 #ifdef TTSC_ABLATE
         if (const char* ev = getenv("TTSC_CONV_DBG")) a.dbg = atoi(ev);
         a.prof = nullptr;

@@ -79,6 +79,10 @@ struct ConvArgs {
     int fold_S, fold_B;
     const float* amax_x;
     const float* amax_w;
+    //   * `amax_out` (or null): the launch ALSO leaves max |y| over the elements it stores in this word (atomic max on the bit pattern; the word is
+    //     zero before the launch) — the next launch that reads y (the following layer's forward, the preceding layer's data gradient, the weight
+    //     gradient) takes its range from it instead of running a reduction launch over y (round 6: 445 amax2_kernel launches per Cubegan step).
+    unsigned* amax_out;
 };
 
 // power of two that moves a magnitude m = f * 2^e (f in [0.5, 1)) to [2^(target-1), 2^target); 1 for zero, subnormal and non-finite m
@@ -107,7 +111,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // serialises 16 dependent round trips per tile.  Each lane only reads the addresses it writes, so this is safe.
 // C/D layout of v_mfma_*_32x32: column (time) = lane & 31, row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 __device__ __forceinline__ void epilogue_tile(const f32x16& acc, const ConvArgs& a, int b, int co_base, long o, bool qok,
-                                              int half, float acc_scale) {
+                                              int half, float acc_scale, float* amax_acc = nullptr) {
     // NOTE: the optional operands are tested once per row group (wave-uniform branches around straight-line load
     // groups).  A per-element `ptr ? ptr[i] : 0` makes hipcc branch around every single load and wait for each one in turn.
     // The tile is processed as four groups of four rows (= the four 8-channel items a lane contributes to): all loads
@@ -164,7 +168,10 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& acc, const ConvArgs&
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int co = co_base + 8 * g + 4 * half + e;
-            if (qok && co < a.Cout) a.y[idx[e]] = res[e];
+            if (qok && co < a.Cout) {
+                a.y[idx[e]] = res[e];
+                if (amax_acc) *amax_acc = fmaxf(*amax_acc, fabsf(res[e]));   // (fmaxf drops NaN, as amax2_kernel does)
+            }
         }
     }
 }
@@ -624,6 +631,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
         if (acc[0][0][0] == 12345.678f) a.y[0] = 1.f;  // keep the accumulators alive
         return;
     }
+    float ymax = 0.f;                                  // FOLD: max |y| over this lane's stored elements (ConvArgs::amax_out)
+    float* const ymax_p = (FOLD && a.amax_out) ? &ymax : nullptr;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -631,7 +640,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
             const int q = q0 + wn * (NJ * 32) + n * 32 + l31;
             if (FOLD) {   // column of the folded sequence -> (sequence, position)
                 const int sq = q / a.fold_S, pp = q - sq * a.fold_S;
-                epilogue_tile(acc[i][n], a, sq < a.fold_B ? sq : 0, (cot0 + i) * 32, (long)pp, sq < a.fold_B && pp < a.Lout, half, w_unscale);
+                epilogue_tile(acc[i][n], a, sq < a.fold_B ? sq : 0, (cot0 + i) * 32, (long)pp, sq < a.fold_B && pp < a.Lout, half, w_unscale, ymax_p);
                 continue;
             }
             if (acc_init) {   // everything but the weight scale is in the sum already
@@ -658,6 +667,20 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs a) {
                 ok = (q < q_hi) && (oo >= 0) && (oo < a.Lout) && (r < a.out_stride);
             }
             epilogue_tile(acc[i][n], a, b, cb, oo, ok, half, w_unscale);
+        }
+    }
+    if constexpr (FOLD) {
+        if (a.amax_out) {   // one atomic per workgroup, and only when it can still raise the word (most workgroups find it raised already)
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, off));
+            float* red = reinterpret_cast<float*>(smem_raw);
+            __syncthreads();   // the last chunk's fragment reads are done
+            if (lane == 0) red[wn] = ymax;
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned bits = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+                if (bits > __hip_atomic_load(a.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.amax_out, bits);
+            }
         }
     }
 }

@@ -175,7 +175,7 @@ extern "C" size_t ttsc_conv_train_workspace_bytes(int32_t Cin, int32_t Cout, int
 static int conv_train_impl(const float* x, const float* w, const _Float16* prepacked, const float* bias, const float* resid, const float* gate, float* y,
                            int32_t B, int32_t Cin, int32_t Cout, int32_t K, int64_t Lin, int32_t padding, int32_t dilation, int32_t groups, int32_t flip,
                            float in_scale, float in_slope, float out_scale, float gate_slope, float* amax_x, float* amax_w, int32_t measure, void* ws,
-                           size_t ws_bytes, void* stream) {
+                           size_t ws_bytes, void* stream, float* amax_y = nullptr) {
     TTSC_REQUIRE(x && (w || prepacked) && y && (ws || prepacked), "ttsc_conv_train: null argument");
     TTSC_REQUIRE(ttsc_conv_train_supported(Cin, Cout, K, dilation, groups), "ttsc_conv_train: shape not supported (Cin %d, Cout %d, K %d, dilation %d, groups %d)",
                  Cin, Cout, K, dilation, groups);
@@ -255,6 +255,7 @@ static int conv_train_impl(const float* x, const float* w, const _Float16* prepa
     a.fold_B = B;
     a.amax_x = amax_x;
     a.amax_w = amax_w;
+    a.amax_out = reinterpret_cast<unsigned*>(amax_y);
     a.q_cnt = (int)(S * B);
     // column tile: 256 wide when that still gives every CU two workgroups, else 128 (and 128 when 21+ taps of weights share the LDS)
     const long cols = S * B;
@@ -291,10 +292,10 @@ extern "C" int ttsc_conv_train(const float* x, const float* w, const float* bias
 extern "C" int ttsc_conv_train_packed(const float* x, const void* wfrag, const float* bias, const float* resid, const float* gate, float* y, int32_t B,
                                       int32_t Cin, int32_t Cout, int32_t K, int64_t Lin, int32_t padding, int32_t dilation, int32_t groups,
                                       float in_scale, float in_slope, float out_scale, float gate_slope, float* amax_x, const float* amax_w,
-                                      int32_t measure, void* stream) {
+                                      int32_t measure, float* amax_y, void* stream) {
     TTSC_REQUIRE(wfrag && amax_x && amax_w, "ttsc_conv_train_packed: null argument");
     return conv_train_impl(x, nullptr, reinterpret_cast<const _Float16*>(wfrag), bias, resid, gate, y, B, Cin, Cout, K, Lin, padding, dilation, groups, 0,
-                           in_scale, in_slope, out_scale, gate_slope, amax_x, const_cast<float*>(amax_w), measure & 5, nullptr, 0, stream);
+                           in_scale, in_slope, out_scale, gate_slope, amax_x, const_cast<float*>(amax_w), measure & 5, nullptr, 0, stream, amax_y);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------

@@ -166,8 +166,19 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgArgs a) {
 
 // G[a][b][j] = sum over splits of part[sp][j][a][b]   (fixed order).  Block = 32 consecutive elements x 8 split lanes: lane q adds
 // the splits q, q+8, ... with four loads in flight, then the 8 lanes are added in index order through LDS.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ G, int splits, int J, long AB) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ G, int splits, int J, long AB,
+                                                           const float* __restrict__ bias_part = nullptr, float* __restrict__ db = nullptr, int A = 0,
+                                                           int bias_S = 0, unsigned bias_b0 = 0) {
     __shared__ float red[8][32];
+    if (bias_part && blockIdx.x >= bias_b0) {   // surplus workgroups: db[c] = the bias_S slices of row c in index order (bias_grad_kernel's second stage)
+        const int c = (int)(blockIdx.x - bias_b0) * 256 + threadIdx.x;
+        if (c < A) {
+            float tot = 0.f;
+            for (int k = 0; k < bias_S; ++k) tot += bias_part[(size_t)c * bias_S + k];
+            db[c] = tot;
+        }
+        return;
+    }
     const long total = (long)J * AB;
     const int ex = threadIdx.x & 31, q = threadIdx.x >> 5;
     const long i = (long)blockIdx.x * 32 + ex;
@@ -230,6 +241,11 @@ struct WgsArgs {
     float q_scale, q_slope;
     int chunks, CH, items;   // 64-position chunks per batch item; work items (batch item, chunk) per workgroup; N * chunks
     int minoff, span;
+    // bias gradient riding along (round 6): the workgroups with blockIdx.y >= bias_y0 are not tiles of the weight gradient — workgroup
+    // k = (blockIdx.y - bias_y0) * gridDim.x + blockIdx.x < A * bias_S sums slice k % bias_S of row k / bias_S of P over all batch items into
+    // bias_part[row][slice] (train_ops.hip::bias_grad_kernel's first stage, same order, same bits); wgrad_reduce_kernel's surplus workgroups add the slices.
+    float* bias_part;
+    int bias_y0, bias_S;
 };
 constexpr int WS_PP = 72, WS_QP = 136;   // row pitches in halves: 144 / 272 bytes = 16 mod 128 (eight rows cover all banks), 16-byte multiples
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -245,6 +261,36 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(WgsArgs a) {
     _Float16* Qh = Pl + 128 * WS_PP;                     // [64][WS_QP]
     _Float16* Ql = Qh + 64 * WS_QP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    if (a.bias_part && (int)blockIdx.y >= a.bias_y0) {   // bias-gradient slice (see WgsArgs::bias_part)
+        const long k = (long)((int)blockIdx.y - a.bias_y0) * gridDim.x + blockIdx.x;
+        if (k >= (long)a.A * a.bias_S) return;
+        const int c = (int)(k / a.bias_S), sl = (int)(k - (long)c * a.bias_S);
+        const int per = (a.LP + a.bias_S - 1) / a.bias_S;
+        const int t0 = sl * per, t1 = min(t0 + per, a.LP);
+        const int w = t1 - t0, n = a.N * w;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        auto at = [&](int i) {
+            const int b = i / w, t = t0 + (i - b * w);
+            return a.P[((size_t)b * a.A + c) * a.LP + t];
+        };
+        int i = tid;
+        for (; i + 768 < n; i += 1024) {
+            const float v0 = at(i), v1 = at(i + 256), v2 = at(i + 512), v3 = at(i + 768);
+            s0 += v0;
+            s1 += v1;
+            s2 += v2;
+            s3 += v3;
+        }
+        for (; i < n; i += 256) s0 += at(i);
+        float v = (s0 + s1) + (s2 + s3);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        float* red = reinterpret_cast<float*>(smraw);
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        if (tid == 0) a.bias_part[(size_t)c * a.bias_S + sl] = (((0.f + red[0]) + red[1]) + red[2]) + red[3];
+        return;
+    }
     const int tb_n = (a.Bc + 63) >> 6;
     const int a0 = (blockIdx.y / tb_n) * 128, b0 = (blockIdx.y % tb_n) * 64;
     const int it_beg = blockIdx.x * a.CH, it_end = min(it_beg + a.CH, a.items);
@@ -365,7 +411,8 @@ static int launch_wgrad_split(const WgsArgs& a, int splits, hipStream_t s) {
     const int tiles = ((a.A + 127) / 128) * ((a.Bc + 63) / 64);
     const size_t lds = (size_t)(2 * 128 * WS_PP + 2 * 64 * WS_QP) * sizeof(_Float16);
     if (int rc = ensure_full_lds(reinterpret_cast<const void*>(wgrad_f16x3_kernel<JT>))) return rc;
-    hipLaunchKernelGGL(wgrad_f16x3_kernel<JT>, dim3(splits, tiles), dim3(256), lds, s, a);
+    const int extra = a.bias_part ? (int)(((long)a.A * a.bias_S + splits - 1) / splits) : 0;   // rows of bias-gradient workgroups behind the tiles
+    hipLaunchKernelGGL(wgrad_f16x3_kernel<JT>, dim3(splits, tiles + extra), dim3(256), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("wgrad_f16x3_kernel launch failed: %s", hipGetErrorString(e));
@@ -488,16 +535,31 @@ extern "C" int32_t ttsc_conv_wgrad_split_supported(int32_t A, int32_t Bc, int32_
     return A >= 64 && Bc >= 32 && J >= 1 && J <= 16 && st >= 1 && st <= 64;
 }
 
+// slices per row of the bias gradient that rides along: train_ops.hip::bias_grad_splits (>= 1024 positions of every batch item per workgroup, ~1024 in all)
+static int wgrad_bias_slices(int32_t A, int64_t LP) {
+    long s = (LP + 1023) / 1024;
+    const long cap = (1024 + A - 1) / A;
+    if (s > cap) s = cap;
+    return (int)(s < 1 ? 1 : s);
+}
+
 extern "C" size_t ttsc_conv_wgrad_split_workspace_bytes(int32_t N, int32_t A, int32_t Bc, int64_t LP, int32_t J) {
     if (N <= 0 || A <= 0 || Bc <= 0 || LP <= 0 || J <= 0) return 0;
     int chunks, CH, items, splits;
     wgrad_split_plan(N, A, Bc, LP, &chunks, &CH, &items, &splits);
-    return 256 + (size_t)splits * J * A * Bc * sizeof(float);
+    return 256 + (size_t)splits * J * A * Bc * sizeof(float) + (size_t)A * wgrad_bias_slices(A, LP) * sizeof(float);
 }
 
 extern "C" int ttsc_conv_wgrad_split(const float* p_dev, const float* q_dev, float* g_dev, int32_t N, int32_t A, int32_t Bc, int64_t LP, int64_t LQ,
                                      int32_t J, int32_t base, int32_t step, float q_scale, float q_slope, float* amax_q, float* amax_p, int32_t measure, void* ws_dev,
                                      size_t ws_bytes, void* stream) {
+    return ttsc_conv_wgrad_split_bias(p_dev, q_dev, g_dev, nullptr, N, A, Bc, LP, LQ, J, base, step, q_scale, q_slope, amax_q, amax_p, measure, ws_dev, ws_bytes,
+                                      stream);
+}
+
+extern "C" int ttsc_conv_wgrad_split_bias(const float* p_dev, const float* q_dev, float* g_dev, float* db_dev, int32_t N, int32_t A, int32_t Bc, int64_t LP,
+                                          int64_t LQ, int32_t J, int32_t base, int32_t step, float q_scale, float q_slope, float* amax_q, float* amax_p,
+                                          int32_t measure, void* ws_dev, size_t ws_bytes, void* stream) {
     TTSC_REQUIRE(p_dev && q_dev && g_dev && ws_dev, "ttsc_conv_wgrad_split: null argument");
     TTSC_REQUIRE(N > 0 && LP > 0 && LQ > 0 && ttsc_conv_wgrad_split_supported(A, Bc, J, step), "ttsc_conv_wgrad_split: shape not supported (N=%d A=%d B=%d J=%d step=%d)",
                  N, A, Bc, J, step);
@@ -529,6 +591,13 @@ extern "C" int ttsc_conv_wgrad_split(const float* p_dev, const float* q_dev, flo
     a.q_slope = q_slope;
     int splits;
     wgrad_split_plan(N, A, Bc, LP, &a.chunks, &a.CH, &a.items, &splits);
+    // the layer's bias gradient db[a] = sum_{n,t} P[n,a,t] in the same two launches (its slices behind the tiles of the first tap group, their sum
+    // behind the reduction): 146 launches of a Cubegan step that were a bias_grad_kernel each (profiles/r06_train_wbank_kernel_stats.csv)
+    const int bias_S = wgrad_bias_slices(A, LP);
+    float* bias_part = a.part + (size_t)splits * J * A * Bc;
+    a.bias_part = db_dev ? bias_part : nullptr;
+    a.bias_S = bias_S;
+    a.bias_y0 = ((A + 127) / 128) * ((Bc + 63) / 64);
     const int st = step < 0 ? -step : step;
     const int jt_max = std::min(5, 64 / st + 1);   // taps per launch: five accumulator pairs, and a Q window of at most 64 extra positions
     for (int j0 = 0; j0 < J;) {
@@ -547,11 +616,14 @@ extern "C" int ttsc_conv_wgrad_split(const float* p_dev, const float* q_dev, flo
         }
         if (rc) return rc;
         j0 += jt;
+        a.bias_part = nullptr;   // (the first tap group's launch carried the slices)
     }
     const long AB = (long)A * Bc;
     const long blocks = (AB * J + 31) / 32;
-    TTSC_REQUIRE(blocks < (1l << 31), "ttsc_conv_wgrad_split: weight tensor too large");
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)a.part, g_dev, splits, (int)J, AB);
+    TTSC_REQUIRE(blocks < (1l << 31) - 4096, "ttsc_conv_wgrad_split: weight tensor too large");
+    const unsigned bias_blocks = db_dev ? (unsigned)((A + 255) / 256) : 0u;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks + bias_blocks), dim3(256), 0, s, (const float*)a.part, g_dev, splits, (int)J, AB,
+                       db_dev ? (const float*)bias_part : nullptr, db_dev, (int)A, bias_S, (unsigned)blocks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("wgrad_reduce_kernel launch failed: %s", hipGetErrorString(e));

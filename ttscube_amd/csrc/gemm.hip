@@ -512,9 +512,11 @@ extern "C" int ttsc_linear_forward_split(const float* x_dev, const float* w_dev,
 
 static int gemm_splits(int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = ceil_div(M, GM) * ceil_div(N, GN);
-    if (tiles >= 256 || K < 4096) return 1;
+    // (round 6: the text side's weight gradients at b = 16 are 1024 x 256 tiles over K = B x T = 3 840 rows — 16 workgroups walking the whole
+    // contraction took 1.0-1.7 ms each, 8 ms of a 79 ms Cubegan step, profiles/r06_train_timeline_b16_start.txt; the threshold was K >= 4096)
+    if (tiles >= 256 || K < 1024) return 1;
     int64_t s = ceil_div(768, tiles);                       // ~3 workgroups per CU
-    const int64_t smax = ceil_div(K, 512);                  // at least 512 rows of K per split
+    const int64_t smax = ceil_div(K, 256);                  // at least 256 rows of K per split
     s = s < smax ? s : smax;
     return (int)(s < 1 ? 1 : (s > 512 ? 512 : s));
 }
@@ -565,7 +567,7 @@ extern "C" int ttsc_gemm(int32_t transA, int32_t transB, int64_t M, int64_t N, i
     return TTSC_OK;
 }
 
-static int colsum_parts(int64_t R) { return (int)(R >= 4096 ? (ceil_div(R, 1024) > 256 ? 256 : ceil_div(R, 1024)) : 1); }
+static int colsum_parts(int64_t R) { return (int)(R >= 1024 ? (ceil_div(R, 256) > 256 ? 256 : ceil_div(R, 256)) : 1); }
 
 extern "C" size_t ttsc_colsum_workspace_bytes(int64_t R, int64_t Cn) { return R > 0 && Cn > 0 ? (size_t)colsum_parts(R) * Cn * sizeof(float) : 0; }
 

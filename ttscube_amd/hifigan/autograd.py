@@ -118,9 +118,11 @@ def _bias_grad(tc, dy):
     return db
 
 
-def _wgrad(P, Q, A, Bc, J, base, step, q_scale, q_slope, groups=1, amax=None, p_measured=False, pooled=False):
+def _wgrad(P, Q, A, Bc, J, base, step, q_scale, q_slope, groups=1, amax=None, p_measured=False, pooled=False, amax_q=None, amax_p=None, db=None):
     """G [A, Bc / groups, J]: weight gradient of a (grouped) Conv1d, torch layout.  amax: the layer's range words [max |Q|, max |w|, max |P|] from
-    the forward launch (max |Q| valid; max |P| valid when `p_measured`), None = measured here"""
+    the forward launch (max |Q| valid; max |P| valid when `p_measured`), None = measured here.  amax_q / amax_p: the two words as separate
+    one-element tensors instead (banked layers: they may belong to the launches that PRODUCED Q and P).  db: a list; when the split-precision
+    kernel takes the layer, the bias gradient sum_{n,t} P[n,a,t] rides in its two launches and is appended to it (else the list stays empty)"""
     Bg = Bc // groups
     G = torch.empty((A, Bg, J), dtype=torch.float32, device=P.device)
     N, _, LP = P.shape
@@ -130,11 +132,19 @@ def _wgrad(P, Q, A, Bc, J, base, step, q_scale, q_slope, groups=1, amax=None, p_
         nbytes = int(L.ttsc_conv_wgrad_split_workspace_bytes(N, A, Bc, LP, J))
         ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=P.device)
         with _lib.on_device(P.device):
-            aq = _lib.dev_ptr(amax[0:1]) if amax is not None else None
-            ap = _lib.dev_ptr(amax[2:3]) if amax is not None else None
-            _lib.check(L.ttsc_conv_wgrad_split(_lib.dev_ptr(P), _lib.dev_ptr(Q), _lib.dev_ptr(G), N, A, Bc, LP, LQ, J, base, step, q_scale, q_slope,
-                                               aq, ap, 0 if amax is None else ((0 if p_measured else 2) | (4 if pooled else 0)), _lib.dev_ptr(ws), nbytes,
-                                               _lib.current_stream()), 'ttsc_conv_wgrad_split')
+            if amax_q is not None:
+                aq, ap, have = _lib.dev_ptr(amax_q), _lib.dev_ptr(amax_p), True
+            else:
+                aq = _lib.dev_ptr(amax[0:1]) if amax is not None else None
+                ap = _lib.dev_ptr(amax[2:3]) if amax is not None else None
+                have = amax is not None
+            dbt = torch.empty(A, dtype=torch.float32, device=P.device) if db is not None else None
+            _lib.check(L.ttsc_conv_wgrad_split_bias(_lib.dev_ptr(P), _lib.dev_ptr(Q), _lib.dev_ptr(G), _lib.dev_ptr(dbt) if dbt is not None else None,
+                                                    N, A, Bc, LP, LQ, J, base, step, q_scale, q_slope, aq, ap,
+                                                    0 if not have else ((0 if p_measured else 2) | (4 if pooled else 0)), _lib.dev_ptr(ws), nbytes,
+                                                    _lib.current_stream()), 'ttsc_conv_wgrad_split')
+            if dbt is not None:
+                db.append(dbt)
         return G
     nbytes = int(L.ttsc_conv_wgrad_workspace_bytes(N, A, Bg, LP, J))
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=P.device)
@@ -172,9 +182,10 @@ def _conv_split(x, w, b, resid, gate, Cin, Cout, K, padding, dilation, flip, in_
 
 
 def _conv_packed(x, frag, amax_w, b, resid, gate, Cin, Cout, K, padding, dilation, amax_x, measure, in_scale=1.0, in_slope=1.0, out_scale=1.0,
-                 gate_slope=1.0, groups=1):
-    """ttsc_conv_train_packed: the same convolution on fragments a WeightBank prepared (wbank.py) — the range reduction of x and the convolution,
-    nothing else.  measure: bit 0 = reduce max |x| into amax_x now, bit 2 = amax_x is a pre-zeroed pooled word"""
+                 gate_slope=1.0, groups=1, amax_y=None):
+    """ttsc_conv_train_packed: the same convolution on fragments a WeightBank prepared (wbank.py) — the range reduction of x (unless amax_x already
+    holds it) and the convolution, nothing else.  measure: bit 0 = reduce max |x| into amax_x now, bit 2 = amax_x is a pre-zeroed pooled word;
+    amax_y: zeroed word that receives max |y| from the convolution's epilogue"""
     L = _lib.lib()
     B, _, Lin = x.shape
     Lout = Lin + 2 * padding - dilation * (K - 1)
@@ -183,7 +194,7 @@ def _conv_packed(x, frag, amax_w, b, resid, gate, Cin, Cout, K, padding, dilatio
     with _lib.on_device(x.device):
         _lib.check(L.ttsc_conv_train_packed(ptr(x), ptr(frag), ptr(b), ptr(resid), ptr(gate), ptr(y), B, Cin, Cout, K, Lin, padding, dilation, groups,
                                             float(in_scale), float(in_slope), float(out_scale), float(gate_slope), ptr(amax_x), ptr(amax_w), int(measure),
-                                            _lib.current_stream()), 'ttsc_conv_train_packed')
+                                            ptr(amax_y), _lib.current_stream()), 'ttsc_conv_train_packed')
     return y
 
 
@@ -194,17 +205,18 @@ class HipConvFn(torch.autograd.Function):
     """y = conv(leaky_relu(in_scale * x, in_slope); w) + b [+ resid]  with HIP forward / dgrad / wgrad."""
 
     @staticmethod
-    def forward(ctx, x, w, b, resid, tc, in_scale, in_slope, pack=None):
+    def forward(ctx, x, w, b, resid, tc, in_scale, in_slope, pack=None, words=None, amax_in=None):
         x = x.contiguous()
         ctx.pack = pack
         if pack is not None:
-            # weight fragments of both orders and max |w| prepared for the whole module by a WeightBank; the range words of x and dy come from the
-            # step's pre-zeroed pool (one memset per step instead of one per launch)
-            from .wbank import AmaxPool
-            ctx.amax = AmaxPool.of(x.device).take()
+            # weight fragments of both orders and max |w| prepared for the whole module by a WeightBank; the range words come from the step's
+            # pre-zeroed pool (one memset per step instead of one per launch): max |x| from the launch that produced x when it left one (amax_in),
+            # else reduced here into words[0]; this launch leaves max |y| in words[1] for whoever reads y next
+            ctx.words = words
+            ctx.amax_x = amax_in if amax_in is not None else words[0:1]
             y = _conv_packed(x, pack[0], pack[2], b.detach().contiguous() if b is not None else None, resid.contiguous() if resid is not None else None,
-                             None, tc.Cin, tc.Cout, tc.K, tc.padding, tc.dilation, ctx.amax[0:1], 5, in_scale=in_scale, in_slope=in_slope,
-                             groups=tc.groups)
+                             None, tc.Cin, tc.Cout, tc.K, tc.padding, tc.dilation, ctx.amax_x, 4 if amax_in is not None else 5, in_scale=in_scale,
+                             in_slope=in_slope, groups=tc.groups, amax_y=words[1:2])
             ctx.save_for_backward(x)
             ctx.tc, ctx.in_scale, ctx.in_slope = tc, in_scale, in_slope
             ctx.has_b, ctx.has_r = b is not None, resid is not None
@@ -231,21 +243,31 @@ class HipConvFn(torch.autograd.Function):
         tc, sc, sl = ctx.tc, ctx.in_scale, ctx.in_slope
         dy = dy.contiguous()
         if ctx.pack is not None:
+            from .wbank import AmaxPool, range_of, tag_range
             (x,) = ctx.saved_tensors
             dx = dw = db = None
-            am = ctx.amax
-            dy_measured = False
+            words = ctx.words
+            # max |dy|: left by the launch that produced dy (the next layer's data gradient) unless autograd has added another gradient into it since
+            adv = range_of(dy)
+            ap = adv if adv is not None else words[2:3]
+            dy_measured = adv is not None
             if ctx.needs_input_grad[0]:
                 pd = tc.dilation * (tc.K - 1) - tc.padding
-                dx = _conv_packed(dy, ctx.pack[1], ctx.pack[2], None, None, x if sl != 1.0 else None, tc.Cout, tc.Cin, tc.K, pd, tc.dilation, am[2:3], 5,
-                                  out_scale=sc, gate_slope=sl, groups=tc.groups)
+                dx = _conv_packed(dy, ctx.pack[1], ctx.pack[2], None, None, x if sl != 1.0 else None, tc.Cout, tc.Cin, tc.K, pd, tc.dilation, ap,
+                                  4 if dy_measured else 5, out_scale=sc, gate_slope=sl, groups=tc.groups, amax_y=words[3:4])
+                tag_range(dx, words[3:4], AmaxPool.of(dx.device))
                 dy_measured = True
+            want_db = ctx.has_b and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:
-                dw = _wgrad(dy, x, tc.Cout, tc.Cin, tc.K, -tc.padding, tc.dilation, sc, sl, tc.groups, amax=am, p_measured=dy_measured, pooled=True)
-            if ctx.has_b and ctx.needs_input_grad[2]:
+                dbl = [] if want_db else None
+                dw = _wgrad(dy, x, tc.Cout, tc.Cin, tc.K, -tc.padding, tc.dilation, sc, sl, tc.groups, p_measured=dy_measured, pooled=True,
+                            amax_q=ctx.amax_x, amax_p=ap, db=dbl)
+                if dbl:
+                    db = dbl[0]
+            if want_db and db is None:
                 db = _bias_grad(tc, dy)
             dr = dy if (ctx.has_r and ctx.needs_input_grad[3]) else None
-            return dx, dw, db, dr, None, None, None, None
+            return dx, dw, db, dr, None, None, None, None, None, None
         x, w = ctx.saved_tensors
         B, _, Lin = x.shape
         dx = dw = db = None
@@ -284,15 +306,21 @@ class HipConvFn(torch.autograd.Function):
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = _bias_grad(tc, dy)
         dr = dy if (ctx.has_r and ctx.needs_input_grad[3]) else None
-        return dx, dw, db, dr, None, None, None, None
+        return dx, dw, db, dr, None, None, None, None, None, None
 
 
 def hip_conv(tc, x, w, b=None, resid=None, in_scale=1.0, in_slope=1.0):
     """w from WeightBank.weight(i) carries the prepared fragments (`_ttsc_pack`); any other weight tensor is prepared per launch"""
     pack = getattr(w, '_ttsc_pack', None)
-    if pack is not None and not (SPLIT_TRAIN and not tc.transposed and tc.stride == 1):
+    if pack is None:
+        return HipConvFn.apply(x, w, b, resid, tc, float(in_scale), float(in_slope), None, None, None)
+    if not (SPLIT_TRAIN and not tc.transposed and tc.stride == 1):
         raise _lib.TTSCError('hip_conv: a banked weight needs the split-precision stride-1 path')
-    return HipConvFn.apply(x, w, b, resid, tc, float(in_scale), float(in_slope), pack)
+    from .wbank import AmaxPool, range_of, tag_range
+    pool = AmaxPool.of(x.device)
+    words = pool.take()
+    y = HipConvFn.apply(x, w, b, resid, tc, float(in_scale), float(in_slope), pack, words, range_of(x) if x.is_contiguous() else None)
+    return tag_range(y, words[1:2], pool)
 
 
 class HipWeightNormFn(torch.autograd.Function):

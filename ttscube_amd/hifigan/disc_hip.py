@@ -39,7 +39,7 @@ class _DeintX(torch.autograd.Function):
             _lib.check(_lib.lib().ttsc_deinterleave_x(_lib.dev_ptr(x), _lib.dev_ptr(out), N, C, LP // P, G, s, P, pad, M, 0, _lib.current_stream()),
                        'ttsc_deinterleave_x')
         ctx.meta = (N, C, LP, G, s, P, pad, M)
-        return out
+        return out      # (HipStridedConv passes x's range word on: a permutation with zero padding / a crop keeps the bound)
 
     @staticmethod
     def backward(ctx, g):
@@ -49,7 +49,8 @@ class _DeintX(torch.autograd.Function):
         with _lib.on_device(g.device):
             _lib.check(_lib.lib().ttsc_deinterleave_x(_lib.dev_ptr(g), _lib.dev_ptr(dx), N, C, LP // P, G, s, P, pad, M, 1, _lib.current_stream()),
                        'ttsc_deinterleave_x')
-        return dx, None, None, None, None, None
+        from .wbank import pass_range
+        return pass_range(g, dx), None, None, None, None, None
 
 
 class _DeintW(torch.autograd.Function):
@@ -99,7 +100,8 @@ class HipStridedConv:
         Lout = (L + 2 * self.p - K) // s + 1
         M = Lout + J - 1
         if banked:               # (the tap de-interleave of the weight is folded into the bank's fragment packing)
-            xr = _DeintX.apply(x, G, s, P, self.p, M)
+            from .wbank import pass_range
+            xr = pass_range(x, _DeintX.apply(x, G, s, P, self.p, M)) if x.is_contiguous() else _DeintX.apply(x, G, s, P, self.p, M)
             wp = w
         elif FUSED_DEINTERLEAVE:   # one gather per operand and direction (csrc/train_ops.hip)
             xr = _DeintX.apply(x, G, s, P, self.p, M)

@@ -143,15 +143,21 @@ class WeightBank:
 
 
 class AmaxPool:
-    """Range words for the convolution launches of a step, zeroed with ONE launch: `take()` hands out three fresh words ([max |x|, -, max |dy|] of
-    one convolution call); `reset()` (start of a step, on the main stream before any side stream forks) zeroes the pool and starts over.  A pool
-    that runs dry, or that nobody resets, falls back to a fresh zeroed tensor per call."""
+    """Range words for the convolution launches of a step, zeroed with ONE launch: `take()` hands out four fresh words of one convolution call —
+    [max |x| (when measured by this call), max |y| (left by the forward launch's epilogue), max |dy| (when measured), max |dx| (left by the
+    data-gradient launch)]; `reset()` (start of a step, on the main stream before any side stream forks) zeroes the pool and starts over.  A pool
+    that runs dry, or that nobody resets, falls back to a fresh zeroed tensor per call.
+
+    A tensor whose producing launch left its maximum in a word carries it as `_ttsc_amax` (`tag_range`); `range_of` hands the word to the next
+    launch that reads the tensor — unless the tensor was written since (autograd accumulates a second gradient INTO the first one in place: the
+    version counter moved) or the pool was reset (the word belongs to a later step now)."""
     _pools = {}
 
     def __init__(self, dev, slots=4096):
         self.buf = torch.zeros(slots * 4, dtype=torch.float32, device=dev)
         self.next = 0
         self.slots = slots
+        self.epoch = 0
 
     @classmethod
     def of(cls, dev):
@@ -165,6 +171,7 @@ class AmaxPool:
         if self.next:
             self.buf[:self.next * 4].zero_()
         self.next = 0
+        self.epoch += 1
 
     def take(self):
         if self.next >= self.slots:
@@ -172,3 +179,32 @@ class AmaxPool:
         i = self.next
         self.next += 1
         return self.buf[4 * i:4 * i + 4]
+
+
+PROPAGATE = __import__('os').environ.get('TTSC_TRAIN_AMAX_PROPAGATE', '1') != '0'   # (measurement switch: 0 = every launch reduces its input itself)
+
+
+def tag_range(t, word, pool):
+    """`t` was just produced by a launch that left max |t| in `word` (a one-element view of `pool`'s buffer, or of a fresh tensor)"""
+    if PROPAGATE:
+        t._ttsc_amax = (word, t._version, pool.epoch, pool)
+    return t
+
+
+def range_of(t):
+    """the word holding max |t| (an upper bound is enough), or None when nobody left one or it can no longer be trusted"""
+    a = getattr(t, '_ttsc_amax', None)
+    if a is None:
+        return None
+    word, version, epoch, pool = a
+    if t._version != version or pool.epoch != epoch:
+        return None
+    return word
+
+
+def pass_range(src, dst):
+    """dst holds a permutation / crop / zero-padding of src's elements (de-interleave, its adjoint): the same bound serves"""
+    a = getattr(src, '_ttsc_amax', None)
+    if a is not None and src._version == a[1] and a[3].epoch == a[2]:
+        dst._ttsc_amax = (a[0], dst._version, a[2], a[3])
+    return dst
