@@ -41,6 +41,26 @@ def measured_traffic(precision, B, T):
     return None
 
 
+PMC_CSV = os.path.join(ROOT, 'profiles', 'r05_bench_pmc.csv')            # per-kernel counter sums of the same command (3 forwards)
+UNFUSED_BYTES_PER_SAMPLE = (5.33 + 8 + 16 + 32) * 51 * 4                 # SURVEY.md §8d "unfused layer-boundary" model: 12.5 KB per output sample
+
+
+def measured_mfma_insts():
+    """SQ_INSTS_MFMA of ONE forward of the headline workload from the committed counter summary (all ttsc:: convolution kernels of
+    `bench.py --steps 1 --warmup 0`: 3 forwards, divided by 3; the register-only probe loop excluded), or None"""
+    try:
+        import csv
+        rows = [l for l in open(PMC_CSV) if not l.startswith('#')]
+        tot = 0.0
+        for r in csv.DictReader(rows):
+            if 'mfma_sustained_kernel' in r['kernel'] or not r.get('SQ_INSTS_MFMA'):
+                continue
+            tot += float(r['SQ_INSTS_MFMA'])
+        return tot / 3.0 if tot else None
+    except Exception:
+        return None
+
+
 def self_check(g, mel, out, h, sd, tol=1e-4):
     """Refuse to report a time for wrong results: the head of utterance 0 (30 frames = 7 200 samples, beyond the ~4.9 k-sample
     receptive field) must equal the oracle run on a 60-frame prefix within the parity gate (1e-4 RMS)."""
@@ -695,7 +715,15 @@ def main():
                          'mfma_executed_tflops': executed, 'mfma_dense_peak_tflops': PEAK_F16_MFMA_TFLOPS if precision == 'f16x3' else PEAK_FP32_MFMA_TFLOPS,
                          'x_fp32_mfma_peak': achieved / PEAK_FP32_MFMA_TFLOPS,
                          'hbm_compulsory_GBs': alg_bytes * args.steps / (dev_ms * 1e-3) / 1e9,
-                         'hbm_frac_compulsory': alg_bytes * args.steps / (dev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+                         'hbm_frac_compulsory': alg_bytes * args.steps / (dev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                         # how far the fusion goes: measured HBM bytes against the model in which every convolution reads its input (+ residual) and
+                         # writes its output through HBM (12.5 KB per output sample)
+                         'traffic_ratio_vs_unfused': (traffic / (UNFUSED_BYTES_PER_SAMPLE * B * Lout)) if traffic else None,
+                         # matrix instructions of one forward: what the arithmetic needs (3 split products per 32x32x16 tile step) and what the kernels
+                         # issue (halo recomputation, channel / column padding included; committed counter summary of this workload)
+                         'mfma_insts_per_forward': {'algorithmic': (3.0 if precision == 'f16x3' else 16.0) * flops_step / (2.0 * 32 * 32 * 16),
+                                                    'issued_pmc': measured_mfma_insts() if precision == 'f16x3' else None,
+                                                    'source': os.path.relpath(PMC_CSV, ROOT) + ' (SQ_INSTS_MFMA, builder-run rocprofv3 pass, NOT measured in this run)'}},
         }
         res['self_check_rms_vs_oracle'] = check_rms
         if precision == 'f16x3':

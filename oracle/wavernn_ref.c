@@ -10,8 +10,13 @@
  *   MOLOutput.sample          cube/networks/loss.py:163-201  (the default of WaveRNN, modules.py:398)
  *   GaussianOutput.sample     cube/networks/loss.py:50-52;   BetaOutput.sample loss.py:83-92
  *
- * Arithmetic contract (shared with the HIP kernel so that µ-law indices are bit-exact): every dot product
- * is ONE k-ordered fp32 fmaf chain seeded with the bias; sigmoid/tanh/log come from include/ttscube_math.h;
+ * Arithmetic contract (shared with the HIP kernel so that µ-law indices are bit-exact): every dot product of the GRU
+ * cells is ONE k-ordered fp32 fmaf chain seeded with the bias; the two output Linears (pre-output H -> 256, output
+ * 256 -> S) are FOUR k-ordered chains over consecutive quarters of the inputs — quarter q covers the 4-input blocks
+ * [q KB / 4, (q + 1) KB / 4) of the KB = K / 4 blocks, the first chain seeded with the bias, the others with 0 — added as
+ * ((p0 + p1) + p2) + p3 (round 6: the kernels run the four quarters side by side; the reference's own order is whatever
+ * MKL's sgemv does on the host, neither is "the" order — the reference-made goldens are the arbiter);
+ * sigmoid/tanh/log come from include/ttscube_math.h;
  * the categorical sample is the Gumbel-max  idx = argmax_s(logits_s + g_s)  (first maximum wins), which is
  * the reference's Categorical(logits).sample() == argmax_s softmax_s / E_s with g = -log E.
  * Pinned against the reference itself (imported, real torch RNG stream replayed) by
@@ -89,6 +94,20 @@ static void matvec_chain(const float* W, int ld, const float* x, int n, const fl
         out[r + 4] = a4, out[r + 5] = a5, out[r + 6] = a6, out[r + 7] = a7;
     }
     for (; r < rows; ++r) out[r] = dot_chain(W + (size_t)r * ld, x, n, bias[r]);
+}
+
+/* out[r] = ((p0 + p1) + p2) + p3, p_q = dot_chain over the q-th quarter of the inputs (blocks of 4), p0 seeded with bias[r]:
+ * the two output Linears (see the contract above).  n must be a multiple of 4. */
+static void matvec_chain4(const float* W, int ld, const float* x, int n, const float* bias, int rows, float* out) {
+    const int KB = n / 4;
+    int lo[5];
+    for (int q = 0; q <= 4; ++q) lo[q] = 4 * ((q * KB) / 4);
+    for (int r = 0; r < rows; ++r) {
+        const float* w = W + (size_t)r * ld;
+        float acc = dot_chain(w + lo[0], x + lo[0], lo[1] - lo[0], bias[r]);
+        for (int q = 1; q < 4; ++q) acc += dot_chain(w + lo[q], x + lo[q], lo[q + 1] - lo[q], 0.f);
+        out[r] = acc;
+    }
 }
 
 /* F.interpolate(x[B,1,Tl], 10*Tl, mode='linear') (align_corners=False), modules.py:353 */
@@ -210,9 +229,9 @@ int wr_decode_at(const wr_cfg* c, const wr_weights* w, const float* mel, const f
                 memcpy(x, hn, sizeof(float) * H);
                 in_l = H;
             }
-            matvec_chain(w->w_pre, H, x, H, w->b_pre, 256, pre);
+            matvec_chain4(w->w_pre, H, x, H, w->b_pre, 256, pre);
             for (int j = 0; j < 256; ++j) pre[j] = ttsc_tanhf(pre[j]);
-            matvec_chain(w->w_out, 256, pre, 256, w->b_out, S, logits);
+            matvec_chain4(w->w_out, 256, pre, 256, w->b_out, S, logits);
             if (out_logits) memcpy(out_logits + ((size_t)b * L + t) * S, logits, sizeof(float) * S);
             int best = 0;
             float wav;

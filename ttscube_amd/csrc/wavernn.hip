@@ -170,6 +170,22 @@ __device__ __forceinline__ void chain_matvec(float (&acc)[BT][NG], const float* 
     }
 }
 
+// The two output Linears (pre-output H -> 256, output 256 -> S): FOUR k-ordered chains over consecutive quarters of the inputs (in blocks of 4:
+// quarter q = blocks [q KB / 4, (q + 1) KB / 4)), the first seeded with the bias, added as ((p0 + p1) + p2) + p3 — the contract of
+// oracle/wavernn_ref.c::matvec_chain4, which the tile kernel (wavernn_tile.hip) evaluates with the four quarters on four waves.
+__device__ __forceinline__ float chain_matvec_quarters(const float* __restrict__ wp, int rows, int row, const float* v, int K, float bias) {
+    const int KB = K >> 2;
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int b0 = (q * KB) >> 2, b1 = ((q + 1) * KB) >> 2;
+        float acc[1][1] = {{q == 0 ? bias : 0.f}};
+        chain_matvec<1, 1, 4>(acc, wp + (size_t)b0 * rows * 4, rows, 0, row, v + 4 * b0, 0, 4 * (b1 - b0));
+        tot = q == 0 ? acc[0][0] : tot + acc[0][0];
+    }
+    return tot;
+}
+
 template <int BT>
 __global__ __launch_bounds__(WR_THREADS) void wr_decode_kernel(WrArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -318,9 +334,7 @@ __global__ __launch_bounds__(WR_THREADS) void wr_decode_kernel(WrArgs a) {
             const float* ht = hbuf + ((size_t)(nxt * NL + (NL - 1)) * BT) * H;
             const int row = tid & 255;
             for (int u = tid >> 8; u < BT; u += WR_THREADS / 256) {
-                float acc[1][1] = {{a.b_pre[row]}};
-                chain_matvec<1, 1, 4>(acc, a.wt_pre, 256, 0, row, ht + u * H, H, H);
-                pre[u * 256 + row] = ttsc_tanhf(acc[0][0]);
+                pre[u * 256 + row] = ttsc_tanhf(chain_matvec_quarters(a.wt_pre, 256, row, ht + u * H, H, a.b_pre[row]));
             }
         }
         __syncthreads();
@@ -329,9 +343,7 @@ __global__ __launch_bounds__(WR_THREADS) void wr_decode_kernel(WrArgs a) {
             const int row = tid & 255;
             for (int u = tid >> 8; u < BT; u += WR_THREADS / 256) {
                 if (row < S) {
-                    float accv[1][1] = {{a.b_out[row]}};
-                    chain_matvec<1, 1, 4>(accv, a.wt_out, S, 0, row, pre + u * 256, 256, 256);
-                    const float acc = accv[0][0];
+                    const float acc = chain_matvec_quarters(a.wt_out, S, row, pre + u * 256, 256, a.b_out[row]);
                     const size_t o = ((size_t)BIDX(u) * a.L + t) * S + row;
                     if (a.out_logits && BOK(u)) a.out_logits[o] = acc;
                     float g = 0.f;
@@ -591,6 +603,7 @@ extern "C" int ttsc_wavernn_set_weight(ttsc_wavernn* w, const char* name, const 
 static size_t tile_lds_bytes(const ttsc_wavernn* w) {
     const auto& c = w->cfg;
     size_t n = (size_t)c.H * 32 + (size_t)256 * 32 + (size_t)WT_NC * (c.H + 4) + (size_t)WT_NC * 260 + (size_t)3 * (c.H / WT_NC) * WT_NC + 64 + (size_t)3 * (c.H / WT_NC) + 64;
+    n += (size_t)2 * 4 * 32 * WT_NC;   // partial sums of the two output Linears: [quarter][32 rows][8 utterances] each
     if (c.num_layers == 2) n += (size_t)WT_NC * (c.H + 4) + (size_t)3 * (c.H / WT_NC) * WT_NC + (size_t)6 * (c.H / WT_NC);   // h2 vector, W_hh2 h2 products, b_ih2 | b_hh2
     return n * sizeof(float);
 }
@@ -848,19 +861,25 @@ extern "C" int ttsc_wavernn_decode(ttsc_wavernn* w, const float* mel, const floa
             std::vector<unsigned long long> hp((size_t)qa.GP * NC * 16);
             TTSC_HIP_CHECK(hipMemcpy(hp.data(), prof_dev, hp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             hipFree(prof_dev);
-            static const char* nm[8] = {"loop", "ih-prefix+join", "lastx-handoff+gate", "h-handoff+stage", "tail:pre", "tail:pre-handoff",
-                                        "tail:out", "tail:logit-handoff+sample"};
+            static const char* nm[14] = {"loop", "ih-prefix+join", "lastx-handoff+gate", "h-handoff+stage", "tail:noise", "tail:wait for the output quarters",
+                                         "tail:add quarters+candidates", "tail:candidate-handoff+sample",
+                                         "w4: rest of the step (join, gates, h hand-off)", "w4: pre-output quarter chain", "w4: wait for the 4 partials",
+                                         "w4: add+tanh+publish", "w4: gather its quarter of pre", "w4: output quarter chain+signal"};
             double tot = 0;
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 14; ++i) {
+                if (i == 8) {
+                    fprintf(stderr, "wt-prof %-28s %7.2f us/step (B=%d, L=%d)\n", "total (wave 0)", tot, B, qa.L);
+                    tot = 0;
+                }
                 double sum = 0;
                 int n = 0;
                 for (size_t wg = 0; wg < (size_t)qa.GP * NC; ++wg)
                     if (hp[wg * 16 + 3]) { sum += (double)hp[wg * 16 + i]; ++n; }
                 const double us = n ? sum / n / 100.0 / qa.L : 0.0;
                 tot += us;
-                fprintf(stderr, "wt-prof %-28s %7.2f us/step\n", nm[i], us);
+                fprintf(stderr, "wt-prof %-46s %7.2f us/step\n", nm[i], us);
             }
-            fprintf(stderr, "wt-prof %-28s %7.2f us/step (B=%d, L=%d)\n", "total", tot, B, qa.L);
+            fprintf(stderr, "wt-prof %-28s %7.2f us/step (B=%d, L=%d)\n", "total (wave 4)", tot, B, qa.L);
         }
 #endif
         w->last_abort_word = qa.abort_word;

@@ -16,10 +16,15 @@
 //
 // Schedule.  A step is  h_t -> pre_t -> logits_t -> sample_t -> (gates of step t+1).  Only the last link needs the sample:
 // the recurrent product W_hh . h_t does not, and it is 80 % of the bytes.  So the workgroup forks after h_t is staged:
-//     wave 0      "tail" of step t:   pre slice -> hand-off -> output slice -> hand-off -> sample utterance m -> hand-off
+//     waves 4..7  "tail" of step t, the two output Linears: wave 4 + q owns QUARTER q of either contraction (round 6: the contract of
+//                 oracle/wavernn_ref.c::matvec_chain4 — four k-ordered chains over consecutive quarters, added in order) — its quarter of the
+//                 member's pre-output slice (H / 4 dependent matrix instructions instead of H fused multiply-adds on one lane: the workgroup
+//                 timeline of round 6 put 9.4 of the step's 16.0 us into that chain and its hand-off, profiles/r06_wavernn_phase_timeline.log),
+//                 the four partials added through LDS, tanh, hand-off; then it gathers ITS quarter of everybody's pre-output vector and runs
+//                 its quarter of the output slice (64 matrix instructions) on it
+//     wave 0      draws the step's Gumbel noise meanwhile, adds the four output partials, reduces / publishes the candidates, samples
 //     waves 1..3  recurrent product of step t+1 (three 64-row blocks, two 4-utterance accumulators each)
-// and joins for the gate math of step t+1 and the h_{t+1} hand-off.  The critical path of a step is the tail (two dependent
-// chains of 512 and 256 matrix instructions) plus four hand-offs; the weight stream hides behind it.
+// and joins for the gate math of step t+1 and the h_{t+1} hand-off.
 //
 // Hand-offs.  Every exchanged value is an 8-byte granule {fp32 value, step tag} written with ONE agent-scope store; a
 // consumer lane polls the granules it needs until they carry the tag of the step (bounded spin, shared abort word).  No
@@ -38,6 +43,9 @@ constexpr int WT_THREADS = 512;
 constexpr int WT_XCDS = 8;
 #ifndef WT_STREAM_UN
 #define WT_STREAM_UN 8   // k-blocks of the recurrent weight stream in flight per wave (16-byte words per lane)
+#endif
+#ifndef WT_TAIL_PRIO
+#define WT_TAIL_PRIO 0   // issue priority of waves 4..7 while they run the output Linears.  Measured (profiles/r06_wavernn_phase_timeline.log): 2 shortens the tail (wave 0 waits 5.7 instead of 7.2 us) and lengthens the recurrent product behind it by more — 14.5 against 14.1 us per step: off
 #endif
 constexpr unsigned WT_SPIN_LIMIT = 1u << 20;   // bounded spins: a member that is not resident must not hang the GPU
 
@@ -377,8 +385,18 @@ __device__ __noinline__ void wt_row_block(const glb_float* W_g, const lds_float*
             plast = now_;                                              \
         }                                                              \
     } while (0)
+// the same for lane 0 of wave 4 (the output Linears' quarter 0): slots 8..
+#define WT_TICKW(i)                                                    \
+    do {                                                               \
+        if (a.prof && tid == 256) {                                    \
+            const unsigned long long now_ = wall_clock64();            \
+            pacc[i] += now_ - plast;                                   \
+            plast = now_;                                              \
+        }                                                              \
+    } while (0)
 #else
 #define WT_TICK(i) do {} while (0)
+#define WT_TICKW(i) do {} while (0)
 #endif
 
 // CONT: continuous output head (MOL / Gaussian / Beta) — a separate instantiation, so that the discrete kernel does not carry
@@ -416,6 +434,11 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
     float* gbuf2 = hvec2 + (size_t)BU * VH;
     float* bias2 = gbuf2 + (size_t)R3 * BU;   // bih2[R3] | bhh2[R3]
     float* hvecT = L2 ? hvec2 : hvec;         // what the tail (pre-output layer) reads: the LAST layer's state
+    // partial sums of the two output Linears, [quarter][row of the member's slice (32)][utterance]: written by wave 4 + quarter, added in quarter order
+    float* ppart = L2 ? bias2 + 2 * R3 : ybuf + 60;
+    float* opart = ppart + 4 * PR * BU;
+    int* part_ready = tail_fail + 2;   // waves 4..7 that have written their pre-output partial (monotonic)
+    int* out_ready = tail_fail + 3;    // ... their output partial (monotonic)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int u = tid % BU;            // utterance slot (element-wise work)
     const int j = tid / BU;            // local hidden unit
@@ -471,6 +494,8 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
         if (tid == 0) {
             *tail_fail = 0;
             *pre_ready = 0;
+            *part_ready = 0;
+            *out_ready = 0;
         }
         if (L2) {
             for (int i = tid; i < BU * VH; i += WT_THREADS) hvec2[i] = 0.f;
@@ -482,30 +507,75 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
     unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, plast = wall_clock64();
 #endif
 
-    // Waves 4..7 stage the pre-output vector of step s (2048 granules, 8 per lane) into pvec while wave 0 computes its own slice.
-    auto stage_pre = [&](int s) {
-        const int hl = tid - 4 * 64;   // 0..255
-        const u64* src = xpre + (size_t)(s & 1) * 256 * BU + hl;
-        float v[8];
-        const bool okh = ld_granules<8>(src, 256, (unsigned)s + 1u, v, a.abort_word);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int i = r * 256 + hl;
-            pvec[(i & 7) * VP + (i >> 3)] = v[r];
+    // wait until the workgroup-scope counter `cnt` (bumped once per wave 4..7 and step) has reached 4 * (s + 1)
+    auto wait_four = [&](int* cnt, int s) -> bool {
+        unsigned spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (s + 1)) {
+            if (++spins > WT_SPIN_LIMIT) return false;
+            __builtin_amdgcn_s_sleep(1);
         }
-        if (!__all(okh) && lane == 0) *tail_fail = 1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        return true;
+    };
+    auto signal_one = [&](int* cnt) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_fetch_add(pre_ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
-    // The member's pre-output slice of step s — 32 rows x 8 utterances = 256 chains of H terms — on the vector ALU of waves 4..7, one chain per
-    // lane (fma_chain_lds), published as granules; the same waves then gather everybody's slices (stage_pre).  On the matrix pipe of wave 0
-    // this chain took 4.9 us of the 15.6 us step (512 dependent 4x4x1 instructions); here it takes about half.
-    auto pre_valu = [&](int s) {
-        const int hl = tid - 4 * 64;   // 0..255
-        const int row = hl & 31, utt = hl >> 5;
-        const float v = fma_chain_lds<8>(reinterpret_cast<const float4*>(wpreL) + row, PR, hvecT + utt * VH, H, bpre_m[row]);
-        st_granule(xpre + ((size_t)(s & 1) * 256 + m * PR + row) * BU + utt, ttsc_tanhf(v), (unsigned)s + 1u);
+    // The two output Linears of step s on waves 4..7 (hvecT holds the last layer's h_s); wave 4 + q owns quarter q of both contractions.
+    //   1. quarter q of the member's pre-output slice: 32 rows x 8 utterances over the H / 4 inputs [q H / 4, (q + 1) H / 4) on the matrix pipe
+    //      (lanes 0..31 utterances 0..3, lanes 32..63 the same rows for 4..7; H / 4 dependent 4x4x1 instructions), quarter 0 seeded with the bias
+    //   2. partials through LDS; once all four are there, thread (row, utterance) adds them in quarter order, tanh, publishes the granule
+    //   3. the wave gathers the rows [64 q, 64 q + 64) of EVERYBODY's pre-output vector — the inputs of its quarter of the output layer — into pvec
+    //   4. quarter q of the output slice (64 dependent instructions) -> opart; wave 0 adds the quarters (tail)
+    auto linears_quarter = [&](int s) {
+        const int q = wave - 4;
+        const int KBq = H >> 4;   // 4-input blocks per quarter of the pre-output contraction (H % 32 == 0)
+        WT_TICKW(8);
+        // these two short dependent chains ARE the step's critical path, and waves 5..7 share their SIMD's matrix pipe with the recurrent product of
+        // waves 1..3 (two independent accumulators: it fills every slot it is given, and has ~10 us to do 4 us of work): the tail goes first
+        if (WT_TAIL_PRIO) __builtin_amdgcn_s_setprio(WT_TAIL_PRIO);
+        {
+            f32x4_t acc[1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[0][i] = q == 0 ? bpre_m[trow + i] : 0.f;
+            mfma_chain<1, 4>(acc, reinterpret_cast<const float4*>(wpreL) + (size_t)q * KBq * PR + (lane & 31), PR, hvecT + tutt * VH + 4 * q * KBq, 0, 4 * KBq);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ppart[(q * PR + trow + i) * BU + tutt] = acc[0][i];
+        }
+        WT_TICKW(9);
+        signal_one(part_ready);
+        bool okq = wait_four(part_ready, s);
+        WT_TICKW(10);
+        {
+            const int hl = tid - 4 * 64;   // 0..255
+            const int row = hl & 31, utt = hl >> 5;
+            const float v = ((ppart[row * BU + utt] + ppart[(PR + row) * BU + utt]) + ppart[(2 * PR + row) * BU + utt]) + ppart[(3 * PR + row) * BU + utt];
+            st_granule(xpre + ((size_t)(s & 1) * 256 + m * PR + row) * BU + utt, ttsc_tanhf(v), (unsigned)s + 1u);
+        }
+        WT_TICKW(11);
+        {
+            const u64* src = xpre + ((size_t)(s & 1) * 256 + 64 * q) * BU + lane;
+            float v[8];
+            okq = ld_granules<8>(src, 64, (unsigned)s + 1u, v, a.abort_word) && okq;
+            WT_TICKW(12);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) pvec[(lane & 7) * VP + 64 * q + r * 8 + (lane >> 3)] = v[r];
+            if (!__all(okq) && lane == 0) *tail_fail = 1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the chain below reads what this wave's own lanes just wrote
+            __builtin_amdgcn_wave_barrier();
+        }
+        {
+            f32x4_t acc[1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[0][i] = q == 0 ? bout_m[trow + i] : 0.f;
+            mfma_chain<1, 4>(acc, reinterpret_cast<const float4*>(woutL) + (size_t)q * 16 * PR + (lane & 31), PR, pvec + tutt * VP + 64 * q, 0, 64);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) opart[(q * PR + trow + i) * BU + tutt] = acc[0][i];
+        }
+        signal_one(out_ready);
+        if (WT_TAIL_PRIO) __builtin_amdgcn_s_setprio(0);
+        WT_TICKW(13);
     };
 
     // The tail of step s on wave 0 (hvec holds h_s): output slice, candidates / sample.  Tag of step s = s + 1.
@@ -530,23 +600,15 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
             }
         }
         WT_TICK(4);
-        {   // the full pre-output vector of the 8 utterances is staged by the helper waves (stage_pre): wait for the four of them
-            unsigned spins = 0;
-            while (__hip_atomic_load(pre_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (s + 1)) {
-                if (++spins > WT_SPIN_LIMIT) {
-                    ok = false;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        }
+        // the four quarters of the member's output slice come from waves 4..7 (linears_quarter): wait for them, add them in quarter order
+        if (!wait_four(out_ready, s)) ok = false;
         WT_TICK(5);
         {   // output layer: SR (<= 32) rows x 8 utterances over the 256 pre-output values
             f32x4_t acc[1];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[0][i] = bout_m[trow + i];
-            mfma_chain<1, 4>(acc, reinterpret_cast<const float4*>(woutL) + (lane & 31), PR, pvec + tutt * VP, 0, 256);
+            for (int i = 0; i < 4; ++i)
+                acc[0][i] = ((opart[(trow + i) * BU + tutt] + opart[(PR + trow + i) * BU + tutt]) + opart[(2 * PR + trow + i) * BU + tutt]) +
+                            opart[(3 * PR + trow + i) * BU + tutt];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int s_ = m * SR + trow + i;
@@ -658,10 +720,7 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
         if (wave == 0) {
             if (t > 0 && !tail(t - 1)) *tail_fail = 1;
         } else if (wave >= 4) {
-            if (t > 0) {
-                pre_valu(t - 1);
-                stage_pre(t - 1);
-            }
+            if (t > 0) linears_quarter(t - 1);
         } else if (wave - 1 < nblk) {
             const int r0 = (wave - 1) * 64;
             if (L2) {   // (two-layer kernel: out-of-line block, see wt_row_block) recurrent products of BOTH layers for this step
@@ -801,14 +860,13 @@ __global__ __launch_bounds__(WT_THREADS) void wr_tile_kernel(WtArgs a) {
         if (++fr_phase == a.up) { fr_phase = 0; ++fr; }
         if (++lo_phase == a.up_low) { lo_phase = 0; ++lo; }
     }
-    if (wave >= 4) {
-        pre_valu(a.L - 1);
-        stage_pre(a.L - 1);
-    }
+    if (wave >= 4) linears_quarter(a.L - 1);
     if (wave == 0) tail(a.L - 1);
 #ifdef TTSC_ABLATE
     if (a.prof && tid == 0)
-        for (int i = 0; i < 16; ++i) a.prof[(size_t)blockIdx.x * 16 + i] = pacc[i];
+        for (int i = 0; i < 8; ++i) a.prof[(size_t)blockIdx.x * 16 + i] = pacc[i];
+    if (a.prof && tid == 256)
+        for (int i = 8; i < 16; ++i) a.prof[(size_t)blockIdx.x * 16 + i] = pacc[i];
 #endif
 }
 
