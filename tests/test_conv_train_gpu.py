@@ -166,3 +166,84 @@ def test_grouped_forward_and_data_gradient_match_float64(B, Cin, Cout, K, L, pad
     dx = _run(dy.float(), w.float().contiguous(), None, None, x.detach().float(), pd, 1, 1, groups=G, out_scale=sc, gate_slope=sl)
     assert dx.shape == dx_ref.shape
     assert float((dx.double() - dx_ref).abs().max()) <= 2e-6 * float(dx_ref.abs().max())
+
+
+# ---- round 6: weight bank, range words left by the producing launch, bias gradient riding in the weight-gradient launches --------------------
+def _banked_chain(seed=5, C=(16, 64, 96, 64), K=(5, 3, 7), d=(1, 3, 1)):
+    """a small chain of weight-normed Conv1d layers + its WeightBank + the per-layer TrainConv handles"""
+    from ttscube_amd.hifigan.autograd import TrainConv
+    from ttscube_amd.hifigan.wbank import WeightBank
+    torch.manual_seed(seed)
+    layers, tcs = [], []
+    for i, (k, dl) in enumerate(zip(K, d)):
+        l = torch.nn.utils.weight_norm(torch.nn.Conv1d(C[i], C[i + 1], k, padding=dl * (k - 1) // 2, dilation=dl)).cuda()
+        layers.append(l)
+        tcs.append(TrainConv(C[i], C[i + 1], k, padding=dl * (k - 1) // 2, dilation=dl))
+    bank = WeightBank([(l, tc.Cin, tc.Cout, tc.K, 1, 1) for l, tc in zip(layers, tcs)])
+    return layers, tcs, bank
+
+
+def _chain_forward(layers, tcs, bank, x):
+    from ttscube_amd.hifigan.autograd import hip_conv
+    ys = []
+    for i, (l, tc) in enumerate(zip(layers, tcs)):
+        x = hip_conv(tc, x, bank.weight(i), l.bias, in_slope=0.1 if i else 1.0)
+        ys.append(x)
+    return ys
+
+
+def test_producing_launch_leaves_the_exact_maximum_and_the_next_launch_takes_it():
+    from ttscube_amd.hifigan import wbank as WB
+    layers, tcs, bank = _banked_chain()
+    WB.AmaxPool.of(torch.device('cuda', 0)).reset()
+    bank.prepare()
+    x = torch.randn(3, 16, 333, device='cuda', requires_grad=True)
+    ys = _chain_forward(layers, tcs, bank, x)
+    for y in ys:
+        word = WB.range_of(y)
+        assert word is not None and float(word) == float(y.detach().abs().max()), 'the epilogue word must be max |y| exactly'
+    ys[-1].square().mean().backward()
+    # a tensor written since its producing launch (version counter moved) must not hand its word on
+    with torch.no_grad():
+        ys[0].mul_(1.0)
+    assert WB.range_of(ys[0]) is None
+    # ... and neither after the pool was reset (the word belongs to a later step)
+    WB.AmaxPool.of(torch.device('cuda', 0)).reset()
+    assert WB.range_of(ys[1]) is None
+
+
+def test_range_word_propagation_does_not_change_a_bit():
+    """the propagated word IS the reduction's result (max is exact), so forward values and every gradient are bit-identical with the switch off"""
+    from ttscube_amd.hifigan import wbank as WB
+    layers, tcs, bank = _banked_chain(seed=9)
+    outs = []
+    for prop in (True, False):
+        WB.PROPAGATE = prop
+        try:
+            for l in layers:
+                l.zero_grad()
+            WB.AmaxPool.of(torch.device('cuda', 0)).reset()
+            bank.prepare()
+            x = torch.randn(2, 16, 500, device='cuda', generator=torch.Generator(device='cuda').manual_seed(3), requires_grad=True)
+            ys = _chain_forward(layers, tcs, bank, x)
+            (ys[-1].abs().mean() + ys[0].square().mean()).backward()   # (the first output gets a second gradient: accumulated by autograd)
+            outs.append([ys[-1].detach().clone(), x.grad.clone()] + [p.grad.clone() for l in layers for p in (l.weight_g, l.weight_v, l.bias)])
+        finally:
+            WB.PROPAGATE = True
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('N,A,Bc,LP,J', [(4, 64, 64, 300, 3), (2, 256, 128, 1500, 5), (3, 128, 32, 77, 7)])
+def test_bias_gradient_riding_in_the_weight_gradient_launches_has_the_bits_of_bias_grad(N, A, Bc, LP, J):
+    from ttscube_amd.hifigan.autograd import TrainConv, _bias_grad, _wgrad
+    g = torch.Generator().manual_seed(N + A + J)
+    P = torch.randn(N, A, LP, generator=g).cuda()
+    Q = torch.randn(N, Bc, LP + J - 1, generator=g).cuda()
+    dbl = []
+    G1 = _wgrad(P, Q, A, Bc, J, 0, 1, 1.0, 1.0, db=dbl)
+    G0 = _wgrad(P, Q, A, Bc, J, 0, 1, 1.0, 1.0)
+    assert len(dbl) == 1 and torch.equal(G0, G1)
+    ref = _bias_grad(TrainConv(Bc, A, J), P)
+    assert torch.equal(dbl[0], ref)
+    assert float((dbl[0].double() - P.double().sum((0, 2))).abs().max()) <= 1e-4 * float(P.abs().sum((0, 2)).max())
