@@ -49,6 +49,16 @@ struct ttsc_hifigan {
     int split_chain = 1;        // env TTSC_HIFIGAN_CHAIN_SPLIT=0: every chained ResBlock1 as ONE launch; 2: split whatever the batch size (see chain_first_pairs)
     bool pad_pitch = true;      // env TTSC_HIFIGAN_PITCH=0: intermediate tensors with their natural row pitch (rows not on 128-byte boundaries)
     bool fuse_post = true;      // env TTSC_HIFIGAN_FUSE_POST=0: conv_post + tanh as their own launch instead of the epilogue of the last chain launch
+    // Branch streams (round 6): the ResBlocks of a stage that runs layer by layer (stages 1 - 2: six launches per block) are independent given the stage
+    // input; on the caller's stream + two side streams their launches fill each other's tails — a launch whose workgroups are not a whole number of
+    // rounds over the 2 x 256 resident slots idles most of the chip for its last round, which is the rule for ragged batches and for single sentences
+    // (a launch of a few dozen workgroups) and the exception for the dense headline batch (64 x 8 s: exactly 4 rounds at stage 1).  The blocks' sums
+    // still enter S in block order (an event between the blocks' LAST launches), so every output bit is what the one-stream schedule gives.
+    // env TTSC_HIFIGAN_BRANCH_STREAMS: 0 = off, 1 = by the rule in branch_streams_for() (default), 2 = whenever the buffers allow.
+    int branch_streams = 1;
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_acc[TTSC_HIFIGAN_MAX_RB] = {nullptr};
+    int side_dev = -1;
     int precision = TTSC_PREC_FP32;
     // Split precision keeps activations as fp16 (hi, lo) pairs, so every layer's input gets a power-of-two pre-scale that
     // centres it in fp16's range (ttsc_conv1d_set_activation_scale).  The scales come from ONE calibration forward, run layer
@@ -80,6 +90,23 @@ struct ttsc_hifigan {
     ~ttsc_hifigan() {
         if (flag_dev) (void)hipFree(flag_dev);
         if (flag_host) (void)hipHostFree(flag_host);
+        for (auto& st : side)
+            if (st) (void)hipStreamDestroy(st);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        for (auto& e : ev_acc)
+            if (e) (void)hipEventDestroy(e);
+    }
+    // side streams and events of the branch schedule, created on first use on the current device
+    int ensure_side_streams() {
+        int dev = 0;
+        TTSC_HIP_CHECK(hipGetDevice(&dev));
+        if (side[0] && side_dev == dev) return TTSC_OK;
+        TTSC_REQUIRE(!side[0], "ttsc_hifigan_forward: the handle's branch streams belong to device %d, the call runs on device %d", side_dev, dev);
+        for (auto& st : side) TTSC_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        TTSC_HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        for (auto& e : ev_acc) TTSC_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        side_dev = dev;
+        return TTSC_OK;
     }
     // pack + upload every layer whose host copy changed; returns the name of the first incomplete layer (or "")
     int flush_weights(std::string* missing) {
@@ -131,6 +158,7 @@ extern "C" int ttsc_hifigan_create(const ttsc_hifigan_cfg* cfg, ttsc_hifigan** o
     if (const char* ev = getenv("TTSC_HIFIGAN_CHAIN_SPLIT")) g->split_chain = atoi(ev);
     if (const char* ev = getenv("TTSC_HIFIGAN_PITCH")) g->pad_pitch = atoi(ev) != 0;
     if (const char* ev = getenv("TTSC_HIFIGAN_FUSE_POST")) g->fuse_post = atoi(ev) != 0;
+    if (const char* ev = getenv("TTSC_HIFIGAN_BRANCH_STREAMS")) g->branch_streams = atoi(ev);
     if (const char* ev = getenv("TTSC_HIFIGAN_CALIBRATE")) {
         const std::string v(ev);
         g->calib_mode = (v == "0" || v == "off") ? 0 : (v == "input" || v == "2") ? 2 : 1;
@@ -264,6 +292,16 @@ static size_t buf_elems(const ttsc_hifigan* g, int32_t B, int64_t T) {
 // per MFMA, 1024-column tile): 3.65 -> 3.71 ms, 4.96 -> 5.96 ms — not split; K = 3: halo 12, nothing to win (64 channels 1.59 -> 1.83 ms; 128 channels 1.57 -> 1.42-1.52 ms
 // alone, nothing in the whole forward).  Whole forward on one box, three alternations: 43.54-43.68 ms as single launches, 43.00-43.11 ms split.  Only when the launch fills the chip several times
 // over: a short batch pays the second launch's latency instead.  Returns the number of pairs of the first launch, 0 = one launch.
+// Branch streams for a layer-by-layer stage?  (ttsc_hifigan::branch_streams.)  Mode 1: ragged batches (their launches are never a whole number of
+// workgroup rounds) and batches whose launches are short of two rounds of the wide kernel's 128 x 256 tiles; the dense headline batch keeps one stream
+// (measured, tools/bench_streams.py / profiles/r06_stream_overlap_experiment.log: +1.7 % at stage 1, -4 .. -7 % at stage 2 — within what one box varies).
+static bool branch_streams_for(const ttsc_hifigan* g, int32_t B, int ch, int64_t L, bool ragged) {
+    if (g->branch_streams <= 0) return false;
+    if (g->branch_streams >= 2) return true;
+    const int64_t wgs = (int64_t)B * ceil_div(L, (int64_t)256) * std::max(1, ch / 128);
+    return ragged || wgs < 2 * 512;
+}
+
 static int chain_first_pairs(const ttsc_hifigan* g, int ch, int k, int nd, int32_t B, int64_t L) {
     if (!g->split_chain || ch != 64 || nd != 3 || (k != 7 && k != 11)) return 0;
     if (g->split_chain < 2 && (int64_t)B * ceil_div(L, (int64_t)400) < 1024) return 0;   // < 4 rounds of workgroups over the 256 CUs
@@ -610,7 +648,8 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
 
     // Lin: row pitch of x (= its length when no lengths are given); Lout_pitch: row pitch of y (0 = natural)
     auto conv = [&](ttsc_conv1d* l, const float* x, int64_t Lin, float* y, const float* resid, const ttsc_conv1d_epilogue& e, const int32_t* il,
-                    const int32_t* ol, int64_t Lout_pitch = 0) {
+                    const int32_t* ol, int64_t Lout_pitch = 0, void* st = nullptr) {
+        if (!st) st = stream;
         if (calib) {   // calibration forward: abs-max of this layer's input -> its pre-scale, then the layer
             float m = 0.f;
             if (hipMemsetAsync(calib_stat, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return (int)TTSC_EHIP;
@@ -624,7 +663,7 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
             arc = ttsc_conv1d_set_activation_scale(l, calib_scale(m * fabsf(e.in_scale)));
             if (arc) return arc;
         }
-        return ttsc_conv1d_forward_pitched(l, x, B, Lin, y, resid, &e, il, ol, (il && ol) ? Lout_pitch : 0, stream);
+        return ttsc_conv1d_forward_pitched(l, x, B, Lin, y, resid, &e, il, ol, (il && ol) ? Lout_pitch : 0, st);
     };
     const float inv_nk = 1.f / (float)c.num_kernels;
     ttsc_conv1d_epilogue ep{1.f, 1.f, 1.f, TTSC_ACT_NONE, 0};
@@ -668,6 +707,40 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
         TTSC_REQUIRE(ttsc_conv1d_out_len(up, Lr[i]) == Lr[i + 1], "ttsc_hifigan_forward: upsampler %d disagrees with the configured rates about its output length", i);
         L = Pp[i + 1];   // from here on L is the ROW PITCH of the stage's tensors; the real lengths are in `ln`
         const int32_t* ln = lens[i + 1];
+        // ---- branch schedule of this stage (see ttsc_hifigan::branch_streams): block j on stream bst[j] with temporaries of its own ----
+        const size_t n_i = (size_t)round_up((int64_t)B * ch * L, 64);
+        bool branch = !calib && !fused_stage && !chain_stage && c.resblock == 1 && c.num_kernels >= 2 && c.num_kernels <= 3 && 3 * n_i <= be &&
+                      branch_streams_for(g, B, ch, L, ln != nullptr && frames != nullptr);
+        void* bst[TTSC_HIFIGAN_MAX_RB];
+        float *bXT[TTSC_HIFIGAN_MAX_RB], *bR[TTSC_HIFIGAN_MAX_RB];
+        for (int j = 0; j < c.num_kernels; ++j) {
+            bst[j] = stream;
+            bXT[j] = XT;
+            bR[j] = R;
+        }
+        if (branch) {
+            if ((rc = g->ensure_side_streams())) return rc;
+            // blocks 1, 2: two temporaries each in the unused tails of the X and XT buffers (a stage-1 / stage-2 tensor is at most a quarter of a buffer)
+            bst[1] = g->side[0];
+            bXT[1] = X + n_i;
+            bR[1] = X + 2 * n_i;
+            if (c.num_kernels > 2) {
+                bst[2] = g->side[1];
+                bXT[2] = XT + n_i;
+                bR[2] = XT + 2 * n_i;
+            }
+            TTSC_HIP_CHECK(hipEventRecord(g->ev_fork, (hipStream_t)stream));   // the stage input (upsampler) is complete
+            for (int j = 1; j < c.num_kernels; ++j) TTSC_HIP_CHECK(hipStreamWaitEvent((hipStream_t)bst[j], g->ev_fork, 0));
+        }
+        // block j's last launch adds into S: behind block j - 1's (same order of the sum as on one stream)
+        auto before_acc = [&](int j) -> int {
+            if (branch && j > 0) TTSC_HIP_CHECK(hipStreamWaitEvent((hipStream_t)bst[j], g->ev_acc[j - 1], 0));
+            return TTSC_OK;
+        };
+        auto after_acc = [&](int j) -> int {
+            if (branch) TTSC_HIP_CHECK(hipEventRecord(g->ev_acc[j], (hipStream_t)bst[j]));
+            return TTSC_OK;
+        };
         for (int j = 0; j < c.num_kernels; ++j) {
             const std::string rb = "resblocks." + std::to_string(i * c.num_kernels + j);
             const int nd = c.num_dilations[j];
@@ -687,13 +760,16 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
                 }
                 const int nf = chain_first_pairs(g, ch, c.resblock_kernel_sizes[j], nd, B, L);
                 if (nf > 0 && ttsc_rbchain_supported(c1, c2, nf) && ttsc_rbchain_supported(c1 + nf, c2 + nf, nd - nf)) {
-                    rc = ttsc_rbchain_forward(c1, c2, nf, X, B, L, R, 0, ln, g->chain_shape, stream);
+                    rc = ttsc_rbchain_forward(c1, c2, nf, X, B, L, bR[j], 0, ln, g->chain_shape, bst[j]);
                     if (rc) return rc;
-                    rc = ttsc_rbchain_forward(c1 + nf, c2 + nf, nd - nf, R, B, L, S, j > 0 ? 1 : 0, ln, g->chain_shape, stream);
+                    if ((rc = before_acc(j))) return rc;
+                    rc = ttsc_rbchain_forward(c1 + nf, c2 + nf, nd - nf, bR[j], B, L, S, j > 0 ? 1 : 0, ln, g->chain_shape, bst[j]);
                 } else {
-                    rc = ttsc_rbchain_forward(c1, c2, nd, X, B, L, S, j > 0 ? 1 : 0, ln, g->chain_shape, stream);
+                    if ((rc = before_acc(j))) return rc;
+                    rc = ttsc_rbchain_forward(c1, c2, nd, X, B, L, S, j > 0 ? 1 : 0, ln, g->chain_shape, bst[j]);
                 }
                 if (rc) return rc;
+                if ((rc = after_acc(j))) return rc;
                 continue;
             }
             if (fused_stage) {
@@ -711,16 +787,20 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
                 continue;
             }
             for (int m = 0; m < nd; ++m) {
-                const float* src = (m == 0) ? X : R;
+                float* const Rj = bR[j];
+                float* const XTj = bXT[j];
+                const float* src = (m == 0) ? X : Rj;
                 const bool last = (m == nd - 1);
-                float* dst = last ? S : R;
+                float* dst = last ? S : Rj;
                 ttsc_conv1d_epilogue e2{1.f, 0.1f, 1.f, TTSC_ACT_NONE, (last && j > 0) ? 1 : 0};
                 if (c.resblock == 1) {
                     ttsc_conv1d_epilogue e1{1.f, 0.1f, 1.f, TTSC_ACT_NONE, 0};
-                    rc = conv(layer(rb + ".convs1." + std::to_string(m)), src, L, XT, nullptr, e1, ln, ln);
+                    rc = conv(layer(rb + ".convs1." + std::to_string(m)), src, L, XTj, nullptr, e1, ln, ln, 0, bst[j]);
                     if (rc) return rc;
-                    rc = conv(layer(rb + ".convs2." + std::to_string(m)), XT, L, dst, src, e2, ln, ln);   // + residual
+                    if (last && (rc = before_acc(j))) return rc;
+                    rc = conv(layer(rb + ".convs2." + std::to_string(m)), XTj, L, dst, src, e2, ln, ln, 0, bst[j]);   // + residual
                     if (rc) return rc;
+                    if (last && (rc = after_acc(j))) return rc;
                 } else {
                     // ResBlock2 reads src both as conv input and residual; dst != src unless m>0 && !last (R->R),
                     // where an in-place update would race with neighbouring tiles' halo reads -> ping-pong via XT.
@@ -732,6 +812,8 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
                 }
             }
         }
+        if (branch)   // the caller's stream goes on when every block has (block j's last launch waited for block j - 1's: the last event covers them all,
+            for (int j = 1; j < c.num_kernels; ++j) TTSC_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, g->ev_acc[j], 0));   // but each stream's own work needs its own)
         sum_scale = inv_nk;
     }
     ttsc_conv1d_epilogue epost{sum_scale, 0.01f, 1.f, TTSC_ACT_TANH, 0};
