@@ -457,3 +457,38 @@ def test_split_chain_launches_do_not_change_a_bit(monkeypatch):
     mel = R.synthetic_mel(8, 900, seed=11).cuda()    # 8 x 54 016 columns at 64 channels = 1 088 tiles: the default rule splits
     with torch.no_grad():
         assert torch.equal(gens['0'](mel), gens['1'](mel))
+
+
+def test_branch_streams_do_not_change_a_bit(monkeypatch):
+    """round 6: the ResBlocks of a layer-by-layer stage run on the caller's stream + two side streams for ragged / small batches (hifigan.cpp::
+    branch_streams_for); the blocks' sums still enter the stage output in block order (an event between the blocks' last launches) and every block
+    has temporaries of its own, so outputs must be bit-identical to the one-stream schedule (TTSC_HIFIGAN_BRANCH_STREAMS=0) — dense, ragged, repeated
+    (the side streams and events are reused from call to call), and under a caller-chosen stream"""
+    h = dict(R.CONFIG_V1)
+    sd = R.synthetic_state_dict(h, seed=79)
+    warm = R.synthetic_mel(1, 2, seed=1).cuda()
+    gens = {}
+    for mode in ('0', '2', '1'):
+        monkeypatch.setenv('TTSC_HIFIGAN_BRANCH_STREAMS', mode)
+        gens[mode] = _gen(h, sd)
+        with torch.no_grad():
+            gens[mode](warm)    # (the C handle reads the switch when the first forward creates it)
+    for B, T in ((1, 7), (1, 300), (3, 33), (8, 120)):
+        mel = R.synthetic_mel(B, T, seed=90 + T).cuda()
+        with torch.no_grad():
+            ref = gens['0'](mel)
+            for mode in ('2', '1'):
+                for _ in range(2):
+                    assert torch.equal(ref, gens[mode](mel)), (B, T, mode)
+    mel = R.synthetic_mel(4, 61, seed=12).cuda()
+    frames = [61, 9, 30, 44]
+    with torch.no_grad():
+        r0 = gens['0'](mel, frames=frames)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            r1 = gens['1'](mel, frames=frames)
+        torch.cuda.current_stream().wait_stream(side)
+    for b in range(4):
+        n = 240 * frames[b] + 64
+        assert torch.equal(r0[b, :, :n], r1[b, :, :n]), b
