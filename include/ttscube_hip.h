@@ -243,6 +243,14 @@ size_t ttsc_conv_wgrad_split_workspace_bytes(int32_t N, int32_t A, int32_t B, in
 int ttsc_conv_wgrad_split(const float* p_dev, const float* q_dev, float* g_dev, int32_t N, int32_t A, int32_t B, int64_t LP, int64_t LQ, int32_t J,
                           int32_t base, int32_t step, float q_scale, float q_slope, float* amax_q_dev, float* amax_p_dev, int32_t measure, void* ws_dev,
                           size_t ws_bytes, void* stream);
+/* Grouped layers (MSD's k = 41 convolutions: groups of 16 .. 64 output channels) on the same split-precision scheme
+ * (csrc/conv_wgrad.hip::wgrad_f16x3_grouped_kernel): p [N][A][LP], q [N][groups * Bg][LQ] -> g [A][Bg][J], group g = rows [g A / groups, (g + 1) A / groups)
+ * against q's channels [g Bg, (g + 1) Bg).  Range words and `measure` as for ttsc_conv_wgrad_split. */
+int32_t ttsc_conv_wgrad_split_grouped_supported(int32_t A, int32_t Bg, int32_t groups, int32_t J, int32_t step);
+size_t ttsc_conv_wgrad_split_grouped_workspace_bytes(int32_t N, int32_t A, int32_t Bg, int32_t groups, int64_t LP, int32_t J);
+int ttsc_conv_wgrad_split_grouped(const float* p_dev, const float* q_dev, float* g_dev, int32_t N, int32_t A, int32_t Bg, int32_t groups, int64_t LP, int64_t LQ,
+                                  int32_t J, int32_t base, int32_t step, float q_scale, float q_slope, float* amax_q_dev, float* amax_p_dev, int32_t measure,
+                                  void* ws_dev, size_t ws_bytes, void* stream);
 /* The same call that also leaves the layer's bias gradient db[a] = sum_{n,t} p[n,a,t] in db_dev [A] (NULL = plain ttsc_conv_wgrad_split): its
  * slices are summed by surplus workgroups of the first weight-gradient launch and added in index order by surplus workgroups of the reduction —
  * the bits of ttsc_bias_grad, no launch of its own (same workspace size). */

@@ -247,3 +247,51 @@ def test_bias_gradient_riding_in_the_weight_gradient_launches_has_the_bits_of_bi
     ref = _bias_grad(TrainConv(Bc, A, J), P)
     assert torch.equal(dbl[0], ref)
     assert float((dbl[0].double() - P.double().sum((0, 2))).abs().max()) <= 1e-4 * float(P.abs().sum((0, 2)).max())
+
+
+WG_GROUPED = [  # N, A (rows), Bg (columns per group), groups, LP, LQ, J, base, step   (MSD's grouped layers after the stride de-interleave)
+    (3, 128, 64, 4, 150, 170, 21, 0, 1),      # 128 -> 128, k41 s2 g4: 32 rows x 64 columns per group
+    (2, 256, 16, 16, 97, 117, 21, 0, 1),      # 128 -> 256, g16: 16 x 16 per group (half a row tile)
+    (2, 512, 64, 16, 60, 70, 11, 0, 1),       # 256 -> 512, k41 s4 g16: 32 x 64
+    (2, 1024, 128, 16, 31, 41, 11, 0, 1),     # 512 -> 1024: 64 x 128 per group (two row tiles, two column tiles)
+    (3, 1024, 64, 16, 47, 47, 41, -20, 1),    # 1024 -> 1024, k41 s1 g16: 41 taps, padding 20
+    (2, 96, 24, 4, 333, 333, 5, -4, 2),       # ragged group sizes (24 rows x 24 columns), dilation 2
+]
+
+
+@pytest.mark.parametrize('N,A,Bg,G,LP,LQ,J,base,step', WG_GROUPED)
+@pytest.mark.parametrize('mag', [1.0, 1e-5])
+def test_grouped_split_weight_gradient_matches_float64(N, A, Bg, G, LP, LQ, J, base, step, mag):
+    """round 6: grouped weight gradients on the split-precision tile kernel (wgrad_f16x3_grouped_kernel) against float64, and against the exact fp32
+    kernel they replace"""
+    from ttscube_amd import _lib
+    from ttscube_amd.hifigan import autograd as AG
+    g = torch.Generator().manual_seed(N * 100 + A + J + G)
+    P = (torch.randn(N, A, LP, generator=g) * mag).cuda()
+    Q = torch.randn(N, G * Bg, LQ, generator=g).cuda()
+    sc, sl = 0.7, 0.1
+    assert _lib.lib().ttsc_conv_wgrad_split_grouped_supported(A, Bg, G, J, step)
+    AG.GROUPED_SPLIT_ALL = True     # (the product only sends groups of more than 32 rows here; the entry point takes them all)
+    try:
+        Gw = AG._wgrad(P, Q, A, G * Bg, J, base, step, sc, sl, groups=G)
+    finally:
+        AG.GROUPED_SPLIT_ALL = False
+    Qa = F.leaky_relu(Q.double() * sc, sl)
+    Ag = A // G
+    ref = torch.zeros(A, Bg, J, dtype=torch.float64, device='cuda')
+    for j in range(J):
+        off = base + j * step
+        Qs = torch.zeros(N, G * Bg, LP, dtype=torch.float64, device='cuda')
+        lo, hi = max(0, -off), min(LP, LQ - off)
+        if hi > lo:
+            Qs[:, :, lo:hi] = Qa[:, :, lo + off:hi + off]
+        for gi in range(G):
+            ref[gi * Ag:(gi + 1) * Ag, :, j] = torch.einsum('nat,nbt->ab', P[:, gi * Ag:(gi + 1) * Ag].double(), Qs[:, gi * Bg:(gi + 1) * Bg])
+    assert Gw.shape == ref.shape
+    assert float((Gw.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    try:
+        AG.GROUPED_SPLIT = False
+        G32 = AG._wgrad(P, Q, A, G * Bg, J, base, step, sc, sl, groups=G)
+    finally:
+        AG.GROUPED_SPLIT = True
+    assert float((G32.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())

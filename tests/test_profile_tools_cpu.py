@@ -5,18 +5,21 @@ import os
 import re
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def test_round5_roofline_table_regenerates_from_the_committed_launch_list(tmp_path, capsys):
+@pytest.mark.parametrize('rnd', ['r05', 'r06'])
+def test_roofline_table_regenerates_from_the_committed_launch_list(tmp_path, capsys, rnd):
     from tools import roofline_table
-    src = os.path.join(ROOT, 'profiles', 'r05_bench_last_forward.csv')
+    src = os.path.join(ROOT, 'profiles', '%s_bench_last_forward.csv' % rnd)
     dst = tmp_path / 'roofline.md'
     roofline_table.main(src, str(dst))
     capsys.readouterr()
     new = dst.read_text()
-    old = open(os.path.join(ROOT, 'profiles', 'r05_roofline.md')).read()
+    old = open(os.path.join(ROOT, 'profiles', '%s_roofline.md' % rnd)).read()
     assert new == old
     n_launches = sum(1 for _ in open(src)) - 1
     assert '(%d launches of one forward' % n_launches in new

@@ -122,6 +122,11 @@ SIGNATURES = {
     'ttsc_conv_wgrad_split': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
                                         C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t,
                                         C.c_void_p]),
+    'ttsc_conv_wgrad_split_grouped_supported': (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    'ttsc_conv_wgrad_split_grouped_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32]),
+    'ttsc_conv_wgrad_split_grouped': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
+                                                C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t,
+                                                C.c_void_p]),
     'ttsc_conv_wgrad_split_bias': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
                                              C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t,
                                              C.c_void_p]),

@@ -421,6 +421,192 @@ static int launch_wgrad_split(const WgsArgs& a, int splits, hipStream_t s) {
     return TTSC_OK;
 }
 
+
+// ---- grouped layers on the same scheme (round 6) ------------------------------------------------------------------------------------------
+// The multi-scale discriminator's k = 41 layers are grouped (4 / 16 groups of 16 .. 64 output channels over 16 .. 128 de-interleaved input channels):
+// their weight gradients were the last convolution work of the step on the exact fp32 matrix instruction (conv_wgrad_kernel: 8.3 ms of a 72 ms
+// step at b = 16, profiles/r06_train_kernel_stats.csv).  A group is a small dense problem with a long contraction, so here a workgroup owns ONE
+// group's rows (RT row tiles of 32: Ag <= 64) x 64 of its columns, and its four waves are (tap half) x (column half): wave (wt, wn) multiplies every
+// 64-position chunk into RT x JT accumulator tiles for the taps j0 + wt JT .. of the launch — 2 JT taps per launch, 120 matrix instructions per wave and
+// staged chunk as in the dense kernel.  (First version: the waves split the POSITIONS of a chunk instead — 42 instructions per staged chunk and three
+// launches for 21 taps: 153 us per launch, slower than the exact kernel it was to replace, profiles/r06_grouped_wgrad_ab.log.)  Operand staging, fp16
+// split, ranges and the unaligned tap reads are wgrad_f16x3_kernel's.
+struct WgsgArgs {
+    const float* P;        // [N][A][LP],  A = G * Ag
+    const float* Q;        // [N][G * Bg][LQ]
+    float* part;           // [gridDim.x][Jtot][A][Bg]
+    const float* amax_q;
+    const float* amax_p;
+    int N, A, Bg, LP, LQ, G, Ag;
+    int Jtot, j0, base, step;
+    float q_scale, q_slope;
+    int chunks, CH, items;
+    int minoff, span;
+};
+
+template <int JT, int RT>
+__global__ __launch_bounds__(256, 2) void wgrad_f16x3_grouped_kernel(WgsgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smraw[];
+    _Float16* Ph = reinterpret_cast<_Float16*>(smraw);   // [32 RT][WS_PP]
+    _Float16* Pl = Ph + 32 * RT * WS_PP;
+    _Float16* Qh = Pl + 32 * RT * WS_PP;                 // [64][WS_QP]
+    _Float16* Ql = Qh + 64 * WS_QP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wt = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    const int ctn = (a.Bg + 63) >> 6;
+    const int g = blockIdx.y / ctn, b0 = (blockIdx.y % ctn) * 64;
+    const int a0 = g * a.Ag;
+    const int it_beg = blockIdx.x * a.CH, it_end = min(it_beg + a.CH, a.items);
+    const float sq = pow2_to(*a.amax_q * a.q_scale, SPLIT_X_TARGET), sp = pow2_to(*a.amax_p, SPLIT_X_TARGET);
+    const float qs = a.q_scale * sq;
+    const int Btot = a.G * a.Bg;
+
+    f32x16 acc[RT][JT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // Operand loads of chunk it + 1 are in flight while chunk it is multiplied (explicit register double buffer, as in conv_wgrad_kernel): the first
+    // version staged load -> convert -> barrier -> multiply per chunk and spent ~7.5 us per 64 positions waiting for HBM (181 us per launch of the
+    // 128 -> 128, k = 41 layer against 154 + 174 us on the exact kernel).
+    float pr[8 * RT], qr[2][16];
+    const bool two = a.span > 0;
+    auto issue = [&](int it) __attribute__((always_inline)) {
+        const int n = it / a.chunks, t0 = (it - n * a.chunks) * 64;
+        int lp = a.LP, lq = a.LQ, rowv = wave * (8 * RT), b0v = b0 + wave * 16;
+        asm volatile("" : "+s"(lp), "+s"(lq), "+v"(rowv), "+v"(b0v));
+        const float* Pn = a.P + ((size_t)n * a.A + a0) * a.LP;
+        const int t = t0 + lane;
+        const unsigned tc = (unsigned)(t < a.LP ? t : a.LP - 1);
+#pragma unroll
+        for (int r = 0; r < 8 * RT; ++r) {
+            const int row = rowv + r;
+            pr[r] = Pn[(unsigned)((row < a.Ag ? row : a.Ag - 1) * lp) + tc];
+        }
+        const float* Qn = a.Q + ((size_t)n * Btot + (size_t)g * a.Bg) * a.LQ;
+        const int q1 = t0 + a.minoff + lane, q2 = q1 + 64;
+        const unsigned c1 = (unsigned)min(max(q1, 0), a.LQ - 1), c2 = (unsigned)min(max(q2, 0), a.LQ - 1);
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            if (ph == 1 && !two) break;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int br = b0v + r;
+                qr[ph][r] = Qn[(unsigned)((br < a.Bg ? br : a.Bg - 1) * lq) + (ph ? c2 : c1)];
+            }
+        }
+    };
+    auto commit = [&](int it) __attribute__((always_inline)) {
+        const int n = it / a.chunks, t0 = (it - n * a.chunks) * 64;
+        const bool tok = t0 + lane < a.LP;
+#pragma unroll
+        for (int r = 0; r < 8 * RT; ++r) {
+            const int row = wave * (8 * RT) + r;
+            const float v = (tok && row < a.Ag) ? pr[r] * sp : 0.f;
+            const _Float16 h = (_Float16)v;
+            Ph[row * WS_PP + lane] = h;
+            Pl[row * WS_PP + lane] = (_Float16)(v - (float)h);
+        }
+        const int q1 = t0 + a.minoff + lane, q2 = q1 + 64;
+        const bool ok1 = q1 >= 0 && q1 < a.LQ, ok2 = lane < a.span && q2 >= 0 && q2 < a.LQ;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            if (ph == 1 && !two) break;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wave * 16 + r;
+                float v = qr[ph][r] * qs;
+                v = fmaxf(v, v * a.q_slope);
+                v = ((ph ? ok2 : ok1) && b0 + row < a.Bg) ? v : 0.f;
+                const _Float16 h = (_Float16)v;
+                Qh[row * WS_QP + ph * 64 + lane] = h;
+                Ql[row * WS_QP + ph * 64 + lane] = (_Float16)(v - (float)h);
+            }
+        }
+    };
+    if (it_beg < it_end) issue(it_beg);
+    for (int it = it_beg; it < it_end; ++it) {
+        __syncthreads();   // the fragment reads of the previous chunk are done
+        commit(it);
+        __syncthreads();
+        if (it + 1 < it_end) issue(it + 1);
+        __builtin_amdgcn_sched_barrier(0);   // (the loads leave before the multiplications, not at their first use)
+        const _Float16* pa = Ph + l31 * WS_PP + half * 8;
+        const _Float16* qb = Qh + (wn * 32 + l31) * WS_QP + half * 8 + (a.base + (a.j0 + wt * JT) * a.step - a.minoff);
+#pragma unroll 1
+        for (int ks = 0; ks < 4; ++ks) {
+            half8 ah[RT], al[RT];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                ah[i] = *reinterpret_cast<const half8*>(pa + i * 32 * WS_PP + ks * 16);
+                al[i] = *reinterpret_cast<const half8*>(pa + 32 * RT * WS_PP + i * 32 * WS_PP + ks * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                const half8 bh = reinterpret_cast<const half8_u*>(qb + ks * 16 + j * a.step)->v;
+                const half8 bl = reinterpret_cast<const half8_u*>(qb + 64 * WS_QP + ks * 16 + j * a.step)->v;
+#pragma unroll
+                for (int i = 0; i < RT; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const float un = 1.f / (sp * sq);
+    const int bcol = b0 + wn * 32 + l31;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+        const int jj = a.j0 + wt * JT + j;
+        if (jj >= a.Jtot) break;   // (the last launch's second tap half may run past the kernel: computed on whatever the window holds, never stored)
+        float* dst = a.part + ((size_t)blockIdx.x * a.Jtot + jj) * a.A * a.Bg;
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lrow = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (lrow < a.Ag && bcol < a.Bg) dst[(size_t)(a0 + lrow) * a.Bg + bcol] = acc[i][j][r] * un;
+            }
+    }
+}
+
+template <int JT, int RT>
+static int launch_wgrad_split_grouped(const WgsgArgs& a, int splits, hipStream_t s) {
+    const int tiles = a.G * ((a.Bg + 63) / 64);
+    const size_t lds = (size_t)(2 * 32 * RT * WS_PP + 2 * 64 * WS_QP) * sizeof(_Float16);
+    hipLaunchKernelGGL((wgrad_f16x3_grouped_kernel<JT, RT>), dim3(splits, tiles), dim3(256), lds, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("wgrad_f16x3_grouped_kernel launch failed: %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    return TTSC_OK;
+}
+template <int RT>
+static int launch_wgrad_split_grouped_jt(const WgsgArgs& a, int jt, int splits, hipStream_t s) {
+    switch (jt) {
+        case 1: return launch_wgrad_split_grouped<1, RT>(a, splits, s);
+        case 2: return launch_wgrad_split_grouped<2, RT>(a, splits, s);
+        case 3: return launch_wgrad_split_grouped<3, RT>(a, splits, s);
+        case 4: return launch_wgrad_split_grouped<4, RT>(a, splits, s);
+        default: break;
+    }
+    if constexpr (RT == 1) {
+        switch (jt) {
+            case 6: return launch_wgrad_split_grouped<6, 1>(a, splits, s);
+            case 7: return launch_wgrad_split_grouped<7, 1>(a, splits, s);
+            case 8: return launch_wgrad_split_grouped<8, 1>(a, splits, s);
+            case 9: return launch_wgrad_split_grouped<9, 1>(a, splits, s);
+            case 10: return launch_wgrad_split_grouped<10, 1>(a, splits, s);
+            default: break;
+        }
+    }
+    return launch_wgrad_split_grouped<5, RT>(a, splits, s);
+}
+
 }  // namespace ttsc
 
 using namespace ttsc;
@@ -624,6 +810,94 @@ extern "C" int ttsc_conv_wgrad_split_bias(const float* p_dev, const float* q_dev
     const unsigned bias_blocks = db_dev ? (unsigned)((A + 255) / 256) : 0u;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks + bias_blocks), dim3(256), 0, s, (const float*)a.part, g_dev, splits, (int)J, AB,
                        db_dev ? (const float*)bias_part : nullptr, db_dev, (int)A, bias_S, (unsigned)blocks);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("wgrad_reduce_kernel launch failed: %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    return TTSC_OK;
+}
+
+// ---- grouped split-precision variant (wgrad_f16x3_grouped_kernel) --------------------------------------------------------------------------
+static void wgrad_split_grouped_plan(int N, int G, int Bg, int64_t LP, int* chunks, int* CH, int* items, int* splits) {
+    *chunks = (int)ceil_div(LP, 64);
+    *items = N * *chunks;
+    const int tiles = G * ((Bg + 63) / 64);
+    long want = (512 + tiles - 1) / tiles;   // ~two workgroups per CU
+    if (want < 1) want = 1;
+    if (want > *items) want = *items;
+    *CH = (int)ceil_div(*items, want);
+    *splits = (int)ceil_div(*items, *CH);
+}
+
+extern "C" int32_t ttsc_conv_wgrad_split_grouped_supported(int32_t A, int32_t Bg, int32_t groups, int32_t J, int32_t step) {
+    const int st = step < 0 ? -step : step;
+    if (groups < 2 || A % groups) return 0;
+    const int Ag = A / groups;
+    return Ag >= 16 && Ag <= 64 && Bg >= 16 && J >= 1 && J <= 64 && step >= 1 && step <= 3;   // (the taps of a launch's two halves share one staged window: 19 steps <= 64)
+}
+
+extern "C" size_t ttsc_conv_wgrad_split_grouped_workspace_bytes(int32_t N, int32_t A, int32_t Bg, int32_t groups, int64_t LP, int32_t J) {
+    if (N <= 0 || A <= 0 || Bg <= 0 || groups <= 0 || LP <= 0 || J <= 0) return 0;
+    int chunks, CH, items, splits;
+    wgrad_split_grouped_plan(N, groups, Bg, LP, &chunks, &CH, &items, &splits);
+    return 256 + (size_t)splits * J * A * Bg * sizeof(float);
+}
+
+extern "C" int ttsc_conv_wgrad_split_grouped(const float* p_dev, const float* q_dev, float* g_dev, int32_t N, int32_t A, int32_t Bg, int32_t groups, int64_t LP,
+                                             int64_t LQ, int32_t J, int32_t base, int32_t step, float q_scale, float q_slope, float* amax_q, float* amax_p,
+                                             int32_t measure, void* ws_dev, size_t ws_bytes, void* stream) {
+    TTSC_REQUIRE(p_dev && q_dev && g_dev && ws_dev, "ttsc_conv_wgrad_split_grouped: null argument");
+    TTSC_REQUIRE(N > 0 && LP > 0 && LQ > 0 && ttsc_conv_wgrad_split_grouped_supported(A, Bg, groups, J, step),
+                 "ttsc_conv_wgrad_split_grouped: shape not supported (N=%d A=%d Bg=%d groups=%d J=%d step=%d)", N, A, Bg, groups, J, step);
+    TTSC_REQUIRE((int64_t)N * A * LP < (1ll << 31) && (int64_t)N * Bg * groups * LQ < (1ll << 31), "ttsc_conv_wgrad_split_grouped: tensor too large");
+    TTSC_REQUIRE(q_slope >= 0.f && q_slope <= 1.f && q_scale > 0.f, "ttsc_conv_wgrad_split_grouped: q_slope must be in [0,1], q_scale positive");
+    TTSC_REQUIRE(ws_bytes >= ttsc_conv_wgrad_split_grouped_workspace_bytes(N, A, Bg, groups, LP, J) && ((uintptr_t)ws_dev & 15) == 0,
+                 "ttsc_conv_wgrad_split_grouped: workspace too small or misaligned");
+    hipStream_t s = (hipStream_t)stream;
+    float* ws_words = reinterpret_cast<float*>(ws_dev);
+    if (!amax_q) { amax_q = ws_words; measure |= 1; }
+    if (!amax_p) { amax_p = ws_words + 1; measure |= 2; }
+    if (int rc = launch_amax2((measure & 1) ? q_dev : nullptr, (long)N * Bg * groups * LQ, amax_q, (measure & 2) ? p_dev : nullptr, (long)N * A * LP, amax_p, s,
+                              (measure & 4) != 0))
+        return rc;
+    WgsgArgs a;
+    a.P = p_dev;
+    a.Q = q_dev;
+    a.part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws_dev) + 256);
+    a.amax_q = amax_q;
+    a.amax_p = amax_p;
+    a.N = N;
+    a.A = A;
+    a.Bg = Bg;
+    a.G = groups;
+    a.Ag = A / groups;
+    a.LP = (int)LP;
+    a.LQ = (int)LQ;
+    a.Jtot = J;
+    a.base = base;
+    a.step = step;
+    a.q_scale = q_scale;
+    a.q_slope = q_slope;
+    int splits;
+    wgrad_split_grouped_plan(N, groups, Bg, LP, &a.chunks, &a.CH, &a.items, &splits);
+    const int RT = a.Ag > 32 ? 2 : 1;
+    const int jt_max = RT == 1 ? 8 : 4;                    // taps per WAVE: RT x JT accumulator tiles (<= 128 registers beside the 16 + 32 prefetch registers); a launch covers 2 JT taps
+    const int nl = (J + 2 * jt_max - 1) / (2 * jt_max);    // launches, with tap ranges of (nearly) equal size
+    const int tl = (J + nl - 1) / nl, jt = (tl + 1) / 2;
+    for (int j0 = 0; j0 < J; j0 += 2 * jt) {
+        a.j0 = j0;
+        const int jlast = std::min(j0 + 2 * jt, (int)J) - 1;
+        a.minoff = base + j0 * step;                       // (step >= 1: the first tap of the launch has the smallest offset)
+        a.span = (jlast - j0) * step;
+        const int rc = RT == 1 ? launch_wgrad_split_grouped_jt<1>(a, jt, splits, s) : launch_wgrad_split_grouped_jt<2>(a, jt, splits, s);
+        if (rc) return rc;
+    }
+    const long AB = (long)A * Bg;
+    const long blocks = (AB * J + 31) / 32;
+    TTSC_REQUIRE(blocks < (1l << 31), "ttsc_conv_wgrad_split_grouped: weight tensor too large");
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)a.part, g_dev, splits, (int)J, AB, (const float*)nullptr,
+                       (float*)nullptr, 0, 0, 0u);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("wgrad_reduce_kernel launch failed: %s", hipGetErrorString(e));

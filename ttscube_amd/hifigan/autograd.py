@@ -146,6 +146,24 @@ def _wgrad(P, Q, A, Bc, J, base, step, q_scale, q_slope, groups=1, amax=None, p_
             if dbt is not None:
                 db.append(dbt)
         return G
+    if SPLIT_TRAIN and GROUPED_SPLIT and groups > 1 and (A // groups > 32 or GROUPED_SPLIT_ALL) and L.ttsc_conv_wgrad_split_grouped_supported(A, Bg, groups, J, step):
+        # grouped layer (MSD's k = 41 convolutions): every group a small dense problem on the split-precision tile kernel (round 6).  Only groups of more
+        # than 32 rows (two MFMA row tiles share every column fragment): with ONE row tile the kernel is bound by its LDS fragment reads (two reads per
+        # three matrix instructions) — 179 us per launch of the 128 -> 128 layer against 154 + 174 us for all 21 taps on the exact kernel, which runs
+        # these shapes at 0.64 of the fp32 matrix peak (profiles/r06_grouped_wgrad_ab.log)
+        nbytes = int(L.ttsc_conv_wgrad_split_grouped_workspace_bytes(N, A, Bg, groups, LP, J))
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=P.device)
+        with _lib.on_device(P.device):
+            if amax_q is not None:
+                aq, ap, have = _lib.dev_ptr(amax_q), _lib.dev_ptr(amax_p), True
+            else:
+                aq = _lib.dev_ptr(amax[0:1]) if amax is not None else None
+                ap = _lib.dev_ptr(amax[2:3]) if amax is not None else None
+                have = amax is not None
+            _lib.check(L.ttsc_conv_wgrad_split_grouped(_lib.dev_ptr(P), _lib.dev_ptr(Q), _lib.dev_ptr(G), N, A, Bg, groups, LP, LQ, J, base, step, q_scale,
+                                                       q_slope, aq, ap, 0 if not have else ((0 if p_measured else 2) | (4 if pooled else 0)),
+                                                       _lib.dev_ptr(ws), nbytes, _lib.current_stream()), 'ttsc_conv_wgrad_split_grouped')
+        return G
     nbytes = int(L.ttsc_conv_wgrad_workspace_bytes(N, A, Bg, LP, J))
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=P.device)
     with _lib.on_device(P.device):
@@ -157,6 +175,8 @@ def _wgrad(P, Q, A, Bc, J, base, step, q_scale, q_slope, groups=1, amax=None, p_
 # Dense stride-1 convolutions run forward and data gradient on the split-precision kernel (csrc/conv_train.hip: fp16 hi/lo x 3 on MFMA, ranges
 # measured on the device per launch, batch folded into the tile columns); TTSC_TRAIN_SPLIT=0 keeps everything on the exact-fp32 kernel.
 SPLIT_TRAIN = os.environ.get('TTSC_TRAIN_SPLIT', '1') != '0'
+GROUPED_SPLIT = os.environ.get('TTSC_TRAIN_GROUPED_SPLIT', '1') != '0'   # (measurement switch: 0 = grouped weight gradients on the exact fp32 kernel, round 5's path)
+GROUPED_SPLIT_ALL = os.environ.get('TTSC_TRAIN_GROUPED_SPLIT', '1') == '2'   # (2 = also groups of <= 32 rows: slower, see _wgrad)
 
 
 def _split_ok(Cin, Cout, K, dilation, groups=1):
