@@ -252,6 +252,10 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 struct __attribute__((packed, aligned(2))) half8_u {
     half8 v;
 };
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) f4u {   // four consecutive floats at a 4-byte aligned address (one global_load_dwordx4)
+    float v[4];
+};
 
 template <int JT>
 __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(WgsArgs a) {
@@ -313,9 +317,74 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(WgsArgs a) {
         int lp = a.LP, lq = a.LQ, a0v = a0 + wave * 32, b0v = b0 + wave * 16;
         asm volatile("" : "+s"(lp), "+s"(lq), "+v"(a0v), "+v"(b0v));
         __syncthreads();   // the fragment reads of the previous chunk are done
-        // Staging: lane = position (coalesced 256-byte row segments).  Loads are ISSUED in batches of 16 into registers with clamped addresses and no
-        // use of the values (hipcc waits for a load right before its first use: load-convert-store per element is one L2 round trip each),
-        // then masked, scaled, split and written as fp16.
+        // A chunk whose positions and Q window lie inside the rows (every chunk but the first / last of a sequence) is staged FOUR positions per lane:
+        // 16-byte loads (a quarter-wave covers the 64 positions of a row, the wave four rows per instruction) and 8-byte LDS writes — per thread
+        // 16 loads + 32 writes instead of 64 + 128.  Measured (round 6, tools/probes/wgrad_time.py, profiles/r06_wgrad_staging.log): with only a
+        // quarter of the 2-byte staging writes issued the launches ran 11 - 36 % faster — the LDS instruction count, not the matrix pipe, bounded them.
+        const int qlo = t0 + a.minoff;
+        const bool interior = t0 + 64 <= a.LP && qlo >= 0 && qlo + 64 + ((a.span + 3) & ~3) <= a.LQ;
+        if (interior) {
+            const int sub = lane >> 4, q4 = 4 * (lane & 15);
+            {
+                const float* Pn = a.P + (size_t)n * a.A * a.LP + t0 + q4;
+                f4u pv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int ar = a0v + 4 * k + sub;
+                    pv[k] = *reinterpret_cast<const f4u*>(Pn + (unsigned)((ar < a.A ? ar : a.A - 1) * lp));
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int row = wave * 32 + 4 * k + sub;
+                    const bool rok = a0 + row < a.A;
+                    half4 h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = rok ? pv[k].v[e] * sp : 0.f;
+                        h[e] = (_Float16)v;
+                        l[e] = (_Float16)(v - (float)h[e]);
+                    }
+                    *reinterpret_cast<half4*>(Ph + row * WS_PP + q4) = h;
+                    *reinterpret_cast<half4*>(Pl + row * WS_PP + q4) = l;
+                }
+            }
+            {
+                const float* Qn = a.Q + (size_t)n * a.Bc * a.LQ + qlo + q4;
+                const bool two = a.span > 0;
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) {
+                    if (ph == 1 && !two) break;
+                    const bool qok = ph == 0 || q4 < a.span;   // (second part: only the quads the taps reach)
+                    f4u qv[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int br = b0v + 4 * k + sub;
+                        qv[k] = *reinterpret_cast<const f4u*>(Qn + (unsigned)((br < a.Bc ? br : a.Bc - 1) * lq) + (qok ? ph * 64 : 0));
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int row = wave * 16 + 4 * k + sub;
+                        const bool rok = b0 + row < a.Bc;
+                        half4 h, l;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = qv[k].v[e] * qs;
+                            v = fmaxf(v, v * a.q_slope);
+                            v = rok ? v : 0.f;
+                            h[e] = (_Float16)v;
+                            l[e] = (_Float16)(v - (float)h[e]);
+                        }
+                        if (qok) {
+                            *reinterpret_cast<half4*>(Qh + row * WS_QP + ph * 64 + q4) = h;
+                            *reinterpret_cast<half4*>(Ql + row * WS_QP + ph * 64 + q4) = l;
+                        }
+                    }
+                }
+            }
+        } else {
+        // Staging of an edge chunk: lane = position (coalesced 256-byte row segments).  Loads are ISSUED in batches of 16 into registers with clamped
+        // addresses and no use of the values (hipcc waits for a load right before its first use: load-convert-store per element is one L2 round trip
+        // each), then masked, scaled, split and written as fp16.
         {   // P: wave w stages rows 32 w .. 32 w + 31
             const float* Pn = a.P + (size_t)n * a.A * a.LP;
             const int t = t0 + lane;
@@ -366,6 +435,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(WgsArgs a) {
                 }
             }
         }
+        }   // (edge chunk)
         __syncthreads();
         const _Float16* pa = Ph + (wm * 64 + l31) * WS_PP + half * 8;
         const _Float16* qb = Qh + (wn * 32 + l31) * WS_QP + half * 8 + (a.base + a.j0 * a.step - a.minoff);
@@ -471,21 +541,45 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_grouped_kernel(WgsgArgs a)
     // Operand loads of chunk it + 1 are in flight while chunk it is multiplied (explicit register double buffer, as in conv_wgrad_kernel): the first
     // version staged load -> convert -> barrier -> multiply per chunk and spent ~7.5 us per 64 positions waiting for HBM (181 us per launch of the
     // 128 -> 128, k = 41 layer against 154 + 174 us on the exact kernel).
-    float pr[8 * RT], qr[2][16];
+    f4u pv[2 * RT], qv[2][4];   // staging registers: pv[r >> 2].v[r & 3] = row r of the wave's share (edge chunks), or four positions of row 4 k + sub (interior chunks)
     const bool two = a.span > 0;
+    const int sub = lane >> 4, q4 = 4 * (lane & 15);
+    // interior chunk (positions and Q window inside the rows): four positions per lane, 16-byte loads and 8-byte LDS writes — see wgrad_f16x3_kernel
+    auto is_interior = [&](int it) __attribute__((always_inline)) -> bool {
+        const int n = it / a.chunks, t0 = (it - n * a.chunks) * 64, qlo = t0 + a.minoff;
+        return t0 + 64 <= a.LP && qlo >= 0 && qlo + 64 + ((a.span + 3) & ~3) <= a.LQ;
+    };
     auto issue = [&](int it) __attribute__((always_inline)) {
         const int n = it / a.chunks, t0 = (it - n * a.chunks) * 64;
         int lp = a.LP, lq = a.LQ, rowv = wave * (8 * RT), b0v = b0 + wave * 16;
         asm volatile("" : "+s"(lp), "+s"(lq), "+v"(rowv), "+v"(b0v));
         const float* Pn = a.P + ((size_t)n * a.A + a0) * a.LP;
+        const float* Qn = a.Q + ((size_t)n * Btot + (size_t)g * a.Bg) * a.LQ;
+        if (is_interior(it)) {
+#pragma unroll
+            for (int k = 0; k < 2 * RT; ++k) {
+                const int row = rowv + 4 * k + sub;
+                pv[k] = *reinterpret_cast<const f4u*>(Pn + (unsigned)((row < a.Ag ? row : a.Ag - 1) * lp) + t0 + q4);
+            }
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                if (ph == 1 && !two) break;
+                const bool qok = ph == 0 || q4 < a.span;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int br = b0v + 4 * k + sub;
+                    qv[ph][k] = *reinterpret_cast<const f4u*>(Qn + (unsigned)((br < a.Bg ? br : a.Bg - 1) * lq) + t0 + a.minoff + q4 + (qok ? ph * 64 : 0));
+                }
+            }
+            return;
+        }
         const int t = t0 + lane;
         const unsigned tc = (unsigned)(t < a.LP ? t : a.LP - 1);
 #pragma unroll
         for (int r = 0; r < 8 * RT; ++r) {
             const int row = rowv + r;
-            pr[r] = Pn[(unsigned)((row < a.Ag ? row : a.Ag - 1) * lp) + tc];
+            pv[r >> 2].v[r & 3] = Pn[(unsigned)((row < a.Ag ? row : a.Ag - 1) * lp) + tc];
         }
-        const float* Qn = a.Q + ((size_t)n * Btot + (size_t)g * a.Bg) * a.LQ;
         const int q1 = t0 + a.minoff + lane, q2 = q1 + 64;
         const unsigned c1 = (unsigned)min(max(q1, 0), a.LQ - 1), c2 = (unsigned)min(max(q2, 0), a.LQ - 1);
 #pragma unroll
@@ -494,17 +588,57 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_grouped_kernel(WgsgArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int br = b0v + r;
-                qr[ph][r] = Qn[(unsigned)((br < a.Bg ? br : a.Bg - 1) * lq) + (ph ? c2 : c1)];
+                qv[ph][r >> 2].v[r & 3] = Qn[(unsigned)((br < a.Bg ? br : a.Bg - 1) * lq) + (ph ? c2 : c1)];
             }
         }
     };
     auto commit = [&](int it) __attribute__((always_inline)) {
         const int n = it / a.chunks, t0 = (it - n * a.chunks) * 64;
+        if (is_interior(it)) {
+#pragma unroll
+            for (int k = 0; k < 2 * RT; ++k) {
+                const int row = wave * (8 * RT) + 4 * k + sub;
+                const bool rok = row < a.Ag;
+                half4 h, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = rok ? pv[k].v[e] * sp : 0.f;
+                    h[e] = (_Float16)v;
+                    l[e] = (_Float16)(v - (float)h[e]);
+                }
+                *reinterpret_cast<half4*>(Ph + row * WS_PP + q4) = h;
+                *reinterpret_cast<half4*>(Pl + row * WS_PP + q4) = l;
+            }
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                if (ph == 1 && !two) break;
+                const bool qok = ph == 0 || q4 < a.span;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = wave * 16 + 4 * k + sub;
+                    const bool rok = b0 + row < a.Bg;
+                    half4 h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = qv[ph][k].v[e] * qs;
+                        v = fmaxf(v, v * a.q_slope);
+                        v = rok ? v : 0.f;
+                        h[e] = (_Float16)v;
+                        l[e] = (_Float16)(v - (float)h[e]);
+                    }
+                    if (qok) {
+                        *reinterpret_cast<half4*>(Qh + row * WS_QP + ph * 64 + q4) = h;
+                        *reinterpret_cast<half4*>(Ql + row * WS_QP + ph * 64 + q4) = l;
+                    }
+                }
+            }
+            return;
+        }
         const bool tok = t0 + lane < a.LP;
 #pragma unroll
         for (int r = 0; r < 8 * RT; ++r) {
             const int row = wave * (8 * RT) + r;
-            const float v = (tok && row < a.Ag) ? pr[r] * sp : 0.f;
+            const float v = (tok && row < a.Ag) ? pv[r >> 2].v[r & 3] * sp : 0.f;
             const _Float16 h = (_Float16)v;
             Ph[row * WS_PP + lane] = h;
             Pl[row * WS_PP + lane] = (_Float16)(v - (float)h);
@@ -517,7 +651,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_grouped_kernel(WgsgArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wave * 16 + r;
-                float v = qr[ph][r] * qs;
+                float v = qv[ph][r >> 2].v[r & 3] * qs;
                 v = fmaxf(v, v * a.q_slope);
                 v = ((ph ? ok2 : ok1) && b0 + row < a.Bg) ? v : 0.f;
                 const _Float16 h = (_Float16)v;
@@ -882,7 +1016,7 @@ extern "C" int ttsc_conv_wgrad_split_grouped(const float* p_dev, const float* q_
     int splits;
     wgrad_split_grouped_plan(N, groups, Bg, LP, &a.chunks, &a.CH, &a.items, &splits);
     const int RT = a.Ag > 32 ? 2 : 1;
-    const int jt_max = RT == 1 ? 8 : 4;                    // taps per WAVE: RT x JT accumulator tiles (<= 128 registers beside the 16 + 32 prefetch registers); a launch covers 2 JT taps
+    const int jt_max = RT == 1 ? 6 : 3;                    // taps per WAVE: RT x JT accumulator tiles (<= 96 registers beside the 16 + 32 prefetch registers and the two staging paths); a launch covers 2 JT taps
     const int nl = (J + 2 * jt_max - 1) / (2 * jt_max);    // launches, with tap ranges of (nearly) equal size
     const int tl = (J + nl - 1) / nl, jt = (tl + 1) / 2;
     for (int j0 = 0; j0 < J; j0 += 2 * jt) {
