@@ -269,7 +269,8 @@ int ttsc_conv_wgrad_split_bias(const float* p_dev, const float* q_dev, float* g_
  * Both fp16 ranges are set per launch from device-side maxima of x and w (no host synchronisation, no calibration state); results agree
  * with the fp32 kernel to ~1e-6 relative.  The two range words (one float each, device) can be shared by the launches of one layer so that every
  * tensor is reduced once per step: forward measures max |x| and max |w| (`measure` = 3), the data gradient re-uses the weight word and measures
- * max |dy| (`measure` = 1), the weight gradient re-uses both; null pointers = measured into the workspace by this call.
+ * max |dy| (`measure` = 1), the weight gradient re-uses both; null pointers = measured into the workspace by this call; `measure` bit 2 = the words to be
+ * measured were zeroed by the caller (words of a pool zeroed once per step: no memset launch).
  * `ttsc_conv_train_supported` says whether a shape is taken (receptive fields beyond 64 positions,
  * more than 41 taps and group sizes that do not tile into 32-row blocks stay on ttsc_conv1d_forward); the workspace holds the two range words and the packed weight fragments. */
 int32_t ttsc_conv_train_supported(int32_t Cin, int32_t Cout, int32_t K, int32_t dilation, int32_t groups);

@@ -286,7 +286,7 @@ extern "C" int ttsc_conv_train(const float* x, const float* w, const float* bias
                                size_t ws_bytes, void* stream) {
     TTSC_REQUIRE(w && ws, "ttsc_conv_train: null argument");
     return conv_train_impl(x, w, nullptr, bias, resid, gate, y, B, Cin, Cout, K, Lin, padding, dilation, groups, flip, in_scale, in_slope, out_scale,
-                           gate_slope, amax_x, amax_w, measure & 3, ws, ws_bytes, stream);
+                           gate_slope, amax_x, amax_w, measure & 7, ws, ws_bytes, stream);   // (bit 2: the caller's words were zeroed by the caller — pooled words)
 }
 
 extern "C" int ttsc_conv_train_packed(const float* x, const void* wfrag, const float* bias, const float* resid, const float* gate, float* y, int32_t B,

@@ -243,11 +243,13 @@ class HipConvFn(torch.autograd.Function):
             return y
         wd = w.detach().contiguous()
         if not tc.transposed and tc.stride == 1 and _split_ok(tc.Cin, tc.Cout, tc.K, tc.dilation, tc.groups):
-            # range words of this layer for this step: [max |x|, max |w|, max |dy|] — each tensor is reduced once, by the first launch that needs it
-            ctx.amax = torch.empty(3, dtype=torch.float32, device=x.device)
+            # range words of this layer for this step: [max |x|, max |w|, max |dy|] — each tensor is reduced once, by the first launch that needs it; the
+            # words come zeroed from the step's pool (no memset launch per reduction)
+            from .wbank import AmaxPool
+            ctx.amax = AmaxPool.of(x.device).take()
             y = _conv_split(x, wd, b.detach().contiguous() if b is not None else None, resid.contiguous() if resid is not None else None, None,
                             tc.Cin, tc.Cout, tc.K, tc.padding, tc.dilation, 0, in_scale=in_scale, in_slope=in_slope, groups=tc.groups,
-                            amax_x=ctx.amax[0:1], amax_w=ctx.amax[1:2], measure=3)
+                            amax_x=ctx.amax[0:1], amax_w=ctx.amax[1:2], measure=7)
         else:
             tc.fwd.set_weight_device(wd, b.detach() if b is not None else None)
             y = tc.fwd(x, resid=resid, in_scale=in_scale, in_slope=in_slope)
@@ -299,14 +301,15 @@ class HipConvFn(torch.autograd.Function):
                     am = ctx.amax
                     dx = _conv_split(dy, w, None, None, x if sl != 1.0 else None, tc.Cout, tc.Cin, tc.K, pd, tc.dilation, 1, out_scale=sc,
                                      gate_slope=sl, groups=tc.groups, amax_x=am[2:3] if am is not None else None,
-                                     amax_w=am[1:2] if am is not None else None, measure=1)
+                                     amax_w=am[1:2] if am is not None else None, measure=5 if am is not None else 1)
                     dy_measured = am is not None
                 else:
                     h = tc.dgrad_handle()
                     h.set_weight_device_dgrad(w)
                     dx = h(dy, out_scale=sc, gate=x if sl != 1.0 else None, gate_slope=sl)
             if ctx.needs_input_grad[1]:
-                dw = _wgrad(dy, x, tc.Cout, tc.Cin, tc.K, -tc.padding, tc.dilation, sc, sl, tc.groups, amax=ctx.amax, p_measured=dy_measured)
+                dw = _wgrad(dy, x, tc.Cout, tc.Cin, tc.K, -tc.padding, tc.dilation, sc, sl, tc.groups, amax=ctx.amax, p_measured=dy_measured,
+                            pooled=ctx.amax is not None)
         else:
             m_lo, _, M = tc.taps_t()
             dyp = tc.deinterleave(dy, Lin)

@@ -23,6 +23,22 @@ def equal_batches(indices, batch_size):
     return [indices[s:s + batch_size] for s in range(0, len(indices), batch_size)]
 
 
+def pin_batch(batch):
+    """page-lock the tensors of a collated batch (on a machine with a HIP device), so that the training step's host-to-device copies are
+    asynchronous: a pageable `.to(device)` blocks the host until the copy has run — 13 copies and ~4 ms of a 72 ms Cubegan step with the GPU idle
+    (round 6, tools/probes/train_host_profile.py).  Done here, one batch ahead, on the loader's thread."""
+    import torch
+    if not (isinstance(batch, dict) and torch.cuda.is_available()):
+        return batch
+    for k, v in list(batch.items()):
+        if torch.is_tensor(v) and v.device.type == 'cpu' and not v.is_pinned() and v.numel() > 0:
+            try:
+                batch[k] = v.pin_memory()
+            except RuntimeError:
+                return batch
+    return batch
+
+
 class BatchLoader:
     """Iterates collate([dataset[i] for i in batch]) over `batches` (lists of indices), prepared `depth` batches ahead by
     `num_workers` threads (numpy / soundfile release the GIL while decoding).  num_workers = 0 loads synchronously."""
@@ -36,7 +52,7 @@ class BatchLoader:
 
     def _load(self, pool, batch):
         items = list(pool.map(self._ds.__getitem__, batch)) if pool else [self._ds[i] for i in batch]
-        return self._collate(items)
+        return pin_batch(self._collate(items))
 
     def __iter__(self):
         if self._nw == 0:

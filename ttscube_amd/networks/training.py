@@ -9,6 +9,25 @@ from ..hip_layers import linear_hip
 from .modules import _char_lengths, _expand_rows
 
 
+def _h2d(X, key, dev):
+    """batch tensor `key` on the device: from page-locked memory and without blocking the host (io_utils.loader.pin_batch; a batch that arrives
+    pageable is pinned here once and the pinned copy kept in the batch dict, so a batch that is stepped on repeatedly is pinned once)"""
+    t = X[key]
+    if not torch.is_tensor(t) or t.device.type != 'cpu' or dev.type != 'cuda':
+        return t.to(dev)
+    if not t.is_pinned() and t.numel() > 0:
+        cache = X.setdefault('_pinned', {})
+        hit = cache.get(key)
+        if hit is None or hit[0] is not t:
+            try:
+                hit = (t, t.pin_memory())
+            except RuntimeError:
+                return t.to(dev)
+            cache[key] = hit
+        t = hit[1]
+    return t.to(dev, non_blocking=True)
+
+
 def languasito_forward(lang, X):
     """Languasito2.forward (modules.py:996-999) with given alignments/pitch:
     returns (output_dur [B,N,D+1], output_pitch [B,F], output_vuv [B,F], conditioning [B,F,80])."""
@@ -148,7 +167,7 @@ def _languasito_branches(lang, X):
         raise NotImplementedError("training with external conditioning ('fasttext:..' / 'hf:..') is not built: the encoders cannot be "
                                   "downloaded here and the conditioning branch (modules.py:963-990) is inference-only; use conditioning=None")
     dev = lang._get_device()
-    x_char, x_speaker = X['x_char'].to(dev), X['x_speaker'].to(dev)
+    x_char, x_speaker = _h2d(X, 'x_char', dev), _h2d(X, 'x_speaker', dev)
 
     _require_device(x_char, 'languasito_forward_train')
     embed, linear, cnn = _text_ops(lang)
@@ -162,15 +181,15 @@ def _languasito_branches(lang, X):
 
     alignments = X['y_frame2phone']
     m_ = max(len(a) for a in alignments)
-    idx = torch.zeros((len(alignments), m_), dtype=torch.long)
+    idx = torch.zeros((len(alignments), m_), dtype=torch.long, pin_memory=(dev.type == 'cuda'))
     for b, a in enumerate(alignments):
         idx[b, :len(a)] = torch.as_tensor(a)
         idx[b, len(a):] = a[-1]
     # frame -> phoneme maps are monotone; with the utterance offsets added the flat index list is non-decreasing, which lets the backward pass
     # sum each phoneme's frames as one contiguous run (checked here, on the host copy: anything else takes the general scatter kernel)
     idx_sorted = bool((idx[:, 1:] >= idx[:, :-1]).all()) if idx.shape[1] > 1 else True
-    idx_dev = idx.to(dev)
-    pitch_in = X['y_pitch'].to(dev).float().unsqueeze(2) / lang._max_pitch
+    idx_dev = idx.to(dev, non_blocking=True)
+    pitch_in = _h2d(X, 'y_pitch', dev).float().unsqueeze(2) / lang._max_pitch
 
     def expand(x):
         """phoneme rows -> frame rows (modules.py:1043-1053).  A row gather whose backward adds the frames of a phoneme in a FIXED order
@@ -296,7 +315,7 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
                 t_.record_stream(s_t)
     with (torch.cuda.stream(s_t) if s_t is not None else contextlib.nullcontext()):
         p_dur, p_pitch, p_vuv = text_fn()
-        loss_duration, loss_pitch = text_losses(p_dur, p_pitch, p_vuv, batch['y_dur'].to(dev), batch['y_pitch'].to(dev), lang._max_pitch,
+        loss_duration, loss_pitch = text_losses(p_dur, p_pitch, p_vuv, _h2d(batch, 'y_dur', dev), _h2d(batch, 'y_pitch', dev), lang._max_pitch,
                                                 int(max(model._encodings.max_pitch, model._encodings.max_duration) + 1))
         loss_text = loss_pitch + loss_duration
         opt_t.zero_grad()
@@ -316,7 +335,7 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
                 reducers[2].reduce()
             opt_t.step()
     conditioning = cond_fn()
-    y = batch['y_audio'].to(dev)
+    y = _h2d(batch, 'y_audio', dev)
     if y.shape[1] > 12000 - 240:   # random 50-frame / 12000-sample crop per item (cubegan.py:116-128)
         ys, cs = [], []
         for ii in range(y.shape[0]):
