@@ -27,6 +27,7 @@ import torch
 
 from .. import _lib
 from ..hip_layers import Conv1dHip
+from .wbank import AmaxPool, range_of, tag_range
 
 
 class TrainConv:
@@ -245,7 +246,6 @@ class HipConvFn(torch.autograd.Function):
         if not tc.transposed and tc.stride == 1 and _split_ok(tc.Cin, tc.Cout, tc.K, tc.dilation, tc.groups):
             # range words of this layer for this step: [max |x|, max |w|, max |dy|] — each tensor is reduced once, by the first launch that needs it; the
             # words come zeroed from the step's pool (no memset launch per reduction)
-            from .wbank import AmaxPool
             ctx.amax = AmaxPool.of(x.device).take()
             y = _conv_split(x, wd, b.detach().contiguous() if b is not None else None, resid.contiguous() if resid is not None else None, None,
                             tc.Cin, tc.Cout, tc.K, tc.padding, tc.dilation, 0, in_scale=in_scale, in_slope=in_slope, groups=tc.groups,
@@ -265,7 +265,6 @@ class HipConvFn(torch.autograd.Function):
         tc, sc, sl = ctx.tc, ctx.in_scale, ctx.in_slope
         dy = dy.contiguous()
         if ctx.pack is not None:
-            from .wbank import AmaxPool, range_of, tag_range
             (x,) = ctx.saved_tensors
             dx = dw = db = None
             words = ctx.words
@@ -339,7 +338,6 @@ def hip_conv(tc, x, w, b=None, resid=None, in_scale=1.0, in_slope=1.0):
         return HipConvFn.apply(x, w, b, resid, tc, float(in_scale), float(in_slope), None, None, None)
     if not (SPLIT_TRAIN and not tc.transposed and tc.stride == 1):
         raise _lib.TTSCError('hip_conv: a banked weight needs the split-precision stride-1 path')
-    from .wbank import AmaxPool, range_of, tag_range
     pool = AmaxPool.of(x.device)
     words = pool.take()
     y = HipConvFn.apply(x, w, b, resid, tc, float(in_scale), float(in_slope), pack, words, range_of(x) if x.is_contiguous() else None)

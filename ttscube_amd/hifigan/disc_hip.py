@@ -20,6 +20,7 @@ import torch.nn.functional as F
 
 from .. import _lib
 from .autograd import HipWeightNormFn, TrainConv, hip_conv
+from .wbank import pass_range
 from .streams import fan_out
 
 LRELU_SLOPE = 0.1
@@ -49,7 +50,6 @@ class _DeintX(torch.autograd.Function):
         with _lib.on_device(g.device):
             _lib.check(_lib.lib().ttsc_deinterleave_x(_lib.dev_ptr(g), _lib.dev_ptr(dx), N, C, LP // P, G, s, P, pad, M, 1, _lib.current_stream()),
                        'ttsc_deinterleave_x')
-        from .wbank import pass_range
         return pass_range(g, dx), None, None, None, None, None
 
 
@@ -100,7 +100,6 @@ class HipStridedConv:
         Lout = (L + 2 * self.p - K) // s + 1
         M = Lout + J - 1
         if banked:               # (the tap de-interleave of the weight is folded into the bank's fragment packing)
-            from .wbank import pass_range
             xr = pass_range(x, _DeintX.apply(x, G, s, P, self.p, M)) if x.is_contiguous() else _DeintX.apply(x, G, s, P, self.p, M)
             wp = w
         elif FUSED_DEINTERLEAVE:   # one gather per operand and direction (csrc/train_ops.hip)

@@ -137,7 +137,11 @@ class WeightBank:
 
     def weight(self, i):
         e = self.entries[i]
-        w = BankWeightFn.apply(e.layer.weight_v, e.layer.weight_g, self, i)
+        v, g = e.layer.weight_v, e.layer.weight_g
+        if (v.requires_grad or g.requires_grad) and torch.is_grad_enabled():
+            w = BankWeightFn.apply(v, g, self, i)
+        else:   # frozen layer (the discriminators during the generator step): no autograd node, just the handle that carries the fragments
+            w = e.w.view(e.conv_shape) if e.stride == 1 else e.placeholder.expand(e.conv_shape)
         w._ttsc_pack = (e.pack_fwd, e.pack_dgrad, e.amax)
         return w
 
