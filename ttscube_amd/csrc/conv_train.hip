@@ -256,6 +256,9 @@ static int conv_train_impl(const float* x, const float* w, const _Float16* prepa
     a.amax_x = amax_x;
     a.amax_w = amax_w;
     a.amax_out = reinterpret_cast<unsigned*>(amax_y);
+#ifdef TTSC_ABLATE
+    if (const char* ev = getenv("TTSC_CONV_DBG")) a.dbg = atoi(ev);   // (measurement build only: see TTSC_DBG in conv_kernels.hpp)
+#endif
     a.q_cnt = (int)(S * B);
     // column tile: 256 wide when that still gives every CU two workgroups, else 128 (and 128 when 21+ taps of weights share the LDS)
     const long cols = S * B;
