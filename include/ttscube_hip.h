@@ -198,6 +198,11 @@ int ttsc_bias_grad(const float* dy_dev, float* db_dev, int32_t B, int32_t C, int
  * as torch's single-tensor AdamW (decoupled weight decay, no amsgrad). */
 int ttsc_adamw_step(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int64_t step, void* stream);
+/* The same update behind a device-side guard: when *guard_dev != 0 at execution time the launch leaves parameters and moments untouched (null = no
+ * guard).  The word is what ttsc_split_status_collect left on the stream: a training step can then queue its update without the host waiting for the
+ * backward pass to learn whether a split recurrence gave up (cube/networks/cubegan.py:172-180 is the update; the reference has no such failure mode). */
+int ttsc_adamw_step_guarded(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, int64_t step, const uint32_t* guard_dev, void* stream);
 /* GAN loss terms over a LIST of tensors in one launch, value and gradient together — hifigan.models.feature_loss / generator_loss /
  * discriminator_loss [EXTERNAL; call sites cube/networks/cubegan.py:144-149,160-167]:
  *   kind 0:  out = sum_k w_k * mean|a_k - b_k|      gb_k = w_k sign(b_k - a_k) / n_k,  ga_k = -gb_k      (feature matching: w = 2)
@@ -512,6 +517,10 @@ int32_t ttsc_lstm_split_status(void);
  * that this stream's backward pass is sound BEFORE its gradients are exchanged and applied (cube/networks/cubegan.py:172-180 is the update it guards),
  * without draining the other streams. */
 int32_t ttsc_split_status_stream(void* stream);
+/* Device-side form of the same question: ONE launch on `stream` ORs the verdict bits of every split recurrence launched on that stream so far (bit 0 LSTM,
+ * bit 1 GRU, bit 2 mel-AR, bit 3 other; bit 4 = the split-precision GEMM's range word when with_gemm != 0) into *dst_dev and re-arms the sticky words;
+ * the host waits for nothing.  Returns the number of status words looked at (0: nothing to ask, no launch), < 0 on a HIP error. */
+int32_t ttsc_split_status_collect(void* stream, uint32_t* dst_dev, int32_t with_gemm);
 /* Utterances per member group of the register-resident split recurrence (H = 256 / 512: 4 / 16 workgroups per group hold W_hh in registers).
  * 0 (default) = automatic: the smallest of 1 / 2 / 4 that takes the padded batch in one launch — the shortest step.  n = 1 / 2 / 4 / 8: n per
  * group whenever the batch has that many — n times fewer CUs held for a somewhat longer step, for callers that run the recurrence beside a

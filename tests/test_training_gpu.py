@@ -492,3 +492,84 @@ def test_cubegan_step_is_reproducible_with_eight_hardware_queues():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('run ')]
     assert len(lines) == 2 and all(' 0 of ' in l for l in lines), out.stdout[-2000:]
+
+
+def test_guarded_adamw_skips_itself_on_a_set_word_and_matches_the_plain_launch_otherwise():
+    """ttsc_adamw_step_guarded: a non-zero device word leaves parameters and moments untouched; a zero word gives ttsc_adamw_step's bits"""
+    from ttscube_amd.optim import FlatAdamW
+    g = torch.Generator().manual_seed(3)
+    def make():
+        ps = [torch.nn.Parameter(torch.randn(n, generator=g).cuda()) for n in (1000, 37, 4096)]
+        for p in ps:
+            p.grad = torch.randn(p.shape, generator=g).cuda()
+        return ps
+    g.manual_seed(3)
+    pa = make()
+    g.manual_seed(3)
+    pb = make()
+    oa, ob = FlatAdamW(pa, 1e-3, betas=(0.8, 0.99)), FlatAdamW(pb, 1e-3, betas=(0.8, 0.99))
+    word = torch.zeros(1, dtype=torch.int32, device='cuda')
+    oa.step()
+    ob.step(guard=word)
+    for a, b in zip(pa, pb):
+        assert torch.equal(a.detach(), b.detach())
+    word.fill_(4)
+    before = [p.detach().clone() for p in pb]
+    m0, v0 = ob.m.clone(), ob.v.clone()
+    ob.step(guard=word)
+    torch.cuda.synchronize()
+    for p0, p in zip(before, pb):
+        assert torch.equal(p0, p.detach())
+    assert torch.equal(m0, ob.m) and torch.equal(v0, ob.v)
+
+
+def test_split_status_collect_is_a_launch_not_a_wait():
+    """ttsc_split_status_collect: after recurrences ran on a stream the call looks at their sticky words with one launch and leaves 0 in the
+    destination when every hand-off completed; a null destination is refused"""
+    from ttscube_amd import _lib
+    from ttscube_amd.networks.lstm_autograd import lstm_forward_train
+    L = _lib.lib()
+    assert L.ttsc_split_status_collect(_lib.current_stream(), None, 0) < 0
+    lstm = torch.nn.LSTM(64, 256, num_layers=1, bidirectional=True, batch_first=True).cuda()
+    x = torch.randn(4, 50, 64, device='cuda', requires_grad=True)
+    lstm_forward_train(lstm, x).sum().backward()
+    word = torch.zeros(1, dtype=torch.int32, device='cuda')
+    n = L.ttsc_split_status_collect(_lib.current_stream(), word.data_ptr(), 1)
+    assert n >= 0
+    assert int(word.item()) == 0
+    _lib.check_split_status('test')
+
+
+def test_lazy_step_result_equals_the_eager_one_bit_for_bit():
+    """TTSC_STEP_LAZY: the device-guarded updates and the deferred read-back change nothing — losses and every parameter after three steps are
+    the bits of the host-checked step; the result is a mapping that fills itself on first access"""
+    import random
+    from ttscube_amd.networks.cubegan import Cubegan
+    from ttscube_amd.networks import training as T
+    rng = np.random.RandomState(0)
+    batch, enc = _batch(2, 12, rng)
+    outs, params = [], []
+    old = T.STEP_LAZY
+    try:
+        for lazy in (True, False):
+            T.STEP_LAZY = lazy
+            torch.manual_seed(0)
+            model = Cubegan(enc, conditioning=None, train=True).cuda()
+            model.train()
+            opts = T.cubegan_configure_optimizers(model)
+            r = random.Random(1)
+            res = [T.cubegan_training_step(model, batch, opts, rng=r) for _ in range(3)]
+            if lazy:
+                assert isinstance(res[-1], T.StepLosses) and res[-1].pending
+                via_class = model.training_step(batch, 0, rng=random.Random(5))
+                assert via_class.pending and set(via_class) >= {'loss_g', 'loss_d', 'loss_t', 'loss_v', 'loss', 'lr'}
+                assert abs(via_class['loss'] - (via_class['loss_g'] + via_class['loss_d'] + via_class['loss_t'])) < 1e-6
+            else:
+                assert isinstance(res[-1], dict)
+                model.training_step(batch, 0, rng=random.Random(5))
+            outs.append([dict(o) for o in res])
+            params.append([p.detach().clone() for p in model.parameters()])
+    finally:
+        T.STEP_LAZY = old
+    assert outs[0] == outs[1], (outs[0], outs[1])
+    assert all(torch.equal(a, b) for a, b in zip(*params))

@@ -109,6 +109,8 @@ SIGNATURES = {
                                               C.c_void_p]),
     'ttsc_adamw_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_float, C.c_int64, C.c_void_p]),
+    'ttsc_adamw_step_guarded': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
+                                          C.c_float, C.c_int64, C.c_void_p, C.c_void_p]),
     'ttsc_rows_gather': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     'ttsc_rows_scatter_add': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     'ttsc_gan_loss_workspace_bytes': (C.c_size_t, [C.c_int32]),
@@ -178,6 +180,7 @@ SIGNATURES = {
     'ttsc_colsum': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     'ttsc_lstm_split_status': (C.c_int32, []),
     'ttsc_split_status_stream': (C.c_int32, [C.c_void_p]),
+    'ttsc_split_status_collect': (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32]),
     'ttsc_lstm_set_group_size': (C.c_int32, [C.c_int32]),
     'ttsc_melar_split_status': (C.c_int32, []),
     'ttsc_lstm_pack_whh_device': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -464,6 +464,16 @@ static unsigned* split_status_word() {
     return w;
 }
 
+namespace ttsc {
+unsigned* gemm_split_word_if_any() {     // (util.cpp: ttsc_split_status_collect) the current device's word if a split GEMM ever ran on it
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    auto it = g_split_words.find(dev);
+    return it == g_split_words.end() ? nullptr : it->second;
+}
+}  // namespace ttsc
+
 extern "C" int32_t ttsc_gemm_split_status(void) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;

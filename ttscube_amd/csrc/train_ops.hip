@@ -122,6 +122,7 @@ struct AdamArgs {
     float inv_bc2s;   // 1 / sqrt(1 - beta2^t)
     float eps;
     float step_size;  // lr / (1 - beta1^t)
+    const unsigned* guard;   // device word; non-zero = the gradients are not to be trusted: leave everything as it is (nullptr = no guard)
 };
 
 __device__ __forceinline__ void adamw_elem(float& p, float g, float& m, float& v, const AdamArgs& a) {
@@ -133,6 +134,7 @@ __device__ __forceinline__ void adamw_elem(float& p, float g, float& m, float& v
 }
 
 __global__ __launch_bounds__(256) void adamw_flat_kernel(AdamArgs a) {
+    if (a.guard && __hip_atomic_load(a.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // (uniform: every workgroup reads the same word)
     const long n4 = a.n >> 2;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -562,6 +564,11 @@ extern "C" int ttsc_bias_grad(const float* dy_dev, float* db_dev, int32_t B, int
 
 extern "C" int ttsc_adamw_step(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr, float beta1, float beta2,
                                float eps, float weight_decay, int64_t step, void* stream) {
+    return ttsc_adamw_step_guarded(p_dev, g_dev, m_dev, v_dev, n, lr, beta1, beta2, eps, weight_decay, step, nullptr, stream);
+}
+
+extern "C" int ttsc_adamw_step_guarded(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr, float beta1, float beta2,
+                                       float eps, float weight_decay, int64_t step, const uint32_t* guard_dev, void* stream) {
     TTSC_REQUIRE(p_dev && g_dev && m_dev && v_dev && n > 0 && step >= 1, "ttsc_adamw_step: bad argument");
     TTSC_REQUIRE((((uintptr_t)p_dev | (uintptr_t)g_dev | (uintptr_t)m_dev | (uintptr_t)v_dev) & 15) == 0, "ttsc_adamw_step: arenas must be 16-byte aligned");
     AdamArgs a;
@@ -578,6 +585,7 @@ extern "C" int ttsc_adamw_step(float* p_dev, const float* g_dev, float* m_dev, f
     a.inv_bc2s = (float)(1.0 / sqrt(bc2));
     a.eps = eps;
     a.step_size = (float)((double)lr / bc1);
+    a.guard = guard_dev;
     const long n4 = n >> 2;
     const unsigned blocks = (unsigned)std::min<long>(std::max<long>((n4 + 255) / 256, 1), 2048);
     hipLaunchKernelGGL(adamw_flat_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);

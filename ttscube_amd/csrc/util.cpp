@@ -141,7 +141,61 @@ int handoff_status_stream(hipStream_t stream) {
         }
     return mask;
 }
+
+// ---- the same verdict WITHOUT the host: collected into a device word by a one-wave launch on the stream itself ----------------------------
+struct CollectArgs {
+    unsigned* word[48];
+    unsigned char bit[48];
+    int n;
+    unsigned* dst;
+};
+__global__ void status_collect_kernel(CollectArgs a) {
+    const int i = threadIdx.x;
+    if (i < a.n) {
+        const unsigned v = atomicExch(a.word[i], 0u);     // reported once, then re-armed (as the host-side readers do)
+        if (v) atomicOr(a.dst, (unsigned)a.bit[i]);
+    }
+}
+unsigned* gemm_split_word_if_any();   // gemm.hip
+
+int handoff_collect_stream(hipStream_t stream, unsigned* dst, int with_gemm) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    CollectArgs a;
+    a.n = 0;
+    a.dst = dst;
+    {
+        std::lock_guard<std::mutex> lk(g_state_mu);
+        for (auto& kv : areas()) {
+            if (kv.first.dev != dev || kv.first.stream != stream || !kv.second.words) continue;
+            if (a.n == 47) break;
+            a.word[a.n] = kv.second.abort_word() + 1;
+            a.bit[a.n++] = kv.first.tag == "lstm" ? 1 : kv.first.tag == "gru" ? 2 : kv.first.tag == "melar" ? 4 : 8;
+        }
+    }
+    if (with_gemm)
+        if (unsigned* w = gemm_split_word_if_any()) {
+            a.word[a.n] = w;
+            a.bit[a.n++] = 16;
+        }
+    if (!a.n) return 0;
+    hipLaunchKernelGGL(status_collect_kernel, dim3(1), dim3(64), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? a.n : -1;
+}
 }  // namespace ttsc
+
+// Device-side form of ttsc_split_status_stream: ONE launch on `stream` that ORs the verdict bits (1 LSTM | 2 GRU | 4 mel-AR | 8 other; 16 = the
+// split-precision GEMM's range word when `with_gemm`) of everything launched on that stream so far into *dst_dev and re-arms the sticky words.  Nothing waits:
+// a later launch on the stream (ttsc_adamw_step_guarded) or a later read-back decides.  Returns the number of words looked at, < 0 on a HIP error.
+extern "C" int32_t ttsc_split_status_collect(void* stream, uint32_t* dst_dev, int32_t with_gemm) {
+    if (!dst_dev) {
+        ttsc::set_error("ttsc_split_status_collect: null destination");
+        return -1;
+    }
+    const int n = ttsc::handoff_collect_stream((hipStream_t)stream, dst_dev, with_gemm);
+    if (n < 0) ttsc::set_error("ttsc_split_status_collect: launch failed");
+    return n;
+}
 
 // Status of the split recurrences launched on ONE stream (every kind), waiting for that stream only: bit 0 LSTM, bit 1 GRU, bit 2 mel-AR
 // (reported once, then re-armed); < 0 on a HIP error.  For callers that drive several streams and must know whether one stream's

@@ -180,11 +180,14 @@ class Cubegan(nn.Module):
 
     def training_step(self, batch, batch_ids=None, rng=None):
         """cubegan.py:85-189: discriminator step, generator step (adversarial + feature matching + 45 x mel-L1), text step; returns the
-        reference's dict (values as floats: the step has already read them back)"""
+        reference's dict (values as floats, read back from the device when first looked at: training.StepLosses)"""
         from .training import cubegan_training_step
         out = cubegan_training_step(self, batch, self.optimizers(), getattr(self, '_reducers', None), rng=rng)
-        out['loss_v'] = out['loss_g'] + out['loss_d']
-        out['loss'] = out['loss_v'] + out['loss_t']
+        derived = lambda d: {'loss_v': d['loss_g'] + d['loss_d'], 'loss': d['loss_g'] + d['loss_d'] + d['loss_t']}
+        if hasattr(out, 'also'):
+            out.also(derived)      # (training.StepLosses: evaluated when the values have arrived, nothing waits here)
+        else:
+            out.update(derived(out))
         self.log_dict(out, prog_bar=True)
         return out
 

@@ -80,6 +80,7 @@ def wavernn_loss(net, X):
 # `generator_forward_with_grad`).  The explicit flat-arena RCCL exchange (ttscube_amd/distributed.py) replaces Lightning's
 # implicit DDP.
 # =====================================================================================================================
+import collections.abc
 import contextlib
 import itertools
 import os
@@ -92,7 +93,15 @@ from .lstm_autograd import lstm_forward_train
 from .gru_autograd import gru_forward_train
 
 
+PHASE_HOOK = None     # measurement only (tools/probes/train_phase_timeline.py): called with a phase name at the boundaries of cubegan_training_step
 TEXT_STREAM = os.environ.get('TTSC_TEXT_STREAM', '1') != '0'
+# where in the step the HOST queues the text side (it runs on its own stream either way): 0 = first (round 5), 1 = after the discriminator step's forward
+# pass, 2 = after its backward pass, 3 = after the generator step's forward pass, 4 = after its backward pass
+TEXT_AT = int(os.environ.get('TTSC_TEXT_AT', '2'))
+# 1 (default): a step without a gradient exchange never makes the host wait for the GPU — the status of its split recurrences guards the AdamW launches on the
+# device and travels back with the losses, which are read when first looked at (StepLosses).  0 = the host checks before each update and reads the losses back
+# at the end of the step (round 5; always so with reducers: a poisoned gradient must not reach the other ranks' sums)
+STEP_LAZY = os.environ.get('TTSC_STEP_LAZY', '1') != '0'
 _TEXT_STREAMS = {}
 
 
@@ -286,6 +295,118 @@ def cubegan_reducers(model, optimizers, force=False, overlap=True, bucket_mb=64)
     return tuple(out)
 
 
+class StepLosses(collections.abc.MutableMapping):
+    """The dict a training step returns (cubegan.py:181-187: loss_g, loss_t, loss_d, ..., lr), with the values read back from the device when somebody first
+    LOOKS at them.  The reference hands its Lightning logger device tensors; this step used to end with four blocking `float()` read-backs and a device-wide
+    status check — the GPU then idled while the host queued the head of the next step (inputs, conditioning recurrence, generator forward: ~5 ms at b = 16).
+    Now the losses and the step's status words travel to page-locked memory in one asynchronous copy; `wait()` (any read access) waits for THAT copy only,
+    raises if a split recurrence of the step gave up on a hand-off (its AdamW launches have skipped themselves on the device: optim.FlatAdamW.step(guard=...))
+    and fills the dict.  A loop that logs the previous step's losses after queueing the next one never stalls the GPU."""
+
+    def __init__(self, fetch):
+        self._fetch = fetch
+        self._d = None
+        self._derive = []
+
+    def also(self, fn):
+        """fn(dict) -> dict of derived entries, evaluated when the values arrive"""
+        if self._d is not None:
+            self._d.update(fn(self._d))
+        else:
+            self._derive.append(fn)
+        return self
+
+    def wait(self):
+        if self._d is None:
+            fetch, self._fetch = self._fetch, None
+            d = fetch()
+            for fn in self._derive:
+                d.update(fn(d))
+            self._d = d
+        return self._d
+
+    @property
+    def pending(self):
+        return self._d is None
+
+    def __getitem__(self, k):
+        return self.wait()[k]
+
+    def __setitem__(self, k, v):
+        self.wait()[k] = v
+
+    def __delitem__(self, k):
+        del self.wait()[k]
+
+    def __iter__(self):
+        return iter(self.wait())
+
+    def __len__(self):
+        return len(self.wait())
+
+    def __repr__(self):
+        return repr(self.wait())
+
+
+class _StepReadback:
+    """per device: the step's status words (device) and a small ring of page-locked result slots"""
+    _of = {}
+    SLOTS = 4
+
+    def __init__(self, dev):
+        self.words = torch.zeros(4, dtype=torch.int32, device=dev)       # [generator side, text side, end of step, -]
+        self.host = [torch.zeros(8, dtype=torch.float32).pin_memory() for _ in range(self.SLOTS)]
+        self.owner = [None] * self.SLOTS
+        self.n = 0
+
+    @classmethod
+    def of(cls, dev):
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        st = cls._of.get(key)
+        if st is None:
+            st = cls._of[key] = cls(torch.device('cuda', key))
+        return st
+
+    def collect(self, slot, with_gemm=False):
+        """status of everything launched on the CURRENT stream so far -> words[slot], by one launch on that stream"""
+        if _lib.lib().ttsc_split_status_collect(_lib.current_stream(), self.words[slot:slot + 1].data_ptr(), int(with_gemm)) < 0:
+            raise _lib.TTSCError('ttsc_split_status_collect: %s' % _lib.lib().ttsc_last_error().decode())
+
+    def send(self, losses, extra):
+        """queue the copy of [losses..., status words] to a page-locked slot on the current stream -> StepLosses"""
+        i = self.n % self.SLOTS
+        self.n += 1
+        prev = self.owner[i]
+        if prev is not None and prev.pending:
+            prev.wait()      # a result nobody looked at for SLOTS steps: its copy finished long ago; a tripped guard must not get lost
+        host = self.host[i]
+        host.copy_(torch.cat([torch.stack([l.detach().float().reshape(()) for l in losses]), self.words.float()]), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        names = list(extra.pop('_names'))
+
+        def fetch():
+            ev.synchronize()
+            v = host.tolist()
+            bad = [int(x) for x in v[len(names):len(names) + 3]]
+            if any(bad):
+                m = bad[0] | bad[1] | bad[2]
+                kinds = '/'.join(n for b, n in ((1, 'LSTM'), (2, 'GRU'), (4, 'mel-AR'), (8, 'other')) if m & b)
+                side = ', '.join(n for b, n in zip(bad, ('generator side', 'text side', 'end of step')) if b)
+                if m & 15:
+                    raise _lib.TTSCError('cubegan_training_step (%s): split %s recurrence aborted on a hand-off timeout — the AdamW update of that side was '
+                                         'skipped on the device (are other kernels occupying the CUs? TTSC_LSTM_SPLIT=1 / TTSC_GRU_SPLIT=1 select the '
+                                         'single-workgroup kernels)' % (side, kinds))
+                raise _lib.TTSCError('cubegan_training_step: an operand of a split-precision GEMM lay beyond the fp16 range (|v| > 65504) or was not finite — '
+                                     'its results are invalid; TTSC_GEMM_SPLIT=0 keeps these projections on the exact fp32 kernel')
+            d = dict(zip(names, v))
+            d.update(extra)
+            return d
+        res = StepLosses(fetch)
+        self.owner[i] = res
+        return res
+
+
 def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
     """Cubegan.training_step (cubegan.py:85-189): discriminator step, generator step (adv + feature + 45 x mel-L1),
     text step (duration CE + pitch/vuv L1); one gradient exchange per backward pass (reducers = (g, d, t))."""
@@ -298,43 +419,72 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
     rng = rng or random
     dev = model.get_device()
     lang = model._languasito
+    from ..optim import FlatAdamW
+    lazy = STEP_LAZY and not reducers and dev.type == 'cuda' and isinstance(opt_g, FlatAdamW) and isinstance(opt_t, FlatAdamW)
+    rb = None
     if dev.type == 'cuda':
         from ..hifigan.wbank import AmaxPool
         AmaxPool.of(dev).reset()       # the convolution launches' range words of this step: one zeroing launch for all of them
+        if lazy:
+            rb = _StepReadback.of(dev)
+            rb.words.zero_()
     # The text side (phoneme stack `t`, duration / pitch recurrences, their losses, backward pass and optimizer: opt_t) shares nothing but
     # inputs with the rest of the step, and it is a chain of latency-bound recurrences on a few dozen CUs.  It runs whole — forward, backward,
     # exchange, AdamW — on a stream of its own, under the discriminator / generator work (reference order: last, cubegan.py:172-180; the
     # parameter sets are disjoint, so the updates are the same).  TTSC_TEXT_STREAM=0 keeps it on the current stream.
+    ph = PHASE_HOOK or (lambda name: None)
+    ph('start')
     text_fn, cond_fn = _languasito_branches(lang, batch)
     cur = torch.cuda.current_stream(dev)
+    ph('inputs')
     s_t = _text_stream(dev) if (TEXT_STREAM and dev.type == 'cuda') else None
-    if s_t is not None:
-        s_t.wait_stream(cur)
-        for t_ in text_fn.shared_inputs:      # allocated on the current stream, read (forward and backward) on the text stream
-            if t_.is_cuda:
-                t_.record_stream(s_t)
-    with (torch.cuda.stream(s_t) if s_t is not None else contextlib.nullcontext()):
-        p_dur, p_pitch, p_vuv = text_fn()
-        loss_duration, loss_pitch = text_losses(p_dur, p_pitch, p_vuv, _h2d(batch, 'y_dur', dev), _h2d(batch, 'y_pitch', dev), lang._max_pitch,
-                                                int(max(model._encodings.max_pitch, model._encodings.max_duration) + 1))
-        loss_text = loss_pitch + loss_duration
-        opt_t.zero_grad()
-        arm(2)
-        loss_text.backward()
+    ev_inputs = cur.record_event() if s_t is not None else None     # the shared inputs are on the device from here on
+    loss_text = None
+
+    def text_side():
+        # forward, losses and backward pass of the text side, queued on its stream.  WHEN the host queues it matters more than where it runs: queued
+        # first (round 5: the reference's order has it last, cubegan.py:172-180) its recurrences ran alone on the chip for ~10 ms while the host had
+        # not reached the generator yet, and the step's critical path — conditioning recurrence -> generator -> discriminators -> back — started
+        # behind them.  Queued at `TEXT_AT` (default: after the discriminator step's backward pass has been queued) the main stream has a backlog
+        # of chip-filling launches by then, the text recurrences run beside them on a few dozen CUs, and the host's ~10 ms of text-side queueing
+        # comes out of the slack it has over the GPU in the discriminator / generator part (35 ms of queueing for 56 ms of kernels at b = 16).
+        nonlocal loss_text
+        if s_t is not None:
+            s_t.wait_event(ev_inputs)          # (not wait_stream: the text side must not wait for the backlog it is meant to run beside)
+            for t_ in text_fn.shared_inputs:      # allocated on the current stream, read (forward and backward) on the text stream
+                if t_.is_cuda:
+                    t_.record_stream(s_t)
+        with (torch.cuda.stream(s_t) if s_t is not None else contextlib.nullcontext()):
+            p_dur, p_pitch, p_vuv = text_fn()
+            loss_duration, loss_pitch = text_losses(p_dur, p_pitch, p_vuv, _h2d(batch, 'y_dur', dev), _h2d(batch, 'y_pitch', dev), lang._max_pitch,
+                                                    int(max(model._encodings.max_pitch, model._encodings.max_duration) + 1))
+            loss_text = loss_pitch + loss_duration
+            opt_t.zero_grad()
+            arm(2)
+            loss_text.backward()
+        ph('text_queued')
 
     def text_update():
         # Exchange + AdamW of the text side, still on its stream — but only after THIS stream's split recurrences have reported that every
         # hand-off completed (they share the chip with the chip-filling discriminator / generator launches; a timed-out recurrence has
         # produced garbage gradients, which must neither reach the other ranks' sums nor AdamW: ADVICE r4).  The check waits for the text
-        # stream alone, and it is made after the discriminator step has been queued, when the text backward has long finished: the host
-        # never stalls on it and nothing on the other streams is drained.
+        # stream alone, and it is made when the text backward has long finished: the host does not stall on it and nothing on the other
+        # streams is drained.
         with (torch.cuda.stream(s_t) if s_t is not None else contextlib.nullcontext()):
+            if lazy:
+                rb.collect(1)                      # the same question asked and answered on the device: the update skips itself
+                opt_t.step(guard=rb.words[1:2])
+                return
             if dev.type == 'cuda':
                 _lib.check_split_status('cubegan_training_step (text side, before its update)', stream=_lib.current_stream().value or 0)
             if reducers:
                 reducers[2].reduce()
             opt_t.step()
+    text_at = TEXT_AT if s_t is not None else 0
+    if text_at == 0:
+        text_side()
     conditioning = cond_fn()
+    ph('cond_fwd')
     y = _h2d(batch, 'y_audio', dev)
     if y.shape[1] > 12000 - 240:   # random 50-frame / 12000-sample crop per item (cubegan.py:116-128)
         ys, cs = [], []
@@ -347,10 +497,12 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
         conditioning = torch.cat(cs, dim=0)
     y = y.unsqueeze(1)
     y_g_hat = generator_forward_with_grad(model._generator, conditioning.permute(0, 2, 1).contiguous())
+    ph('gen_fwd')
     m = min(y.shape[2], y_g_hat.shape[2])
     y, y_g_hat = y[:, :, :m], y_g_hat[:, :, :m]
     y_mel = mel_spectrogram(y.squeeze(1), 1024, 80, 24000, 240, 1024, 0, 12000)
     y_g_hat_mel = mel_spectrogram(y_g_hat.squeeze(1), 1024, 80, 24000, 240, 1024, 0, 12000)
+    ph('mels')
     opt_b.zero_grad()
     opt_d.zero_grad()
     arm(1)
@@ -359,11 +511,19 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
     y_ds_hat_r, y_ds_hat_g, _, _ = msd(y, y_g_hat.detach(), False)
     loss_disc_s, _, _ = discriminator_loss(y_ds_hat_r, y_ds_hat_g)
     loss_disc_all = loss_disc_s + loss_disc_f
+    ph('d_fwd')
+    if text_at == 1:
+        text_side()
     loss_disc_all.backward()
+    ph('d_bwd')
+    if text_at == 2:
+        text_side()
     if reducers:
         reducers[1].reduce()
     opt_d.step()
-    text_update()
+    ph('d_opt')
+    if text_at == 0:
+        text_update()
     opt_g.zero_grad()
     arm(0)
     loss_mel = F.l1_loss(y_mel, y_g_hat_mel) * 45
@@ -378,27 +538,49 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
         y_ds_hat_r, y_ds_hat_g, fmap_s_r, fmap_s_g = msd(y, y_g_hat)
         loss_gen_all = (generator_loss(y_ds_hat_g)[0] + generator_loss(y_df_hat_g)[0] + feature_loss(fmap_s_r, fmap_s_g)
                         + feature_loss(fmap_f_r, fmap_f_g) + loss_mel)
+        ph('g_fwd')
+        if text_at == 3:
+            text_side()
         loss_gen_all.backward()          # (the reference retains the graph for the text loss; here that graph is a separate one)
+        ph('g_bwd')
+        if text_at == 4:
+            text_side()
     finally:
         for p in d_params:
             p.requires_grad_(True)
-    if dev.type == 'cuda':
-        # the generator side holds the `g` phoneme stack's split recurrences: the same question before ITS exchange and update.  (The step
-        # reads its losses back a few lines further down anyway, so waiting for the current stream here costs the queueing of two launches.)
-        _lib.check_split_status('cubegan_training_step (generator side, before its update)', stream=_lib.current_stream().value or 0)
-    if reducers:
-        reducers[0].reduce()
-    opt_g.step()
+    if lazy:
+        rb.collect(0)
+        opt_g.step(guard=rb.words[0:1])
+    else:
+        if dev.type == 'cuda':
+            # the generator side holds the `g` phoneme stack's split recurrences: the same question before ITS exchange and update (the host waits
+            # for the current stream here)
+            _lib.check_split_status('cubegan_training_step (generator side, before its update)', stream=_lib.current_stream().value or 0)
+        if reducers:
+            reducers[0].reduce()
+        opt_g.step()
     opt_b.step()
+    ph('g_opt')
+    if text_at != 0:
+        text_update()
     if s_t is not None:
         cur.wait_stream(s_t)          # the step ends when both sides have
-    _lib.check_split_status('cubegan_training_step')
+    ph('joined')
+    if not lazy:
+        _lib.check_split_status('cubegan_training_step')
     model._global_step += 1
     model._current_lr = model._compute_lr(model._learning_rate, 1e-5, model._global_step)
     for o in (opt_d, opt_g, opt_t):
         o.param_groups[0]['lr'] = model._current_lr
-    return {'loss_g': float(loss_gen_all.detach()), 'loss_t': float(loss_text.detach()), 'loss_d': float(loss_disc_all.detach()),
-            'loss_mel': float(loss_mel.detach()) / 45, 'lr': model._current_lr}
+    if lazy:
+        rb.collect(2, with_gemm=True)     # whatever ran after the two guarded updates, and the split-precision GEMMs' range word
+        res = rb.send([loss_gen_all, loss_text, loss_disc_all, loss_mel], {'_names': ('loss_g', 'loss_t', 'loss_d', 'loss_mel'), 'lr': model._current_lr})
+        res.also(lambda d: {'loss_mel': d['loss_mel'] / 45})
+        ph('end')
+        return res
+    ph('end')
+    vals = torch.stack([loss_gen_all.detach(), loss_text.detach(), loss_disc_all.detach(), loss_mel.detach()]).tolist()   # ONE read-back
+    return {'loss_g': vals[0], 'loss_t': vals[1], 'loss_d': vals[2], 'loss_mel': vals[3] / 45, 'lr': model._current_lr}
 
 
 def cubegan_validation_step(model, batch, rng=None):

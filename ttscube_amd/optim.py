@@ -190,7 +190,9 @@ class FlatAdamW:
         self._dirty = False
 
     @torch.no_grad()
-    def step(self):
+    def step(self, guard=None):
+        """guard: a one-element device tensor (32-bit); the update is skipped ON THE DEVICE when it holds a non-zero value at execution time
+        (ttsc_adamw_step_guarded: the word ttsc_split_status_collect left on this stream — the host does not wait to find out)"""
         if not self.built:
             self._build()
         if self.step_count < 4 or self.step_count % 64 == 0:     # (a Python loop over ~900 parameters: every step while the run is young, then sampled)
@@ -203,9 +205,10 @@ class FlatAdamW:
         self.step_count += 1
         pg = self.param_groups[0]
         with _lib.on_device(self.p.device):
-            _lib.check(_lib.lib().ttsc_adamw_step(_lib.dev_ptr(self.p), _lib.dev_ptr(self.g), _lib.dev_ptr(self.m), _lib.dev_ptr(self.v),
-                                                  self.numel, float(pg['lr']), float(pg['betas'][0]), float(pg['betas'][1]), float(pg['eps']),
-                                                  float(pg['weight_decay']), self.step_count, _lib.current_stream()), 'ttsc_adamw_step')
+            _lib.check(_lib.lib().ttsc_adamw_step_guarded(_lib.dev_ptr(self.p), _lib.dev_ptr(self.g), _lib.dev_ptr(self.m), _lib.dev_ptr(self.v),
+                                                          self.numel, float(pg['lr']), float(pg['betas'][0]), float(pg['betas'][1]), float(pg['eps']),
+                                                          float(pg['weight_decay']), self.step_count, guard.data_ptr() if guard is not None else None,
+                                                          _lib.current_stream()), 'ttsc_adamw_step')
         # the kernel wrote through raw pointers: tell autograd / the weight caches of the inference handles (version counters)
         torch.autograd.graph.increment_version([self.params[i] for i in self.live])
 
