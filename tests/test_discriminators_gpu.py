@@ -138,7 +138,7 @@ def test_native_discriminators_match_torch_modules(which):
 
 
 @pytest.mark.parametrize('N,C,L,G,s,P,pad,K', [(3, 8, 100, 1, 3, 1, 2, 5), (2, 12, 61, 3, 2, 1, 20, 41), (2, 4, 37, 1, 3, 7, 2, 5), (1, 16, 50, 4, 4, 1, 20, 41),
-                                              (2, 1, 200, 1, 3, 11, 2, 5)])
+                                              (2, 1, 200, 1, 3, 11, 2, 5), (2, 6, 3000, 2, 2, 1, 20, 41), (2, 4, 1500, 1, 3, 5, 2, 5), (1, 3, 5000, 1, 4, 1, 20, 41)])
 def test_fused_deinterleave_equals_the_torch_views(N, C, L, G, s, P, pad, K):
     """`ttsc_deinterleave_x` / `_w` forward and backward == pad + view + permute + reshape and their autograd, exactly (pure data movement)"""
     from ttscube_amd.hifigan.disc_hip import _DeintW, _DeintX

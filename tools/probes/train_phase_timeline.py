@@ -42,17 +42,33 @@ def main():
         ev.record(torch.cuda.current_stream())
         rec.append((name, time.perf_counter(), ev))
     T.PHASE_HOOK = hook
-    steps = []
     t_all = time.perf_counter()
+    marks = []
     for _ in range(a.iters):
-        rec.clear()
-        T.cubegan_training_step(model, batch, opts, rng=r)
-        t_ret = time.perf_counter()
-        torch.cuda.synchronize()
-        t0, e0 = rec[0][1], rec[0][2]
-        steps.append([(n, (t - t0) * 1e3, e0.elapsed_time(e)) for n, t, e in rec] + [('returned', (t_ret - t0) * 1e3, float('nan'))])
-    print('b = %d, TTSC_TEXT_AT = %d: %.1f ms per step (with the probe\'s events and a device synchronisation per step)'
-          % (a.batch, T.TEXT_AT, (time.perf_counter() - t_all) / a.iters * 1e3))
+        marks.append(len(rec))
+        T.cubegan_training_step(model, batch, opts, rng=r)      # (no synchronisation between steps: with TTSC_STEP_LAZY=1 the host runs ahead)
+        rec.append(('returned', time.perf_counter(), None))
+    marks.append(len(rec))
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t_all) / a.iters * 1e3
+    # reference points: host clock and GPU clock are tied together at the first event of the first step (the device was idle there)
+    t00, e00 = rec[0][1], rec[0][2]
+    steps = []
+    for k in range(1, a.iters):          # (step 0 starts on an idle device; the steady state is what the others show)
+        seg = rec[marks[k]:marks[k + 1]]
+        t0 = seg[0][1]
+        g0 = e00.elapsed_time(seg[0][2])
+        steps.append([(n, (t - t0) * 1e3, (e00.elapsed_time(e) - g0) if e is not None else float('nan'), ((e00.elapsed_time(e) - (t - t00) * 1e3) if e is not None else float('nan')))
+                      for n, t, e in seg])
+    print('b = %d, TTSC_TEXT_AT = %d, TTSC_STEP_LAZY = %d: %.1f ms per step (with the probe\'s events)' % (a.batch, T.TEXT_AT, int(T.STEP_LAZY), wall))
+    print('%-12s %10s %10s %12s' % ('phase end', 'host ms', 'GPU ms', 'GPU behind host'))
+    names = [n for n, _, _, _ in steps[0]]
+    for i, n in enumerate(names):
+        h = np.mean([s[i][1] for s in steps])
+        g = np.mean([s[i][2] for s in steps])
+        lag = np.mean([s[i][3] for s in steps])
+        print('%-12s %10.2f %10.2f %12.2f' % (n, h, g, lag))
+    return
     print('%-12s %10s %10s %10s' % ('phase end', 'host ms', 'GPU ms', 'GPU - host'))
     names = [n for n, _, _ in steps[0]]
     for i, n in enumerate(names):
