@@ -228,6 +228,13 @@ int ttsc_deinterleave_w(const float* src_dev, float* dst_dev, int32_t Cout, int3
 size_t ttsc_gan_loss_workspace_bytes(int32_t nseg);
 int ttsc_gan_loss(int32_t kind, int32_t nseg, const void* const* a_dev, const void* const* b_dev, void* const* ga_dev, void* const* gb_dev,
                   const int64_t* numel, const float* weight, float target, float* out_dev, void* ws_dev, size_t ws_bytes, void* stream);
+/* kind 0 over PRE-activations: slope[k] in [0, 1] (null = all 1) passes both operands of segment k through leaky_relu(., slope[k]) before the
+ * difference and multiplies the gradients by the activation's derivative — the discriminators' feature maps are leaky_relu(conv output, 0.1)
+ * ([EXTERNAL hifigan/models.py DiscriminatorP / DiscriminatorS forward]; feature_loss call sites cube/networks/cubegan.py:162-163): the training
+ * step hands the convolution outputs over as they are instead of materialising ~90 activated copies and their backward launches per step. */
+int ttsc_gan_loss_lrelu(int32_t kind, int32_t nseg, const void* const* a_dev, const void* const* b_dev, void* const* ga_dev, void* const* gb_dev,
+                        const int64_t* numel, const float* weight, const float* slope, float target, float* out_dev, void* ws_dev, size_t ws_bytes,
+                        void* stream);
 size_t ttsc_conv_wgrad_workspace_bytes(int32_t N, int32_t A, int32_t B, int64_t LP, int32_t J);
 /* grouped variant (torch Conv1d groups): P [N,A,LP], Q [N,groups*Bg,LQ], G [A,Bg,J] — row a only meets the Bg channels of its own
  * group.  Workspace: ttsc_conv_wgrad_workspace_bytes(N, A, Bg, LP, J). */

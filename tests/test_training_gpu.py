@@ -573,3 +573,55 @@ def test_lazy_step_result_equals_the_eager_one_bit_for_bit():
         T.STEP_LAZY = old
     assert outs[0] == outs[1], (outs[0], outs[1])
     assert all(torch.equal(a, b) for a, b in zip(*params))
+
+
+@pytest.mark.parametrize('switch', ['fmap_raw', 'wbank_reuse'])
+def test_step_shortcuts_do_not_change_a_bit(switch):
+    """TTSC_FMAP_RAW (the feature-matching loss applies the discriminators' leaky-relu inside its launch instead of reading materialised
+    activations) and TTSC_WBANK_REUSE (a weight bank whose parameters did not move since its last preparation is not prepared again): losses
+    and every parameter after three steps are the bits of the long way round"""
+    import random
+    from ttscube_amd.hifigan import wbank as W
+    from ttscube_amd.networks.cubegan import Cubegan
+    from ttscube_amd.networks import training as T
+    rng = np.random.RandomState(0)
+    batch, enc = _batch(2, 12, rng)
+    outs, params = [], []
+    old = (T.FMAP_RAW, W.REUSE)
+    try:
+        for on in (True, False):
+            T.FMAP_RAW, W.REUSE = old
+            if switch == 'fmap_raw':
+                T.FMAP_RAW = on
+            else:
+                W.REUSE = on
+            torch.manual_seed(0)
+            model = Cubegan(enc, conditioning=None, train=True).cuda()
+            model.train()
+            opts = T.cubegan_configure_optimizers(model)
+            r = random.Random(1)
+            outs.append([dict(T.cubegan_training_step(model, batch, opts, rng=r)) for _ in range(3)])
+            params.append([p.detach().clone() for p in model.parameters()])
+    finally:
+        T.FMAP_RAW, W.REUSE = old
+    assert outs[0] == outs[1], (outs[0], outs[1])
+    assert all(torch.equal(a, b) for a, b in zip(*params))
+
+
+def test_feature_loss_over_raw_feature_maps_equals_the_activated_one():
+    """losses_hip.feature_loss over RawFmap pairs (leaky-relu inside the launch) against the same loss over materialised activations: value and
+    both gradients, bit for bit (x * slope is the activation's own product; its derivative is the factor torch's backward applies)"""
+    from ttscube_amd.hifigan.losses_hip import RawFmap, feature_loss
+    g = torch.Generator().manual_seed(11)
+    shapes = [(2, 32, 700), (2, 128, 233), (2, 1, 51)]
+    xr = [torch.randn(s, generator=g).cuda() for s in shapes]
+    xg = [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in shapes]
+    slopes = [0.1, 0.1, 1.0]
+    l_raw = feature_loss([[RawFmap(a, s) for a, s in zip(xr, slopes)]], [[RawFmap(b, s) for b, s in zip(xg, slopes)]])
+    g_raw = torch.autograd.grad(l_raw * 3.0, xg)
+    act = lambda t, s: torch.nn.functional.leaky_relu(t, s) if s != 1.0 else t
+    l_act = feature_loss([[act(a, s) for a, s in zip(xr, slopes)]], [[act(b, s) for b, s in zip(xg, slopes)]])
+    g_act = torch.autograd.grad(l_act * 3.0, xg)
+    assert torch.equal(l_raw, l_act)
+    for a, b in zip(g_raw, g_act):
+        assert torch.equal(a, b)

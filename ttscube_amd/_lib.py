@@ -116,6 +116,8 @@ SIGNATURES = {
     'ttsc_gan_loss_workspace_bytes': (C.c_size_t, [C.c_int32]),
     'ttsc_gan_loss': (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                 C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'ttsc_gan_loss_lrelu': (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'ttsc_bias_grad_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int64]),
     'ttsc_bias_grad': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     'ttsc_conv_wgrad_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32]),

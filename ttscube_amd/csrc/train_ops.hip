@@ -173,6 +173,7 @@ struct LossSeg {
     long n;
     float w;
     float target;
+    float slope;   // kind 0: both operands pass through leaky_relu(., slope) first (1 = as they are)
 };
 
 constexpr int GAN_LOSS_MAX_SEG = 64;
@@ -191,11 +192,13 @@ __global__ __launch_bounds__(256) void gan_loss_kernel(const LossTable tab, int 
     for (long i = (long)bi * 256 + threadIdx.x; i < sg.n; i += (long)blocks_per_seg * 256) {
         const float a = sg.a[i];
         if (kind == 0) {
-            const float d = sg.b[i] - a;
+            const float b = sg.b[i];
+            const float sa = a > 0.f ? 1.f : sg.slope, sb = b > 0.f ? 1.f : sg.slope;   // (slope 1: x * 1 is exact, the plain difference)
+            const float d = b * sb - a * sa;
             acc += fabsf(d);
             const float gsign = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
-            if (sg.gb) sg.gb[i] = gsign;
-            if (sg.ga) sg.ga[i] = -gsign;
+            if (sg.gb) sg.gb[i] = gsign * sb;
+            if (sg.ga) sg.ga[i] = -gsign * sa;
         } else {
             const float d = a - sg.target;
             acc += d * d;
@@ -617,6 +620,12 @@ extern "C" size_t ttsc_gan_loss_workspace_bytes(int32_t nseg) {
 extern "C" int ttsc_gan_loss(int32_t kind, int32_t nseg, const void* const* a_dev, const void* const* b_dev, void* const* ga_dev,
                              void* const* gb_dev, const int64_t* numel, const float* weight, float target, float* out_dev, void* ws_dev,
                              size_t ws_bytes, void* stream) {
+    return ttsc_gan_loss_lrelu(kind, nseg, a_dev, b_dev, ga_dev, gb_dev, numel, weight, nullptr, target, out_dev, ws_dev, ws_bytes, stream);
+}
+
+extern "C" int ttsc_gan_loss_lrelu(int32_t kind, int32_t nseg, const void* const* a_dev, const void* const* b_dev, void* const* ga_dev,
+                                   void* const* gb_dev, const int64_t* numel, const float* weight, const float* slope, float target, float* out_dev,
+                                   void* ws_dev, size_t ws_bytes, void* stream) {
     TTSC_REQUIRE(kind == 0 || kind == 1, "ttsc_gan_loss: kind must be 0 (L1 between pairs) or 1 (squared distance to a target)");
     TTSC_REQUIRE(nseg > 0 && nseg <= GAN_LOSS_MAX_SEG && a_dev && numel && weight && out_dev && ws_dev, "ttsc_gan_loss: bad argument (1..%d tensors per call)", GAN_LOSS_MAX_SEG);
     TTSC_REQUIRE(kind == 1 || b_dev, "ttsc_gan_loss: kind 0 needs the second operand list");
@@ -627,7 +636,8 @@ extern "C" int ttsc_gan_loss(int32_t kind, int32_t nseg, const void* const* a_de
     for (int i = 0; i < nseg; ++i) {
         TTSC_REQUIRE(a_dev[i] && numel[i] > 0, "ttsc_gan_loss: empty segment %d", i);
         tab.seg[i] = LossSeg{(const float*)a_dev[i], kind == 0 ? (const float*)b_dev[i] : nullptr, ga_dev ? (float*)ga_dev[i] : nullptr,
-                             (kind == 0 && gb_dev) ? (float*)gb_dev[i] : nullptr, (long)numel[i], weight[i], target};
+                             (kind == 0 && gb_dev) ? (float*)gb_dev[i] : nullptr, (long)numel[i], weight[i], target, slope ? slope[i] : 1.f};
+        TTSC_REQUIRE(tab.seg[i].slope >= 0.f && tab.seg[i].slope <= 1.f && (kind == 0 || tab.seg[i].slope == 1.f), "ttsc_gan_loss: slope of segment %d (in [0, 1]; kind 0 only)", i);
         TTSC_REQUIRE(kind == 1 || tab.seg[i].b, "ttsc_gan_loss: null operand in segment %d", i);
         nmax = std::max<long>(nmax, numel[i]);
     }

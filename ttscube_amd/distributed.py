@@ -322,5 +322,8 @@ def broadcast_parameters(module, src=0, group=None):
     """Replicated parameters: every rank starts from rank `src`'s values."""
     if not is_dist():
         return
-    for t in list(module.parameters()) + list(module.buffers()):
+    ts = list(module.parameters()) + list(module.buffers())
+    for t in ts:
         dist.broadcast(t.data, src=src, group=group)
+    # written through `.data`: move the version counters, which the weight caches of the HIP layers key on (hip_layers.LSTMHip._sync, hifigan/wbank.py)
+    torch.autograd.graph.increment_version(ts)

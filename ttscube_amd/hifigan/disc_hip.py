@@ -20,6 +20,7 @@ import torch.nn.functional as F
 
 from .. import _lib
 from .autograd import HipWeightNormFn, TrainConv, hip_conv
+from .losses_hip import RawFmap
 from .wbank import pass_range
 from .streams import fan_out
 
@@ -235,7 +236,9 @@ def _run(d, kind, x, want_fmap, bank=None, index=None):
                 w = w.squeeze(-1)
         x = h(x, w, l.bias, in_slope=slope)
         slope = LRELU_SLOPE
-        if want_fmap:
+        if want_fmap == 'raw':       # the training step's feature-matching loss applies the activation itself (losses_hip.RawFmap)
+            fmap.append(RawFmap(x, LRELU_SLOPE if i < len(mods) - 1 else 1.0))
+        elif want_fmap:
             f = F.leaky_relu(x, LRELU_SLOPE) if i < len(mods) - 1 else x
             fmap.append(f.view(f.shape[0], f.shape[1], -1, d.period) if kind == 'p' else f)
     return torch.flatten(x, 1, -1), fmap
@@ -251,7 +254,8 @@ def _pair(d, kind, y, y_hat, batch_ok, want_fmap, bank=None, index=None):
     if batch_ok and not y_hat.requires_grad and y.shape == y_hat.shape:   # discriminator step: real + generated as one batch
         n = y.shape[0]
         out, fmap = _run(d, kind, torch.cat([y, y_hat], dim=0), want_fmap, bank, index)
-        return out[:n], [f[:n] for f in fmap], out[n:], [f[n:] for f in fmap]
+        cut = (lambda f, a, b: RawFmap(f.x[a:b], f.slope)) if want_fmap == 'raw' else (lambda f, a, b: f[a:b])
+        return out[:n], [cut(f, 0, n) for f in fmap], out[n:], [cut(f, n, None) for f in fmap]
     out_r, fmap_r = _run(d, kind, y, want_fmap, bank, index)
     out_g, fmap_g = _run(d, kind, y_hat, want_fmap, bank, index)
     return out_r, fmap_r, out_g, fmap_g

@@ -17,6 +17,9 @@ class _ListLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, kind, target, weight, *tensors):
+        slopes = None
+        if isinstance(weight, tuple):      # (weight, per-pair leaky-relu slopes): kind 0 over pre-activations (ttsc_gan_loss_lrelu)
+            weight, slopes = weight
         n = len(tensors) if kind == 1 else len(tensors) // 2
         a = [t.contiguous() for t in tensors[:n]]
         b = [t.contiguous() for t in tensors[n:]] if kind == 0 else []
@@ -44,9 +47,10 @@ class _ListLoss(torch.autograd.Function):
         P = C.c_void_p * n
         ptrs = lambda ts: P(*[(t.data_ptr() if t is not None else None) for t in ts])
         with _lib.on_device(dev):
-            _lib.check(L.ttsc_gan_loss(kind, n, ptrs(a), ptrs(b) if kind == 0 else None, ptrs(ga), ptrs(gb) if kind == 0 else None,
-                                       (C.c_int64 * n)(*sizes), (C.c_float * n)(*([float(weight)] * n)), float(target),
-                                       _lib.dev_ptr(out), _lib.dev_ptr(ws), ws.numel(), _lib.current_stream()), 'ttsc_gan_loss')
+            _lib.check(L.ttsc_gan_loss_lrelu(kind, n, ptrs(a), ptrs(b) if kind == 0 else None, ptrs(ga), ptrs(gb) if kind == 0 else None,
+                                             (C.c_int64 * n)(*sizes), (C.c_float * n)(*([float(weight)] * n)),
+                                             (C.c_float * n)(*[float(v) for v in slopes]) if slopes is not None else None, float(target),
+                                             _lib.dev_ptr(out), _lib.dev_ptr(ws), ws.numel(), _lib.current_stream()), 'ttsc_gan_loss')
         ctx.grads = ga + (gb if kind == 0 else [])
         ctx.gbuf = gbuf
         return out
@@ -66,9 +70,28 @@ def _flat(list_of_lists):
     return [t for sub in list_of_lists for t in sub]
 
 
+class RawFmap:
+    """a discriminator feature map as the convolution left it: the feature map proper is leaky_relu(x, slope) (slope 1: x itself).  What
+    disc_hip.mpd_forward / msd_forward hand out with want_fmap='raw'; `feature_loss` applies the activation inside its one launch."""
+    __slots__ = ('x', 'slope')
+
+    def __init__(self, x, slope):
+        self.x, self.slope = x, slope
+
+    def materialize(self):
+        return torch.nn.functional.leaky_relu(self.x, self.slope) if self.slope != 1.0 else self.x
+
+
 def feature_loss(fmap_r, fmap_g):
     r, g = _flat(fmap_r), _flat(fmap_g)
+    if r and isinstance(r[0], RawFmap):
+        if any(a.slope != b.slope for a, b in zip(r, g)):
+            raise _lib.TTSCError('feature_loss: real and generated feature maps of a layer carry different activations')
+        return _ListLoss.apply(0, 0.0, (2.0, tuple(a.slope for a in r)), *([a.x for a in r] + [b.x for b in g]))
     return _ListLoss.apply(0, 0.0, 2.0, *(r + g))
+
+
+feature_loss.accepts_raw = True
 
 
 def generator_loss(disc_outputs):

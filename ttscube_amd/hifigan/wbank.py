@@ -17,6 +17,9 @@ import torch
 from .. import _lib
 
 
+REUSE = __import__('os').environ.get('TTSC_WBANK_REUSE', '1') != '0'   # (measurement switch: 0 = prepare on every call)
+
+
 class _Entry:
     __slots__ = ('layer', 'Cin', 'Cout', 'K', 'groups', 'stride', 'J', 'w', 'norm', 'amax', 'pack_fwd', 'pack_dgrad', 'conv_shape', 'placeholder')
 
@@ -68,6 +71,7 @@ class WeightBank:
         self._handle = None
         self._ptrs = None
         self._bufs = None
+        self._sig = None          # (parameter versions, stream) of the last preparation
 
     def __del__(self):
         try:
@@ -132,8 +136,23 @@ class WeightBank:
                     raise _lib.TTSCError('WeightBank: parameters must be contiguous fp32 tensors')
             self._build(dev)
             self._ptrs = ps
+            self._sig = None
+        # Unchanged parameters -> the buffers still hold what this call would write: the discriminators' banks are prepared for the generator step
+        # AFTER opt_d.step() and again for the next step's discriminator pass, with nothing written in between (two of the four large
+        # preparations of a Cubegan step; FlatAdamW.step and every in-place torch op move the version counters).  The skip needs the last
+        # preparation to be ordered before this call's consumers: same stream (side streams fork behind the current one).
+        sig = (tuple(e.layer.weight_v._version for e in self.entries), tuple(e.layer.weight_g._version for e in self.entries),
+               _lib.current_stream().value)
+        if REUSE and sig == self._sig:
+            return
         with _lib.on_device(dev):
             _lib.check(_lib.lib().ttsc_wbank_prepare(self._handle, _lib.current_stream()), 'ttsc_wbank_prepare')
+        self._sig = sig
+
+    def invalidate(self):
+        """after a write to the parameters that bypassed their version counters (through `.data`, or a raw-pointer kernel that did not call
+        torch.autograd.graph.increment_version): the next prepare() refills the buffers"""
+        self._sig = None
 
     def weight(self, i):
         e = self.entries[i]

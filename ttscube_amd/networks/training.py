@@ -102,6 +102,7 @@ TEXT_AT = int(os.environ.get('TTSC_TEXT_AT', '2'))
 # device and travels back with the losses, which are read when first looked at (StepLosses).  0 = the host checks before each update and reads the losses back
 # at the end of the step (round 5; always so with reducers: a poisoned gradient must not reach the other ranks' sums)
 STEP_LAZY = os.environ.get('TTSC_STEP_LAZY', '1') != '0'
+FMAP_RAW = os.environ.get('TTSC_FMAP_RAW', '1') != '0'      # (measurement switch: 0 = activated feature maps through ATen, round 5's path)
 _TEXT_STREAMS = {}
 
 
@@ -142,8 +143,10 @@ def _gan_loss_fns():
 def _discriminator_fns(model):
     """(mpd(y, y_hat, want_fmap), msd(...)): every convolution of MPD / MSD on the HIP kernels (hifigan/disc_hip.py)"""
     from ..hifigan.disc_hip import mpd_forward, msd_forward
-    return (lambda a_, b_, fm=True: mpd_forward(model._mpd, a_, b_, want_fmap=fm),
-            lambda a_, b_, fm=True: msd_forward(model._msd, a_, b_, want_fmap=fm))
+    mpd = lambda a_, b_, fm=True: mpd_forward(model._mpd, a_, b_, want_fmap=fm)
+    msd = lambda a_, b_, fm=True: msd_forward(model._msd, a_, b_, want_fmap=fm)
+    mpd.accepts_raw = msd.accepts_raw = True     # fm='raw': feature maps as (convolution output, slope) pairs (losses_hip.RawFmap)
+    return mpd, msd
 
 
 def _lowres_features(net, hidden):
@@ -534,8 +537,11 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
     for p in d_params:
         p.requires_grad_(False)
     try:
-        y_df_hat_r, y_df_hat_g, fmap_f_r, fmap_f_g = mpd(y, y_g_hat)
-        y_ds_hat_r, y_ds_hat_g, fmap_s_r, fmap_s_g = msd(y, y_g_hat)
+        # the feature maps are only ever read by the feature-matching loss: the native pair hands them over un-activated and the loss launch applies
+        # the leaky-relu (no materialised copies, no activation backward launches: ~130 launches of a step); substituted formulations get tensors
+        fm = 'raw' if (FMAP_RAW and all(getattr(f, 'accepts_raw', False) for f in (mpd, msd, feature_loss))) else True
+        y_df_hat_r, y_df_hat_g, fmap_f_r, fmap_f_g = mpd(y, y_g_hat, fm)
+        y_ds_hat_r, y_ds_hat_g, fmap_s_r, fmap_s_g = msd(y, y_g_hat, fm)
         loss_gen_all = (generator_loss(y_ds_hat_g)[0] + generator_loss(y_df_hat_g)[0] + feature_loss(fmap_s_r, fmap_s_g)
                         + feature_loss(fmap_f_r, fmap_f_g) + loss_mel)
         ph('g_fwd')
