@@ -87,13 +87,20 @@ def _train(params):
     best = 9999.0
     val_rng = random.Random(7)
     for epoch in range(params.epochs):
-        mel_loss, nb = 0.0, 0
+        mel_loss, nb, prev = 0.0, 0, None
         order = list(my_items)
         random.Random(1000 * epoch + rank).shuffle(order)
         for batch in BatchLoader(trainset, equal_batches(order, params.batch_size), collate.collate_fn, params.num_workers):
             out = T.cubegan_training_step(model, batch, opts, reducers, rng=crop_rng)
-            mel_loss += out['loss_mel']
+            # the step's losses are read back when first looked at (training.StepLosses): look at the PREVIOUS step's after queueing this one, so
+            # that the host never waits for the GPU inside the loop
+            if prev is not None:
+                mel_loss += prev['loss_mel']
+            prev = out
             nb += 1
+        if prev is not None:
+            mel_loss += prev['loss_mel']
+            prev = None
         # validation (train_cubegan.py:38-76 + cubegan.py:191-273): mean dev-set mel-L1 -> _val_loss -> .best.  Every rank validates
         # its shard of the dev set (nobody idles in a barrier long enough to trip the RCCL watchdog); (sum, count) are all-reduced.
         model.eval()
