@@ -98,9 +98,9 @@ TEXT_STREAM = os.environ.get('TTSC_TEXT_STREAM', '1') != '0'
 # where in the step the HOST queues the text side (it runs on its own stream either way): 0 = first (round 5), 1 = after the discriminator step's forward
 # pass, 2 = after its backward pass, 3 = after the generator step's forward pass, 4 = after its backward pass
 TEXT_AT = int(os.environ.get('TTSC_TEXT_AT', '2'))
-# 1 (default): a step without a gradient exchange never makes the host wait for the GPU — the status of its split recurrences guards the AdamW launches on the
-# device and travels back with the losses, which are read when first looked at (StepLosses).  0 = the host checks before each update and reads the losses back
-# at the end of the step (round 5; always so with reducers: a poisoned gradient must not reach the other ranks' sums)
+# 1 (default): the step never makes the host wait for the GPU — the status of its split recurrences guards the AdamW launches on the device (with a gradient
+# exchange: its maximum over the ranks, so that no rank applies sums a failed rank has sent garbage into) and travels back with the losses, which are read
+# when first looked at (StepLosses).  0 = the host checks before each exchange / update and reads the losses back at the end of the step (round 5)
 STEP_LAZY = os.environ.get('TTSC_STEP_LAZY', '1') != '0'
 FMAP_RAW = os.environ.get('TTSC_FMAP_RAW', '1') != '0'      # (measurement switch: 0 = activated feature maps through ATen, round 5's path)
 _TEXT_STREAMS = {}
@@ -423,7 +423,18 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
     dev = model.get_device()
     lang = model._languasito
     from ..optim import FlatAdamW
-    lazy = STEP_LAZY and not reducers and dev.type == 'cuda' and isinstance(opt_g, FlatAdamW) and isinstance(opt_t, FlatAdamW)
+    lazy = STEP_LAZY and dev.type == 'cuda' and isinstance(opt_g, FlatAdamW) and isinstance(opt_t, FlatAdamW)
+
+    def agreed(slot, reducer):
+        # with a gradient exchange every rank must take the same decision about an update: the status word becomes the MAXIMUM over the ranks (one
+        # 4-byte all-reduce, queued like the gradient collectives — nothing waits on the host).  It is issued AFTER the reducer's reduce(): all of
+        # this reducer's chunks have been launched on every rank by then, hooked or not (distributed.ArenaReducer: one agreed launch sequence per
+        # communicator), and no other backward pass — no other hook — runs between reduce() and here.  A rank whose recurrence gave up has sent
+        # garbage into the sums; no rank applies them.
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(getattr(reducer, 'group', None)) > 1:
+            dist.all_reduce(rb.words[slot:slot + 1], op=dist.ReduceOp.MAX, group=getattr(reducer, 'group', None))
+        return rb.words[slot:slot + 1]
     rb = None
     if dev.type == 'cuda':
         from ..hifigan.wbank import AmaxPool
@@ -476,7 +487,9 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
         with (torch.cuda.stream(s_t) if s_t is not None else contextlib.nullcontext()):
             if lazy:
                 rb.collect(1)                      # the same question asked and answered on the device: the update skips itself
-                opt_t.step(guard=rb.words[1:2])
+                if reducers:
+                    reducers[2].reduce()
+                opt_t.step(guard=agreed(1, reducers[2]) if reducers else rb.words[1:2])
                 return
             if dev.type == 'cuda':
                 _lib.check_split_status('cubegan_training_step (text side, before its update)', stream=_lib.current_stream().value or 0)
@@ -556,7 +569,9 @@ def cubegan_training_step(model, batch, optimizers, reducers=None, rng=None):
             p.requires_grad_(True)
     if lazy:
         rb.collect(0)
-        opt_g.step(guard=rb.words[0:1])
+        if reducers:
+            reducers[0].reduce()
+        opt_g.step(guard=agreed(0, reducers[0]) if reducers else rb.words[0:1])
     else:
         if dev.type == 'cuda':
             # the generator side holds the `g` phoneme stack's split recurrences: the same question before ITS exchange and update (the host waits
