@@ -1017,9 +1017,23 @@ static int lstm_split_members(int B, int ndir, int H) {
 }
 
 // Counters / abort words / granule ring of the split recurrences: one area per (device, stream) — common.hpp HandoffArea
-static HandoffArea* lstm_area(hipStream_t s, size_t ring_bytes) {
+// counters, this launch's abort word and (zero_ring) the granule ring restart at zero — ONE small launch.  Two hipMemsetAsync calls were THREE
+// fill kernels per recurrence launch (the runtime splits the 32 772-byte counter block into an aligned part and a 4-byte tail): at B = 1 that is 14 us
+// of a 150 us layer, eight layers per sentence (profiles/r06_e2e_single_sentence_launches.txt)
+__global__ __launch_bounds__(256) void lstm_rearm_kernel(unsigned* __restrict__ words, unsigned nwords, lstm_u64* __restrict__ ring, size_t n64) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += stride) words[i] = 0u;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n64; i += stride) ring[i] = 0ull;
+}
+
+static HandoffArea* lstm_area(hipStream_t s, size_t ring_bytes, bool zero_ring = false) {
     HandoffArea* ar = handoff_area("lstm", s, 8192, ring_bytes);
-    if (!ar || ar->rearm(s) != hipSuccess) return nullptr;   // counters and this launch's abort word restart at zero
+    if (!ar) return nullptr;
+    const size_t n64 = zero_ring ? ring_bytes / sizeof(lstm_u64) : 0;
+    const size_t work = std::max<size_t>(ar->nwords + 1, n64);
+    const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>((work + 2047) / 2048, 1), 2048);
+    hipLaunchKernelGGL(lstm_rearm_kernel, dim3(blocks), dim3(256), 0, s, ar->words, (unsigned)(ar->nwords + 1), reinterpret_cast<lstm_u64*>(ar->buf), n64);
+    if (hipGetLastError() != hipSuccess) return nullptr;
     return ar;
 }
 
@@ -1080,12 +1094,8 @@ extern "C" int ttsc_lstm_seq_backward(const float* dy_dev, const float* gates_de
     const int G = lstm_split_members(B, ndir, H);
     if (G > 1) {
         TTSC_REQUIRE(B * ndir <= 8192, "ttsc_lstm_seq_backward: too many sequences for the split kernel");
-        HandoffArea* ar = lstm_area((hipStream_t)stream, 0);
-        TTSC_REQUIRE(ar, "ttsc_lstm_seq_backward: cannot allocate the hand-off counters");
         LstmSplitArgs sa{};
         sa.bw = a;
-        sa.cnt = ar->words;
-        sa.abort_word = ar->abort_word();
         sa.G = G;
         sa.HU = H / G;
         sa.KS = 512 / sa.HU;
@@ -1093,15 +1103,19 @@ extern "C" int ttsc_lstm_seq_backward(const float* dy_dev, const float* gates_de
         static const bool bwd_resident = !(getenv("TTSC_LSTM_BWD_RESIDENT") && atoi(getenv("TTSC_LSTM_BWD_RESIDENT")) == 0);
         if (bwd_resident && 4 * H / sa.KS == 128) {   // H = 256 over 4 members: 128 rows of W_hh^T per thread stay in registers, granule hand-off
             const size_t ring_bytes = (size_t)B * ndir * 2 * 4 * H * sizeof(lstm_u64);
-            HandoffArea* ar2 = lstm_area((hipStream_t)stream, ring_bytes);
+            HandoffArea* ar2 = lstm_area((hipStream_t)stream, ring_bytes, true);
             TTSC_REQUIRE(ar2, "ttsc_lstm_seq_backward: cannot allocate the hand-off ring");
             sa.cnt = ar2->words;
             sa.abort_word = ar2->abort_word();
             lstm_u64* ring = reinterpret_cast<lstm_u64*>(ar2->buf);
-            TTSC_HIP_CHECK(hipMemsetAsync(ring, 0, ring_bytes, (hipStream_t)stream));
             hipLaunchKernelGGL(lstm_bwd_split_res_kernel<128>, dim3((unsigned)G, (unsigned)B, (unsigned)ndir), dim3(512), lds, (hipStream_t)stream, sa, ring);
-        } else
+        } else {
+            HandoffArea* ar = lstm_area((hipStream_t)stream, 0);
+            TTSC_REQUIRE(ar, "ttsc_lstm_seq_backward: cannot allocate the hand-off counters");
+            sa.cnt = ar->words;
+            sa.abort_word = ar->abort_word();
             hipLaunchKernelGGL(lstm_bwd_split_kernel, dim3((unsigned)G, (unsigned)B, (unsigned)ndir), dim3(512), lds, (hipStream_t)stream, sa);
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             set_error("lstm_bwd_split_kernel launch failed: %s", hipGetErrorString(e));
@@ -1183,13 +1197,12 @@ static int lstm_forward_impl(const float* xg_dev, const float* whh_packed_dev, f
             const int groups = ((B + NB - 1) / NB) * ndir;
             if (cap >= 1 && groups <= 3 * cap && pairs <= 16384) {
                 // granule ring [pairs][2 slots][H]: sized for this launch, grown on demand, one per (device, stream)
-                HandoffArea* ar = lstm_area((hipStream_t)stream, (size_t)pairs * 2 * H * sizeof(lstm_u64));
+                HandoffArea* ar = lstm_area((hipStream_t)stream, (size_t)pairs * 2 * H * sizeof(lstm_u64), true);
                 if (!ar) {
                     set_error("ttsc_lstm_seq_forward: cannot allocate the hand-off counters / ring");
                     return TTSC_ENOMEM;
                 }
                 lstm_u64* ring = reinterpret_cast<lstm_u64*>(ar->buf);
-                TTSC_HIP_CHECK(hipMemsetAsync(ring, 0, (size_t)pairs * 2 * H * sizeof(lstm_u64), (hipStream_t)stream));
                 LstmSplitArgs sa{};
                 sa.f = a;
                 sa.cnt = ar->words;

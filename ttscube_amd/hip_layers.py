@@ -235,6 +235,8 @@ class LSTMHip:
         for l in range(self.num_layers):
             g = lambda n: getattr(self.m, n).detach().float()
             wih = torch.cat([g('weight_ih_l%d%s' % (l, s)) for s in sfx], dim=0).contiguous()             # [ndir*4H, in]
+            if wih.shape[1] % 4:      # the split-precision GEMM takes K % 4 == 0 only (Languasito2._cond_rnn reads 641 features: the exact kernel ran its
+                wih = torch.nn.functional.pad(wih, (0, 4 - wih.shape[1] % 4)).contiguous()   # projection in 152 us against ~40): zero columns, zero-padded input
             bias = torch.cat([g('bias_ih_l%d%s' % (l, s)) + g('bias_hh_l%d%s' % (l, s)) for s in sfx], dim=0).contiguous()
             whh = torch.stack([g('weight_hh_l%d%s' % (l, s)) for s in sfx], dim=0).cpu().contiguous()      # [ndir,4H,H]
             ptr = C.c_void_p()
@@ -260,6 +262,8 @@ class LSTMHip:
         cur = x.float().contiguous()
         for l in range(self.num_layers):
             # hoisted input projection of all steps: split-precision MFMA GEMM, padding tiles skipped (the recurrence never reads them)
+            if cur.shape[-1] != self._wih[l].shape[1]:
+                cur = torch.nn.functional.pad(cur, (0, self._wih[l].shape[1] - cur.shape[-1]))
             xg = linear_hip(cur, self._wih[l], self._bias[l], split=True, lengths_dev=len_dev, period=T)   # [B, T, nd*4H]
             y = torch.empty((B, T, nd * H), dtype=torch.float32, device=x.device)
             h0 = c0 = None

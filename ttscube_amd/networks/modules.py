@@ -5,6 +5,8 @@ goes through the C ABI of libttscube_hip.so."""
 import ctypes as C
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -400,6 +402,18 @@ def _expand_rows(x, alignments, stride=1):
     return torch.gather(x, 1, idx_t[:, :, None].expand(-1, -1, x.shape[2])).contiguous(), [len(s) for s in sel]
 
 
+G_STREAM = os.environ.get('TTSC_LANG_G_STREAM', '1') != '0'          # (measurement switch: 0 = the `g` stack after the pitch recurrence, on the same stream)
+G_STREAM_MAX_B = int(os.environ.get('TTSC_LANG_G_STREAM_MAX_B', '8'))
+_G_STREAMS = {}
+
+
+def _g_stream(dev):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _G_STREAMS:
+        _G_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _G_STREAMS[key]
+
+
 class Languasito2(nn.Module):
     """cube/networks/modules.py:805-1094 — text -> 80-d per-frame conditioning for the HiFi-GAN generator.
     Same constructor and state_dict keys; `inference` runs on the HIP conv / GEMM / LSTM kernels and additionally
@@ -511,6 +525,21 @@ class Languasito2(nn.Module):
             hcs = self._text_stack('t', x_char, x_speaker, lengths, X, hf_cond)
             hd = self._lstm('_dur_rnn')(hcs, lengths=lengths)
             out_dur = linear_hip(hd, self._dur_output.linear_layer.weight, self._dur_output.linear_layer.bias)
+            # The `g` phoneme stack (embedding, char CNN, two BiLSTM layers: ~0.6 ms of latency-bound launches at B = 1) shares nothing with the
+            # `t` stack but the inputs and is not needed before `_cond_rnn`: for small batches it is queued NOW — behind the duration head on the
+            # host, which then waits for the frame counts anyway — on a stream of its own, and runs beside the `t` / duration / pitch recurrences
+            # instead of after them (each split recurrence holds 8 CUs per utterance; hand-off areas are per stream).  Same launches, same bits.
+            g_side = None
+            if G_STREAM and B <= G_STREAM_MAX_B and x_char.is_cuda:
+                cur_s = torch.cuda.current_stream(dev)
+                g_side = _g_stream(dev)
+                g_side.wait_stream(cur_s)       # (inputs and length table are uploaded on the current stream)
+                with torch.cuda.stream(g_side):
+                    g_char = self._text_stack('g', x_char, x_speaker, lengths, X, hf_cond)
+                for t_ in (x_char, x_speaker, getattr(lengths, 'dev', None)):
+                    if t_ is not None:
+                        t_.record_stream(g_side)
+                g_char.record_stream(cur_s)
             mark('text')
             # duration head -> frame->phone map on the device (the reference goes through the host here, modules.py:946-953)
             f2p = align_durations(out_dur, lengths)
@@ -527,7 +556,11 @@ class Languasito2(nn.Module):
             vuv = torch.round(op[:, :, 1])
             pitch = (op[:, :, 0] * self._max_pitch) * vuv
             X['y_pitch'] = pitch
-            g = self._text_stack('g', x_char, X['x_speaker'].to(dev), lengths, X, hf_cond)
+            if g_side is not None:
+                torch.cuda.current_stream(dev).wait_stream(g_side)
+                g = g_char
+            else:
+                g = self._text_stack('g', x_char, x_speaker, lengths, X, hf_cond)
             g, _ = _expand_rows(g, f2p)
             g = torch.cat([g, (pitch / self._max_pitch).unsqueeze(2)], dim=-1).contiguous()
             g = self._lstm('_cond_rnn')(g, lengths=flens)
