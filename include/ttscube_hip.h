@@ -525,9 +525,10 @@ int32_t ttsc_lstm_split_status(void);
  * without draining the other streams. */
 int32_t ttsc_split_status_stream(void* stream);
 /* Device-side form of the same question: ONE launch on `stream` ORs the verdict bits of every split recurrence launched on that stream so far (bit 0 LSTM,
- * bit 1 GRU, bit 2 mel-AR, bit 3 other; bit 4 = the split-precision GEMM's range word when with_gemm != 0) into *dst_dev and re-arms the sticky words;
- * the host waits for nothing.  Returns the number of status words looked at (0: nothing to ask, no launch), < 0 on a HIP error. */
-int32_t ttsc_split_status_collect(void* stream, uint32_t* dst_dev, int32_t with_gemm);
+ * bit 1 GRU, bit 2 mel-AR, bit 3 other; bit 4 = the split-precision GEMM's range word) into *dst_dev and re-arms the sticky words; the host waits for
+ * nothing.  flags: bit 0 = include the GEMM's range word, bit 1 = the recurrences of EVERY stream of the device (the caller has made `stream` wait for
+ * them).  Returns the number of status words looked at (0: nothing to ask, no launch), < 0 on a HIP error. */
+int32_t ttsc_split_status_collect(void* stream, uint32_t* dst_dev, int32_t flags);
 /* Utterances per member group of the register-resident split recurrence (H = 256 / 512: 4 / 16 workgroups per group hold W_hh in registers).
  * 0 (default) = automatic: the smallest of 1 / 2 / 4 that takes the padded batch in one launch — the shortest step.  n = 1 / 2 / 4 / 8: n per
  * group whenever the batch has that many — n times fewer CUs held for a somewhat longer step, for callers that run the recurrence beside a

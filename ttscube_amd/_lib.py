@@ -321,6 +321,88 @@ def check_split_status(where, stream=None):
                         'finite — its results are invalid; TTSC_GEMM_SPLIT=0 keeps these projections on the exact fp32 kernel' % where)
 
 
+class _StagingRing:
+    """page-locked staging buffers for small host-to-device uploads, reused round-robin (allocating page-locked memory per call costs more than the
+    copy); a slot is reused only after the copy that last read it has completed"""
+    SLOTS = 8
+
+    def __init__(self):
+        self.buf = [None] * self.SLOTS
+        self.ev = [None] * self.SLOTS
+        self.n = 0
+
+    def upload(self, tensors, dev):
+        """tensors: CPU int64 tensors -> device int64 views of ONE non-blocking upload, in order"""
+        import torch
+        total = sum(t.numel() for t in tensors)
+        i = self.n % self.SLOTS
+        self.n += 1
+        if self.ev[i] is not None:
+            self.ev[i].synchronize()
+        if self.buf[i] is None or self.buf[i].numel() < total:
+            self.buf[i] = torch.empty(max(total, 4096), dtype=torch.int64).pin_memory()
+        host, off = self.buf[i], 0
+        for t in tensors:
+            host[off:off + t.numel()].copy_(t.reshape(-1))
+            off += t.numel()
+        d = host[:total].to(dev, non_blocking=True)
+        self.ev[i] = torch.cuda.Event()
+        self.ev[i].record()
+        out, off = [], 0
+        for t in tensors:
+            out.append(d[off:off + t.numel()].view(t.shape))
+            off += t.numel()
+        return out
+
+
+_STAGING = {}
+
+
+def upload_ints(tensors, dev):
+    """several small CPU int64 tensors to `dev` in one page-locked, non-blocking copy (the synthesis calls' phone ids, speaker ids and lengths: three
+    uploads, two of them blocking pageable copies, were ~0.1 ms of GPU idle time in front of every sentence)"""
+    import torch
+    dev = torch.device(dev)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ring = _STAGING.get(key)
+    if ring is None:
+        ring = _STAGING[key] = _StagingRing()
+    return ring.upload(tensors, dev)
+
+
+_STATUS_WORDS = {}
+
+
+def check_split_status_once(where):
+    """The same verdict as check_split_status(where) for a caller whose CURRENT stream is ordered behind every stream it ran recurrences on:
+    one collecting launch (ttsc_split_status_collect: every stream's recurrences + the split GEMM's range word), one 4-byte copy to page-locked
+    memory and ONE wait for the current stream — instead of one blocking read-back per kernel family (four at the end of every synthesis call:
+    ~100 us of a 5 ms sentence)."""
+    import torch
+    L = lib()
+    dev = torch.cuda.current_device()
+    st = _STATUS_WORDS.get(dev)
+    if st is None:
+        st = _STATUS_WORDS[dev] = (torch.zeros(1, dtype=torch.int32, device='cuda:%d' % dev), torch.zeros(1, dtype=torch.int32).pin_memory())
+    word, host = st
+    n = int(L.ttsc_split_status_collect(current_stream(), word.data_ptr(), 3))
+    if n < 0:
+        raise TTSCError('%s: ttsc_split_status_collect failed: %s' % (where, L.ttsc_last_error().decode()))
+    if n == 0:
+        return
+    host.copy_(word, non_blocking=True)
+    word.zero_()
+    torch.cuda.current_stream().synchronize()
+    m = int(host[0])
+    if m & 15:
+        kinds = '/'.join(k for b, k in ((1, 'LSTM'), (2, 'GRU'), (4, 'mel-AR'), (8, 'other')) if m & b)
+        raise TTSCError('%s: split %s recurrence aborted on a hand-off timeout (are other kernels occupying the CUs? '
+                        'TTSC_LSTM_SPLIT=1 / TTSC_GRU_SPLIT=1 select the single-workgroup kernels)' % (where, kinds))
+    if m & 16:
+        raise TTSCError('%s: an operand of a split-precision GEMM (ttsc_linear_forward_split) lay beyond the fp16 range (|v| > 65504) or was not '
+                        'finite — its results are invalid; TTSC_GEMM_SPLIT=0 keeps these projections on the exact fp32 kernel' % where)
+
+
 class lstm_group_size:
     """`with lstm_group_size(8): ...` — utterances per member group of the split LSTM recurrences inside the block (ttsc_lstm_set_group_size:
     fewer CUs held per padded batch, same results); the previous setting is restored on exit."""

@@ -158,7 +158,8 @@ __global__ void status_collect_kernel(CollectArgs a) {
 }
 unsigned* gemm_split_word_if_any();   // gemm.hip
 
-int handoff_collect_stream(hipStream_t stream, unsigned* dst, int with_gemm) {
+int handoff_collect_stream(hipStream_t stream, unsigned* dst, int flags) {
+    const int with_gemm = flags & 1, all_streams = flags & 2;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
     CollectArgs a;
@@ -167,7 +168,7 @@ int handoff_collect_stream(hipStream_t stream, unsigned* dst, int with_gemm) {
     {
         std::lock_guard<std::mutex> lk(g_state_mu);
         for (auto& kv : areas()) {
-            if (kv.first.dev != dev || kv.first.stream != stream || !kv.second.words) continue;
+            if (kv.first.dev != dev || (!all_streams && kv.first.stream != stream) || !kv.second.words) continue;
             if (a.n == 47) break;
             a.word[a.n] = kv.second.abort_word() + 1;
             a.bit[a.n++] = kv.first.tag == "lstm" ? 1 : kv.first.tag == "gru" ? 2 : kv.first.tag == "melar" ? 4 : 8;
@@ -185,14 +186,15 @@ int handoff_collect_stream(hipStream_t stream, unsigned* dst, int with_gemm) {
 }  // namespace ttsc
 
 // Device-side form of ttsc_split_status_stream: ONE launch on `stream` that ORs the verdict bits (1 LSTM | 2 GRU | 4 mel-AR | 8 other; 16 = the
-// split-precision GEMM's range word when `with_gemm`) of everything launched on that stream so far into *dst_dev and re-arms the sticky words.  Nothing waits:
+// split-precision GEMM's range word when flags bit 0) of everything launched on that stream so far — flags bit 1: on ANY stream of the device; the
+// caller has ordered those streams before `stream` — into *dst_dev and re-arms the sticky words.  Nothing waits:
 // a later launch on the stream (ttsc_adamw_step_guarded) or a later read-back decides.  Returns the number of words looked at, < 0 on a HIP error.
-extern "C" int32_t ttsc_split_status_collect(void* stream, uint32_t* dst_dev, int32_t with_gemm) {
+extern "C" int32_t ttsc_split_status_collect(void* stream, uint32_t* dst_dev, int32_t flags) {
     if (!dst_dev) {
         ttsc::set_error("ttsc_split_status_collect: null destination");
         return -1;
     }
-    const int n = ttsc::handoff_collect_stream((hipStream_t)stream, dst_dev, with_gemm);
+    const int n = ttsc::handoff_collect_stream((hipStream_t)stream, dst_dev, flags);
     if (n < 0) ttsc::set_error("ttsc_split_status_collect: launch failed");
     return n;
 }

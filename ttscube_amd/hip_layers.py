@@ -222,7 +222,10 @@ class LSTMHip:
             pass
 
     def _sync(self):
-        sig = tuple((p.data_ptr(), p._version) for p in self.m.parameters())
+        pl = getattr(self, '_plist', None)
+        if pl is None:      # (an nn.LSTM's Parameter objects are fixed: walk the module once)
+            pl = self._plist = list(self.m.parameters())
+        sig = tuple((p.data_ptr(), p._version) for p in pl)
         if sig == self._sig:
             return
         _lib.require_gpu()

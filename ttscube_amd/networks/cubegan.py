@@ -56,7 +56,7 @@ class Cubegan(nn.Module):
         """cubegan.py:74-83: text -> conditioning (predicted durations/pitch) -> waveform [B,1,L] in (-1,1).
         With a padded batch (B>1, new capability) `return_lengths=True` also returns each utterance's sample count."""
         with torch.no_grad():
-            cond, _, flens = self._languasito.inference(X, return_aux=True, check_status=False, timers=timers)
+            cond, _, flens = self._languasito.inference(X, return_aux='device', check_status=False, timers=timers)
             if cond.shape[1] == 0:
                 cond = torch.zeros((cond.shape[0], 1, cond.shape[2]), device=self.get_device())
                 flens = [1] * cond.shape[0]
@@ -67,7 +67,7 @@ class Cubegan(nn.Module):
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record()
                 timers.append(('generator', ev))
-        _lib.check_split_status('Cubegan.inference')   # the BiLSTM recurrences may run split over several workgroups
+        _lib.check_split_status_once('Cubegan.inference')   # the BiLSTM recurrences may run split over several workgroups
         if return_lengths:
             return wav, [self._generator.out_len(f) if f > 0 else 0 for f in flens]
         return wav
@@ -102,7 +102,7 @@ class Cubegan(nn.Module):
                 # recurrences packed `lstm_group` utterances per member group: they hold that many times fewer CUs (which the generator of the
                 # previous batch is using) for a slightly longer step — the step time is hidden here, the CUs are not
                 with torch.cuda.stream(s_txt), torch.no_grad(), _lib.lstm_group_size(lstm_group):
-                    cond, _, flens = self._languasito.inference(X, return_aux=True, check_status=False)   # (waits for ITS stream only: frame counts)
+                    cond, _, flens = self._languasito.inference(X, return_aux='device', check_status=False)   # (waits for ITS stream only: frame counts)
                     if cond.shape[1] == 0:
                         cond = torch.zeros((cond.shape[0], 1, cond.shape[2]), device=dev)
                         flens = [1] * cond.shape[0]

@@ -215,8 +215,11 @@ class _ConvStack:
         self.h = None
 
     def sync(self):
-        mods = [m for it in self.items for m in it if m is not None]
-        sig = tuple((t.data_ptr(), t._version) for m in mods for t in list(m.parameters()) + list(m.buffers()))
+        ts = getattr(self, '_tensors', None)
+        if ts is None:      # (the modules' parameter / buffer objects are fixed: walk them once)
+            mods = [m for it in self.items for m in it if m is not None]
+            ts = self._tensors = [t for m in mods for t in list(m.parameters()) + list(m.buffers())]
+        sig = tuple((t.data_ptr(), t._version) for t in ts)
         if sig == self._sig:
             return self.h
         self.h = []
@@ -516,10 +519,17 @@ class Languasito2(nn.Module):
                 timers.append((name, ev))
         X.pop('y_frame2phone', None)
         dev = self._get_device()
-        x_char = X['x_char'].to(dev)
-        x_speaker = X['x_speaker'].to(dev)
+        xc, xs = X['x_char'], X['x_speaker']
+        if xc.device.type == 'cpu' and xs.device.type == 'cpu' and xc.dtype == torch.int64 and xs.dtype == torch.int64 and dev.type == 'cuda':
+            # phone ids, speaker ids and lengths in ONE page-locked upload (lengths counted on the host copy)
+            lens = _char_lengths(X, xc)
+            x_char, x_speaker, len64 = _lib.upload_ints([xc, xs, torch.tensor(lens, dtype=torch.int64)], dev)
+            lengths = _lib.DevLengths(lens, dev_tensor=len64.to(torch.int32))
+        else:
+            x_char = xc.to(dev)
+            x_speaker = xs.to(dev)
+            lengths = _lib.DevLengths(_char_lengths(X, x_char), device=dev)   # one upload; every layer below takes the device copy
         B, N = x_char.shape
-        lengths = _lib.DevLengths(_char_lengths(X, x_char), device=dev)   # one upload; every layer below takes the device copy
         with torch.no_grad():
             mark('start')
             hcs = self._text_stack('t', x_char, x_speaker, lengths, X, hf_cond)
@@ -550,7 +560,7 @@ class Languasito2(nn.Module):
             if F_ == 0:
                 X['y_pitch'] = torch.zeros((B, 0), device=dev)
                 cond = torch.zeros((B, 0, 80), device=dev)
-                return (cond, f2p.durations(), flens) if return_aux else cond
+                return (cond, f2p if return_aux == 'device' else f2p.durations(), flens) if return_aux else cond
             hp = self._lstm('_pitch_rnn')(hexp, lengths=flens)
             op = linear_hip(hp, self._pitch_output.linear_layer.weight, self._pitch_output.linear_layer.bias, act='sigmoid')
             vuv = torch.round(op[:, :, 1])
@@ -571,7 +581,9 @@ class Languasito2(nn.Module):
             mark('frames')
         if check_status:   # (Cubegan.inference polls once for the whole synthesis instead)
             _lib.check_split_status('Languasito2.inference')
-        return (cond, f2p.durations(), flens) if return_aux else cond
+        # return_aux='device': the Alignment itself (durations stay on the device — reading them back here made the host wait for the whole frame-level
+        # stack before it could queue the generator: ~0.15 ms of GPU idle time per sentence)
+        return (cond, f2p if return_aux == 'device' else f2p.durations(), flens) if return_aux else cond
 
     @torch.jit.ignore
     def save(self, path):
