@@ -388,6 +388,12 @@ int ttsc_hifigan_get_activation_scale(const ttsc_hifigan* g, const char* layer_n
  * weights are uploaded first; the handle then counts as calibrated until its weights change. */
 int ttsc_hifigan_set_activation_scales(ttsc_hifigan* g, const char* const* layer_names, const float* scales, int32_t n);
 int32_t ttsc_hifigan_recalibrations(const ttsc_hifigan* g);
+/* The two side streams of the branch schedule (the ResBlocks of a layer-by-layer stage beside each other for ragged / small batches, TTSC_HIFIGAN_BRANCH_STREAMS):
+ * by default the handle creates its own on first use; a host that keeps a stream pool hands two of ITS streams in (borrowed: never destroyed here; the caller
+ * keeps them alive while the handle can run).  Why it matters: the runtime multiplexes all streams of a process onto four hardware queues, and two more
+ * streams shift the queue every stream created after them lands on — a training step that followed a small-batch forward in the same process ran 61.5 -> 69 ms
+ * (profiles/r06_branch_stream_queues.log).  Outputs are identical bit for bit whichever streams are used.  (nullptr, nullptr): back to the handle's own. */
+int ttsc_hifigan_set_branch_streams(ttsc_hifigan* g, void* stream_a, void* stream_b);
 /* Range guard mode: 1 (default) = every forward synchronises its stream, re-calibrates + reruns when tripped; 2 = deferred: forwards
  * never wait, the guard word stays sticky on the device until ttsc_hifigan_range_status() (which synchronises `stream`) reads and
  * clears it: 1 = some forward since the last call emitted a non-finite sample — its output must be discarded / recomputed —, 0 = all

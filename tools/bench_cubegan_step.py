@@ -35,22 +35,32 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--ragged', action='store_true', help="bench.py's batch: synthetic_examples(b, 777, min_ph=30, max_ph=50) through the class surface")
     a = ap.parse_args()
     from ttscube_amd.networks.cubegan import Cubegan
     from ttscube_amd.networks import training as T
     rng = np.random.RandomState(0)
-    batch, enc = make_batch(a.batch, 40, rng)
+    if a.ragged:
+        from ttscube_amd.io_utils.io_cubegan import CubeganCollate
+        from ttscube_amd.io_utils.synthetic import synthetic_encodings, synthetic_examples
+        enc = synthetic_encodings()
+        batch = CubeganCollate(enc).collate_fn(list(synthetic_examples(a.batch, 777, min_ph=30, max_ph=50)))
+    else:
+        batch, enc = make_batch(a.batch, 40, rng)
     torch.manual_seed(0)
     model = Cubegan(enc, conditioning=None, train=True).cuda()
     model.train()
     opts = T.cubegan_configure_optimizers(model)
     r = random.Random(1)
-    for _ in range(2):
-        T.cubegan_training_step(model, batch, opts, rng=r)
+    step = (lambda: model.training_step(batch, 0, rng=r)) if a.ragged else (lambda: T.cubegan_training_step(model, batch, opts, rng=r))
+    if a.ragged:
+        model._optimizers = opts
+    for _ in range(3):
+        step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.iters):
-        out = T.cubegan_training_step(model, batch, opts, rng=r)
+        out = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.iters
     print('cubegan training step  b=%d x 12000 samples: %.1f ms/step  %.2f M samples/s  losses %s' %

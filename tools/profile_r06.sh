@@ -21,13 +21,22 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $O/train -o r -- python bench.py
 python tools/rocpd_stats.py $O/train/r_results.db $O/train_kernel_stats.csv -300 $O/train_last300ms_kernel_stats.csv >> $O/train.log 2>&1
 python tools/gpu_timeline.py $O/train/r_results.db 100 2 > $O/train_timeline.txt 2>&1
 rm -rf $O/train
+# the un-armed step (tools/bench_cubegan_step.py: what bench.py's cubegan_training_step_b16 leg runs): kernel stats of the last ~300 ms, phase timeline
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/step -o s -- python tools/bench_cubegan_step.py --iters 8 > $O/step.log 2>&1
+python tools/rocpd_stats.py $O/step/s_results.db $O/train_step_kernel_stats.csv -300 $O/train_step_last300ms_kernel_stats.csv >> $O/step.log 2>&1
+python tools/gpu_timeline.py $O/step/s_results.db 100 2 > $O/train_step_timeline.txt 2>&1
+rm -rf $O/step
+timeout 200 python tools/probes/train_phase_timeline.py 2>&1 | grep -v Warn | tail -17 > $O/train_phase_timeline.log
+(for i in 1 2 3; do timeout 200 python tools/bench_cubegan_step.py --iters 10; done; timeout 300 python tools/bench_cubegan_step.py --iters 5 --batch 128) 2>&1 | grep ms/step | cut -c1-90 > $O/train_step_bench.log
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/wr -o v -- python tools/bench_wavernn.py > $O/wavernn.log 2>&1
 python tools/rocpd_stats.py $O/wr/v_results.db $O/wavernn_kernel_stats.csv >> $O/wavernn.log 2>&1
 rm -rf $O/wr
 (timeout 200 python tools/bench_wavernn.py --frames 100; timeout 120 python tools/bench_wavernn.py --frames 20 --layers 2) 2>&1 | grep 'net:' > $O/wavernn_bench.log
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/e2e1 -o e -- python tools/probes/e2e_b1.py > $O/e2e_single_sentence.log 2>&1
 python tools/rocpd_stats.py $O/e2e1/e_results.db $O/e2e_single_sentence_kernel_stats.csv >> $O/e2e_single_sentence.log 2>&1
+python tools/rocpd_tail.py $O/e2e1/e_results.db 5.4 > $O/e2e_single_sentence_launches.txt 2>&1
 rm -rf $O/e2e1
+(for i in 1 2 3; do timeout 120 python tools/probes/e2e_b1.py; done) 2>&1 | grep "B=1" > $O/e2e_single_sentence_bench.log
 timeout 300 python bench.py --mode e2e --steps 5 --warmup 2 2>/dev/null | grep '^{' > $O/bench_e2e.json
 timeout 300 python bench.py --mode train --steps 6 --warmup 2 2>/dev/null | grep '^{' > $O/bench_train_b16.json
 timeout 400 python bench.py --mode train --train-batch 128 --steps 3 --warmup 1 2>/dev/null | grep '^{' > $O/bench_train_b128.json

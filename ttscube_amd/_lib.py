@@ -69,6 +69,7 @@ SIGNATURES = {
     'ttsc_hifigan_get_activation_scale': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_float)]),
     'ttsc_hifigan_set_activation_scales': (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int32]),
     'ttsc_hifigan_recalibrations': (C.c_int32, [C.c_void_p]),
+    'ttsc_hifigan_set_branch_streams': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'ttsc_hifigan_set_range_check': (C.c_int, [C.c_void_p, C.c_int32]),
     'ttsc_hifigan_range_status': (C.c_int32, [C.c_void_p, C.c_void_p]),
     'ttsc_conv1d_set_nonfinite_flag': (C.c_int, [C.c_void_p, C.c_void_p]),

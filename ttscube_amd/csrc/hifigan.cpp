@@ -19,6 +19,7 @@
 // [B, C_i, L_i] fp32 channel-major, sized for the largest stage.
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <utility>
@@ -57,6 +58,7 @@ struct ttsc_hifigan {
     // env TTSC_HIFIGAN_BRANCH_STREAMS: 0 = off, 1 = by the rule in branch_streams_for() (default), 2 = whenever the buffers allow.
     int branch_streams = 1;
     hipStream_t side[2] = {nullptr, nullptr};
+    bool side_owned = false;   // false: handed in by ttsc_hifigan_set_branch_streams (not destroyed with the handle)
     hipEvent_t ev_fork = nullptr, ev_acc[TTSC_HIFIGAN_MAX_RB] = {nullptr};
     int side_dev = -1;
     int precision = TTSC_PREC_FP32;
@@ -91,7 +93,7 @@ struct ttsc_hifigan {
         if (flag_dev) (void)hipFree(flag_dev);
         if (flag_host) (void)hipHostFree(flag_host);
         for (auto& st : side)
-            if (st) (void)hipStreamDestroy(st);
+            if (st && side_owned) (void)hipStreamDestroy(st);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         for (auto& e : ev_acc)
             if (e) (void)hipEventDestroy(e);
@@ -100,9 +102,16 @@ struct ttsc_hifigan {
     int ensure_side_streams() {
         int dev = 0;
         TTSC_HIP_CHECK(hipGetDevice(&dev));
-        if (side[0] && side_dev == dev) return TTSC_OK;
-        TTSC_REQUIRE(!side[0], "ttsc_hifigan_forward: the handle's branch streams belong to device %d, the call runs on device %d", side_dev, dev);
+        if (side[0] && ev_fork && side_dev == dev) return TTSC_OK;
+        TTSC_REQUIRE(!side[0] || !ev_fork, "ttsc_hifigan_forward: the handle's branch streams belong to device %d, the call runs on device %d", side_dev, dev);
+        if (side[0]) {   // streams handed in by the caller: only the events are the handle's
+            TTSC_REQUIRE(side_dev == dev, "ttsc_hifigan_forward: the branch streams handed in belong to device %d, the call runs on device %d", side_dev, dev);
+            TTSC_HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+            for (auto& e : ev_acc) TTSC_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            return TTSC_OK;
+        }
         for (auto& st : side) TTSC_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        side_owned = true;
         TTSC_HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         for (auto& e : ev_acc) TTSC_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         side_dev = dev;
@@ -453,6 +462,25 @@ extern "C" int ttsc_hifigan_set_activation_scales(ttsc_hifigan* g, const char* c
     }
     g->calibrated = true;
     if (!(g->calib_in_absmax > 0.f)) g->calib_in_absmax = 5.f;   // restored scales: assume the log-mel range of the built-in probe
+    return TTSC_OK;
+}
+
+// Branch streams of the caller's choosing (see ttscube_hip.h).  Both null: back to streams the handle creates on first use.
+extern "C" int ttsc_hifigan_set_branch_streams(ttsc_hifigan* g, void* stream_a, void* stream_b) {
+    TTSC_REQUIRE(g, "ttsc_hifigan_set_branch_streams: null handle");
+    TTSC_REQUIRE((stream_a == nullptr) == (stream_b == nullptr) && (!stream_a || stream_a != stream_b),
+                 "ttsc_hifigan_set_branch_streams: two distinct streams, or two nulls");
+    int dev = 0;
+    TTSC_HIP_CHECK(hipGetDevice(&dev));
+    TTSC_REQUIRE(!g->ev_fork || g->side_dev == dev, "ttsc_hifigan_set_branch_streams: the handle already ran its branch schedule on device %d", g->side_dev);
+    for (auto& st : g->side) {
+        if (st && g->side_owned) TTSC_HIP_CHECK(hipStreamDestroy(st));
+        st = nullptr;
+    }
+    g->side_owned = false;
+    g->side[0] = (hipStream_t)stream_a;
+    g->side[1] = (hipStream_t)stream_b;
+    if (stream_a) g->side_dev = dev;
     return TTSC_OK;
 }
 

@@ -22,6 +22,7 @@
 //   everything else     lstm_seq_kernel<BT>           one workgroup per (utterance tile, direction), rows streamed from L2
 #include <algorithm>
 #include <atomic>
+#include <cstring>
 
 #include "common.hpp"
 #include "../../include/ttscube_math.h"
@@ -1029,6 +1030,12 @@ __global__ __launch_bounds__(256) void lstm_rearm_kernel(unsigned* __restrict__ 
 static HandoffArea* lstm_area(hipStream_t s, size_t ring_bytes, bool zero_ring = false) {
     HandoffArea* ar = handoff_area("lstm", s, 8192, ring_bytes);
     if (!ar) return nullptr;
+    static const bool by_memset = getenv("TTSC_LSTM_REARM") && !strcmp(getenv("TTSC_LSTM_REARM"), "memset");   // (measurement switch: round 5's fills)
+    if (by_memset) {
+        if (ar->rearm(s) != hipSuccess) return nullptr;
+        if (zero_ring && ring_bytes && hipMemsetAsync(ar->buf, 0, ring_bytes, s) != hipSuccess) return nullptr;
+        return ar;
+    }
     const size_t n64 = zero_ring ? ring_bytes / sizeof(lstm_u64) : 0;
     const size_t work = std::max<size_t>(ar->nwords + 1, n64);
     const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>((work + 2047) / 2048, 1), 2048);

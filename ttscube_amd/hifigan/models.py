@@ -178,6 +178,7 @@ class Generator(nn.Module):
             cfg = self._cfg()
             _lib.check(L.ttsc_hifigan_create(C.byref(cfg), C.byref(hnd)), 'ttsc_hifigan_create')
             self._handle = hnd
+            self._branch_dev = None
             self.set_precision(self._precision)
         for name, l in self._named_convs():
             for suffix, t in (('.weight', l.folded_weight()), ('.bias', l.bias.detach())):
@@ -282,6 +283,12 @@ class Generator(nn.Module):
             self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
         y = torch.empty((B, 1, Lout), dtype=torch.float32, device=x.device)
         with _lib.on_device(x.device):
+            if getattr(self, '_branch_dev', None) != x.device and os.environ.get('TTSC_BRANCH_STREAMS_OWN', '0') != '1':   # (1: measurement switch)
+                # the branch schedule borrows two of the package's reserved streams instead of creating its own (see streams._reserve)
+                from .streams import branch_stream_handles
+                sa, sb = branch_stream_handles(x.device)
+                _lib.check(L.ttsc_hifigan_set_branch_streams(self._handle, C.c_void_p(sa), C.c_void_p(sb)), 'ttsc_hifigan_set_branch_streams')
+                self._branch_dev = x.device
             fr = None
             if frames is not None:
                 assert len(frames) == B

@@ -12,12 +12,41 @@ _SIDE = {}
 _OFF_TAGS = set(v for v in os.environ.get('TTSC_STREAMS_OFF', '').split(',') if v)   # measurement switch: 'gen', 'mpd', 'msd'
 
 
-def _side_streams(dev, n):
+_TEXT = {}
+N_RESERVED = 8     # side streams taken together with the text stream at first use (5 period + 3 scale sub-discriminators)
+
+
+def _reserve(dev):
+    """All streams this package uses beside the caller's, taken from torch's pool in ONE go and in a fixed order — text stream, then the side streams.
+    The HIP runtime multiplexes the streams of a process onto four hardware queues in creation order, so WHICH queue the text stream and each side stream
+    share with the main stream depends on what was created before them: a Cubegan training step ran 61.5 ms in a fresh process and 69 ms after a small-batch
+    generator forward had created two branch streams first (profiles/r06_branch_stream_queues.log).  With one reservation, and the generator's branch
+    schedule borrowing two of these streams (ttsc_hifigan_set_branch_streams), the mapping no longer depends on the order in which the features of the
+    package are first used."""
     key = (dev.index if dev.index is not None else torch.cuda.current_device())
-    ss = _SIDE.setdefault(key, [])
+    if key not in _TEXT:
+        d = torch.device('cuda', key)
+        _TEXT[key] = torch.cuda.Stream(device=d)
+        _SIDE[key] = [torch.cuda.Stream(device=d) for _ in range(N_RESERVED)]
+    return key
+
+
+def text_stream(dev):
+    """the stream of the text side of a training step (networks/training.py), normal priority"""
+    return _TEXT[_reserve(dev)]
+
+
+def _side_streams(dev, n):
+    ss = _SIDE[_reserve(dev)]
     while len(ss) < n:
         ss.append(torch.cuda.Stream(device=dev))
     return ss[:n]
+
+
+def branch_stream_handles(dev):
+    """raw handles of the two side streams the generator's inference branch schedule borrows (hifigan/models.py)"""
+    a, b = _side_streams(dev, 2)
+    return a.cuda_stream, b.cuda_stream
 
 
 def _tensors(nest):

@@ -15,6 +15,8 @@ from ..hifigan.env import AttrDict
 from ..hifigan.models import Generator
 from .modules import Languasito2
 
+_AUX = True if os.environ.get('TTSC_DUR_DEVICE', '1') == '0' else 'device'   # (measurement switch: 0 = durations read back inside Languasito2.inference)
+
 
 def _load_hifigan_config():
     for p in ('hifigan/config_v1.json', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'hifigan', 'config_v1.json')):
@@ -102,7 +104,7 @@ class Cubegan(nn.Module):
                 # recurrences packed `lstm_group` utterances per member group: they hold that many times fewer CUs (which the generator of the
                 # previous batch is using) for a slightly longer step — the step time is hidden here, the CUs are not
                 with torch.cuda.stream(s_txt), torch.no_grad(), _lib.lstm_group_size(lstm_group):
-                    cond, _, flens = self._languasito.inference(X, return_aux='device', check_status=False)   # (waits for ITS stream only: frame counts)
+                    cond, _, flens = self._languasito.inference(X, return_aux=_AUX, check_status=False)   # (waits for ITS stream only: frame counts)
                     if cond.shape[1] == 0:
                         cond = torch.zeros((cond.shape[0], 1, cond.shape[2]), device=dev)
                         flens = [1] * cond.shape[0]

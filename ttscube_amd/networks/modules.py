@@ -406,6 +406,7 @@ def _expand_rows(x, alignments, stride=1):
 
 
 G_STREAM = os.environ.get('TTSC_LANG_G_STREAM', '1') != '0'          # (measurement switch: 0 = the `g` stack after the pitch recurrence, on the same stream)
+UPLOAD_RING = os.environ.get('TTSC_UPLOAD_RING', '1') != '0'             # (measurement switch: 0 = three separate uploads)
 G_STREAM_MAX_B = int(os.environ.get('TTSC_LANG_G_STREAM_MAX_B', '8'))
 _G_STREAMS = {}
 
@@ -413,7 +414,8 @@ _G_STREAMS = {}
 def _g_stream(dev):
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     if key not in _G_STREAMS:
-        _G_STREAMS[key] = torch.cuda.Stream(device=dev)
+        from ..hifigan.streams import _side_streams    # (one of the package's reserved streams — no stream of its own: hifigan/streams.py::_reserve)
+        _G_STREAMS[key] = _side_streams(dev, 1)[0]
     return _G_STREAMS[key]
 
 
@@ -520,8 +522,10 @@ class Languasito2(nn.Module):
         X.pop('y_frame2phone', None)
         dev = self._get_device()
         xc, xs = X['x_char'], X['x_speaker']
-        if xc.device.type == 'cpu' and xs.device.type == 'cpu' and xc.dtype == torch.int64 and xs.dtype == torch.int64 and dev.type == 'cuda':
+        if UPLOAD_RING and xc.shape[0] <= G_STREAM_MAX_B and xc.device.type == 'cpu' and xs.device.type == 'cpu' and xc.dtype == torch.int64 and xs.dtype == torch.int64 and dev.type == 'cuda':
             # phone ids, speaker ids and lengths in ONE page-locked upload (lengths counted on the host copy)
+            # (small batches only: behind a generator that fills the chip — Cubegan.inference_pipelined — the asynchronous copy starts late and the
+            # text stack of the next batch loses its overlap: 64 sentences 30.7 ms with blocking copies, 33.8-36.2 with the ring, profiles/r06_e2e_upload_ring_ab.log)
             lens = _char_lengths(X, xc)
             x_char, x_speaker, len64 = _lib.upload_ints([xc, xs, torch.tensor(lens, dtype=torch.int64)], dev)
             lengths = _lib.DevLengths(lens, dev_tensor=len64.to(torch.int32))

@@ -109,7 +109,9 @@ _TEXT_STREAMS = {}
 def _text_stream(dev):
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     if key not in _TEXT_STREAMS:
-        _TEXT_STREAMS[key] = torch.cuda.Stream(device=dev, priority=int(os.environ.get('TTSC_TEXT_STREAM_PRIORITY', '0')))
+        prio = int(os.environ.get('TTSC_TEXT_STREAM_PRIORITY', '0'))
+        from ..hifigan.streams import text_stream     # (reserved together with the side streams, in a fixed order: hifigan/streams.py::_reserve)
+        _TEXT_STREAMS[key] = text_stream(dev) if prio == 0 else torch.cuda.Stream(device=dev, priority=prio)
         # (normal priority on purpose: a high-priority stream gets a hardware queue of its own, and with MORE than the runtime's default four
         # queues really running side by side this step gets slower, not faster — 77 ms vs 101 ms at b = 16, tools/probes/train_host_bound.py)
     return _TEXT_STREAMS[key]
