@@ -115,6 +115,9 @@ class FlatBucketReducer:
 # measurement switches (tools/probes/train_hook_overhead.py): which stream prepares and sends an early chunk ('own' = a dedicated stream that waits for
 # the default stream and all side streams; 'current' = round 3's behaviour), and whether anything leaves before reduce() at all
 _EX_STREAM_MODE = __import__('os').environ.get('TTSC_EXCHANGE_STREAM', 'own')
+_EX_STREAM_SHARED = _EX_STREAM_MODE != 'per_reducer'
+if _EX_STREAM_MODE == 'per_reducer':
+    _EX_STREAM_MODE = 'own'
 _EARLY_OFF = __import__('os').environ.get('TTSC_EXCHANGE_EARLY', '1') == '0'
 
 
@@ -257,7 +260,10 @@ class ArenaReducer:
             _mode = _EX_STREAM_MODE
             if _mode == 'own':
                 if self._ex_stream is None:
-                    self._ex_stream = torch.cuda.Stream(device=g.device)
+                    # one exchange stream per device for every reducer, out of the package's reserved pool (a stream per reducer was three more
+                    # streams on the runtime's four hardware queues: hifigan/streams.py::_reserve); TTSC_EXCHANGE_STREAM=per_reducer: round 5's
+                    from .hifigan.streams import exchange_stream
+                    self._ex_stream = exchange_stream(g.device) if _EX_STREAM_SHARED else torch.cuda.Stream(device=g.device)
                 ex = self._ex_stream
                 ex.wait_stream(torch.cuda.current_stream(g.device))
                 ex.wait_stream(torch.cuda.default_stream(g.device))

@@ -13,6 +13,7 @@ _OFF_TAGS = set(v for v in os.environ.get('TTSC_STREAMS_OFF', '').split(',') if 
 
 
 _TEXT = {}
+_EXCHANGE = {}
 N_RESERVED = 8     # side streams taken together with the text stream at first use (5 period + 3 scale sub-discriminators)
 
 
@@ -28,7 +29,13 @@ def _reserve(dev):
         d = torch.device('cuda', key)
         _TEXT[key] = torch.cuda.Stream(device=d)
         _SIDE[key] = [torch.cuda.Stream(device=d) for _ in range(N_RESERVED)]
+        _EXCHANGE[key] = torch.cuda.Stream(device=d)
     return key
+
+
+def exchange_stream(dev):
+    """the ONE stream the gradient exchanges of a step are prepared and sent from (distributed.ArenaReducer: the three reducers of a Cubegan step share it)"""
+    return _EXCHANGE[_reserve(dev)]
 
 
 def text_stream(dev):
