@@ -131,6 +131,8 @@ __global__ __launch_bounds__(512) void lstm_seq_kernel(LstmArgs a) {
 // hidden update by the H threads of gate i, two barriers.  The input-projection value of the NEXT step is loaded before the
 // current step's chain.  lstm_seq_kernel (one thread per unit, rows streamed from L2 by a single wave at H = 64) took
 // 3.4 us per step and layer at H = 64; this kernel: tools/bench_lstm.py.
+typedef float lstm_v2 __attribute__((ext_vector_type(2)));
+
 template <int HH>
 __global__ __launch_bounds__(4 * HH) void lstm_seq_resident_kernel(LstmArgs a) {
     constexpr int H = HH, H4 = 4 * HH;
@@ -168,24 +170,27 @@ __global__ __launch_bounds__(4 * HH) void lstm_seq_resident_kernel(LstmArgs a) {
         if (s + 1 < len) xnext = xb[(size_t)tpos_of(s + 1) * xstride];
         if (ok) {
             const float4* h4 = reinterpret_cast<const float4*>(hbuf[cur]);
-            float p0 = xcur, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+            // the four interleaved partial sums as two packed pairs: (p0, p1) and (p2, p3) advance with one v_pk_fma_f32 each (per lane the fused
+            // multiply-add of the scalar form: same bits, half the vector instructions)
+            lstm_v2 p01 = {xcur, 0.f}, p23 = {0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < H / 4; ++kb) {
                 const float4 hv = h4[kb];
-                p0 = fmaf(w[4 * kb], hv.x, p0);
-                p1 = fmaf(w[4 * kb + 1], hv.y, p1);
-                p2 = fmaf(w[4 * kb + 2], hv.z, p2);
-                p3 = fmaf(w[4 * kb + 3], hv.w, p3);
+                p01 = __builtin_elementwise_fma((lstm_v2){w[4 * kb], w[4 * kb + 1]}, (lstm_v2){hv.x, hv.y}, p01);
+                p23 = __builtin_elementwise_fma((lstm_v2){w[4 * kb + 2], w[4 * kb + 3]}, (lstm_v2){hv.z, hv.w}, p23);
             }
-            gbuf[r] = (p0 + p1) + (p2 + p3);
+            // every thread applies ITS gate's activation (gate = r / H is uniform per wave): the four gates' transcendental functions run side by side on
+            // four waves instead of in series on the update threads, which then only form c and h.  Same functions of the same values: same bits.
+            const float pre = (p01.x + p01.y) + (p23.x + p23.y);
+            gbuf[r] = (r / H == 2) ? ttsc_tanhf(pre) : ttsc_sigmoidf(pre);
         }
         __syncthreads();
         if (upd) {
             if (ok) {
-                const float ig = ttsc_sigmoidf(gbuf[j]);
-                const float fg = ttsc_sigmoidf(gbuf[H + j]);
-                const float gg = ttsc_tanhf(gbuf[2 * H + j]);
-                const float og = ttsc_sigmoidf(gbuf[3 * H + j]);
+                const float ig = gbuf[j];
+                const float fg = gbuf[H + j];
+                const float gg = gbuf[2 * H + j];
+                const float og = gbuf[3 * H + j];
                 const float cn = fmaf(fg, c, ig * gg);
                 const float hv = og * ttsc_tanhf(cn);
                 c = cn;
@@ -485,10 +490,11 @@ __global__ __launch_bounds__(512) void lstm_seq_split_kernel(LstmSplitArgs s) {
 // suffice).  Summation order = lstm_seq_split_kernel's (k-ordered chain per k-slice, slices added in order), so results are
 // bit-identical to it; what changes is the step time: no 256 KB weight stream and one round trip instead of three per step.
 typedef unsigned long long lstm_u64;
+typedef float lstm_f32x2 __attribute__((ext_vector_type(2)));
 
 template <int KL>
 __global__ __launch_bounds__(512) void lstm_seq_split_res_kernel(LstmSplitArgs s, lstm_u64* ring) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // h[H] | part[KS][4][HU]
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // h[H] | part[KS][4][HU] | act[4][HU]
     const LstmArgs& a = s.f;
     const int H = a.H, H4 = 4 * H, HU = s.HU, KS = s.KS;
     const int tid = threadIdx.x, u = tid % HU, ks = tid / HU;
@@ -496,11 +502,14 @@ __global__ __launch_bounds__(512) void lstm_seq_split_res_kernel(LstmSplitArgs s
     const int j = m * HU + u;
     float* hs = sm;
     float* part = sm + H;
+    float* act = part + KS * 4 * HU;   // [4][HU] activated gates of this step
     lstm_u64* rg = ring + (size_t)pair * 2 * H;
     const bool owner = ks == 0;
     const int len = a.lengths ? a.lengths[b] : a.T;
     float* yb = a.y + (size_t)b * a.T * a.ldy + a.yoff + dir * H;
-    float w[4][KL];
+    // gate pairs (i, f) and (g, o) side by side: one v_pk_fma_f32 advances two of the four k-ordered chains of a thread (each lane of the packed
+    // instruction is the fused multiply-add the scalar form issues: same bits, half the vector instructions of the step's 128)
+    lstm_f32x2 w[2][KL];
     {
         // packed [H/4][4H][4]: row g*H + j, k-block kb holds k = 4*kb .. 4*kb+3
         const float4* w4 = reinterpret_cast<const float4*>(a.whh + (size_t)dir * H * H4) + j;
@@ -509,10 +518,10 @@ __global__ __launch_bounds__(512) void lstm_seq_split_res_kernel(LstmSplitArgs s
 #pragma unroll
             for (int kb = 0; kb < KL / 4; ++kb) {
                 const float4 v = w4[(size_t)(ks * (KL / 4) + kb) * H4 + g * H];
-                w[g][4 * kb] = v.x;
-                w[g][4 * kb + 1] = v.y;
-                w[g][4 * kb + 2] = v.z;
-                w[g][4 * kb + 3] = v.w;
+                w[g >> 1][4 * kb][g & 1] = v.x;
+                w[g >> 1][4 * kb + 1][g & 1] = v.y;
+                w[g >> 1][4 * kb + 2][g & 1] = v.z;
+                w[g >> 1][4 * kb + 3][g & 1] = v.w;
             }
     }
     float c = (owner && a.c_0) ? a.c_0[((size_t)dir * a.B + b) * H + j] : 0.f;
@@ -521,12 +530,12 @@ __global__ __launch_bounds__(512) void lstm_seq_split_res_kernel(LstmSplitArgs s
         for (int t = len; t < a.T; ++t) yb[(size_t)t * a.ldy + j] = 0.f;   // pad_packed_sequence: zeros beyond the length
     for (int st = 0; st < len; ++st) {
         const int tpos = dir == 0 ? st : (len - 1 - st);
-        float xv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (owner) {   // in flight while the other members finish the previous step
-            const float* xr = a.xg + ((size_t)b * a.T + tpos) * ((size_t)a.ndir * H4) + (size_t)dir * H4 + j;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) xv[g] = xr[g * H];
-        }
+        // gate g of the member's units is finished by k-slice row g (ks = 0..3: input-projection value + the KS partial sums in slice order + its
+        // activation) — four rows working side by side instead of row 0 walking all four gates and five transcendental functions in series; row 0 then
+        // only forms c and h.  Per value the same operations in the same order as before: same bits.
+        float xv = 0.f;
+        if (ks < 4)    // in flight while the other members finish the previous step
+            xv = a.xg[((size_t)b * a.T + tpos) * ((size_t)a.ndir * H4) + (size_t)dir * H4 + (size_t)ks * H + j];
         bool fail = false;
         if (st > 0) {
             const lstm_u64* src = rg + (size_t)((st - 1) & 1) * H;
@@ -550,35 +559,34 @@ __global__ __launch_bounds__(512) void lstm_seq_split_res_kernel(LstmSplitArgs s
             for (int i = tid; i < H; i += 512) hs[i] = a.h_0 ? a.h_0[((size_t)dir * a.B + b) * H + i] : 0.f;
         }
         if (__syncthreads_or(fail)) return;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        lstm_f32x2 acc[2] = {{0.f, 0.f}, {0.f, 0.f}};
         {
             const float4* h4 = reinterpret_cast<const float4*>(hs + ks * KL);
 #pragma unroll
             for (int kb = 0; kb < KL / 4; ++kb) {
                 const float4 hv = h4[kb];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float x = acc[g];
-                    x = fmaf(w[g][4 * kb], hv.x, x);
-                    x = fmaf(w[g][4 * kb + 1], hv.y, x);
-                    x = fmaf(w[g][4 * kb + 2], hv.z, x);
-                    x = fmaf(w[g][4 * kb + 3], hv.w, x);
-                    acc[g] = x;
+                for (int gp = 0; gp < 2; ++gp) {
+                    lstm_f32x2 x = acc[gp];
+                    x = __builtin_elementwise_fma(w[gp][4 * kb], (lstm_f32x2){hv.x, hv.x}, x);
+                    x = __builtin_elementwise_fma(w[gp][4 * kb + 1], (lstm_f32x2){hv.y, hv.y}, x);
+                    x = __builtin_elementwise_fma(w[gp][4 * kb + 2], (lstm_f32x2){hv.z, hv.z}, x);
+                    x = __builtin_elementwise_fma(w[gp][4 * kb + 3], (lstm_f32x2){hv.w, hv.w}, x);
+                    acc[gp] = x;
                 }
             }
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) part[(ks * 4 + g) * HU + u] = acc[g];
+        for (int g = 0; g < 4; ++g) part[(ks * 4 + g) * HU + u] = acc[g >> 1][g & 1];
+        __syncthreads();
+        if (ks < 4) {
+            float gsum = xv;
+            for (int q = 0; q < KS; ++q) gsum += part[(q * 4 + ks) * HU + u];
+            act[ks * HU + u] = ks == 2 ? ttsc_tanhf(gsum) : ttsc_sigmoidf(gsum);
+        }
         __syncthreads();
         if (owner) {
-            float gs[4] = {xv[0], xv[1], xv[2], xv[3]};
-            for (int q = 0; q < KS; ++q)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) gs[g] += part[(q * 4 + g) * HU + u];
-            const float ig = ttsc_sigmoidf(gs[0]);
-            const float fg = ttsc_sigmoidf(gs[1]);
-            const float gg = ttsc_tanhf(gs[2]);
-            const float og = ttsc_sigmoidf(gs[3]);
+            const float ig = act[u], fg = act[HU + u], gg = act[2 * HU + u], og = act[3 * HU + u];
             c = fmaf(fg, c, ig * gg);
             hlast = og * ttsc_tanhf(c);
             __hip_atomic_store(rg + (size_t)(st & 1) * H + j, ((lstm_u64)(unsigned)(st + 1) << 32) | (lstm_u64)__float_as_uint(hlast), __ATOMIC_RELAXED,
@@ -1217,7 +1225,7 @@ static int lstm_forward_impl(const float* xg_dev, const float* whh_packed_dev, f
                 sa.G = Gm;
                 sa.HU = H / Gm;
                 sa.KS = 512 / sa.HU;
-                const size_t lds = (size_t)NB * ((size_t)H + (size_t)sa.KS * 4 * sa.HU) * sizeof(float);
+                const size_t lds = ((size_t)NB * ((size_t)H + (size_t)sa.KS * 4 * sa.HU) + (NB == 1 ? (size_t)4 * sa.HU : 0)) * sizeof(float);
                 for (int p0 = 0; p0 < groups; p0 += cap) {
                     sa.p0 = p0;
                     const int n = groups - p0 < cap ? groups - p0 : cap;
