@@ -628,7 +628,7 @@ __device__ __forceinline__ void lstm_pkfma_hi(lstm_f2& acc, const lstm_f2& w, co
 template <int KL, int NB>
 __global__ __launch_bounds__(512) void lstm_seq_split_res_nb_kernel(LstmSplitArgs s, lstm_u64* ring) {
     static_assert(NB == 2 || NB == 4 || NB == 8, "utterances per member group");
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // h[H][NB] (utterance-interleaved) | part[NB][KS][4][HU]
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // h[H][NB] (utterance-interleaved) | part[NB][KS][4][HU] | act[NB][4][HU]
     const LstmArgs& a = s.f;
     const int H = a.H, H4 = 4 * H, HU = s.HU, KS = s.KS;
     const int tid = threadIdx.x, u = tid % HU, ks = tid / HU;
@@ -636,6 +636,10 @@ __global__ __launch_bounds__(512) void lstm_seq_split_res_nb_kernel(LstmSplitArg
     const int j = m * HU + u;
     float* hs = sm;
     float* part = sm + NB * H;
+    float* act = part + (size_t)NB * KS * 4 * HU;   // [NB][4][HU] activated gates of this step
+    const int NG = KS / NB < 4 ? KS / NB : 4, GPR = 4 / NG;          // gate sets, gates per row
+    const int aq = ks % NB, gset = ks / NB;
+    const bool actor = gset < NG && b0 + aq < a.B;
     int len[NB], maxlen = 0;
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
@@ -645,9 +649,12 @@ __global__ __launch_bounds__(512) void lstm_seq_split_res_nb_kernel(LstmSplitArg
     // k-slice thread row `ks` owns utterance b0 + ks (KS >= 8 >= NB)
     const int ob = b0 + ks;
     const bool owner = ks < NB && ob < a.B;
-    int olen = 0;
+    int olen = 0, alen = 0;
 #pragma unroll
-    for (int q = 0; q < NB; ++q) olen = (q == ks) ? len[q] : olen;
+    for (int q = 0; q < NB; ++q) {
+        olen = (q == ks) ? len[q] : olen;
+        alen = (q == aq) ? len[q] : alen;
+    }
     lstm_u64* org = ring + (size_t)(ob * a.ndir + dir) * 2 * H;
     float* yb = a.y + (size_t)ob * a.T * a.ldy + a.yoff + dir * H;
     lstm_f2 w[4][KL / 2];
@@ -669,11 +676,18 @@ __global__ __launch_bounds__(512) void lstm_seq_split_res_nb_kernel(LstmSplitArg
     for (int st = 0; st < maxlen; ++st) {
         const bool mine = owner && st < olen;
         const int tpos = dir == 0 ? st : (olen - 1 - st);
+        // (utterance, gate) items of the step's finish — input-projection value + KS partial sums in slice order + activation — spread over the k-slice
+        // rows: row ks takes utterance ks % NB and the gates gset, gset + NG, ... (gset = ks / NB, NG = min(4, KS / NB) gate sets), so that with NB = 2 every
+        // gate of both utterances has a row of its own and with NB = 4 every row takes two gates, instead of NB rows walking four gates and five
+        // transcendental functions each while the others wait.  The owner rows then only form c and h.  Per value the same operations in the same order.
+        const bool acting = actor && st < alen;
         float xv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (mine) {
-            const float* xr = a.xg + ((size_t)ob * a.T + tpos) * ((size_t)a.ndir * H4) + (size_t)dir * H4 + j;
+        if (acting) {
+            const int atpos = dir == 0 ? st : (alen - 1 - st);
+            const float* xr = a.xg + ((size_t)(b0 + aq) * a.T + atpos) * ((size_t)a.ndir * H4) + (size_t)dir * H4 + j;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) xv[g] = xr[g * H];
+            for (int i = 0; i < 4; ++i)
+                if (i < GPR) xv[i] = xr[(gset + i * NG) * H];
         }
         bool fail = false;
         for (int e = tid; e < NB * H; e += 512) {
@@ -734,16 +748,21 @@ __global__ __launch_bounds__(512) void lstm_seq_split_res_nb_kernel(LstmSplitArg
                 part[(((2 * p + 1) * KS + ks) * 4 + g) * HU + u] = acc[p][g].y;
             }
         __syncthreads();
-        if (mine) {
-            float gs[4] = {xv[0], xv[1], xv[2], xv[3]};
-            const float* pq = part + (size_t)ks * KS * 4 * HU;
-            for (int q = 0; q < KS; ++q)
+        if (acting) {
+            const float* pq = part + (size_t)aq * KS * 4 * HU;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) gs[g] += pq[(q * 4 + g) * HU + u];
-            const float ig = ttsc_sigmoidf(gs[0]);
-            const float fg = ttsc_sigmoidf(gs[1]);
-            const float gg = ttsc_tanhf(gs[2]);
-            const float og = ttsc_sigmoidf(gs[3]);
+            for (int i = 0; i < 4; ++i)
+                if (i < GPR) {
+                    const int g = gset + i * NG;
+                    float gsum = xv[i];
+                    for (int q = 0; q < KS; ++q) gsum += pq[(q * 4 + g) * HU + u];
+                    act[(aq * 4 + g) * HU + u] = g == 2 ? ttsc_tanhf(gsum) : ttsc_sigmoidf(gsum);
+                }
+        }
+        __syncthreads();
+        if (mine) {
+            const float* aw = act + (size_t)ks * 4 * HU + u;
+            const float ig = aw[0], fg = aw[HU], gg = aw[2 * HU], og = aw[3 * HU];
             c = fmaf(fg, c, ig * gg);
             hlast = og * ttsc_tanhf(c);
             __hip_atomic_store(org + (size_t)(st & 1) * H + j, ((lstm_u64)(unsigned)(st + 1) << 32) | (lstm_u64)__float_as_uint(hlast), __ATOMIC_RELAXED,
@@ -1225,7 +1244,7 @@ static int lstm_forward_impl(const float* xg_dev, const float* whh_packed_dev, f
                 sa.G = Gm;
                 sa.HU = H / Gm;
                 sa.KS = 512 / sa.HU;
-                const size_t lds = ((size_t)NB * ((size_t)H + (size_t)sa.KS * 4 * sa.HU) + (NB == 1 ? (size_t)4 * sa.HU : 0)) * sizeof(float);
+                const size_t lds = ((size_t)NB * ((size_t)H + (size_t)sa.KS * 4 * sa.HU) + (size_t)NB * 4 * sa.HU) * sizeof(float);
                 for (int p0 = 0; p0 < groups; p0 += cap) {
                     sa.p0 = p0;
                     const int n = groups - p0 < cap ? groups - p0 : cap;
