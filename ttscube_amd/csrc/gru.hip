@@ -298,6 +298,7 @@ __global__ __launch_bounds__(512) void gru_bwd_split_kernel(GruSplitArgs s) {
 // member and step from L2 and pay counter + data round trips: 8 + 12 us per time step at H = 512, i.e. 0.48 s for the vocoder's 24 000-step
 // training sequences.
 typedef unsigned long long gru_u64;
+typedef float gru_f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ bool gru_poll(const gru_u64* src, unsigned tag, unsigned* abort_word, float* out) {
     gru_u64 gq;
@@ -318,7 +319,7 @@ __device__ __forceinline__ bool gru_poll(const gru_u64* src, unsigned tag, unsig
 
 template <int KL>   // inputs per k-slice = H / KS
 __global__ __launch_bounds__(512) void gru_seq_split_res_kernel(GruSplitArgs s, gru_u64* ring) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // h[H] | part[KS][3][HU]
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // h[H] | part[KS][3][HU] | act[3][HU]
     const GruArgs& a = s.f;
     const int H = a.H, H3 = 3 * H, HU = s.HU, KS = s.KS;
     const int tid = threadIdx.x, u = tid % HU, ks = tid / HU;
@@ -326,39 +327,40 @@ __global__ __launch_bounds__(512) void gru_seq_split_res_kernel(GruSplitArgs s, 
     const int j = m * HU + u;
     float* hs = sm;
     float* part = sm + H;
+    float* act = part + KS * 3 * HU;   // [3][HU]: r, z, W_hn h + b_hn of this step
     gru_u64* rg = ring + (size_t)b * 2 * H;
     const bool owner = ks == 0;
-    float w[3][KL];
+    // gates r and z side by side: one v_pk_fma_f32 advances both k-ordered chains (per lane the fused multiply-add of the scalar form: same bits)
+    gru_f32x2 wrz[KL];
+    float wn[KL];
     {
         // packed [H/4][3H][4]: row g*H + j, k-block kb holds k = 4*kb .. 4*kb+3
         const float4* w4 = reinterpret_cast<const float4*>(a.whh) + j;
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-            for (int kb = 0; kb < KL / 4; ++kb) {
-                const float4 v = w4[(size_t)(ks * (KL / 4) + kb) * H3 + g * H];
-                w[g][4 * kb] = v.x;
-                w[g][4 * kb + 1] = v.y;
-                w[g][4 * kb + 2] = v.z;
-                w[g][4 * kb + 3] = v.w;
-            }
+        for (int kb = 0; kb < KL / 4; ++kb) {
+            const float4 vr = w4[(size_t)(ks * (KL / 4) + kb) * H3];
+            const float4 vz = w4[(size_t)(ks * (KL / 4) + kb) * H3 + H];
+            const float4 vn = w4[(size_t)(ks * (KL / 4) + kb) * H3 + 2 * H];
+            wrz[4 * kb] = gru_f32x2{vr.x, vz.x};
+            wrz[4 * kb + 1] = gru_f32x2{vr.y, vz.y};
+            wrz[4 * kb + 2] = gru_f32x2{vr.z, vz.z};
+            wrz[4 * kb + 3] = gru_f32x2{vr.w, vz.w};
+            wn[4 * kb] = vn.x;
+            wn[4 * kb + 1] = vn.y;
+            wn[4 * kb + 2] = vn.z;
+            wn[4 * kb + 3] = vn.w;
+        }
     }
-    float br = 0.f, bz = 0.f, bn = 0.f;
-    if (owner) {
-        br = a.bhh[j];
-        bz = a.bhh[H + j];
-        bn = a.bhh[2 * H + j];
-    }
+    // k-slice row g (ks = 0, 1, 2) finishes gate g of the member's units: bias + the KS partial sums in slice order (+ the sigmoid for r and z) — three rows side
+    // by side instead of row 0 walking all three; row 0 then forms the candidate and h.  Per value the same operations in the same order: same bits.
+    float bg = 0.f;
+    if (ks < 3) bg = a.bhh[ks * H + j];
     const float* xb = a.xg + (size_t)b * a.T * H3 + j;
     float* yb = a.y + (size_t)b * a.T * H;
     for (int t = 0; t < a.T; ++t) {
-        float xr = 0.f, xz = 0.f, xn = 0.f;
-        if (owner) {   // issued before the wait: in flight while the other members finish step t-1
-            const float* xp = xb + (size_t)t * H3;
-            xr = xp[0];
-            xz = xp[H];
-            xn = xp[2 * H];
-        }
+        float xg = 0.f, xg_n = 0.f;   // issued before the wait: in flight while the other members finish step t-1
+        if (ks < 2) xg = xb[(size_t)t * H3 + ks * H];
+        if (owner) xg_n = xb[(size_t)t * H3 + 2 * H];
         bool fail = false;
         if (t > 0) {
             const gru_u64* src = rg + (size_t)((t - 1) & 1) * H;
@@ -368,37 +370,36 @@ __global__ __launch_bounds__(512) void gru_seq_split_res_kernel(GruSplitArgs s, 
         }
         if (__syncthreads_or(fail)) return;
         const float hprev = owner ? hs[j] : 0.f;   // (hs is rewritten by the next step's poll while the owners are still combining)
-        float acc[3] = {0.f, 0.f, 0.f};
+        gru_f32x2 arz = {0.f, 0.f};
+        float an = 0.f;
         {
             const float4* h4 = reinterpret_cast<const float4*>(hs + ks * KL);
 #pragma unroll
             for (int kb = 0; kb < KL / 4; ++kb) {
                 const float4 hv = h4[kb];
-#pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    float x = acc[g];
-                    x = fmaf(w[g][4 * kb], hv.x, x);
-                    x = fmaf(w[g][4 * kb + 1], hv.y, x);
-                    x = fmaf(w[g][4 * kb + 2], hv.z, x);
-                    x = fmaf(w[g][4 * kb + 3], hv.w, x);
-                    acc[g] = x;
-                }
+                arz = __builtin_elementwise_fma(wrz[4 * kb], (gru_f32x2){hv.x, hv.x}, arz);
+                arz = __builtin_elementwise_fma(wrz[4 * kb + 1], (gru_f32x2){hv.y, hv.y}, arz);
+                arz = __builtin_elementwise_fma(wrz[4 * kb + 2], (gru_f32x2){hv.z, hv.z}, arz);
+                arz = __builtin_elementwise_fma(wrz[4 * kb + 3], (gru_f32x2){hv.w, hv.w}, arz);
+                an = fmaf(wn[4 * kb], hv.x, an);
+                an = fmaf(wn[4 * kb + 1], hv.y, an);
+                an = fmaf(wn[4 * kb + 2], hv.z, an);
+                an = fmaf(wn[4 * kb + 3], hv.w, an);
             }
         }
-        part[(ks * 3 + 0) * HU + u] = acc[0];
-        part[(ks * 3 + 1) * HU + u] = acc[1];
-        part[(ks * 3 + 2) * HU + u] = acc[2];
+        part[(ks * 3 + 0) * HU + u] = arz.x;
+        part[(ks * 3 + 1) * HU + u] = arz.y;
+        part[(ks * 3 + 2) * HU + u] = an;
+        __syncthreads();
+        if (ks < 3) {
+            float hg = bg;
+            for (int q = 0; q < KS; ++q) hg += part[(q * 3 + ks) * HU + u];
+            act[ks * HU + u] = ks == 2 ? hg : ttsc_sigmoidf(xg + hg);
+        }
         __syncthreads();
         if (owner) {
-            float hr = br, hz = bz, hl = bn;
-            for (int q = 0; q < KS; ++q) {
-                hr += part[(q * 3 + 0) * HU + u];
-                hz += part[(q * 3 + 1) * HU + u];
-                hl += part[(q * 3 + 2) * HU + u];
-            }
-            const float r = ttsc_sigmoidf(xr + hr);
-            const float z = ttsc_sigmoidf(xz + hz);
-            const float n = ttsc_tanhf(fmaf(r, hl, xn));
+            const float r = act[u], z = act[HU + u], hl = act[2 * HU + u];
+            const float n = ttsc_tanhf(fmaf(r, hl, xg_n));
             const float hv = fmaf(z, hprev - n, n);
             __hip_atomic_store(rg + (size_t)(t & 1) * H + j, ((gru_u64)(unsigned)(t + 1) << 32) | (gru_u64)__float_as_uint(hv), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -608,7 +609,7 @@ extern "C" int ttsc_gru_seq_forward(const float* xg_dev, const float* whh_packed
         sa.G = Gr;
         sa.HU = H / Gr;
         sa.KS = 512 / sa.HU;
-        const size_t lds = ((size_t)H + (size_t)sa.KS * 3 * sa.HU) * sizeof(float);
+        const size_t lds = ((size_t)H + (size_t)sa.KS * 3 * sa.HU + (size_t)3 * sa.HU) * sizeof(float);
         hipLaunchKernelGGL(gru_seq_split_res_kernel<32>, dim3((unsigned)Gr, (unsigned)B), dim3(512), lds, (hipStream_t)stream, sa, reinterpret_cast<gru_u64*>(ar->buf));
         return gru_check_launch("gru_seq_split_res_kernel");
     }
