@@ -41,6 +41,66 @@ def measured_traffic(precision, B, T):
     return None
 
 
+def live_traffic(precision, B, T, timeout_s=150):
+    """HBM bytes of ONE forward measured NOW: two child runs of this script (`--steps 1 --warmup 0`: 3 identical forwards, TTSC_HIFIGAN_CALIBRATE=0) under
+    `rocprofv3 --pmc FETCH_SIZE`, `--pmc WRITE_SIZE` and `--pmc SQ_INSTS_MFMA` (separate passes, --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes), counters summed
+    over all ttsc:: kernels, divided by 3, FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads: an upper bound), WRITE_SIZE checked against
+    the launch that writes exactly the waveform.  The recipe of tools/profile_r06.sh + tools/hbm_from_pmc.py, run after every timed region of this process.
+    Returns (bytes or None, detail): any failure (no rocprofv3, a pass that does not finish in `timeout_s`, an unreadable database) returns None and the caller
+    falls back to the committed summary."""
+    import glob
+    import shutil
+    import signal
+    import sqlite3
+    import subprocess
+    import tempfile
+    rp = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(rp):
+        return None, 'rocprofv3 not found'
+    tmp = tempfile.mkdtemp(prefix='ttsc_pmc_', dir='/tmp')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(TMPDIR='/tmp', TTSC_HIFIGAN_CALIBRATE='0')
+    tot, post = {}, {}
+    try:
+        for cn in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_INSTS_MFMA'):
+            d = os.path.join(tmp, cn)
+            cmd = [rp, '--pmc', cn, '--kernel-trace', '-d', d, '-o', 'p', '--', sys.executable, os.path.abspath(__file__), '--no-extra', '--no-cpu-baseline',
+                   '--steps', '1', '--warmup', '0', '--batch', str(B), '--frames', str(T)]
+            pr = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                pr.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(pr.pid, signal.SIGKILL)      # (exactly the process group started above)
+                pr.wait()
+                return None, '%s pass did not finish in %d s' % (cn, timeout_s)
+            dbs = glob.glob(os.path.join(d, '**', '*_results.db'), recursive=True)
+            if pr.returncode != 0 or not dbs:
+                return None, '%s pass failed (rc %s)' % (cn, pr.returncode)
+            c = sqlite3.connect(dbs[0])
+            rows = c.execute('select kernel_name, sum(value), count(*) from counters_collection where counter_name = ? group by kernel_name', (cn,)).fetchall()
+            c.close()
+            mine = [(k, v, n) for k, v, n in rows if 'ttsc::' in k and 'mfma_sustained_kernel' not in k]   # (the register-only probe loop is not part of a forward)
+            if not mine:
+                return None, '%s pass recorded no ttsc:: kernel' % cn
+            tot[cn] = sum(v for _, v, _ in mine) * (1.0 if cn == 'SQ_INSTS_MFMA' else 1024.0) / 3.0           # byte counters in KiB; 3 forwards in the child run
+            if cn == 'WRITE_SIZE':
+                pk = [(v, n) for k, v, n in mine if 'rbchain_f16x3_kernel' in k and k.split('>')[0].rstrip().endswith('true, true')]
+                if pk:
+                    post = {'per_launch': pk[0][0] * 1024.0 / pk[0][1]}
+    except Exception as e:
+        return None, 'live PMC passes failed: %s' % str(e)[:120]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    Lout = T
+    for u, k in ((5, 16), (3, 16), (4, 4), (4, 4)):
+        Lout = (Lout - 1) * u - 2 * ((k - u) // 2) + k
+    want = B * Lout * 4
+    detail = {'fetch_size_raw_bytes': tot['FETCH_SIZE'], 'write_size_raw_bytes': tot['WRITE_SIZE'], 'sq_insts_mfma_per_forward': tot['SQ_INSTS_MFMA'],
+              'write_calibration_ratio': (post['per_launch'] / want) if post else None,
+              'recipe': 'bytes = 2 x FETCH_SIZE + WRITE_SIZE over all ttsc:: kernels of 3 forwards / 3 (KiB counters; gfx950: FETCH_SIZE reports half the bytes of wide reads)'}
+    return 2.0 * tot['FETCH_SIZE'] + tot['WRITE_SIZE'], detail
+
+
 PMC_CSV = os.path.join(ROOT, 'profiles', 'r06_bench_pmc.csv')            # per-kernel counter sums of the same command (3 forwards)
 UNFUSED_BYTES_PER_SAMPLE = (5.33 + 8 + 16 + 32) * 51 * 4                 # SURVEY.md §8d "unfused layer-boundary" model: 12.5 KB per output sample
 
@@ -625,6 +685,7 @@ def main():
     ap.add_argument('--frames', type=int, default=800, help='mel frames per utterance (800 = 8 s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the secondary legs (fp32, B=1, WaveRNN)')
+    ap.add_argument('--no-live-traffic', action='store_true', help='keep roofline.traffic from the committed PMC summary instead of measuring it with two rocprofv3 --pmc child passes (N = 1, default run only)')
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, torch.distributed.run, rendezvous on
@@ -781,6 +842,21 @@ def main():
                     g.set_precision('f16x3')
                 except Exception as e:
                     res['extra']['exact_fp32_same_workload'] = {'error': str(e)[:200]}
+        if world == 1 and not args.no_extra and not args.no_live_traffic and precision == 'f16x3':
+            # roofline.traffic measured NOW (after every timed region of this process): two rocprofv3 --pmc child passes of this workload
+            lt, detail = live_traffic(precision, B, T)
+            if lt is not None:
+                res['roofline']['traffic_committed_summary'] = res['roofline']['traffic']
+                res['roofline']['traffic'] = lt
+                res['roofline']['traffic_unit'] = 'HBM bytes per step (rocprofv3 PMC, measured in this run)'
+                res['roofline']['traffic_source'] = ('measured in this run: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` child passes of `bench.py --steps 1 --warmup 0` '
+                                                     'after the timed regions (bench.py::live_traffic)')
+                res['roofline']['traffic_detail'] = detail
+                res['roofline']['traffic_ratio_vs_unfused'] = lt / (UNFUSED_BYTES_PER_SAMPLE * B * Lout)
+                res['roofline']['mfma_insts_per_forward']['issued_pmc'] = detail['sq_insts_mfma_per_forward']
+                res['roofline']['mfma_insts_per_forward']['source'] = 'SQ_INSTS_MFMA, rocprofv3 --pmc child pass of this run (bench.py::live_traffic)'
+            else:
+                res['roofline']['traffic_live_error'] = detail
         if world == 1 and not args.no_cpu_baseline:   # reported baseline: rank 0 at N=1 only
             res['cpu_baseline'] = cpu_baseline(h, sd, mel)
         else:
