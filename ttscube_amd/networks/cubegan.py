@@ -15,6 +15,7 @@ from ..hifigan.env import AttrDict
 from ..hifigan.models import Generator
 from .modules import Languasito2
 
+_PIPE_TXT_PRIORITY = int(os.environ.get('TTSC_PIPE_TXT_PRIORITY', '-1'))   # inference_pipelined's text stream: -1 = high priority (own hardware-queue pool), 0 = reserved pool
 _AUX = True if os.environ.get('TTSC_DUR_DEVICE', '1') == '0' else 'device'   # (measurement switch: 0 = durations read back inside Languasito2.inference)
 
 
@@ -83,7 +84,13 @@ class Cubegan(nn.Module):
         dev = self.get_device()
         # the recurrences' stream gets the higher priority: their workgroups are few and must all be resident to make progress, the generator's are
         # thousands and short — the dispatcher should hand a freed CU to the recurrence first
-        s_txt, s_gen = torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev)
+        if _PIPE_TXT_PRIORITY == 0:
+            # both pipeline streams out of the package's reserved pool (hifigan/streams.py::_reserve): no stream of another priority, i.e. no second
+            # hardware-queue pool in the process
+            from ..hifigan.streams import _side_streams, text_stream
+            s_txt, s_gen = text_stream(dev), _side_streams(dev, 3)[2]     # (side streams 0 / 1 are the generator's branch streams)
+        else:
+            s_txt, s_gen = torch.cuda.Stream(device=dev, priority=_PIPE_TXT_PRIORITY), torch.cuda.Stream(device=dev)
         main = torch.cuda.current_stream(dev)
         s_txt.wait_stream(main)
         s_gen.wait_stream(main)
