@@ -311,6 +311,17 @@ static bool branch_streams_for(const ttsc_hifigan* g, int32_t B, int ch, int64_t
     return ragged || wgs < 2 * 512;
 }
 
+// Branch streams for a stage whose ResBlocks are ONE chain launch each?  Only where a launch leaves most of the chip idle (a sentence, a few short utterances:
+// one 3 s utterance is 51 workgroups at 64 channels): blocks 1 and 2 then run all pairs but the last into temporaries (the R / XT buffers, unused by a chained
+// stage) BESIDE block 0, and only their last pair — the launch that adds into S — waits for the block before.  A cut chain gives the bits of the whole one
+// (tools/bench_chain_split.py), the sums enter S in block order: outputs identical bit for bit.  Large batches keep the single launches (the cut costs MFMAs
+// at 32 channels: 4.96 -> 5.96 ms for the K = 11 block at config[1]).
+static bool chain_branch_for(const ttsc_hifigan* g, int32_t B, int ch, int64_t L) {
+    if (g->branch_streams <= 0) return false;
+    if (g->branch_streams >= 2) return true;
+    return (int64_t)B * ceil_div(L, (int64_t)(ch == 32 ? 900 : 400)) < 256;
+}
+
 static int chain_first_pairs(const ttsc_hifigan* g, int ch, int k, int nd, int32_t B, int64_t L) {
     if (!g->split_chain || ch != 64 || nd != 3 || (k != 7 && k != 11)) return 0;
     if (g->split_chain < 2 && (int64_t)B * ceil_div(L, (int64_t)400) < 1024) return 0;   // < 4 rounds of workgroups over the 256 CUs
@@ -737,8 +748,9 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
         const int32_t* ln = lens[i + 1];
         // ---- branch schedule of this stage (see ttsc_hifigan::branch_streams): block j on stream bst[j] with temporaries of its own ----
         const size_t n_i = (size_t)round_up((int64_t)B * ch * L, 64);
-        bool branch = !calib && !fused_stage && !chain_stage && c.resblock == 1 && c.num_kernels >= 2 && c.num_kernels <= 3 && 3 * n_i <= be &&
-                      branch_streams_for(g, B, ch, L, ln != nullptr && frames != nullptr);
+        const bool chain_branch = chain_stage && chain_branch_for(g, B, ch, L);
+        bool branch = !calib && !fused_stage && c.resblock == 1 && c.num_kernels >= 2 && c.num_kernels <= 3 &&
+                      (chain_stage ? chain_branch : (3 * n_i <= be && branch_streams_for(g, B, ch, L, ln != nullptr && frames != nullptr)));
         void* bst[TTSC_HIFIGAN_MAX_RB];
         float *bXT[TTSC_HIFIGAN_MAX_RB], *bR[TTSC_HIFIGAN_MAX_RB];
         for (int j = 0; j < c.num_kernels; ++j) {
@@ -749,13 +761,14 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
         if (branch) {
             if ((rc = g->ensure_side_streams())) return rc;
             // blocks 1, 2: two temporaries each in the unused tails of the X and XT buffers (a stage-1 / stage-2 tensor is at most a quarter of a buffer)
+            // (a chained stage needs one temporary per block, for the cut chains of blocks 1 and 2: the R and XT buffers, which it does not use otherwise)
             bst[1] = g->side[0];
-            bXT[1] = X + n_i;
-            bR[1] = X + 2 * n_i;
+            bXT[1] = chain_stage ? nullptr : X + n_i;
+            bR[1] = chain_stage ? R : X + 2 * n_i;
             if (c.num_kernels > 2) {
                 bst[2] = g->side[1];
-                bXT[2] = XT + n_i;
-                bR[2] = XT + 2 * n_i;
+                bXT[2] = chain_stage ? nullptr : XT + n_i;
+                bR[2] = chain_stage ? XT : XT + 2 * n_i;
             }
             TTSC_HIP_CHECK(hipEventRecord(g->ev_fork, (hipStream_t)stream));   // the stage input (upsampler) is complete
             for (int j = 1; j < c.num_kernels; ++j) TTSC_HIP_CHECK(hipStreamWaitEvent((hipStream_t)bst[j], g->ev_fork, 0));
@@ -784,9 +797,24 @@ static int hifigan_run(ttsc_hifigan* g, const float* mel, int32_t B, int64_t T, 
                     // the LAST block of the LAST stage: the block sum meets conv_post + tanh in the epilogue of this launch — S is read, never
                     // written, and the waveform is the only thing that leaves (one launch and two passes over the widest tensor less)
                     ttsc_conv1d_epilogue epost{inv_nk, 0.01f, 1.f, TTSC_ACT_TANH, 0};
+                    if (branch && j > 0) {
+                        // branch schedule: all pairs but the last beside the other blocks (-> this block's temporary), then — on the caller's stream, behind the
+                        // block before — the last pair with conv_post in its epilogue
+                        if (nd >= 2 && ttsc_rbchain_supported(c1, c2, nd - 1) && ttsc_rbchain_post_supported(c1 + nd - 1, c2 + nd - 1, 1, layer("conv_post")) &&
+                            ((uintptr_t)bR[j] % 16 == 0)) {
+                            rc = ttsc_rbchain_forward(c1, c2, nd - 1, X, B, L, bR[j], 0, ln, g->chain_shape, bst[j]);
+                            if (rc) return rc;
+                            TTSC_HIP_CHECK(hipEventRecord(g->ev_acc[j], (hipStream_t)bst[j]));
+                            TTSC_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, g->ev_acc[j - 1], 0));
+                            TTSC_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, g->ev_acc[j], 0));
+                            return ttsc_rbchain_post_forward(c1 + nd - 1, c2 + nd - 1, 1, bR[j], B, L, S, layer("conv_post"), &epost, wav, ln, stream);
+                        }
+                        TTSC_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, g->ev_acc[j - 1], 0));   // (the blocks before added into S on their own streams)
+                    }
                     return ttsc_rbchain_post_forward(c1, c2, nd, X, B, L, j > 0 ? S : nullptr, layer("conv_post"), &epost, wav, ln, stream);
                 }
-                const int nf = chain_first_pairs(g, ch, c.resblock_kernel_sizes[j], nd, B, L);
+                int nf = chain_first_pairs(g, ch, c.resblock_kernel_sizes[j], nd, B, L);
+                if (branch && chain_stage) nf = (j > 0 && nd >= 2) ? nd - 1 : 0;   // (block 0 whole — R / XT belong to blocks 1 / 2; blocks 1, 2: only the last pair waits)
                 if (nf > 0 && ttsc_rbchain_supported(c1, c2, nf) && ttsc_rbchain_supported(c1 + nf, c2 + nf, nd - nf)) {
                     rc = ttsc_rbchain_forward(c1, c2, nf, X, B, L, bR[j], 0, ln, g->chain_shape, bst[j]);
                     if (rc) return rc;
