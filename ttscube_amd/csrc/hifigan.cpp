@@ -319,7 +319,8 @@ static bool branch_streams_for(const ttsc_hifigan* g, int32_t B, int ch, int64_t
 static bool chain_branch_for(const ttsc_hifigan* g, int32_t B, int ch, int64_t L) {
     if (g->branch_streams <= 0) return false;
     if (g->branch_streams >= 2) return true;
-    return (int64_t)B * ceil_div(L, (int64_t)(ch == 32 ? 900 : 400)) < 256;
+    static const int tiles = getenv("TTSC_CHAIN_BRANCH_TILES") ? atoi(getenv("TTSC_CHAIN_BRANCH_TILES")) : 128;   // (measurement switch; tools/probes/gen_small_batches.py: the schedule pays for ONE utterance — 1.08 -> 0.92-0.99 ms at 3 s —, is a wash from two on)
+    return (int64_t)B * ceil_div(L, (int64_t)(ch == 32 ? 900 : 400)) < tiles;
 }
 
 static int chain_first_pairs(const ttsc_hifigan* g, int ch, int k, int nd, int32_t B, int64_t L) {
