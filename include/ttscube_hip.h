@@ -599,6 +599,12 @@ int ttsc_align_durations(const float* logits_dev, const int32_t* len_dev, int32_
                          int32_t* f2p_dev, int32_t* flen_dev, int32_t Fcap, void* stream);
 int ttsc_expand_rows(const float* x_dev, const int32_t* f2p_dev, const int32_t* flen_dev, int32_t B, int32_t N, int32_t C, int32_t Fcap,
                      int32_t stride, int32_t F, float* out_dev, void* stream);
+/* Input of Languasito2's conditioning recurrence in one launch (cube/networks/modules.py:962-994: vuv = round(p[..., 1]), pitch = p[..., 0] * max_pitch * vuv,
+ * cat[expand(g), pitch / max_pitch]): out [B,F,Cp] = rows of g [B,N,C] gathered through f2p (ttsc_expand_rows' rule at stride 1), column C = pitch * (1 / max_pitch),
+ * columns C + 1 .. Cp - 1 zero (Cp = C + 1 rounded up to the split GEMM's multiple of 4); pitch [B,F] is written too.  pitch_out_dev [B,F,2] = the pitch head's
+ * sigmoid outputs. */
+int ttsc_cond_input(const float* g_dev, const int32_t* f2p_dev, const int32_t* flen_dev, const float* pitch_out_dev, float max_pitch, int32_t B, int32_t N,
+                    int32_t C, int32_t Cp, int32_t Fcap, int32_t F, float* pitch_dev, float* out_dev, void* stream);
 
 /* STFT-magnitude / mel-spectrogram helpers around ttsc_linear_forward (the DFT and the mel projection are GEMMs):
  * hifigan.meldataset.mel_spectrogram [EXTERNAL; cube/networks/cubegan.py:137-138,247-248 — the 45 x mel-L1 loss of the GAN step,

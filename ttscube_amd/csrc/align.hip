@@ -80,9 +80,51 @@ __global__ __launch_bounds__(256) void expand_rows_kernel(const float* __restric
     }
 }
 
+// Input of Languasito2's conditioning recurrence in ONE launch (modules.py:962-994 of the reference: vuv = round(p_vuv), pitch = p * max_pitch * vuv,
+// g = cat[expand(g_phoneme), pitch / max_pitch]): out[b, f, :C] = the gathered phoneme row (expand_rows_kernel's rule at stride 1), out[b, f, C] = pitch *
+// (1 / max_pitch) — the product form torch's division by a host scalar takes on the device —, out[b, f, C + 1 .. Cp) = 0 (the split GEMM's K % 4 padding);
+// pitch[b, f] is written beside it (X['y_pitch']).  The reference's graph is nine elementwise launches here, ~9 us each on the critical path of a sentence.
+__global__ __launch_bounds__(256) void cond_input_kernel(const float* __restrict__ x, const int* __restrict__ f2p, const int* __restrict__ flen,
+                                                         const float* __restrict__ op, float max_pitch, int N, int C, int Cp, int Fcap, int F,
+                                                         float* __restrict__ pitch, float* __restrict__ out) {
+    const int f = blockIdx.x, b = blockIdx.y;
+    const int nf = flen[b];
+    const int row = f < nf ? f2p[(size_t)b * Fcap + f] : (nf == 0 ? 0 : f2p[(size_t)b * Fcap + (nf - 1)]);
+    const float* src = x + ((size_t)b * N + row) * C;
+    float* dst = out + ((size_t)b * F + f) * Cp;
+    if ((C & 3) == 0) {
+        for (int i = threadIdx.x; i < (C >> 2); i += blockDim.x) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+    } else {
+        for (int i = threadIdx.x; i < C; i += blockDim.x) dst[i] = src[i];
+    }
+    if (threadIdx.x == 0) {
+        const float* o = op + ((size_t)b * F + f) * 2;
+        const float vuv = rintf(o[1]);                    // torch.round: half to even
+        const float p = (o[0] * max_pitch) * vuv;
+        pitch[(size_t)b * F + f] = p;
+        const float inv = 1.0f / max_pitch;
+        dst[C] = p * inv;
+        for (int i = C + 1; i < Cp; ++i) dst[i] = 0.f;
+    }
+}
+
 }  // namespace ttsc
 
 using namespace ttsc;
+
+extern "C" int ttsc_cond_input(const float* g_dev, const int32_t* f2p_dev, const int32_t* flen_dev, const float* pitch_out_dev, float max_pitch, int32_t B,
+                               int32_t N, int32_t C, int32_t Cp, int32_t Fcap, int32_t F, float* pitch_dev, float* out_dev, void* stream) {
+    TTSC_REQUIRE(g_dev && f2p_dev && flen_dev && pitch_out_dev && pitch_dev && out_dev, "ttsc_cond_input: null argument");
+    TTSC_REQUIRE(B > 0 && N > 0 && C > 0 && Cp > C && Fcap > 0 && F > 0 && max_pitch > 0.f, "ttsc_cond_input: bad sizes (B=%d N=%d C=%d Cp=%d F=%d)", B, N, C, Cp, F);
+    hipLaunchKernelGGL(cond_input_kernel, dim3((unsigned)F, (unsigned)B), dim3(C >= 1024 ? 256 : 64), 0, (hipStream_t)stream, g_dev, f2p_dev, flen_dev,
+                       pitch_out_dev, max_pitch, N, C, Cp, Fcap, F, pitch_dev, out_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("cond_input_kernel launch failed: %s", hipGetErrorString(e));
+        return TTSC_EHIP;
+    }
+    return TTSC_OK;
+}
 
 extern "C" int ttsc_align_durations(const float* logits_dev, const int32_t* len_dev, int32_t B, int32_t N, int32_t D, int32_t* durs_dev,
                                     int32_t* f2p_dev, int32_t* flen_dev, int32_t Fcap, void* stream) {

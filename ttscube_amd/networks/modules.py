@@ -406,6 +406,7 @@ def _expand_rows(x, alignments, stride=1):
 
 
 G_STREAM = os.environ.get('TTSC_LANG_G_STREAM', '1') != '0'          # (measurement switch: 0 = the `g` stack after the pitch recurrence, on the same stream)
+COND_INPUT_FUSED = os.environ.get('TTSC_COND_INPUT_FUSED', '1') != '0'   # (measurement / test switch: 0 = the elementwise formulation)
 UPLOAD_RING = os.environ.get('TTSC_UPLOAD_RING', '1') != '0'             # (measurement switch: 0 = three separate uploads)
 G_STREAM_MAX_B = int(os.environ.get('TTSC_LANG_G_STREAM_MAX_B', '8'))
 _G_STREAMS = {}
@@ -567,16 +568,32 @@ class Languasito2(nn.Module):
                 return (cond, f2p if return_aux == 'device' else f2p.durations(), flens) if return_aux else cond
             hp = self._lstm('_pitch_rnn')(hexp, lengths=flens)
             op = linear_hip(hp, self._pitch_output.linear_layer.weight, self._pitch_output.linear_layer.bias, act='sigmoid')
-            vuv = torch.round(op[:, :, 1])
-            pitch = (op[:, :, 0] * self._max_pitch) * vuv
-            X['y_pitch'] = pitch
             if g_side is not None:
                 torch.cuda.current_stream(dev).wait_stream(g_side)
                 g = g_char
             else:
                 g = self._text_stack('g', x_char, x_speaker, lengths, X, hf_cond)
-            g, _ = _expand_rows(g, f2p)
-            g = torch.cat([g, (pitch / self._max_pitch).unsqueeze(2)], dim=-1).contiguous()
+            if COND_INPUT_FUSED and op.is_cuda:
+                # voiced flag, pitch, row expansion, the pitch feature and the split GEMM's zero columns in ONE launch (ttsc_cond_input: nine elementwise
+                # launches of ~9 us each on the critical path of a sentence otherwise); per element the operations of the lines below
+                g = g.float().contiguous()
+                Cg = g.shape[2]
+                Cp = (Cg + 1 + 3) // 4 * 4
+                pitch = torch.empty((B, F_), dtype=torch.float32, device=dev)
+                gin = torch.empty((B, F_, Cp), dtype=torch.float32, device=dev)
+                opc = op.float().contiguous()
+                with _lib.on_device(dev):
+                    _lib.check(_lib.lib().ttsc_cond_input(_lib.dev_ptr(g), _lib.dev_ptr(f2p.f2p), _lib.dev_ptr(f2p.flen_dev), _lib.dev_ptr(opc),
+                                                          float(self._max_pitch), B, g.shape[1], Cg, Cp, f2p.f2p.shape[1], F_, _lib.dev_ptr(pitch),
+                                                          _lib.dev_ptr(gin), _lib.current_stream()), 'ttsc_cond_input')
+                X['y_pitch'] = pitch
+                g = gin
+            else:
+                vuv = torch.round(op[:, :, 1])
+                pitch = (op[:, :, 0] * self._max_pitch) * vuv
+                X['y_pitch'] = pitch
+                g, _ = _expand_rows(g, f2p)
+                g = torch.cat([g, (pitch / self._max_pitch).unsqueeze(2)], dim=-1).contiguous()
             g = self._lstm('_cond_rnn')(g, lengths=flens)
             cond = linear_hip(g, self._cond_output.linear_layer.weight, self._cond_output.linear_layer.bias)
             if B > 1:
