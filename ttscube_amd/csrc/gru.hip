@@ -317,6 +317,35 @@ __device__ __forceinline__ bool gru_poll(const gru_u64* src, unsigned tag, unsig
     return true;
 }
 
+// Up to N granules per thread (src + i0 + r * stride for r < n) in ONE round trip: all loads are issued before the first tag is looked at, and only a pass in
+// which some granule is still missing is repeated.  gru_poll in a loop pays the L2 round trip once per granule even when every granule has arrived (the backward
+// recurrence hands over 3H values to 512 threads: three dependent round trips per step).
+template <int N>
+__device__ __forceinline__ bool gru_poll_n(const gru_u64* src, int i0, int stride, int n, unsigned tag, unsigned* abort_word, float* out) {
+    gru_u64 g[N];
+    unsigned spins = 0;
+    for (;;) {
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+            if (r < n) g[r] = __hip_atomic_load(src + i0 + r * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool all = true;
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+            if (r < n) all = all && ((unsigned)(g[r] >> 32) == tag);
+        if (all) break;
+        if (++spins > GS_SPIN_LIMIT || ((spins & 63u) == 0u && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+            __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(abort_word + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sticky copy
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+        if (r < n) out[i0 + r * stride] = __uint_as_float((unsigned)g[r]);
+    return true;
+}
+
 template <int KL>   // inputs per k-slice = H / KS
 __global__ __launch_bounds__(512) void gru_seq_split_res_kernel(GruSplitArgs s, gru_u64* ring) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // h[H] | part[KS][3][HU] | act[3][HU]
@@ -487,7 +516,10 @@ __global__ __launch_bounds__(512) void gru_bwd_split_res_kernel(GruSplitArgs s, 
         if (t == 0) break;   // dh_{-1} is not needed
         if (owner) fetch(t - 1);   // in flight while the exchange completes
         bool fail = false;
-        for (int i = tid; i < H3; i += 512) fail = !gru_poll(slot + i, tag, s.abort_word, &dg[i]) || fail;
+        for (int i0 = tid; i0 < H3; i0 += 4 * 512) {   // (H = 512: all three granules of a thread in one round trip)
+            const int n = (H3 - i0 + 511) / 512;
+            fail = !gru_poll_n<4>(slot, i0, 512, n < 4 ? n : 4, tag, s.abort_word, dg) || fail;
+        }
         if (__syncthreads_or(fail)) return;
         float x = 0.f;
         {

@@ -492,6 +492,35 @@ __global__ __launch_bounds__(512) void lstm_seq_split_kernel(LstmSplitArgs s) {
 typedef unsigned long long lstm_u64;
 typedef float lstm_f32x2 __attribute__((ext_vector_type(2)));
 
+// Up to N granules per thread in ONE round trip: every load (src[off[r]] for the r set in `mask`) is issued before the first tag is looked at; a pass is repeated only while
+// some granule is missing.  Polling granule by granule pays the L2 round trip once per granule even when all of them have arrived (the backward recurrence
+// hands 4H values to 512 threads: two dependent round trips per step; the batched forward kernel NB * H).  Values land in out[dst[r]].
+template <int N>
+__device__ __forceinline__ bool lstm_poll_n(const lstm_u64* src, const int (&off)[N], const int (&dst)[N], unsigned mask, unsigned tag, unsigned* abort_word, float* out) {
+    lstm_u64 g[N];
+    unsigned spins = 0;
+    for (;;) {
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+            if (mask >> r & 1u) g[r] = __hip_atomic_load(src + off[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool all = true;
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+            if (mask >> r & 1u) all = all && ((unsigned)(g[r] >> 32) == tag);
+        if (all) break;
+        if (++spins > GS_SPIN_LIMIT || ((spins & 63u) == 0u && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+            __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(abort_word + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sticky copy
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+        if (mask >> r & 1u) out[dst[r]] = __uint_as_float((unsigned)g[r]);
+    return true;
+}
+
 template <int KL>
 __global__ __launch_bounds__(512) void lstm_seq_split_res_kernel(LstmSplitArgs s, lstm_u64* ring) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // h[H] | part[KS][4][HU] | act[4][HU]
@@ -673,6 +702,20 @@ __global__ __launch_bounds__(512) void lstm_seq_split_res_nb_kernel(LstmSplitArg
     float hlast = (owner && a.h_0) ? a.h_0[((size_t)dir * a.B + ob) * H + j] : 0.f;
     if (owner)
         for (int t = olen; t < a.T; ++t) yb[(size_t)t * a.ldy + j] = 0.f;
+    // the (up to four) granules this thread fetches per step: ring offset without the parity term, LDS slot, length of the granule's utterance
+    int pb[4], pd[4], pl[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int e = tid + r * 512;
+        pb[r] = pd[r] = pl[r] = 0;
+        if (e < NB * H) {
+            const int q = e / H, i = e - q * H;
+#pragma unroll
+            for (int r2 = 0; r2 < NB; ++r2) pl[r] = (r2 == q) ? len[r2] : pl[r];
+            pb[r] = (int)((size_t)((b0 + q) * a.ndir + dir) * 2 * H + i);
+            pd[r] = i * NB + q;
+        }
+    }
     for (int st = 0; st < maxlen; ++st) {
         const bool mine = owner && st < olen;
         const int tpos = dir == 0 ? st : (olen - 1 - st);
@@ -690,29 +733,63 @@ __global__ __launch_bounds__(512) void lstm_seq_split_res_nb_kernel(LstmSplitArg
                 if (i < GPR) xv[i] = xr[(gset + i * NG) * H];
         }
         bool fail = false;
-        for (int e = tid; e < NB * H; e += 512) {
-            const int q = e / H, i = e - q * H;
-            int lq = 0;
-#pragma unroll
-            for (int r = 0; r < NB; ++r) lq = (r == q) ? len[r] : lq;
-            if (st == 0) {
+        if (st == 0) {
+            for (int e = tid; e < NB * H; e += 512) {
+                const int q = e / H, i = e - q * H;
                 hs[i * NB + q] = (a.h_0 && b0 + q < a.B) ? a.h_0[((size_t)dir * a.B + b0 + q) * H + i] : 0.f;
-            } else if (st < lq) {
-                const lstm_u64* src = ring + (size_t)((b0 + q) * a.ndir + dir) * 2 * H + (size_t)((st - 1) & 1) * H + i;
-                lstm_u64 gq;
-                unsigned spins = 0;
-                for (;;) {
-                    gq = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((unsigned)(gq >> 32) == (unsigned)st) break;
-                    if (++spins > GS_SPIN_LIMIT || ((spins & 63u) == 0u && __hip_atomic_load(s.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                        __hip_atomic_store(s.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(s.abort_word + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sticky copy
-                        fail = true;
-                        break;
+            }
+        } else {
+            // the thread's granules (one per 512 elements of the NB * H staged values; those of utterances that have ended are skipped and keep their
+            // last value, which nothing reads) in one round trip; the first four are described by pb / pd / pl, set up before the loop
+            if (NB * H <= 512) {   // one granule per thread (two utterances at H = 256, the padded batch's usual launch): the plain poll
+                if (tid < NB * H && st < pl[0]) {
+                    const lstm_u64* src = ring + pb[0] + ((st - 1) & 1) * H;
+                    lstm_u64 gq;
+                    unsigned spins = 0;
+                    for (;;) {
+                        gq = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned)(gq >> 32) == (unsigned)st) break;
+                        if (++spins > GS_SPIN_LIMIT || ((spins & 63u) == 0u && __hip_atomic_load(s.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                            __hip_atomic_store(s.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(s.abort_word + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sticky copy
+                            fail = true;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
                     }
-                    __builtin_amdgcn_s_sleep(1);
+                    hs[pd[0]] = __uint_as_float((unsigned)gq);
                 }
-                hs[i * NB + q] = __uint_as_float((unsigned)gq);
+            } else {
+                const int par = ((st - 1) & 1) * H;
+                int off[4];
+                unsigned mask = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    off[r] = pb[r] + par;
+                    mask |= st < pl[r] ? 1u << r : 0u;
+                }
+                if (mask) fail = !lstm_poll_n<4>(ring, off, pd, mask, (unsigned)st, s.abort_word, hs) || fail;
+            }
+            for (int e0 = tid + 4 * 512; e0 < NB * H; e0 += 4 * 512) {   // (H = 512 with 8 utterances per group: a second round)
+                int off[4], dst[4];
+                unsigned mask = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int e = e0 + r * 512;
+                    off[r] = dst[r] = 0;
+                    if (e < NB * H) {
+                        const int q = e / H, i = e - q * H;
+                        int lq = 0;
+#pragma unroll
+                        for (int r2 = 0; r2 < NB; ++r2) lq = (r2 == q) ? len[r2] : lq;
+                        if (st < lq) {
+                            off[r] = (int)(((size_t)((b0 + q) * a.ndir + dir) * 2 + (size_t)((st - 1) & 1)) * H + i);
+                            dst[r] = i * NB + q;
+                            mask |= 1u << r;
+                        }
+                    }
+                }
+                if (mask) fail = !lstm_poll_n<4>(ring, off, dst, mask, (unsigned)st, s.abort_word, hs) || fail;
             }
         }
         if (__syncthreads_or(fail)) return;
@@ -945,21 +1022,15 @@ __global__ __launch_bounds__(512) void lstm_bwd_split_res_kernel(LstmSplitArgs s
         if (st == 0) break;
         if (owner) fetch(st - 1);   // in flight while the exchange completes
         bool fail = false;
-        for (int i = tid; i < H4; i += 512) {
-            lstm_u64 gq;
-            unsigned spins = 0;
-            for (;;) {
-                gq = __hip_atomic_load(slot + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned)(gq >> 32) == tag) break;
-                if (++spins > GS_SPIN_LIMIT || ((spins & 63u) == 0u && __hip_atomic_load(s.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                    __hip_atomic_store(s.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(s.abort_word + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sticky copy
-                    fail = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
+        for (int i0 = tid; i0 < H4; i0 += 4 * 512) {   // (H = 256: both granules of a thread in one round trip)
+            int off[4];
+            unsigned mask = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                off[r] = i0 + r * 512;
+                mask |= off[r] < H4 ? 1u << r : 0u;
             }
-            dg[i] = __uint_as_float((unsigned)gq);
+            fail = !lstm_poll_n<4>(slot, off, off, mask, tag, s.abort_word, dg) || fail;
         }
         if (__syncthreads_or(fail)) return;
         float x = 0.f;
